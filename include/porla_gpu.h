@@ -1,0 +1,74 @@
+/* porla_gpu.h -- C ABI of the MI355X engine beyond the 14 cgo symbols of libmultiexp.h.
+ *
+ * Plain pointers and sizes only.  "d_" pointers are device (HBM) addresses on the current HIP
+ * device; `hip_stream` is a hipStream_t passed as void* (NULL = default stream).  All functions
+ * return 0 on success and a negative code on failure (porla_gpu_last_error() gives the text);
+ * nothing here ever falls back to a CPU implementation of the hot path.
+ *
+ * What each entry point replaces in the reference:
+ *   porla_bn254_msm_*        compute_multi_exp, porla/main.go:118-138 (libmultiexp.h:77), for callers that
+ *                            keep the (scalar, point) arrays resident in HBM (bench, multi-GPU sharding)
+ *   porla_bn254_jac_sum      the partial-sum fold of range-sharded MSMs; the reference does the same fold
+ *                            across its 8 pool threads with gej_add_var, porla/Client/Client.hpp:761-787
+ *   porla_kzg_commit_batch   compute_digest_from_srs (main.go:103-116) hoisted over many rows
+ *                            (callers Server.hpp:550-560, 1077-1078, 2061-2062)
+ *   porla_secp256k1_msm_*    secp256k1_ecmult_multi_var with g_sc = 0,
+ *                            porla/Utils/secp256k1_lib/ecmult_impl.h:814-860 (call sites Server.hpp:842-848,
+ *                            Client.hpp:395,778), reached through the include shim in INTEGRATION.md
+ *   porla_icc_encode_*       the CRebuild_Cached butterfly network, porla/Server/Server.hpp:1548-1687, and the
+ *                            align_MAC scalar derivation, Server.hpp:531-541 (no function boundary exists
+ *                            in the reference: INTEGRATION.md documents the patch site)
+ *
+ * Byte formats (identical to the reference's wire formats):
+ *   scalar   32 bytes big-endian (bn254_scalar, utils.h:64,307-318); reduced mod the group order
+ *   point    64 bytes X||Y big-endian, regular (non-Montgomery) form; 64 zero bytes = infinity
+ *            (KZG MAC_Block, utils.h:65; config.hpp:26)
+ *   jacobian 96 bytes X||Y||Z big-endian regular form, x = X/Z^2, y = Y/Z^3, Z = 0 = infinity
+ */
+#ifndef PORLA_GPU_H
+#define PORLA_GPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PORLA_OK            0
+#define PORLA_ERR_NO_DEVICE (-1)   /* no gfx950 device / HIP runtime failure */
+#define PORLA_ERR_HIP       (-2)   /* a HIP call failed (see porla_gpu_last_error) */
+#define PORLA_ERR_ARG       (-3)   /* bad argument */
+#define PORLA_ERR_STATE     (-4)   /* e.g. SRS not initialised */
+
+/* ---- runtime ---- */
+int         porla_gpu_device_count(void);
+int         porla_gpu_set_device(int device);
+const char *porla_gpu_last_error(void);
+/* Per-kernel timing with HIP events recorded on the launch stream.  enable=1 starts (and clears) the
+ * accumulation; porla_gpu_profile_get(i, ...) returns kernel name, summed milliseconds and launch count
+ * for slot i, or a negative value past the last slot. */
+int         porla_gpu_profile_enable(int enable);
+int         porla_gpu_profile_get(int slot, char *name, size_t name_cap, double *total_ms, long long *launches);
+/* MSM tuning override (0 = automatic): window bits c */
+int         porla_gpu_set_msm_window(int c);
+
+/* ---- BN254 G1 MSM ---- */
+int porla_bn254_msm_device(const void *d_scalars, const void *d_points, size_t n, uint8_t out_affine[64],
+                           void *hip_stream);
+int porla_bn254_msm_device_partial(const void *d_scalars, const void *d_points, size_t n, uint8_t out_jacobian[96],
+                                   void *hip_stream);
+int porla_bn254_msm_host(const uint8_t *scalars, const uint8_t *points, size_t n, uint8_t out_affine[64]);
+int porla_bn254_jac_sum(const uint8_t *jacobians, size_t count, uint8_t out_affine[64]);
+
+/* ---- secp256k1 MSM (canonical encodings: 32-byte BE scalar, 64-byte x||y BE affine, zeros = infinity) ---- */
+int porla_secp256k1_msm_device(const void *d_scalars, const void *d_points, size_t n, uint8_t out_affine[64],
+                               void *hip_stream);
+int porla_secp256k1_msm_device_partial(const void *d_scalars, const void *d_points, size_t n,
+                                       uint8_t out_jacobian[96], void *hip_stream);
+int porla_secp256k1_msm_host(const uint8_t *scalars, const uint8_t *points, size_t n, uint8_t out_affine[64]);
+int porla_secp256k1_jac_sum(const uint8_t *jacobians, size_t count, uint8_t out_affine[64]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

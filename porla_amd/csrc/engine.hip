@@ -1,0 +1,197 @@
+// MI355X engine: HIP launch logic for the bucket MSM + the device-pointer C ABI (include/porla_gpu.h).
+// Host language is C++ (the reference's plug-in is Go over cgo; no Go toolchain exists in this image,
+// and the reference's callers are C++: porla/Utils/utils.h:277-292).
+#include "engine.hpp"
+#include "../../include/porla_gpu.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <vector>
+
+namespace porla {
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& s) { g_last_error = s; }
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+    set_last_error(buf);
+    return PORLA_ERR_HIP;
+}
+
+int ensure_device() {
+    static std::once_flag once;
+    static int status = PORLA_ERR_NO_DEVICE;
+    std::call_once(once, [] {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || n <= 0) {
+            set_last_error("porla: no HIP device available (the MSM path has no CPU fallback)");
+            status = PORLA_ERR_NO_DEVICE;
+            return;
+        }
+        status = PORLA_OK;
+    });
+    if (status != PORLA_OK) set_last_error("porla: no HIP device available (the MSM path has no CPU fallback)");
+    return status;
+}
+
+// ------------------------------------------------------------------------------------------------ profiling
+struct ProfSlot { std::string name; double ms = 0; long long launches = 0; };
+struct PendingEv { int slot; hipEvent_t e0, e1; };
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfSlot> g_prof;
+static std::vector<PendingEv> g_pending;
+
+static int prof_slot(const char* name) {
+    for (size_t i = 0; i < g_prof.size(); i++) if (g_prof[i].name == name) return (int)i;
+    g_prof.push_back(ProfSlot{name, 0, 0});
+    return (int)g_prof.size() - 1;
+}
+ProfScope::ProfScope(const char* name, hipStream_t s) : slot(-1), stream(s), e0(nullptr), e1(nullptr), on(false) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_on) return;
+    on = true;
+    slot = prof_slot(name);
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, stream);
+}
+ProfScope::~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(e1, stream);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_pending.push_back(PendingEv{slot, e0, e1});
+}
+void prof_flush() {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& p : g_pending) {
+        float ms = 0;
+        (void)hipEventSynchronize(p.e1);
+        if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+            g_prof[p.slot].ms += ms;
+            g_prof[p.slot].launches += 1;
+        }
+        (void)hipEventDestroy(p.e0);
+        (void)hipEventDestroy(p.e1);
+    }
+    g_pending.clear();
+}
+
+// ------------------------------------------------------------------------------------------------ workspace
+std::mutex g_ws_mu;  // serialises MSM calls (compute_digest_from_srs may be called from 8 threads)
+static std::vector<Workspace*> g_ws;
+int g_window_override = 0;
+
+int get_workspace(Workspace** out) {
+    int dev = 0;
+    PORLA_HIP(hipGetDevice(&dev));
+    for (auto* w : g_ws) if (w->device == dev) { *out = w; return PORLA_OK; }
+    Workspace* w = new Workspace();
+    w->device = dev;
+    PORLA_HIP(hipStreamCreateWithFlags(&w->own_stream, hipStreamNonBlocking));
+    g_ws.push_back(w);
+    *out = w;
+    return PORLA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI helpers
+template <class C>
+static int abi_msm_device(const void* d_scalars, const void* d_points, size_t n, uint8_t* out, void* stream, bool jac) {
+    using M = typename C::Fp;
+    if (n && (!d_scalars || !d_points || !out)) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    XYZZ<M> tot;
+    int rc = msm_device<C>((const uint8_t*)d_scalars, (const uint8_t*)d_points, n, (hipStream_t)stream, &tot);
+    if (rc) return rc;
+    if (jac) h_xyzz_to_jac_bytes<M>(out, tot);
+    else h_affine_to_bytes<M>(out, h_xyzz_to_affine<M>(tot));
+    return PORLA_OK;
+}
+template <class C>
+static int abi_msm_host(const uint8_t* scalars, const uint8_t* points, size_t n, uint8_t* out) {
+    using M = typename C::Fp;
+    if (n && (!scalars || !points || !out)) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    XYZZ<M> tot;
+    int rc = msm_host<C>(scalars, points, n, &tot);
+    if (rc) return rc;
+    h_affine_to_bytes<M>(out, h_xyzz_to_affine<M>(tot));
+    return PORLA_OK;
+}
+template <class C>
+static int abi_jac_sum(const uint8_t* jacs, size_t count, uint8_t* out) {
+    using M = typename C::Fp;
+    if (count && !jacs) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    XYZZ<M> acc = xyzz_inf<M>();
+    for (size_t i = 0; i < count; i++) {
+        XYZZ<M> p = h_xyzz_from_jac_bytes<M>(jacs + 96 * i);
+        xyzz_add<M>(acc, p);
+    }
+    h_affine_to_bytes<M>(out, h_xyzz_to_affine<M>(acc));
+    return PORLA_OK;
+}
+
+}  // namespace porla
+
+using namespace porla;
+
+extern "C" {
+
+int porla_gpu_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int porla_gpu_set_device(int device) {
+    PORLA_HIP(hipSetDevice(device));
+    return PORLA_OK;
+}
+const char* porla_gpu_last_error(void) { return g_last_error.c_str(); }
+
+int porla_gpu_profile_enable(int enable) {
+    prof_flush();
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = enable != 0;
+    if (enable) g_prof.clear();
+    return PORLA_OK;
+}
+int porla_gpu_profile_get(int slot, char* name, size_t name_cap, double* total_ms, long long* launches) {
+    prof_flush();
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (slot < 0 || (size_t)slot >= g_prof.size()) return PORLA_ERR_ARG;
+    if (name && name_cap) snprintf(name, name_cap, "%s", g_prof[slot].name.c_str());
+    if (total_ms) *total_ms = g_prof[slot].ms;
+    if (launches) *launches = g_prof[slot].launches;
+    return PORLA_OK;
+}
+int porla_gpu_set_msm_window(int c) { g_window_override = c; return PORLA_OK; }
+
+int porla_bn254_msm_device(const void* d_scalars, const void* d_points, size_t n, uint8_t out_affine[64], void* s) {
+    return abi_msm_device<Bn254G1>(d_scalars, d_points, n, out_affine, s, false);
+}
+int porla_bn254_msm_device_partial(const void* d_scalars, const void* d_points, size_t n, uint8_t out_jac[96], void* s) {
+    return abi_msm_device<Bn254G1>(d_scalars, d_points, n, out_jac, s, true);
+}
+int porla_bn254_msm_host(const uint8_t* scalars, const uint8_t* points, size_t n, uint8_t out_affine[64]) {
+    return abi_msm_host<Bn254G1>(scalars, points, n, out_affine);
+}
+int porla_bn254_jac_sum(const uint8_t* jacs, size_t count, uint8_t out_affine[64]) {
+    return abi_jac_sum<Bn254G1>(jacs, count, out_affine);
+}
+
+int porla_secp256k1_msm_device(const void* d_scalars, const void* d_points, size_t n, uint8_t out_affine[64], void* s) {
+    return abi_msm_device<Secp256k1G>(d_scalars, d_points, n, out_affine, s, false);
+}
+int porla_secp256k1_msm_device_partial(const void* d_scalars, const void* d_points, size_t n, uint8_t out_jac[96], void* s) {
+    return abi_msm_device<Secp256k1G>(d_scalars, d_points, n, out_jac, s, true);
+}
+int porla_secp256k1_msm_host(const uint8_t* scalars, const uint8_t* points, size_t n, uint8_t out_affine[64]) {
+    return abi_msm_host<Secp256k1G>(scalars, points, n, out_affine);
+}
+int porla_secp256k1_jac_sum(const uint8_t* jacs, size_t count, uint8_t out_affine[64]) {
+    return abi_jac_sum<Secp256k1G>(jacs, count, out_affine);
+}
+
+}  // extern "C"

@@ -1,0 +1,337 @@
+// The 14 cgo symbols of the reference's libmultiexp.so (porla/Utils/libmultiexp.h:71-84, generated from
+// porla/main.go:31-230), re-implemented over the MI355X engine.  Same names, same GoSlice ABI, same
+// (absent) error behaviour: failures of the GPU path print one line and abort(), as there is no error
+// channel at this boundary and silently wrong MACs would be worse.
+//
+//   MSMs (compute_multi_exp, compute_digest_from_srs, create_proof)  -> HIP kernels (engine.hip / msm.cuh)
+//   single-point ops, Horner evaluation, pairing check               -> host (latency-bound, 64-byte operands)
+#include "engine.hpp"
+#include "pairing_host.hpp"
+#include "../../include/libmultiexp.h"
+#include "../../include/porla_gpu.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <random>
+#include <vector>
+
+using namespace porla;
+using Fp = Bn254Fp;
+using Fr = Bn254Fr;
+
+namespace {
+
+struct KzgState {
+    std::mutex mu;
+    bool have_key = false;
+    Fe<Fr> tau, alpha;            // Montgomery form mod r
+    uint8_t tau_raw[32] = {0};    // big.Int of the raw key bytes, reduced mod r, big-endian
+    long long n_samples = 0;
+    std::vector<Affine<Fp>> srs;  // SRS.G1, Montgomery form (host copy)
+    Affine<Fp>* d_srs = nullptr;  // resident copy in HBM
+    size_t d_srs_cap = 0;
+    int d_srs_device = -1;
+    bool d_srs_dirty = true;      // host copy changed since the last upload
+    bool have_g2 = false;
+    G2Affine g2[2];               // SRS.G2[0], SRS.G2[1]
+    Affine<Fp> h_mac;             // MAC hiding base (main.go:28,58-59)
+};
+KzgState g;
+
+[[noreturn]] void die(const char* where, int rc) {
+    fprintf(stderr, "libmultiexp (MI355X): %s failed (%d): %s\n", where, rc, porla_gpu_last_error());
+    abort();
+}
+
+Affine<Fp> generator() {
+    Affine<Fp> a;
+    a.x = fe_zero<Fp>(); a.x.v[0] = 1; a.x = fe_to_mont<Fp>(a.x);
+    a.y = fe_zero<Fp>(); a.y.v[0] = 2; a.y = fe_to_mont<Fp>(a.y);
+    return a;
+}
+
+// G1Affine.Unmarshal on a 64-byte slice (main.go:130,144,198,...): flag bits 00 -> uncompressed.
+// gnark would treat flag bits 10/11/01 as a compressed encoding; Porla never produces them in
+// 64-byte buffers (coordinates are < p < 2^254), they are decoded the gnark way for completeness.
+Affine<Fp> unmarshal64(const uint8_t* b) {
+    uint8_t flags = b[0] & 0xC0;
+    if (flags == 0x00) return h_affine_from_bytes<Fp>(b);
+    Affine<Fp> a;
+    if (flags == 0x40 || !g1_decompress(b, &a)) { a.x = fe_zero<Fp>(); a.y = fe_zero<Fp>(); }
+    return a;
+}
+
+void fr_plain_be(uint8_t out[32], const Fe<Fr>& a) { h_fe_to_be<Fr>(out, a); }
+
+// upload the SRS to HBM in Montgomery form (done once per init; the base is then resident)
+int upload_srs() {
+    int rc = ensure_device();
+    if (rc) return rc;
+    int dev = 0;
+    PORLA_HIP(hipGetDevice(&dev));
+    size_t bytes = g.srs.size() * sizeof(Affine<Fp>);
+    if (g.d_srs && (g.d_srs_cap < bytes || g.d_srs_device != dev)) { PORLA_HIP(hipFree(g.d_srs)); g.d_srs = nullptr; }
+    if (!g.d_srs) { PORLA_HIP(hipMalloc((void**)&g.d_srs, bytes ? bytes : 64)); g.d_srs_cap = bytes; g.d_srs_device = dev; }
+    PORLA_HIP(hipMemcpy(g.d_srs, g.srs.data(), bytes, hipMemcpyHostToDevice));
+    return PORLA_OK;
+}
+
+// kzg.Commit(f, srs) (main.go:114,164): MSM of len coefficients (32-byte BE each) against SRS.G1[:len]
+Affine<Fp> commit_gpu(const uint8_t* coeffs_be, size_t len, const char* where) {
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        if (g.d_srs_dirty && !g.srs.empty()) {
+            int rc = upload_srs();
+            if (rc) die(where, rc);
+            g.d_srs_dirty = false;
+        }
+    }
+    if (!g.d_srs || len > g.srs.size()) {
+        fprintf(stderr, "libmultiexp (MI355X): %s: SRS not initialised (need %zu points, have %zu)\n", where, len,
+                g.srs.size());
+        abort();
+    }
+    XYZZ<Fp> tot;
+    int rc = msm_host_scalars<Bn254G1>(coeffs_be, g.d_srs, len, &tot);
+    if (rc) die(where, rc);
+    return h_xyzz_to_affine<Fp>(tot);
+}
+
+void copy_out(GoSlice* dst, const uint8_t* src, size_t n) {  // Go copy(): min(len(dst), len(src))
+    size_t m = (size_t)(dst->len < 0 ? 0 : dst->len);
+    if (m > n) m = n;
+    memcpy(dst->data, src, m);
+}
+
+}  // namespace
+
+extern "C" {
+
+// main.go:31-40
+void init_key(GoSlice* tau_key_in, GoSlice* alpha_key_in) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    g.tau = h_fe_from_be_var<Fr>((const uint8_t*)tau_key_in->data, (size_t)tau_key_in->len);
+    g.alpha = h_fe_from_be_var<Fr>((const uint8_t*)alpha_key_in->data, (size_t)alpha_key_in->len);
+    fr_plain_be(g.tau_raw, g.tau);
+    g.have_key = true;
+}
+
+// main.go:42-60.  kzg.NewSRS: G1[i] = tau^i * G, G2 = {G2gen, tau * G2gen}; WriteTo: 4-byte BE count,
+// n compressed G1 (32 B), 2 compressed G2 (64 B) = 32n + 132 bytes (Client.hpp:350-357).
+void init_SRS(GoInt SRS_size, GoSlice* out, GoInt64* out_len) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!g.have_key || SRS_size <= 0) { fprintf(stderr, "libmultiexp (MI355X): init_SRS before init_key\n"); abort(); }
+    g.n_samples = SRS_size;
+    g.srs.assign((size_t)SRS_size, Affine<Fp>());
+    Affine<Fp> G = generator();
+    Fe<Fr> t = fe_one<Fr>();
+    std::vector<XYZZ<Fp>> proj((size_t)SRS_size);
+    for (long long i = 0; i < SRS_size; i++) {
+        uint32_t k[8];
+        h_fe_to_plain<Fr>(k, t);
+        proj[(size_t)i] = h_scalar_mul<Fp>(G, k);
+        t = fe_mul<Fr>(t, g.tau);
+    }
+    for (long long i = 0; i < SRS_size; i++) g.srs[(size_t)i] = h_xyzz_to_affine<Fp>(proj[(size_t)i]);
+    uint32_t tau_plain[8];
+    h_fe_to_plain<Fr>(tau_plain, g.tau);
+    g.g2[0] = g2_generator();
+    g.g2[1] = g2_scalar_mul(g.g2[0], tau_plain);
+    g.have_g2 = true;
+
+    std::vector<uint8_t> blob(4 + 32 * (size_t)SRS_size + 128);
+    blob[0] = (uint8_t)(SRS_size >> 24); blob[1] = (uint8_t)(SRS_size >> 16);
+    blob[2] = (uint8_t)(SRS_size >> 8);  blob[3] = (uint8_t)SRS_size;
+    for (long long i = 0; i < SRS_size; i++) g1_compress(&blob[4 + 32 * (size_t)i], g.srs[(size_t)i]);
+    g2_compress(&blob[4 + 32 * (size_t)SRS_size], g.g2[0]);
+    g2_compress(&blob[4 + 32 * (size_t)SRS_size + 64], g.g2[1]);
+    if (out_len) *out_len = (GoInt64)blob.size();
+    copy_out(out, blob.data(), blob.size());
+
+    // MAC hiding h = random * G1[0] (main.go:52-59: fr.SetRandom -> crypto/rand; non-reproducible by design)
+    std::random_device rd;
+    uint8_t rb[32];
+    for (int i = 0; i < 32; i += 4) { uint32_t v = rd(); memcpy(rb + i, &v, 4); }
+    Fe<Fr> rnd = h_fe_from_be<Fr>(rb);
+    uint32_t k[8];
+    h_fe_to_plain<Fr>(k, rnd);
+    g.h_mac = h_xyzz_to_affine<Fp>(h_scalar_mul<Fp>(g.srs[0], k));
+
+    g.d_srs_dirty = true;  // uploaded to HBM on first use by a commit (the client side never needs the GPU)
+}
+
+// main.go:62-68: SRS.ReadFrom
+void init_SRS_from_data(GoInt SRS_size, GoSlice* in) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    const uint8_t* b = (const uint8_t*)in->data;
+    size_t len = (size_t)in->len;
+    g.n_samples = SRS_size;
+    if (len < 4) { fprintf(stderr, "libmultiexp (MI355X): init_SRS_from_data: short buffer\n"); abort(); }
+    size_t cnt = ((size_t)b[0] << 24) | ((size_t)b[1] << 16) | ((size_t)b[2] << 8) | b[3];
+    if (len < 4 + 32 * cnt) { fprintf(stderr, "libmultiexp (MI355X): init_SRS_from_data: short buffer\n"); abort(); }
+    g.srs.assign(cnt, Affine<Fp>());
+    for (size_t i = 0; i < cnt; i++) {
+        if (!g1_decompress(b + 4 + 32 * i, &g.srs[i])) {
+            fprintf(stderr, "libmultiexp (MI355X): init_SRS_from_data: G1[%zu] is not on the curve\n", i);
+            abort();
+        }
+    }
+    g.have_g2 = false;
+    if (len >= 4 + 32 * cnt + 128) {
+        g.have_g2 = g2_decompress(b + 4 + 32 * cnt, &g.g2[0]) && g2_decompress(b + 4 + 32 * cnt + 64, &g.g2[1]);
+    }
+    g.d_srs_dirty = true;
+}
+
+// main.go:70-89: alpha * f(tau) * G1[0] -- Horner over Fr and ONE scalar multiplication (host)
+void compute_digest(GoSlice* data_in, GoSlice* data_out) {
+    const uint8_t* d = (const uint8_t*)data_in->data;
+    Fe<Fr> acc = fe_zero<Fr>();
+    for (long long i = g.n_samples - 1; i >= 0; i--)
+        acc = fe_add<Fr>(fe_mul<Fr>(acc, g.tau), h_fe_from_be<Fr>(d + 32 * i));
+    acc = fe_mul<Fr>(acc, g.alpha);
+    uint32_t k[8];
+    h_fe_to_plain<Fr>(k, acc);
+    uint8_t out[64];
+    h_affine_to_bytes<Fp>(out, h_xyzz_to_affine<Fp>(h_scalar_mul<Fp>(g.srs[0], k)));
+    copy_out(data_out, out, 64);
+}
+
+// main.go:91-101
+void compute_digest_complement(GoSlice* data_in, GoSlice* data_out) {
+    Fe<Fr> s = h_fe_from_be_var<Fr>((const uint8_t*)data_in->data, (size_t)data_in->len);
+    uint32_t k[8];
+    h_fe_to_plain<Fr>(k, s);
+    uint8_t out[64];
+    h_affine_to_bytes<Fp>(out, h_xyzz_to_affine<Fp>(h_scalar_mul<Fp>(g.h_mac, k)));
+    copy_out(data_out, out, 64);
+}
+
+// main.go:103-116: kzg.Commit -- GPU MSM against the resident SRS
+void compute_digest_from_srs(GoSlice* data_in, GoSlice* data_out) {
+    uint8_t out[64];
+    h_affine_to_bytes<Fp>(out, commit_gpu((const uint8_t*)data_in->data, (size_t)g.n_samples, "compute_digest_from_srs"));
+    copy_out(data_out, out, 64);
+}
+
+// main.go:118-138: the large MSM -- GPU
+void compute_multi_exp(GoSlice* scalars, GoSlice* points, GoInt length, GoSlice* result_out) {
+    uint8_t out[64];
+    int rc = porla_bn254_msm_host((const uint8_t*)scalars->data, (const uint8_t*)points->data,
+                                  (size_t)(length < 0 ? 0 : length), out);
+    if (rc) die("compute_multi_exp", rc);
+    copy_out(result_out, out, 64);
+}
+
+// main.go:140-151
+GoUint8 compare_commitment(GoSlice* commitment_a, GoSlice* commitment_b) {
+    Affine<Fp> a = unmarshal64((const uint8_t*)commitment_a->data);
+    Affine<Fp> b = unmarshal64((const uint8_t*)commitment_b->data);
+    if (!(fe_eq<Fp>(a.x, b.x) && fe_eq<Fp>(a.y, b.y))) {
+        printf("error KZG commitment\n");
+        return 0;
+    }
+    return 1;
+}
+
+// main.go:153-175: commitment = Commit(f); y = f(z); h = (f - y)/(X - z); H = Commit(h)
+void create_proof(GoUint64 random_point, GoSlice* data_in, GoSlice* commitment_out, GoSlice* proof_H,
+                  GoSlice* proof_point, GoSlice* proof_claim) {
+    const uint8_t* d = (const uint8_t*)data_in->data;
+    size_t n = (size_t)g.n_samples;
+    uint8_t buf[64];
+    h_affine_to_bytes<Fp>(buf, commit_gpu(d, n, "create_proof (commit)"));
+    copy_out(commitment_out, buf, 64);
+
+    uint8_t zb[32] = {0};
+    for (int i = 0; i < 8; i++) zb[31 - i] = (uint8_t)(random_point >> (8 * i));
+    Fe<Fr> z = h_fe_from_be<Fr>(zb);
+    std::vector<Fe<Fr>> f(n);
+    for (size_t i = 0; i < n; i++) f[i] = h_fe_from_be<Fr>(d + 32 * i);
+    Fe<Fr> y = fe_zero<Fr>();
+    for (size_t i = n; i-- > 0;) y = fe_add<Fr>(fe_mul<Fr>(y, z), f[i]);
+    // synthetic division: h[n-2] = f[n-1]; h[i-1] = f[i] + z*h[i]
+    std::vector<uint8_t> hb(32 * (n ? n - 1 : 0));
+    Fe<Fr> carry = fe_zero<Fr>();
+    for (size_t i = n; i-- > 1;) {
+        carry = fe_add<Fr>(fe_mul<Fr>(carry, z), f[i]);
+        fr_plain_be(&hb[32 * (i - 1)], carry);
+    }
+    h_affine_to_bytes<Fp>(buf, commit_gpu(hb.data(), n ? n - 1 : 0, "create_proof (open)"));
+    copy_out(proof_H, buf, 64);
+    uint8_t t[32];
+    fr_plain_be(t, z); copy_out(proof_point, t, 32);
+    fr_plain_be(t, y); copy_out(proof_claim, t, 32);
+}
+
+// main.go:177-193: kzg.Verify -- e(C - y*G1, G2) == e(H, tau*G2 - z*G2), as one product of two pairings
+GoUint8 verify_proof(GoSlice* commitment_in, GoSlice* proof_H, GoSlice* proof_point, GoSlice* proof_claim) {
+    Affine<Fp> C = unmarshal64((const uint8_t*)commitment_in->data);
+    Affine<Fp> H = unmarshal64((const uint8_t*)proof_H->data);
+    Fe<Fr> z = h_fe_from_be_var<Fr>((const uint8_t*)proof_point->data, (size_t)proof_point->len);
+    Fe<Fr> y = h_fe_from_be_var<Fr>((const uint8_t*)proof_claim->data, (size_t)proof_claim->len);
+    if (!g.have_g2) {
+        printf("Verifying is wrong\n");
+        return 0;
+    }
+    uint32_t yk[8], zk[8];
+    h_fe_to_plain<Fr>(yk, y);
+    h_fe_to_plain<Fr>(zk, z);
+    // A = C - y*G1
+    XYZZ<Fp> A = h_scalar_mul<Fp>(g.srs.empty() ? generator() : g.srs[0], yk);
+    A.y = fe_neg<Fp>(A.y);
+    xyzz_madd<Fp>(A, C);
+    Affine<Fp> Aaff = h_xyzz_to_affine<Fp>(A);
+    // Q = tau*G2 - z*G2
+    G2Affine zG2 = g2_scalar_mul(g.g2[0], zk);
+    G2Affine Q = g2_add(g.g2[1], g2_neg(zG2));
+    // e(A, G2) * e(-H, Q) == 1
+    Affine<Fp> negH = aff_neg_if<Fp>(H, true);
+    if (aff_is_inf<Fp>(H)) negH = H;
+    bool ok = pairing_product_is_one(Aaff, g.g2[0], negH, Q);
+    if (!ok) {
+        printf("Verifying is wrong\n");
+        return 0;
+    }
+    return 1;
+}
+
+// main.go:195-202
+void add_point(GoSlice* point_a, GoSlice* point_b) {
+    Affine<Fp> a = unmarshal64((const uint8_t*)point_a->data);
+    Affine<Fp> b = unmarshal64((const uint8_t*)point_b->data);
+    XYZZ<Fp> p = xyzz_from_affine<Fp>(a);
+    xyzz_madd<Fp>(p, b);
+    uint8_t out[64];
+    h_affine_to_bytes<Fp>(out, h_xyzz_to_affine<Fp>(p));
+    copy_out(point_a, out, 64);
+}
+
+// main.go:204-214
+void mult_point(GoSlice* point_a, GoSlice* scalar) {
+    Affine<Fp> a = unmarshal64((const uint8_t*)point_a->data);
+    Fe<Fr> s = h_fe_from_be_var<Fr>((const uint8_t*)scalar->data, (size_t)scalar->len);
+    uint32_t k[8];
+    h_fe_to_plain<Fr>(k, s);
+    uint8_t out[64];
+    h_affine_to_bytes<Fp>(out, h_xyzz_to_affine<Fp>(h_scalar_mul<Fp>(a, k)));
+    copy_out(point_a, out, 64);
+}
+
+// main.go:216-222
+void neg_point(GoSlice* point) {
+    Affine<Fp> a = unmarshal64((const uint8_t*)point->data);
+    if (!aff_is_inf<Fp>(a)) a.y = fe_neg<Fp>(a.y);
+    uint8_t out[64];
+    h_affine_to_bytes<Fp>(out, a);
+    copy_out(point, out, 64);
+}
+
+// main.go:224-230
+void set_inf_point(GoSlice* point) {
+    uint8_t out[64] = {0};
+    copy_out(point, out, 64);
+}
+
+}  // extern "C"

@@ -1,0 +1,313 @@
+// Pippenger bucket multi-scalar multiplication for gfx950 (MI355X), templated on the curve.
+//
+// Replaces the reference's MSM providers behind their own boundaries:
+//   BN254     compute_multi_exp -> G1Affine.MultiExp          porla/main.go:118-138
+//   secp256k1 secp256k1_ecmult_multi_var (pippenger_batch)     porla/Utils/secp256k1_lib/ecmult_impl.h:814-860, :646-720
+// The reference algorithms (gnark: signed c-bit windows + extended-Jacobian buckets, one goroutine
+// per window; libsecp256k1: GLV + wNAF + buckets, single thread) fix WHAT is computed
+// (sum (s_i mod order) * P_i); the decomposition below is designed for 256 CUs:
+//
+//   k_points_to_mont   64-B big-endian affine -> Montgomery limbs (one coalesced pass, 64 B in / 64 B out)
+//   k_scalar_digits    32-B big-endian scalar -> reduce mod order -> signed c-bit digits; per-(window,bucket)
+//                      histogram with device-scope atomics
+//   k_bucket_offsets   one slot range per bucket (wave prefix + one cursor atomic per wave; bucket order in
+//                      memory is irrelevant, so no global scan is needed)
+//   k_scatter          counting-sort scatter of point indices into their bucket's range
+//   k_bucket_sum       ONE THREAD PER BUCKET: walks its index list, gathers 64-B points (L2 / Infinity-Cache
+//                      resident: 2^20 points = 64 MiB) and accumulates with the 8M+2S mixed add
+//   k_bucket_reduce    per window sum_b (b+1)*B_b: per-thread running sums over L buckets, small scalar
+//                      multiple for the segment offset, wave-shuffle tree
+//   k_window_reduce    one wave per window folds the per-wave partials
+//   host               Horner over the W window sums (W*c doublings), affine normalisation, marshal
+//
+// HBM traffic per pair (c = 16, W = 16): 96 B input + 64 B converted point + 2*W*4 B keys + W*4 B index
+// + W * 64 B gathers (cache-resident) -- the kernel is VALU (integer multiply) bound, see DESIGN.md.
+#pragma once
+#include "ec.cuh"
+
+namespace porla {
+
+struct Bn254G1 {
+    using Fp = Bn254Fp;
+    // group order r (scalar field), little-endian 32-bit limbs
+    static constexpr uint32_t ORDER[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u,
+                                          0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    static constexpr int SCALAR_BITS = 254;
+    static constexpr int MAX_Q = 5;  // floor((2^256-1)/r)
+};
+struct Secp256k1G {
+    using Fp = Secp256k1Fp;
+    static constexpr uint32_t ORDER[8] = {0xd0364141u, 0xbfd25e8cu, 0xaf48a03bu, 0xbaaedce6u,
+                                          0xfffffffeu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    static constexpr int SCALAR_BITS = 256;
+    static constexpr int MAX_Q = 1;
+};
+
+constexpr uint32_t KEY_NONE = 0xffffffffu;
+
+// ------------------------------------------------------------------------------------------------
+// 32 big-endian bytes -> 8 little-endian 32-bit limbs (two 16-byte loads)
+__device__ __forceinline__ void load_be256(uint32_t t[8], const uint8_t* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 hi = q[0], lo = q[1];
+    t[7] = __builtin_bswap32(hi.x); t[6] = __builtin_bswap32(hi.y);
+    t[5] = __builtin_bswap32(hi.z); t[4] = __builtin_bswap32(hi.w);
+    t[3] = __builtin_bswap32(lo.x); t[2] = __builtin_bswap32(lo.y);
+    t[1] = __builtin_bswap32(lo.z); t[0] = __builtin_bswap32(lo.w);
+}
+__device__ __forceinline__ void store_be256(uint8_t* p, const uint32_t t[8]) {
+    uint4 hi, lo;
+    hi.x = __builtin_bswap32(t[7]); hi.y = __builtin_bswap32(t[6]);
+    hi.z = __builtin_bswap32(t[5]); hi.w = __builtin_bswap32(t[4]);
+    lo.x = __builtin_bswap32(t[3]); lo.y = __builtin_bswap32(t[2]);
+    lo.z = __builtin_bswap32(t[1]); lo.w = __builtin_bswap32(t[0]);
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = hi; q[1] = lo;
+}
+
+template <class M>
+__device__ __forceinline__ Affine<M> load_affine(const Affine<M>* pts, uint32_t idx) {
+    const uint4* q = reinterpret_cast<const uint4*>(pts + idx);
+    uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+    Affine<M> r;
+    r.x.v[0] = a.x; r.x.v[1] = a.y; r.x.v[2] = a.z; r.x.v[3] = a.w;
+    r.x.v[4] = b.x; r.x.v[5] = b.y; r.x.v[6] = b.z; r.x.v[7] = b.w;
+    r.y.v[0] = c.x; r.y.v[1] = c.y; r.y.v[2] = c.z; r.y.v[3] = c.w;
+    r.y.v[4] = d.x; r.y.v[5] = d.y; r.y.v[6] = d.z; r.y.v[7] = d.w;
+    return r;
+}
+template <class M>
+__device__ __forceinline__ void store_fe(uint32_t* dst, const Fe<M>& f) {
+    uint4* q = reinterpret_cast<uint4*>(dst);
+    q[0] = make_uint4(f.v[0], f.v[1], f.v[2], f.v[3]);
+    q[1] = make_uint4(f.v[4], f.v[5], f.v[6], f.v[7]);
+}
+template <class M>
+__device__ __forceinline__ Fe<M> load_fe(const uint32_t* src) {
+    const uint4* q = reinterpret_cast<const uint4*>(src);
+    uint4 a = q[0], b = q[1];
+    Fe<M> f;
+    f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
+    f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+    return f;
+}
+template <class M>
+__device__ __forceinline__ void store_xyzz(XYZZ<M>* dst, const XYZZ<M>& p) {
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+    store_fe<M>(d, p.x); store_fe<M>(d + 8, p.y); store_fe<M>(d + 16, p.zz); store_fe<M>(d + 24, p.zzz);
+}
+template <class M>
+__device__ __forceinline__ XYZZ<M> load_xyzz(const XYZZ<M>* src) {
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
+    XYZZ<M> p;
+    p.x = load_fe<M>(s); p.y = load_fe<M>(s + 8); p.zz = load_fe<M>(s + 16); p.zzz = load_fe<M>(s + 24);
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// G1Affine.Unmarshal semantics for the uncompressed form (main.go:130): X, Y <- SetBytes (reduced
+// mod p); (0,0) stays (0,0) = infinity.  Output: Montgomery limbs, 64 B per point.
+template <class C>
+__global__ void k_points_to_mont(const uint8_t* __restrict__ in, Affine<typename C::Fp>* __restrict__ out, uint32_t n) {
+    using M = typename C::Fp;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe<M> x, y;
+    load_be256(x.v, in + (size_t)i * 64);
+    load_be256(y.v, in + (size_t)i * 64 + 32);
+    fe_reduce_plain<M>(x.v, 6);
+    fe_reduce_plain<M>(y.v, 6);
+    x = fe_to_mont<M>(x);
+    y = fe_to_mont<M>(y);
+    uint32_t* d = reinterpret_cast<uint32_t*>(out + i);
+    store_fe<M>(d, x);
+    store_fe<M>(d + 8, y);
+}
+
+// fr.Element.SetBytes (main.go:127): big-endian, reduced mod the group order; then signed c-bit digits.
+// keys[w*n + i] = bucket | sign<<31, or KEY_NONE for a zero digit; counts[w*B + bucket]++.
+template <class C>
+__global__ void k_scalar_digits(const uint8_t* __restrict__ scalars, uint32_t n, int c, int W,
+                                uint32_t* __restrict__ keys, uint32_t* __restrict__ counts) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t t[8];
+    load_be256(t, scalars + (size_t)i * 32);
+    // reduce mod order: at most MAX_Q subtractions
+    for (int q = 0; q < C::MAX_Q; q++) {
+        uint32_t s[8];
+        uint32_t br = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            uint64_t d = (uint64_t)t[k] - C::ORDER[k] - br;
+            s[k] = (uint32_t)d;
+            br = (uint32_t)(d >> 63);
+        }
+        if (br) break;
+#pragma unroll
+        for (int k = 0; k < 8; k++) t[k] = s[k];
+    }
+    const uint32_t B = 1u << (c - 1);
+    const uint32_t mask = (1u << c) - 1;
+    uint32_t carry = 0;
+    for (int w = 0; w < W; w++) {
+        int lo = w * c;
+        uint32_t raw = 0;
+        if (lo < 256) {
+            int limb = lo >> 5, sh = lo & 31;
+            // dynamic limb index into registers -> select chain (8 limbs)
+            uint32_t a = 0, b = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                a = (k == limb) ? t[k] : a;
+                b = (k == limb + 1) ? t[k] : b;
+            }
+            uint64_t v = ((uint64_t)b << 32) | a;
+            raw = (uint32_t)(v >> sh) & mask;
+        }
+        raw += carry;
+        uint32_t key;
+        if (raw > B) {           // negative digit: raw - 2^c
+            uint32_t mag = (1u << c) - raw;  // 1 .. B-1
+            carry = 1;
+            key = (mag - 1) | 0x80000000u;
+        } else {
+            carry = 0;
+            key = raw ? (raw - 1) : KEY_NONE;
+        }
+        keys[(size_t)w * n + i] = key;
+        if (key != KEY_NONE) atomicAdd(&counts[(size_t)w * B + (key & 0x7fffffffu)], 1u);
+    }
+}
+
+// one contiguous slot range per bucket; also resets the fill counters
+static __global__ void k_bucket_offsets(const uint32_t* __restrict__ counts, uint32_t* __restrict__ starts,
+                                 uint32_t* __restrict__ fill, uint32_t nb, uint32_t* __restrict__ cursor) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t cnt = (i < nb) ? counts[i] : 0;
+    // inclusive prefix over the 64-lane wave
+    uint32_t lane = threadIdx.x & 63;
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= (uint32_t)d) incl += o;
+    }
+    uint32_t total = __shfl(incl, 63, 64);
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(cursor, total);
+    base = __shfl(base, 0, 64);
+    if (i < nb) {
+        starts[i] = base + incl - cnt;
+        fill[i] = 0;
+    }
+}
+
+static __global__ void k_scatter(const uint32_t* __restrict__ keys, uint32_t n, int W, uint32_t B,
+                          const uint32_t* __restrict__ starts, uint32_t* __restrict__ fill,
+                          uint32_t* __restrict__ entries) {
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (size_t)W * n) return;
+    uint32_t key = keys[g];
+    if (key == KEY_NONE) return;
+    uint32_t w = (uint32_t)(g / n);
+    uint32_t i = (uint32_t)(g - (size_t)w * n);
+    uint32_t b = w * B + (key & 0x7fffffffu);
+    uint32_t pos = atomicAdd(&fill[b], 1u);
+    entries[starts[b] + pos] = i | (key & 0x80000000u);
+}
+
+// ONE THREAD PER BUCKET.
+template <class C>
+__global__ void __launch_bounds__(256)
+k_bucket_sum(const Affine<typename C::Fp>* __restrict__ pts, const uint32_t* __restrict__ entries,
+             const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
+             XYZZ<typename C::Fp>* __restrict__ buckets, uint32_t nb) {
+    using M = typename C::Fp;
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    uint32_t cnt = counts[b];
+    const uint32_t* e = entries + starts[b];
+    XYZZ<M> acc = xyzz_inf<M>();
+    for (uint32_t k = 0; k < cnt; k++) {
+        uint32_t ent = e[k];
+        Affine<M> a = load_affine<M>(pts, ent & 0x7fffffffu);
+        a = aff_neg_if<M>(a, (ent >> 31) != 0);
+        xyzz_madd<M>(acc, a);
+    }
+    store_xyzz<M>(buckets + b, acc);
+}
+
+template <class M>
+__device__ __forceinline__ XYZZ<M> xyzz_shfl_xor(const XYZZ<M>& p, int mask) {
+    XYZZ<M> r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        r.x.v[i] = __shfl_xor(p.x.v[i], mask, 64);
+        r.y.v[i] = __shfl_xor(p.y.v[i], mask, 64);
+        r.zz.v[i] = __shfl_xor(p.zz.v[i], mask, 64);
+        r.zzz.v[i] = __shfl_xor(p.zzz.v[i], mask, 64);
+    }
+    return r;
+}
+template <class M>
+__device__ __forceinline__ XYZZ<M> wave_sum(XYZZ<M> p) {
+#pragma unroll 1
+    for (int m = 32; m >= 1; m >>= 1) {
+        XYZZ<M> o = xyzz_shfl_xor<M>(p, m);
+        xyzz_add_cold<M>(&p, &o);
+    }
+    return p;
+}
+
+// window w: sum_b (b+1) * bucket[w*B + b].  Thread t of the window owns buckets [t*L, t*L + L).
+// Grid: W * wavesPerWindow blocks of 64 threads; partial[w*wavesPerWindow + j] per wave.
+template <class C>
+__global__ void __launch_bounds__(64)
+k_bucket_reduce(const XYZZ<typename C::Fp>* __restrict__ buckets, uint32_t B, uint32_t L,
+                uint32_t wavesPerWindow, XYZZ<typename C::Fp>* __restrict__ partial) {
+    using M = typename C::Fp;
+    uint32_t w = blockIdx.x / wavesPerWindow;
+    uint32_t j = blockIdx.x % wavesPerWindow;
+    uint32_t t = j * 64 + threadIdx.x;  // segment index inside the window
+    uint32_t T = B / L;
+    XYZZ<M> res = xyzz_inf<M>();
+    if (t < T) {
+        const XYZZ<M>* seg = buckets + (size_t)w * B + (size_t)t * L;
+        XYZZ<M> run = xyzz_inf<M>(), sum = xyzz_inf<M>();
+        for (uint32_t k = L; k-- > 0;) {
+            XYZZ<M> bk = load_xyzz<M>(seg + k);
+            xyzz_add_cold<M>(&run, &bk);
+            xyzz_add_cold<M>(&sum, &run);
+        }
+        // res = sum + (t*L) * run
+        uint32_t off = t * L;
+        XYZZ<M> acc = xyzz_inf<M>();
+        for (int bit = 31 - __clz(off | 1); bit >= 0; bit--) {
+            xyzz_double_cold<M>(&acc);
+            if ((off >> bit) & 1) xyzz_add_cold<M>(&acc, &run);
+        }
+        xyzz_add_cold<M>(&sum, &acc);
+        res = sum;
+    }
+    res = wave_sum<M>(res);
+    if (threadIdx.x == 0) store_xyzz<M>(partial + blockIdx.x, res);
+}
+
+// one wave per window folds its partials
+template <class C>
+__global__ void __launch_bounds__(64)
+k_window_reduce(const XYZZ<typename C::Fp>* __restrict__ partial, uint32_t perWindow,
+                XYZZ<typename C::Fp>* __restrict__ out) {
+    using M = typename C::Fp;
+    uint32_t w = blockIdx.x;
+    XYZZ<M> acc = xyzz_inf<M>();
+    for (uint32_t k = threadIdx.x; k < perWindow; k += 64) {
+        XYZZ<M> p = load_xyzz<M>(partial + (size_t)w * perWindow + k);
+        xyzz_add_cold<M>(&acc, &p);
+    }
+    acc = wave_sum<M>(acc);
+    if (threadIdx.x == 0) store_xyzz<M>(out + w, acc);
+}
+
+}  // namespace porla

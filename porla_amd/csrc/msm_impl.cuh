@@ -1,0 +1,155 @@
+// Launch sequence of the bucket MSM, templated on the curve; included by one translation unit per curve
+// (msm_bn254.hip, msm_secp256k1.hip) so that the two instantiations compile in parallel.
+#pragma once
+#include "engine.hpp"
+#include "../../include/porla_gpu.h"
+
+namespace porla {
+
+static inline int ilog2(size_t n) { int l = 0; while (n >>= 1) l++; return l; }
+
+static inline int choose_window(size_t n) {
+    if (g_window_override >= 2 && g_window_override <= 20) return g_window_override;
+    int c = ilog2(n) - 3;
+    if (c < 2) c = 2;
+    if (c > 16) c = 16;
+    return c;
+}
+
+template <class C>
+static int msm_core(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_points_be,
+                    const Affine<typename C::Fp>* d_points_mont, size_t n, hipStream_t stream,
+                    XYZZ<typename C::Fp>* total) {
+    using M = typename C::Fp;
+    if (n == 0) { *total = xyzz_inf<M>(); return PORLA_OK; }
+    if (n >= (1ull << 31)) { set_last_error("porla: MSM length must be < 2^31"); return PORLA_ERR_ARG; }
+    const int c = choose_window(n);
+    const int W = (C::SCALAR_BITS + 1 + c - 1) / c;
+    const uint32_t B = 1u << (c - 1);
+    const uint32_t L = B < 8 ? B : 8;
+    const uint32_t T = B / L;
+    const uint32_t wavesPerWindow = (T + 63) / 64;
+    const size_t nb = (size_t)W * B;
+    const uint32_t n32 = (uint32_t)n;
+
+    int rc;
+    if (!d_points_mont) { if ((rc = ws->pts.ensure(n * sizeof(Affine<M>)))) return rc; }
+    if ((rc = ws->keys.ensure((size_t)W * n * 4))) return rc;
+    if ((rc = ws->entries.ensure((size_t)W * n * 4))) return rc;
+    if ((rc = ws->counts.ensure(nb * 4))) return rc;
+    if ((rc = ws->starts.ensure(nb * 4))) return rc;
+    if ((rc = ws->fill.ensure(nb * 4))) return rc;
+    if ((rc = ws->cursor.ensure(256))) return rc;
+    if ((rc = ws->buckets.ensure(nb * sizeof(XYZZ<M>)))) return rc;
+    if ((rc = ws->partial.ensure((size_t)W * wavesPerWindow * sizeof(XYZZ<M>)))) return rc;
+    if ((rc = ws->windows.ensure((size_t)W * sizeof(XYZZ<M>)))) return rc;
+    if (ws->h_windows_cap < (size_t)W * sizeof(XYZZ<M>)) {
+        if (ws->h_windows) PORLA_HIP(hipHostFree(ws->h_windows));
+        ws->h_windows_cap = 64 * 1024;
+        PORLA_HIP(hipHostMalloc(&ws->h_windows, ws->h_windows_cap, hipHostMallocDefault));
+    }
+
+    const Affine<M>* pts = d_points_mont;
+    PORLA_HIP(hipMemsetAsync(ws->counts.p, 0, nb * 4, stream));
+    PORLA_HIP(hipMemsetAsync(ws->cursor.p, 0, 4, stream));
+    if (!pts) {
+        ProfScope ps("points_to_mont", stream);
+        hipLaunchKernelGGL((k_points_to_mont<C>), dim3((n32 + 255) / 256), dim3(256), 0, stream, d_points_be,
+                           (Affine<M>*)ws->pts.p, n32);
+        pts = (const Affine<M>*)ws->pts.p;
+    }
+    {
+        ProfScope ps("scalar_digits", stream);
+        hipLaunchKernelGGL((k_scalar_digits<C>), dim3((n32 + 255) / 256), dim3(256), 0, stream, d_scalars, n32, c, W,
+                           (uint32_t*)ws->keys.p, (uint32_t*)ws->counts.p);
+    }
+    {
+        ProfScope ps("bucket_offsets", stream);
+        hipLaunchKernelGGL(k_bucket_offsets, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, stream,
+                           (const uint32_t*)ws->counts.p, (uint32_t*)ws->starts.p, (uint32_t*)ws->fill.p,
+                           (uint32_t)nb, (uint32_t*)ws->cursor.p);
+    }
+    {
+        ProfScope ps("scatter", stream);
+        size_t tot = (size_t)W * n;
+        hipLaunchKernelGGL(k_scatter, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream,
+                           (const uint32_t*)ws->keys.p, n32, W, B, (const uint32_t*)ws->starts.p,
+                           (uint32_t*)ws->fill.p, (uint32_t*)ws->entries.p);
+    }
+    {
+        ProfScope ps("bucket_sum", stream);
+        hipLaunchKernelGGL((k_bucket_sum<C>), dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, stream, pts,
+                           (const uint32_t*)ws->entries.p, (const uint32_t*)ws->starts.p,
+                           (const uint32_t*)ws->counts.p, (XYZZ<M>*)ws->buckets.p, (uint32_t)nb);
+    }
+    {
+        ProfScope ps("bucket_reduce", stream);
+        hipLaunchKernelGGL((k_bucket_reduce<C>), dim3(W * wavesPerWindow), dim3(64), 0, stream,
+                           (const XYZZ<M>*)ws->buckets.p, B, L, wavesPerWindow, (XYZZ<M>*)ws->partial.p);
+    }
+    {
+        ProfScope ps("window_reduce", stream);
+        hipLaunchKernelGGL((k_window_reduce<C>), dim3(W), dim3(64), 0, stream, (const XYZZ<M>*)ws->partial.p,
+                           wavesPerWindow, (XYZZ<M>*)ws->windows.p);
+    }
+    PORLA_HIP(hipGetLastError());
+    PORLA_HIP(hipMemcpyAsync(ws->h_windows, ws->windows.p, (size_t)W * sizeof(XYZZ<M>), hipMemcpyDeviceToHost, stream));
+    PORLA_HIP(hipStreamSynchronize(stream));
+    *total = h_fold_windows<M>((const XYZZ<M>*)ws->h_windows, W, c);
+    return PORLA_OK;
+}
+
+template <class C>
+int msm_device(const uint8_t* d_scalars, const uint8_t* d_points, size_t n, hipStream_t stream,
+               XYZZ<typename C::Fp>* total) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    Workspace* ws;
+    if ((rc = get_workspace(&ws))) return rc;
+    return msm_core<C>(ws, d_scalars, d_points, nullptr, n, stream, total);
+}
+template <class C>
+int msm_device_mont(const uint8_t* d_scalars, const Affine<typename C::Fp>* d_points_mont, size_t n,
+                    hipStream_t stream, XYZZ<typename C::Fp>* total) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    Workspace* ws;
+    if ((rc = get_workspace(&ws))) return rc;
+    return msm_core<C>(ws, d_scalars, nullptr, d_points_mont, n, stream, total);
+}
+template <class C>
+int msm_host(const uint8_t* scalars, const uint8_t* points, size_t n, XYZZ<typename C::Fp>* total) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    Workspace* ws;
+    if ((rc = get_workspace(&ws))) return rc;
+    if (n == 0) { *total = xyzz_inf<typename C::Fp>(); return PORLA_OK; }
+    if ((rc = ws->in_scalars.ensure(n * 32))) return rc;
+    if ((rc = ws->in_points.ensure(n * 64))) return rc;
+    hipStream_t s = ws->own_stream;
+    PORLA_HIP(hipMemcpyAsync(ws->in_scalars.p, scalars, n * 32, hipMemcpyHostToDevice, s));
+    PORLA_HIP(hipMemcpyAsync(ws->in_points.p, points, n * 64, hipMemcpyHostToDevice, s));
+    return msm_core<C>(ws, (const uint8_t*)ws->in_scalars.p, (const uint8_t*)ws->in_points.p, nullptr, n, s, total);
+}
+
+template <class C>
+int msm_host_scalars(const uint8_t* scalars, const Affine<typename C::Fp>* d_points_mont, size_t n,
+                     XYZZ<typename C::Fp>* total) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    Workspace* ws;
+    if ((rc = get_workspace(&ws))) return rc;
+    if (n == 0) { *total = xyzz_inf<typename C::Fp>(); return PORLA_OK; }
+    if ((rc = ws->in_scalars.ensure(n * 32))) return rc;
+    hipStream_t s = ws->own_stream;
+    PORLA_HIP(hipMemcpyAsync(ws->in_scalars.p, scalars, n * 32, hipMemcpyHostToDevice, s));
+    return msm_core<C>(ws, (const uint8_t*)ws->in_scalars.p, nullptr, d_points_mont, n, s, total);
+}
+
+
+
+}  // namespace porla

@@ -1,0 +1,278 @@
+// Host-only BN254 helpers needed to keep the full 14-symbol surface of libmultiexp.so:
+//   * G1 / G2 compressed (de)serialisation of the SRS wire blob  (kzg.SRS.WriteTo / ReadFrom, main.go:48,67)
+//   * G2 scalar multiplication for SRS.G2[1] = tau * G2gen        (kzg.NewSRS, main.go:46)
+//   * a pairing-product check for kzg.Verify                       (main.go:187)
+// None of this is on the data-parallel hot path (one call per audit, Client.hpp:1635-1663), so it is written for
+// clarity, not speed: Fp12 = Fp2[w]/(w^6 - xi), xi = 9 + u, the plain ate pairing f_{t-1,Q}(P) (no Frobenius
+// constants needed) and a final exponentiation by the literal integer (p^12 - 1)/r.  kzg.Verify only tests
+// e(A,G2)*e(-H,Q) == 1, and every non-degenerate bilinear pairing on G1 x G2 agrees on that predicate.
+#pragma once
+#include "host_curve.hpp"
+#include <vector>
+
+namespace porla {
+
+using FpE = Fe<Bn254Fp>;
+
+inline FpE fp_small(uint32_t v) { FpE a = fe_zero<Bn254Fp>(); a.v[0] = v; return fe_to_mont<Bn254Fp>(a); }
+
+// regular value > (p-1)/2 ?   (fp.Element.LexicographicallyLargest)
+inline bool fp_lex_largest(const FpE& a) {
+    uint32_t v[8];
+    h_fe_to_plain<Bn254Fp>(v, a);
+    // half = (p-1)/2
+    uint32_t half[8];
+    for (int i = 0; i < 8; i++) half[i] = (Bn254Fp::P[i] >> 1) | (i < 7 ? (Bn254Fp::P[i + 1] << 31) : 0);
+    for (int i = 7; i >= 0; i--) { if (v[i] != half[i]) return v[i] > half[i]; }
+    return false;
+}
+// sqrt in Fp (p = 3 mod 4): a^((p+1)/4); returns false if a is not a square
+inline bool fp_sqrt(FpE* r, const FpE& a) {
+    uint32_t e[8];
+    uint64_t c = 1;
+    for (int i = 0; i < 8; i++) { uint64_t s = (uint64_t)Bn254Fp::P[i] + c; e[i] = (uint32_t)s; c = s >> 32; }
+    for (int i = 0; i < 8; i++) e[i] = (e[i] >> 2) | (i < 7 ? (e[i + 1] << 30) : 0);
+    FpE s = h_fe_pow<Bn254Fp>(a, e);
+    *r = s;
+    return fe_eq<Bn254Fp>(fe_sqr<Bn254Fp>(s), a);
+}
+
+// ---------------------------------------------------------------- G1 compressed form (gnark marshal.go)
+inline void g1_compress(uint8_t out[32], const Affine<Bn254Fp>& a) {
+    if (aff_is_inf<Bn254Fp>(a)) { memset(out, 0, 32); out[0] = 0x40; return; }
+    h_fe_to_be<Bn254Fp>(out, a.x);
+    out[0] |= fp_lex_largest(a.y) ? 0xC0 : 0x80;
+}
+inline bool g1_decompress(const uint8_t in[32], Affine<Bn254Fp>* a) {
+    uint8_t flags = in[0] & 0xC0;
+    if (flags == 0x40) { a->x = fe_zero<Bn254Fp>(); a->y = fe_zero<Bn254Fp>(); return true; }
+    uint8_t t[32];
+    memcpy(t, in, 32);
+    t[0] &= 0x3F;
+    a->x = h_fe_from_be<Bn254Fp>(t);
+    FpE rhs = fe_add<Bn254Fp>(fe_mul<Bn254Fp>(fe_sqr<Bn254Fp>(a->x), a->x), fp_small(3));
+    FpE y;
+    if (!fp_sqrt(&y, rhs)) return false;
+    if (fp_lex_largest(y) != (flags == 0xC0)) y = fe_neg<Bn254Fp>(y);
+    a->y = y;
+    return true;
+}
+
+// ---------------------------------------------------------------- Fp2 = Fp[u]/(u^2 + 1)
+struct Fp2 { FpE a0, a1; };
+inline Fp2 f2_zero() { return Fp2{fe_zero<Bn254Fp>(), fe_zero<Bn254Fp>()}; }
+inline Fp2 f2_one() { return Fp2{fe_one<Bn254Fp>(), fe_zero<Bn254Fp>()}; }
+inline bool f2_is_zero(const Fp2& a) { return fe_is_zero<Bn254Fp>(a.a0) && fe_is_zero<Bn254Fp>(a.a1); }
+inline bool f2_eq(const Fp2& a, const Fp2& b) { return fe_eq<Bn254Fp>(a.a0, b.a0) && fe_eq<Bn254Fp>(a.a1, b.a1); }
+inline Fp2 f2_add(const Fp2& a, const Fp2& b) { return Fp2{fe_add<Bn254Fp>(a.a0, b.a0), fe_add<Bn254Fp>(a.a1, b.a1)}; }
+inline Fp2 f2_sub(const Fp2& a, const Fp2& b) { return Fp2{fe_sub<Bn254Fp>(a.a0, b.a0), fe_sub<Bn254Fp>(a.a1, b.a1)}; }
+inline Fp2 f2_neg(const Fp2& a) { return Fp2{fe_neg<Bn254Fp>(a.a0), fe_neg<Bn254Fp>(a.a1)}; }
+inline Fp2 f2_mul(const Fp2& a, const Fp2& b) {
+    FpE t0 = fe_mul<Bn254Fp>(a.a0, b.a0), t1 = fe_mul<Bn254Fp>(a.a1, b.a1);
+    FpE s = fe_mul<Bn254Fp>(fe_add<Bn254Fp>(a.a0, a.a1), fe_add<Bn254Fp>(b.a0, b.a1));
+    return Fp2{fe_sub<Bn254Fp>(t0, t1), fe_sub<Bn254Fp>(fe_sub<Bn254Fp>(s, t0), t1)};
+}
+inline Fp2 f2_sqr(const Fp2& a) { return f2_mul(a, a); }
+inline Fp2 f2_mul_fp(const Fp2& a, const FpE& k) { return Fp2{fe_mul<Bn254Fp>(a.a0, k), fe_mul<Bn254Fp>(a.a1, k)}; }
+inline Fp2 f2_inv(const Fp2& a) {
+    FpE n = fe_add<Bn254Fp>(fe_sqr<Bn254Fp>(a.a0), fe_sqr<Bn254Fp>(a.a1));
+    FpE i = h_fe_inv<Bn254Fp>(n);
+    return Fp2{fe_mul<Bn254Fp>(a.a0, i), fe_neg<Bn254Fp>(fe_mul<Bn254Fp>(a.a1, i))};
+}
+inline Fp2 f2_xi() { return Fp2{fp_small(9), fp_small(1)}; }  // 9 + u
+inline bool f2_lex_largest(const Fp2& a) {  // E2.LexicographicallyLargest
+    if (fe_is_zero<Bn254Fp>(a.a1)) return fp_lex_largest(a.a0);
+    return fp_lex_largest(a.a1);
+}
+inline bool f2_sqrt(Fp2* r, const Fp2& a) {
+    if (f2_is_zero(a)) { *r = a; return true; }
+    FpE half = h_fe_inv<Bn254Fp>(fp_small(2));
+    Fp2 cand;
+    if (fe_is_zero<Bn254Fp>(a.a1)) {
+        FpE s;
+        if (fp_sqrt(&s, a.a0)) cand = Fp2{s, fe_zero<Bn254Fp>()};
+        else { if (!fp_sqrt(&s, fe_neg<Bn254Fp>(a.a0))) return false; cand = Fp2{fe_zero<Bn254Fp>(), s}; }
+    } else {
+        FpE norm = fe_add<Bn254Fp>(fe_sqr<Bn254Fp>(a.a0), fe_sqr<Bn254Fp>(a.a1));
+        FpE alpha;
+        if (!fp_sqrt(&alpha, norm)) return false;
+        FpE delta = fe_mul<Bn254Fp>(fe_add<Bn254Fp>(a.a0, alpha), half);
+        FpE x0;
+        if (!fp_sqrt(&x0, delta)) {
+            delta = fe_mul<Bn254Fp>(fe_sub<Bn254Fp>(a.a0, alpha), half);
+            if (!fp_sqrt(&x0, delta)) return false;
+        }
+        FpE x1 = fe_mul<Bn254Fp>(fe_mul<Bn254Fp>(a.a1, half), h_fe_inv<Bn254Fp>(x0));
+        cand = Fp2{x0, x1};
+    }
+    *r = cand;
+    return f2_eq(f2_sqr(cand), a);
+}
+
+// ---------------------------------------------------------------- G2: E'(Fp2): y^2 = x^3 + 3/xi, affine
+struct G2Affine { Fp2 x, y; bool inf; };
+inline Fp2 g2_b() { return f2_mul(Fp2{fp_small(3), fe_zero<Bn254Fp>()}, f2_inv(f2_xi())); }
+inline FpE fp_from_hex_be(const char* hex) {  // 64 hex digits
+    uint8_t b[32];
+    for (int i = 0; i < 32; i++) {
+        auto nib = [](char c) -> int { return c <= '9' ? c - '0' : (c | 32) - 'a' + 10; };
+        b[i] = (uint8_t)((nib(hex[2 * i]) << 4) | nib(hex[2 * i + 1]));
+    }
+    return h_fe_from_be<Bn254Fp>(b);
+}
+inline G2Affine g2_generator() {  // the standard alt_bn128 G2 generator (EIP-197; gnark g2Gen)
+    G2Affine g;
+    g.x.a0 = fp_from_hex_be("1800deef121f1e76426a00665e5c4479674322d4f75edadd46debd5cd992f6ed");
+    g.x.a1 = fp_from_hex_be("198e9393920d483a7260bfb731fb5d25f1aa493335a9e71297e485b7aef312c2");
+    g.y.a0 = fp_from_hex_be("12c85ea5db8c6deb4aab71808dcb408fe3d1e7690c43d37b4ce6cc0166fa7daa");
+    g.y.a1 = fp_from_hex_be("090689d0585ff075ec9e99ad690c3395bc4b313370b38ef355acdadcd122975b");
+    g.inf = false;
+    return g;
+}
+inline G2Affine g2_neg(const G2Affine& p) { G2Affine r = p; if (!p.inf) r.y = f2_neg(p.y); return r; }
+inline G2Affine g2_double(const G2Affine& p) {
+    if (p.inf || f2_is_zero(p.y)) return G2Affine{f2_zero(), f2_zero(), true};
+    Fp2 xx = f2_sqr(p.x);
+    Fp2 lam = f2_mul(f2_add(f2_add(xx, xx), xx), f2_inv(f2_add(p.y, p.y)));
+    G2Affine r;
+    r.x = f2_sub(f2_sub(f2_sqr(lam), p.x), p.x);
+    r.y = f2_sub(f2_mul(lam, f2_sub(p.x, r.x)), p.y);
+    r.inf = false;
+    return r;
+}
+inline G2Affine g2_add(const G2Affine& p, const G2Affine& q) {
+    if (p.inf) return q;
+    if (q.inf) return p;
+    if (f2_eq(p.x, q.x)) {
+        if (f2_eq(p.y, q.y)) return g2_double(p);
+        return G2Affine{f2_zero(), f2_zero(), true};
+    }
+    Fp2 lam = f2_mul(f2_sub(q.y, p.y), f2_inv(f2_sub(q.x, p.x)));
+    G2Affine r;
+    r.x = f2_sub(f2_sub(f2_sqr(lam), p.x), q.x);
+    r.y = f2_sub(f2_mul(lam, f2_sub(p.x, r.x)), p.y);
+    r.inf = false;
+    return r;
+}
+inline G2Affine g2_scalar_mul(const G2Affine& p, const uint32_t k[8]) {
+    G2Affine acc{f2_zero(), f2_zero(), true};
+    for (int i = 255; i >= 0; i--) {
+        acc = g2_double(acc);
+        if ((k[i >> 5] >> (i & 31)) & 1) acc = g2_add(acc, p);
+    }
+    return acc;
+}
+// G2Affine.Bytes(): X.A1 || X.A0 big-endian, flags in the top two bits of byte 0
+inline void g2_compress(uint8_t out[64], const G2Affine& p) {
+    if (p.inf) { memset(out, 0, 64); out[0] = 0x40; return; }
+    h_fe_to_be<Bn254Fp>(out, p.x.a1);
+    h_fe_to_be<Bn254Fp>(out + 32, p.x.a0);
+    out[0] |= f2_lex_largest(p.y) ? 0xC0 : 0x80;
+}
+inline bool g2_decompress(const uint8_t in[64], G2Affine* p) {
+    uint8_t flags = in[0] & 0xC0;
+    if (flags == 0x40) { *p = G2Affine{f2_zero(), f2_zero(), true}; return true; }
+    uint8_t t[32];
+    memcpy(t, in, 32);
+    t[0] &= 0x3F;
+    p->x.a1 = h_fe_from_be<Bn254Fp>(t);
+    p->x.a0 = h_fe_from_be<Bn254Fp>(in + 32);
+    Fp2 rhs = f2_add(f2_mul(f2_sqr(p->x), p->x), g2_b());
+    Fp2 y;
+    if (!f2_sqrt(&y, rhs)) return false;
+    if (f2_lex_largest(y) != (flags == 0xC0)) y = f2_neg(y);
+    p->y = y;
+    p->inf = false;
+    return true;
+}
+
+// ---------------------------------------------------------------- Fp12 = Fp2[w]/(w^6 - xi)
+struct Fp12 { Fp2 c[6]; };
+inline Fp12 f12_one() { Fp12 r; for (int i = 0; i < 6; i++) r.c[i] = f2_zero(); r.c[0] = f2_one(); return r; }
+inline Fp12 f12_mul(const Fp12& a, const Fp12& b) {
+    Fp2 t[11];
+    for (int i = 0; i < 11; i++) t[i] = f2_zero();
+    for (int i = 0; i < 6; i++) {
+        if (f2_is_zero(a.c[i])) continue;
+        for (int j = 0; j < 6; j++) {
+            if (f2_is_zero(b.c[j])) continue;
+            t[i + j] = f2_add(t[i + j], f2_mul(a.c[i], b.c[j]));
+        }
+    }
+    Fp2 xi = f2_xi();
+    Fp12 r;
+    for (int i = 0; i < 6; i++) r.c[i] = (i + 6 < 11) ? f2_add(t[i], f2_mul(t[i + 6], xi)) : t[i];
+    return r;
+}
+inline bool f12_is_one(const Fp12& a) {
+    if (!f2_eq(a.c[0], f2_one())) return false;
+    for (int i = 1; i < 6; i++) if (!f2_is_zero(a.c[i])) return false;
+    return true;
+}
+
+// line through T and Q (twist points, T != -Q) evaluated at P = (xP, yP) in G1, then T <- T + Q
+// l(P) = yP - lambda*xP * w + (lambda*xT - yT) * w^3     (psi(x',y') = (x' w^2, y' w^3))
+inline Fp12 line_and_add(G2Affine* T, const G2Affine& Q, const Affine<Bn254Fp>& P, bool dbl) {
+    Fp2 lam;
+    if (dbl) {
+        Fp2 xx = f2_sqr(T->x);
+        lam = f2_mul(f2_add(f2_add(xx, xx), xx), f2_inv(f2_add(T->y, T->y)));
+    } else {
+        lam = f2_mul(f2_sub(Q.y, T->y), f2_inv(f2_sub(Q.x, T->x)));
+    }
+    Fp12 l;
+    for (int i = 0; i < 6; i++) l.c[i] = f2_zero();
+    l.c[0] = Fp2{P.y, fe_zero<Bn254Fp>()};
+    l.c[1] = f2_neg(f2_mul_fp(lam, P.x));
+    l.c[3] = f2_sub(f2_mul(lam, T->x), T->y);
+    const G2Affine& O = dbl ? *T : Q;
+    G2Affine R;
+    R.x = f2_sub(f2_sub(f2_sqr(lam), T->x), O.x);
+    R.y = f2_sub(f2_mul(lam, f2_sub(T->x, R.x)), T->y);
+    R.inf = false;
+    *T = R;
+    return l;
+}
+
+// Miller function f_{t-1,Q}(P), t - 1 = 6 x^2, x = 4965661367192848881 (plain ate pairing)
+inline Fp12 miller_ate(const Affine<Bn254Fp>& P, const G2Affine& Q) {
+    // 6*x^2 = 147946756881789318990833708069417712966 = 0x6f4d8248eeb859fbf83e9682e87cfd46
+    static const uint32_t S[4] = {0xe87cfd46u, 0xf83e9682u, 0xeeb859fbu, 0x6f4d8248u};
+    Fp12 f = f12_one();
+    if (aff_is_inf<Bn254Fp>(P) || Q.inf) return f;
+    G2Affine T = Q;
+    int top = 127;
+    while (!((S[top >> 5] >> (top & 31)) & 1)) top--;
+    for (int i = top - 1; i >= 0; i--) {
+        f = f12_mul(f, f);
+        f = f12_mul(f, line_and_add(&T, T, P, true));
+        if ((S[i >> 5] >> (i & 31)) & 1) {
+            // T + Q never hits T == +-Q for Q of prime order r inside the loop (i*Q, i < r)
+            f = f12_mul(f, line_and_add(&T, Q, P, false));
+        }
+    }
+    return f;
+}
+
+// (p^12 - 1)/r as 32-bit little-endian limbs; generated by tools/gen_constants.py, checked in tests
+#include "final_exp_limbs.inc"
+
+inline Fp12 f12_pow_final(const Fp12& a) {
+    Fp12 acc = f12_one();
+    int top = FINAL_EXP_NLIMBS * 32 - 1;
+    while (!((FINAL_EXP[top >> 5] >> (top & 31)) & 1)) top--;
+    for (int i = top; i >= 0; i--) {
+        acc = f12_mul(acc, acc);
+        if ((FINAL_EXP[i >> 5] >> (i & 31)) & 1) acc = f12_mul(acc, a);
+    }
+    return acc;
+}
+
+// e(P1,Q1) * e(P2,Q2) == 1 ?
+inline bool pairing_product_is_one(const Affine<Bn254Fp>& P1, const G2Affine& Q1, const Affine<Bn254Fp>& P2,
+                                   const G2Affine& Q2) {
+    Fp12 f = f12_mul(miller_ate(P1, Q1), miller_ate(P2, Q2));
+    return f12_is_one(f12_pow_final(f));
+}
+
+}  // namespace porla

@@ -1,0 +1,72 @@
+"""ctypes loader for libmultiexp.so (fails loudly when the HIP extension is not built)."""
+import ctypes
+import os
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+lib_path = os.path.join(_HERE, "libmultiexp.so")
+_lib = None
+
+
+class GoSlice(ctypes.Structure):
+    """cgo slice header, porla/Utils/libmultiexp.h:61."""
+    _fields_ = [("data", ctypes.c_void_p), ("len", ctypes.c_longlong), ("cap", ctypes.c_longlong)]
+
+
+def load():
+    """Load the engine.  When torch is importable it is imported FIRST so that the HIP runtime the process
+    ends up with is the one torch ships (both have soname libamdhip64.so.7; two runtimes in one process
+    cannot share device pointers)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(lib_path):
+        raise ImportError(
+            "porla_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C porla_amd/csrc` (hipcc, gfx950). There is no CPU fallback." % lib_path)
+    if os.environ.get("PORLA_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    _lib = ctypes.CDLL(lib_path, mode=ctypes.RTLD_GLOBAL)
+    _declare(_lib)
+    return _lib
+
+
+def _declare(L):
+    P = ctypes.POINTER(GoSlice)
+    vp, sz, u8p = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p
+    L.init_key.argtypes = [P, P]; L.init_key.restype = None
+    L.init_SRS.argtypes = [ctypes.c_longlong, P, ctypes.POINTER(ctypes.c_longlong)]; L.init_SRS.restype = None
+    L.init_SRS_from_data.argtypes = [ctypes.c_longlong, P]; L.init_SRS_from_data.restype = None
+    for name in ("compute_digest", "compute_digest_complement", "compute_digest_from_srs", "add_point", "mult_point"):
+        getattr(L, name).argtypes = [P, P]; getattr(L, name).restype = None
+    L.compute_multi_exp.argtypes = [P, P, ctypes.c_longlong, P]; L.compute_multi_exp.restype = None
+    L.compare_commitment.argtypes = [P, P]; L.compare_commitment.restype = ctypes.c_ubyte
+    L.create_proof.argtypes = [ctypes.c_ulonglong, P, P, P, P, P]; L.create_proof.restype = None
+    L.verify_proof.argtypes = [P, P, P, P]; L.verify_proof.restype = ctypes.c_ubyte
+    L.neg_point.argtypes = [P]; L.neg_point.restype = None
+    L.set_inf_point.argtypes = [P]; L.set_inf_point.restype = None
+
+    L.porla_gpu_device_count.argtypes = []; L.porla_gpu_device_count.restype = ctypes.c_int
+    L.porla_gpu_set_device.argtypes = [ctypes.c_int]; L.porla_gpu_set_device.restype = ctypes.c_int
+    L.porla_gpu_last_error.argtypes = []; L.porla_gpu_last_error.restype = ctypes.c_char_p
+    L.porla_gpu_profile_enable.argtypes = [ctypes.c_int]; L.porla_gpu_profile_enable.restype = ctypes.c_int
+    L.porla_gpu_profile_get.argtypes = [ctypes.c_int, ctypes.c_char_p, sz, ctypes.POINTER(ctypes.c_double),
+                                        ctypes.POINTER(ctypes.c_longlong)]
+    L.porla_gpu_profile_get.restype = ctypes.c_int
+    L.porla_gpu_set_msm_window.argtypes = [ctypes.c_int]; L.porla_gpu_set_msm_window.restype = ctypes.c_int
+    for curve in ("bn254", "secp256k1"):
+        f = getattr(L, "porla_%s_msm_device" % curve); f.argtypes = [vp, vp, sz, u8p, vp]; f.restype = ctypes.c_int
+        f = getattr(L, "porla_%s_msm_device_partial" % curve); f.argtypes = [vp, vp, sz, u8p, vp]; f.restype = ctypes.c_int
+        f = getattr(L, "porla_%s_msm_host" % curve); f.argtypes = [u8p, u8p, sz, u8p]; f.restype = ctypes.c_int
+        f = getattr(L, "porla_%s_jac_sum" % curve); f.argtypes = [u8p, sz, u8p]; f.restype = ctypes.c_int
+
+
+class _LazyLib:
+    def __getattr__(self, name):
+        return getattr(load(), name)
+
+
+lib = _LazyLib()

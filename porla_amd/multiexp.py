@@ -1,0 +1,180 @@
+"""Host-side mirror of the reference's KZG wrapper layer (porla/Utils/utils.h:235-305) over libmultiexp.so.
+
+Same names and argument meaning as the C++ wrappers the reference's Server/Client call:
+  bn254_add / bn254_mult / bn254_neg / bn254_set_infinity      utils.h:235-269
+  bn254_scalar_set_int                                          utils.h:271-275
+  bn254_multi_exp                                               utils.h:277-292
+  bn254_compare                                                 utils.h:294-305
+plus the direct GoSlice calls (init_key, init_SRS, ... Client.hpp:159-167,348-354,411-419,445-453,1637-1662;
+Server.hpp:183-188,365-397,550-558).  Buffers are Python bytes/bytearray; results are returned as bytes.
+"""
+import ctypes
+
+from .loader import GoSlice, lib
+
+MAC_SIZE = 64       # COMMITMENT_MAC_SIZE with ENABLE_KZG, config.hpp:26
+SCALAR_SIZE = 32    # bn254_scalar = uint32_t[8], utils.h:64
+
+
+def _slice(buf):
+    """GoSlice over a mutable ctypes buffer."""
+    return GoSlice(ctypes.cast(buf, ctypes.c_void_p), len(buf), len(buf))
+
+
+def _buf(data):
+    return ctypes.create_string_buffer(bytes(data), len(data))
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError("porla engine error %d: %s" % (rc, lib.porla_gpu_last_error().decode()))
+
+
+# ---- utils.h wrappers ---------------------------------------------------------------------------
+def bn254_add(a, b):
+    """utils.h:235-244 -> add_point (in place on a; returned here)."""
+    ba, bb = _buf(a), _buf(b)
+    sa, sb = _slice(ba), _slice(bb)
+    lib.add_point(ctypes.byref(sa), ctypes.byref(sb))
+    return ba.raw
+
+
+def bn254_mult(a, scalar):
+    """utils.h:246-255 -> mult_point."""
+    ba, bs = _buf(a), _buf(scalar)
+    sa, ss = _slice(ba), _slice(bs)
+    lib.mult_point(ctypes.byref(sa), ctypes.byref(ss))
+    return ba.raw
+
+
+def bn254_neg(a):
+    """utils.h:257-262 -> neg_point."""
+    ba = _buf(a)
+    sa = _slice(ba)
+    lib.neg_point(ctypes.byref(sa))
+    return ba.raw
+
+
+def bn254_set_infinity():
+    """utils.h:264-269 -> set_inf_point."""
+    ba = _buf(b"\xff" * MAC_SIZE)
+    sa = _slice(ba)
+    lib.set_inf_point(ctypes.byref(sa))
+    return ba.raw
+
+
+def bn254_scalar_set_int(v):
+    """utils.h:271-275: 28 zero bytes then v big-endian."""
+    return bytes(28) + int(v & 0xffffffff).to_bytes(4, "big")
+
+
+def bn254_multi_exp(points, scalars, n):
+    """utils.h:277-292 -> compute_multi_exp(scalars, points, n, result)."""
+    bs, bp, out = _buf(scalars), _buf(points), _buf(bytes(MAC_SIZE))
+    ss, sp, so = _slice(bs), _slice(bp), _slice(out)
+    lib.compute_multi_exp(ctypes.byref(ss), ctypes.byref(sp), n, ctypes.byref(so))
+    return out.raw
+
+
+def bn254_compare(a, b):
+    """utils.h:294-305 -> compare_commitment."""
+    ba, bb = _buf(a), _buf(b)
+    sa, sb = _slice(ba), _slice(bb)
+    return bool(lib.compare_commitment(ctypes.byref(sa), ctypes.byref(sb)))
+
+
+# ---- direct cgo calls ---------------------------------------------------------------------------
+def init_key(tau, alpha):
+    bt, ba = _buf(tau), _buf(alpha)
+    st, sa = _slice(bt), _slice(ba)
+    lib.init_key(ctypes.byref(st), ctypes.byref(sa))
+
+
+def init_SRS(n):
+    """Client.hpp:348-354: returns the 32n+132-byte wire blob."""
+    out = _buf(bytes(32 * n + 132 + 64))
+    so = _slice(out)
+    ln = ctypes.c_longlong(0)
+    lib.init_SRS(n, ctypes.byref(so), ctypes.byref(ln))
+    return out.raw[:ln.value]
+
+
+def init_SRS_from_data(n, blob):
+    bb = _buf(blob)
+    sb = _slice(bb)
+    lib.init_SRS_from_data(n, ctypes.byref(sb))
+
+
+def _in_out(fn, data, out_len):
+    bi, bo = _buf(data), _buf(bytes(out_len))
+    si, so = _slice(bi), _slice(bo)
+    fn(ctypes.byref(si), ctypes.byref(so))
+    return bo.raw
+
+
+def compute_digest(data):
+    return _in_out(lib.compute_digest, data, MAC_SIZE)
+
+
+def compute_digest_complement(data):
+    return _in_out(lib.compute_digest_complement, data, MAC_SIZE)
+
+
+def compute_digest_from_srs(data):
+    return _in_out(lib.compute_digest_from_srs, data, MAC_SIZE)
+
+
+def create_proof(random_point, data):
+    """Server.hpp:363-398: returns (commitment 64, H 64, point 32, claim 32)."""
+    bi = _buf(data)
+    outs = [_buf(bytes(64)), _buf(bytes(64)), _buf(bytes(32)), _buf(bytes(32))]
+    si = _slice(bi)
+    so = [_slice(o) for o in outs]
+    lib.create_proof(random_point, ctypes.byref(si), *[ctypes.byref(s) for s in so])
+    return tuple(o.raw for o in outs)
+
+
+def verify_proof(commitment, proof_h, point, claim):
+    bufs = [_buf(commitment), _buf(proof_h), _buf(point), _buf(claim)]
+    sl = [_slice(b) for b in bufs]
+    return bool(lib.verify_proof(*[ctypes.byref(s) for s in sl]))
+
+
+# ---- device-pointer API (include/porla_gpu.h) -------------------------------------------------------
+def msm_device(curve, d_scalars, d_points, n, stream=0, partial=False):
+    """d_scalars / d_points: integer device addresses (e.g. torch tensor .data_ptr())."""
+    out = ctypes.create_string_buffer(96 if partial else 64)
+    fn = getattr(lib, "porla_%s_msm_device%s" % (curve, "_partial" if partial else ""))
+    _check(fn(ctypes.c_void_p(d_scalars), ctypes.c_void_p(d_points), n, out, ctypes.c_void_p(stream)))
+    return out.raw
+
+
+def msm_host(curve, scalars, points, n):
+    out = ctypes.create_string_buffer(64)
+    _check(getattr(lib, "porla_%s_msm_host" % curve)(bytes(scalars), bytes(points), n, out))
+    return out.raw
+
+
+def jac_sum(curve, jacobians, count):
+    out = ctypes.create_string_buffer(64)
+    _check(getattr(lib, "porla_%s_jac_sum" % curve)(bytes(jacobians), count, out))
+    return out.raw
+
+
+def profile_enable(on=True):
+    lib.porla_gpu_profile_enable(1 if on else 0)
+
+
+def profile_get():
+    """[(kernel name, total ms, launches)]"""
+    res = []
+    i = 0
+    while True:
+        name = ctypes.create_string_buffer(64)
+        ms = ctypes.c_double(0)
+        cnt = ctypes.c_longlong(0)
+        if lib.porla_gpu_profile_get(i, name, 64, ctypes.byref(ms), ctypes.byref(cnt)) != 0:
+            break
+        res.append((name.value.decode(), ms.value, cnt.value))
+        i += 1
+    return res

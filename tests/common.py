@@ -1,0 +1,73 @@
+"""Shared test helpers: oracle loading (CPU checker) and the synthetic input generator of SURVEY.md s8(d)."""
+import ctypes
+import hashlib
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
+if ORACLE_DIR not in sys.path:
+    sys.path.insert(0, ORACLE_DIR)
+
+_oracle = None
+
+
+def oracle():
+    """The C restatement (oracle/*_ref.c), built on demand with gcc."""
+    global _oracle
+    if _oracle is None:
+        srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
+        if not os.path.exists(ORACLE_SO) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_SO) for s in srcs):
+            subprocess.check_call(["make", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
+        _oracle = ctypes.CDLL(ORACLE_SO)
+    return _oracle
+
+
+def ncpu():
+    return max(1, min(32, os.cpu_count() or 1))
+
+
+def synth_scalars(n, start=0):
+    """s_i = SHA-256("porla-msm-sc" || LE32(i)), raw 32 big-endian bytes (~81 % are >= r)."""
+    return b"".join(hashlib.sha256(b"porla-msm-sc" + (start + i).to_bytes(4, "little")).digest() for i in range(n))
+
+
+def synth_point_scalars(n, start=0):
+    return b"".join(hashlib.sha256(b"porla-msm-pt" + (start + i).to_bytes(4, "little")).digest() for i in range(n))
+
+
+def synth_points(n, start=0):
+    """P_i = (SHA-256("porla-msm-pt" || LE32(i)) mod r) * G as 64-byte X||Y big-endian (oracle fixed-base)."""
+    out = ctypes.create_string_buffer(64 * n)
+    oracle().oracle_bn254_fixed_base(synth_point_scalars(n, start), ctypes.c_size_t(n), out, ncpu())
+    return out.raw
+
+
+def synth_inputs(n, start=0):
+    return synth_scalars(n, start), synth_points(n, start)
+
+
+def oracle_msm(scalars, points, n, naive=False, threads=None):
+    out = ctypes.create_string_buffer(64)
+    oracle().oracle_bn254_multi_exp(bytes(scalars), bytes(points), ctypes.c_size_t(n), out,
+                                    threads or ncpu(), 1 if naive else 0)
+    return out.raw
+
+
+def cached_inputs(n):
+    """synth_inputs(n) cached under /tmp (generation of 2^20 points costs tens of CPU-seconds)."""
+    path = os.path.join(os.environ.get("PORLA_CACHE", "/tmp"), "porla_bn254_inputs_%d.bin" % n)
+    if os.path.exists(path) and os.path.getsize(path) == 96 * n:
+        raw = open(path, "rb").read()
+        return raw[:32 * n], raw[32 * n:]
+    sc, pt = synth_inputs(n)
+    try:
+        with open(path + ".tmp", "wb") as f:
+            f.write(sc)
+            f.write(pt)
+        os.replace(path + ".tmp", path)
+    except OSError:
+        pass
+    return sc, pt

@@ -1,0 +1,153 @@
+"""Parity of the HIP BN254 G1 MSM against the oracle, through the C ABI (GPU box only).
+
+Mirrors what the reference's callers do: bn254_multi_exp(result, points, scalars, n)
+(porla/Utils/utils.h:277-292 -> compute_multi_exp, porla/main.go:118-138).  Bar: bit-exact 64-byte output.
+"""
+import ctypes
+import os
+
+import pytest
+
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+R = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+
+
+@pytest.fixture(scope="module")
+def mx():
+    from porla_amd import multiexp
+    return multiexp
+
+
+@pytest.fixture(scope="module")
+def inputs():
+    n = 1 << 14
+    return common.synth_inputs(n)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 63, 64, 65, 127, 128, 1000, 1408, 3200, 1 << 14])
+def test_multi_exp_matches_oracle(mx, inputs, n):
+    sc, pt = inputs
+    got = mx.bn254_multi_exp(pt[:64 * n], sc[:32 * n], n)
+    assert got == common.oracle_msm(sc, pt, n)
+
+
+@pytest.mark.parametrize("c", [2, 3, 5, 8, 11, 13, 16])
+def test_every_window_width(mx, inputs, c):
+    """forces the window width (bucket count, segment length, carries into the top window)"""
+    from porla_amd import lib
+    sc, pt = inputs
+    n = 2000
+    lib.porla_gpu_set_msm_window(c)
+    try:
+        got = mx.msm_host("bn254", sc[:32 * n], pt[:64 * n], n)
+    finally:
+        lib.porla_gpu_set_msm_window(0)
+    assert got == common.oracle_msm(sc, pt, n)
+
+
+def test_edge_scalars(mx, inputs):
+    """zero, one, r-1, r, r+1, 2^256-1 (SetBytes reduction), 2^128: main.go:127"""
+    _, pt = inputs
+    vals = [0, 1, 2, R - 1, R, R + 1, (1 << 256) - 1, 1 << 128, (1 << 255) + 12345, 5 * R, 5 * R + 7]
+    n = len(vals)
+    sc = b"".join(v.to_bytes(32, "big") for v in vals)
+    got = mx.bn254_multi_exp(pt[:64 * n], sc, n)
+    assert got == common.oracle_msm(sc, pt, n, naive=True)
+
+
+def test_edge_points(mx, inputs):
+    """infinity operands, P and -P pairs (cancel), repeated points in one bucket (P + P)"""
+    import bn254_py as o
+    sc, pt = inputs
+    P0 = pt[:64]
+    negP0 = o.neg_point(P0)
+    pts = P0 + negP0 + bytes(64) + P0 + P0 + pt[64:128] + bytes(64)
+    s7 = (7).to_bytes(32, "big")
+    scs = s7 + s7 + sc[:32] + s7 + s7 + sc[32:64] + (0).to_bytes(32, "big")
+    n = 7
+    got = mx.bn254_multi_exp(pts, scs, n)
+    assert got == common.oracle_msm(scs, pts, n, naive=True)
+    # everything cancels -> infinity = 64 zero bytes
+    got = mx.bn254_multi_exp(P0 + negP0, s7 + s7, 2)
+    assert got == bytes(64)
+
+
+def test_audit_like_distribution(mx, inputs):
+    """abs(int32) coefficients (utils.h:271-275) over 64-way repeated points: the real audit's shape"""
+    import random
+    sc, pt = inputs
+    rnd = random.Random(7)
+    n = 3200
+    scs = b"".join(mx.bn254_scalar_set_int(rnd.getrandbits(31)) for _ in range(n))
+    pts = b"".join(pt[64 * (i % 50):64 * (i % 50) + 64] for i in range(n))
+    got = mx.bn254_multi_exp(pts, scs, n)
+    assert got == common.oracle_msm(scs, pts, n)
+
+
+def test_all_same_point_same_scalar(mx, inputs):
+    """worst-case skew: every pair lands in the same bucket of every window"""
+    sc, pt = inputs
+    n = 512
+    got = mx.bn254_multi_exp(pt[:64] * n, sc[:32] * n, n)
+    assert got == common.oracle_msm(sc[:32] * n, pt[:64] * n, n)
+
+
+def test_device_pointer_api_and_partials(mx, inputs):
+    """porla_bn254_msm_device + range-sharded partial Jacobians folded by porla_bn254_jac_sum"""
+    import torch
+    sc, pt = inputs
+    n = 1 << 14
+    d_sc = torch.frombuffer(bytearray(sc), dtype=torch.uint8).cuda()
+    d_pt = torch.frombuffer(bytearray(pt), dtype=torch.uint8).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    want = common.oracle_msm(sc, pt, n)
+    assert mx.msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n, stream) == want
+    shards = 4
+    parts = b""
+    for g in range(shards):
+        lo, hi = n * g // shards, n * (g + 1) // shards
+        parts += mx.msm_device("bn254", d_sc.data_ptr() + 32 * lo, d_pt.data_ptr() + 64 * lo, hi - lo, stream, partial=True)
+    assert mx.jac_sum("bn254", parts, shards) == want
+
+
+def test_kzg_commit_and_open_on_gpu(mx):
+    """compute_digest_from_srs / create_proof (main.go:103-116,153-175) vs the Python big-int oracle, and the
+    in-reference identity compute_digest(f) == alpha * compute_digest_from_srs(f)"""
+    import bn254_py as o
+    tau = bytes.fromhex("ffeeddccbbaa99887766554433221100")     # TAU_KEY, config.hpp:39
+    alpha = bytes.fromhex("00112233445566778899aabbccddeeff")   # SECRET_KEY, config.hpp:38
+    n = 128
+    mx.init_key(tau, alpha)
+    blob = mx.init_SRS(n)
+    assert len(blob) == 32 * n + 132
+    data = common.synth_scalars(n, start=1000)
+    k = o.KZG(); k.init_key(tau, alpha); k.init_srs(n)
+    commit = mx.compute_digest_from_srs(data)
+    assert commit == k.compute_digest_from_srs(data)
+    assert mx.compute_digest(data) == mx.bn254_mult(commit, alpha.rjust(32, b"\0"))
+    c, h, z, y = mx.create_proof(0x1234567890abcdef, data)
+    assert (c, h, z, y) == k.create_proof(0x1234567890abcdef, data)
+    assert mx.verify_proof(c, h, z, y)
+    # server side: SRS from the wire blob
+    mx.init_SRS_from_data(n, blob)
+    assert mx.compute_digest_from_srs(data) == commit
+
+
+@pytest.mark.parametrize("dist", ["uniform", "audit"])
+def test_full_size_2_20(mx, dist):
+    """BASELINE.json config 2: one 2^20-point MSM, bit-exact vs the oracle's multi-threaded bucket MSM"""
+    import torch
+    n = 1 << 20
+    sc, pt = common.cached_inputs(n)
+    if dist == "audit":
+        import random
+        rnd = random.Random(11)
+        sc = b"".join((rnd.getrandbits(31)).to_bytes(32, "big") for _ in range(n))
+        pt = pt[:64 * (n // 64)] * 64
+    d_sc = torch.frombuffer(bytearray(sc), dtype=torch.uint8).cuda()
+    d_pt = torch.frombuffer(bytearray(pt), dtype=torch.uint8).cuda()
+    got = mx.msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    assert got == common.oracle_msm(sc, pt, n)
