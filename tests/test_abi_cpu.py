@@ -1,0 +1,100 @@
+"""CPU: the C-ABI library loads and exports every symbol include/*.h declares; the host-side (latency-bound)
+entry points of the plug-in -- which legitimately run on the CPU in the product too -- match the golden vectors.
+No device compute is invoked here."""
+import json
+import os
+import re
+
+import pytest
+
+from tests import common
+
+ROOT = common.ROOT
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bn254_golden.json")))
+
+
+def declared_symbols():
+    syms = []
+    for h in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        for m in re.finditer(r"^\s*(?:extern\s+)?[A-Za-z_][\w\s\*]*?\b(\w+)\s*\([^;{]*\)\s*;", text, flags=re.M):
+            syms.append(m.group(1))
+    return sorted(set(syms))
+
+
+def test_every_declared_symbol_is_exported():
+    from porla_amd import lib
+    syms = declared_symbols()
+    # the 14 cgo symbols of the reference (porla/Utils/libmultiexp.h:71-84) must all be there
+    ref14 = ["init_key", "init_SRS", "init_SRS_from_data", "compute_digest", "compute_digest_complement",
+             "compute_digest_from_srs", "compute_multi_exp", "compare_commitment", "create_proof", "verify_proof",
+             "add_point", "mult_point", "neg_point", "set_inf_point"]
+    for s in ref14:
+        assert s in syms
+    assert len(syms) >= 14 + 8
+    for s in syms:
+        assert getattr(lib, s) is not None, s
+
+
+def test_point_ops_match_golden():
+    from porla_amd import multiexp as mx
+    G = (1).to_bytes(32, "big") + (2).to_bytes(32, "big")
+    for e in GOLD["scalar_mul_G"]:
+        assert mx.bn254_mult(G, bytes.fromhex(e["k"])).hex() == e["P"]
+    for e in GOLD["point_ops"]:
+        a, b = bytes.fromhex(e["a"]), bytes.fromhex(e["b"])
+        assert mx.bn254_add(a, b).hex() == e["add"]
+        assert mx.bn254_neg(a).hex() == e["neg_a"]
+        assert mx.bn254_compare(a, a)
+        if e["add"] != e["a"]:
+            assert not mx.bn254_compare(a, bytes.fromhex(e["add"]))
+    for e in GOLD["mult_point"]:
+        assert mx.bn254_mult(bytes.fromhex(e["a"]), bytes.fromhex(e["s"])).hex() == e["r"]
+    assert mx.bn254_set_infinity() == bytes(64)
+    assert mx.bn254_scalar_set_int(0x7fffffff) == bytes(28) + bytes.fromhex("7fffffff")
+
+
+def test_kzg_host_side_matches_golden():
+    """init_key / init_SRS (wire blob, G1 part) / compute_digest / verify_proof: the client-side calls
+    (Client.hpp:159-167,348-354,411-419,1637-1662) need no GPU."""
+    from porla_amd import multiexp as mx
+    kz = GOLD["kzg"]
+    tau, alpha, n = bytes.fromhex(kz["tau"]), bytes.fromhex(kz["alpha"]), kz["n"]
+    mx.init_key(tau, alpha)
+    blob = mx.init_SRS(n)
+    assert len(blob) == 32 * n + 132          # Client.hpp:350-357
+    assert blob[:4 + 32 * n].hex() == kz["srs_g1_blob"]
+    for c in kz["cases"]:
+        assert mx.compute_digest(bytes.fromhex(c["f"])).hex() == c["digest"]
+        for op in c["open"]:
+            args = [bytes.fromhex(op[k]) for k in ("commitment", "H", "point", "claim")]
+            assert mx.verify_proof(*args)
+    op = kz["cases"][0]["open"][0]
+    bad_claim = (int(op["claim"], 16) ^ 1).to_bytes(32, "big")
+    assert not mx.verify_proof(bytes.fromhex(op["commitment"]), bytes.fromhex(op["H"]), bytes.fromhex(op["point"]), bad_claim)
+    assert not mx.verify_proof(bytes.fromhex(op["H"]), bytes.fromhex(op["commitment"]), bytes.fromhex(op["point"]),
+                               bytes.fromhex(op["claim"]))
+    # server side: SRS from the wire blob (incl. compressed G2), then verify again
+    mx.init_SRS_from_data(n, blob)
+    assert mx.verify_proof(*[bytes.fromhex(op[k]) for k in ("commitment", "H", "point", "claim")])
+    # complement is linear in its scalar (h_MAC is random by design, main.go:52-59)
+    s1, s2 = common.synth_scalars(1, 1), common.synth_scalars(1, 2)
+    r = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+    s3 = ((int.from_bytes(s1, "big") + int.from_bytes(s2, "big")) % r).to_bytes(32, "big")
+    mx.init_SRS(n)
+    assert mx.bn254_add(mx.compute_digest_complement(s1), mx.compute_digest_complement(s2)) == mx.compute_digest_complement(s3)
+
+
+def test_jac_sum_folds_partials():
+    """porla_bn254_jac_sum (the N-GPU fold) on hand-made Jacobian partials"""
+    import bn254_py as o
+    from porla_amd import multiexp as mx
+    pts = [o.g1_mul(o.G1, k) for k in (5, 7, 11)]
+    parts = b""
+    for i, (x, y) in enumerate(pts):
+        z = 3 + i
+        parts += (x * z * z % o.P).to_bytes(32, "big") + (y * z ** 3 % o.P).to_bytes(32, "big") + z.to_bytes(32, "big")
+    parts += (1).to_bytes(32, "big") + (1).to_bytes(32, "big") + bytes(32)      # infinity
+    assert mx.jac_sum("bn254", parts, 4) == o.g1_marshal(o.g1_mul(o.G1, 23))
+    assert mx.jac_sum("bn254", b"", 0) == bytes(64)

@@ -1,0 +1,48 @@
+"""CPU: every hard-coded numeric table in the engine sources equals the value derived from the modulus alone."""
+import os
+import re
+import sys
+
+from tests import common
+
+sys.path.insert(0, os.path.join(common.ROOT, "tools"))
+import gen_constants as gc  # noqa: E402
+
+CSRC = os.path.join(common.ROOT, "porla_amd", "csrc")
+
+
+def struct_tables(path, struct):
+    text = open(path).read()
+    m = re.search(r"struct %s\s*\{(.*?)\n\};" % struct, text, flags=re.S)
+    assert m, struct
+    body = m.group(1)
+    out = {}
+    for name in ("P", "R1", "R2", "ORDER"):
+        mm = re.search(r"\b%s\[8\]\s*=\s*\{([^}]*)\}" % name, body)
+        if mm:
+            out[name] = [int(x.strip().rstrip("u"), 0) for x in mm.group(1).split(",") if x.strip()]
+    mm = re.search(r"\bINV\s*=\s*(0x[0-9a-fA-F]+)u", body)
+    if mm:
+        out["INV"] = int(mm.group(1), 16)
+    return out
+
+
+def test_field_parameter_packs():
+    for path, struct, p in ((os.path.join(CSRC, "fe.cuh"), "Bn254Fp", gc.BN_P),
+                            (os.path.join(CSRC, "fe.cuh"), "Secp256k1Fp", gc.SECP_P),
+                            (os.path.join(CSRC, "host_curve.hpp"), "Bn254Fr", gc.BN_R)):
+        t = struct_tables(path, struct)
+        m = gc.mont(p)
+        assert t["P"] == m["P"] and t["INV"] == m["INV"] and t["R1"] == m["R1"] and t["R2"] == m["R2"], struct
+
+
+def test_group_orders():
+    assert struct_tables(os.path.join(CSRC, "msm.cuh"), "Bn254G1")["ORDER"] == gc.limbs(gc.BN_R)
+    assert struct_tables(os.path.join(CSRC, "msm.cuh"), "Secp256k1G")["ORDER"] == gc.limbs(gc.SECP_N)
+
+
+def test_final_exponent_and_ate_loop():
+    assert open(os.path.join(CSRC, "final_exp_limbs.inc")).read() == gc.final_exp_inc()
+    text = open(os.path.join(CSRC, "pairing_host.hpp")).read()
+    m = re.search(r"S\[4\]\s*=\s*\{([^}]*)\}", text)
+    assert [int(x.strip().rstrip("u"), 0) for x in m.group(1).split(",")] == gc.limbs(6 * gc.BN_X ** 2, 4)
