@@ -68,6 +68,23 @@ int porla_secp256k1_msm_device_partial(const void *d_scalars, const void *d_poin
 int porla_secp256k1_msm_host(const uint8_t *scalars, const uint8_t *points, size_t n, uint8_t out_affine[64]);
 int porla_secp256k1_jac_sum(const uint8_t *jacobians, size_t count, uint8_t out_affine[64]);
 
+/* ---- ICC encode (CRebuild_Cached data part + align_MAC scalar part) ----
+ * rows_in : n_rows * n_cols elements, 32 bytes little-endian each (8 x uint32 LE words, utils.h:353-364; the layout
+ *           of the U/<i> block files, utils.h:592-608), row-major; n_rows a power of two >= 2; n_cols = NUM_CHUNKS = 128
+ * curve   : 0 = BN254 order (ENABLE_KZG), 1 = secp256k1 order (IPA)  -- selects q in LCM = p_icc * q (utils.h:33-34,42-43)
+ * part    : 0 = X part; 1 = Y part (elements pre-scaled by wt = w^reverse_bits(write_step % n_rows, height-1),
+ *           Server.hpp:1494,1522)
+ * x_out   : n_rows * n_cols * 64 bytes, values in [0, LCM) little-endian (512-bit row format, utils.h:473-517)  (or NULL)
+ * aligned : n_rows * n_cols * 32 bytes, values mod p_icc little-endian (256-bit row format)                     (or NULL)
+ * scalars : n_rows * n_cols * 32 bytes, alignment scalars c = (A mod p_icc - A) mod q (Server.hpp:535-538),
+ *           big-endian (bn254_scalar, utils.h:307-318) or, with scalar_le = 1, little-endian limbs
+ *           (secp256k1_scalar d[4], scalar_4x64.h:13-15)                                                        (or NULL) */
+int porla_icc_encode_device(const void *d_rows_in, size_t n_rows, size_t n_cols, int curve, unsigned long long write_step,
+                            int part, void *d_x_out, void *d_aligned_out, void *d_scalars_out, int scalar_le,
+                            void *hip_stream);
+int porla_icc_encode_host(const uint8_t *rows_in, size_t n_rows, size_t n_cols, int curve, unsigned long long write_step,
+                          int part, uint8_t *x_out, uint8_t *aligned_out, uint8_t *scalars_out, int scalar_le);
+
 #ifdef __cplusplus
 }
 #endif

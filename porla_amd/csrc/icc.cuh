@@ -1,0 +1,273 @@
+// ICC (incrementally constructible code) encode on gfx950: the radix-2 butterfly network that the reference
+// open-codes on NTL big integers in Server::CRebuild_Cached (porla/Server/Server.hpp:1548-1687 X part, :1691-1830
+// Y part, init scaling :1494,1512-1522) and the scalar part of Server::align_MAC (Server.hpp:531-541 KZG,
+// :495-504 IPA).  Constants: porla/Utils/utils.h:27-43.
+//
+// WHAT is computed (bit-exact): for s = 1..log2 N: m = 2^s, m2 = m/2, v = w^(N/m2) mod p_icc; for j < m2, k = j (step m):
+//   t = v^j * X[k+m2];  X[k] = (X[k] + t) mod LCM;  X[k+m2] = (X[k] - t) mod LCM,   LCM = p_icc * q,
+// element-wise over 128-wide rows, natural order in, no permutation, w = GENERATOR^((p_icc-1)/(2N)) (order N).
+//
+// HOW (MI355X): Z/LCM = Z/p_icc x Z/q (both prime), so every element is carried as a pair of 256-bit Montgomery
+// residues (64 B) -- two 8-limb products per butterfly instead of one 16-limb product plus a 768->512-bit
+// reduction -- and recombined once at the end with p_icc = 207*2^248 + 1 (a shift-and-add CRT).  The network is
+// HBM-bound: one thread owns 4 rows x 1 column and fuses TWO stages per pass in registers (radix-4), lanes run along
+// the 128 columns of a row so every access is a fully coalesced 64-B-per-lane stream, and the N-entry twiddle
+// table (N * 64 B) stays L2-resident.  No MFMA: there is no contraction.
+#pragma once
+#include "fe.cuh"
+
+namespace porla {
+
+struct IccFp {  // p_icc = 207 * 2^248 + 1 (utils.h:31-32)
+    static constexpr uint32_t P[8]  = {0x00000001u, 0, 0, 0, 0, 0, 0, 0xcf000000u};
+    static constexpr uint32_t INV   = 0xffffffffu;
+    static constexpr uint32_t R1[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu,
+                                       0xffffffffu, 0xffffffffu, 0xffffffffu, 0x30ffffffu};
+    static constexpr uint32_t R2[8] = {0xe1150631u, 0xfb0d9a96u, 0x845418bbu, 0xec366a5bu,
+                                       0x115062efu, 0xb0d9a96eu, 0x45418bbfu, 0x6266a5b8u};
+    static constexpr int SPARE_BITS = 0;
+};
+struct IccBn254Fr {  // q = BN254 group order (utils.h:36), with the CRT constant p_icc^-1 mod q
+    static constexpr uint32_t P[8]  = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u,
+                                       0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    static constexpr uint32_t INV   = 0xefffffffu;
+    static constexpr uint32_t R1[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u,
+                                       0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+    static constexpr uint32_t R2[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u,
+                                       0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+    static constexpr int SPARE_BITS = 2;
+    static constexpr uint32_t PINV[8] = {0xf7cceac7u, 0x74a3c74fu, 0x32b19079u, 0xa1c013fcu,
+                                         0xdaf96adbu, 0xe53d9858u, 0x7d59bd98u, 0x2d305e1eu};  // p_icc^-1 mod q (plain)
+    static constexpr int MAX_Q_IN = 5;   // floor((2^256-1)/q): subtractions to reduce a raw 256-bit chunk
+    static constexpr int MAX_Q_P  = 4;   // floor((p_icc-1)/q)
+};
+struct IccSecp256k1Fn {  // q = secp256k1 group order (utils.h:27)
+    static constexpr uint32_t P[8]  = {0xd0364141u, 0xbfd25e8cu, 0xaf48a03bu, 0xbaaedce6u,
+                                       0xfffffffeu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    static constexpr uint32_t INV   = 0x5588b13fu;
+    static constexpr uint32_t R1[8] = {0x2fc9bebfu, 0x402da173u, 0x50b75fc4u, 0x45512319u, 0x00000001u, 0, 0, 0};
+    static constexpr uint32_t R2[8] = {0x67d7d140u, 0x896cf214u, 0x0e7cf878u, 0x741496c2u,
+                                       0x5bcd07c6u, 0xe697f5e4u, 0x81c69bc5u, 0x9d671cd5u};
+    static constexpr int SPARE_BITS = 0;
+    static constexpr uint32_t PINV[8] = {0x62768be0u, 0x61996758u, 0x398bec83u, 0x15831c63u,
+                                         0x74f03b2fu, 0x43030579u, 0xeb08b927u, 0x8d224d74u};
+    static constexpr int MAX_Q_IN = 1;
+    static constexpr int MAX_Q_P  = 0;
+};
+// GENERATOR (utils.h:29-30), plain little-endian limbs
+struct IccGen {
+    static constexpr uint32_t G[8] = {0x1ea0a8b6u, 0x3bd639dau, 0xc05b565bu, 0x8daf5cecu,
+                                      0x693fe88eu, 0x7b4b58b0u, 0x5de0999du, 0x001559f5u};
+};
+
+template <class Q>
+struct IccElem {  // one code symbol: residues mod p_icc and mod q, Montgomery form; 64 B
+    Fe<IccFp> p;
+    Fe<Q> q;
+};
+
+template <class M>
+__device__ __forceinline__ Fe<M> ld_fe(const uint32_t* s) {
+    const uint4* q = reinterpret_cast<const uint4*>(s);
+    uint4 a = q[0], b = q[1];
+    Fe<M> f;
+    f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w; f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+    return f;
+}
+template <class M>
+__device__ __forceinline__ void st_fe(uint32_t* d, const Fe<M>& f) {
+    uint4* q = reinterpret_cast<uint4*>(d);
+    q[0] = make_uint4(f.v[0], f.v[1], f.v[2], f.v[3]);
+    q[1] = make_uint4(f.v[4], f.v[5], f.v[6], f.v[7]);
+}
+template <class Q>
+__device__ __forceinline__ IccElem<Q> ld_elem(const IccElem<Q>* p) {
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(p);
+    IccElem<Q> e;
+    e.p = ld_fe<IccFp>(s);
+    e.q = ld_fe<Q>(s + 8);
+    return e;
+}
+template <class Q>
+__device__ __forceinline__ void st_elem(IccElem<Q>* p, const IccElem<Q>& e) {
+    uint32_t* d = reinterpret_cast<uint32_t*>(p);
+    st_fe<IccFp>(d, e.p);
+    st_fe<Q>(d + 8, e.q);
+}
+
+// raw 256-bit little-endian chunk (utils.h:353-364) -> residue pair, optionally times wt (the Y part)
+template <class Q>
+__global__ void k_icc_load(const uint8_t* __restrict__ in, IccElem<Q>* __restrict__ work, size_t total,
+                           IccElem<Q> wt, int use_wt) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    Fe<IccFp> xp = ld_fe<IccFp>(reinterpret_cast<const uint32_t*>(in + 32 * i));
+    Fe<Q> xq;
+#pragma unroll
+    for (int k = 0; k < 8; k++) xq.v[k] = xp.v[k];
+    fe_reduce_plain<IccFp>(xp.v, 1);
+    fe_reduce_plain<Q>(xq.v, Q::MAX_Q_IN);
+    IccElem<Q> e;
+    e.p = fe_to_mont<IccFp>(xp);
+    e.q = fe_to_mont<Q>(xq);
+    if (use_wt) {
+        e.p = fe_mul<IccFp>(e.p, wt.p);
+        e.q = fe_mul<Q>(e.q, wt.q);
+    }
+    st_elem<Q>(work + i, e);
+}
+
+// tw[e] = w^e for e in [0, n): residue pair of the INTEGER (w^e mod p_icc), as the reference multiplies by the
+// integer vi_ZZ (Server.hpp:1651).  wpow[i] = w^(2^i) in Montgomery form mod p_icc.
+template <class Q>
+__global__ void k_icc_twiddles(IccElem<Q>* __restrict__ tw, uint32_t n, const Fe<IccFp>* __restrict__ wpow, int logn) {
+    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    Fe<IccFp> acc = fe_one<IccFp>();
+    for (int i = 0; i < logn; i++) {
+        if ((e >> i) & 1) acc = fe_mul<IccFp>(acc, wpow[i]);
+    }
+    Fe<IccFp> plain = fe_from_mont<IccFp>(acc);
+    Fe<Q> tq;
+#pragma unroll
+    for (int k = 0; k < 8; k++) tq.v[k] = plain.v[k];
+    fe_reduce_plain<Q>(tq.v, Q::MAX_Q_P + 1);
+    IccElem<Q> t;
+    t.p = acc;
+    t.q = fe_to_mont<Q>(tq);
+    st_elem<Q>(tw + e, t);
+}
+
+template <class Q>
+__device__ __forceinline__ void butterfly(IccElem<Q>& a, IccElem<Q>& b, const IccElem<Q>& tw, bool neg_tw) {
+    Fe<IccFp> tp = fe_mul<IccFp>(tw.p, b.p);
+    Fe<Q> tq = fe_mul<Q>(tw.q, b.q);
+    Fe<IccFp> sp = fe_add<IccFp>(a.p, tp), dp = fe_sub<IccFp>(a.p, tp);
+    Fe<Q> sq = fe_add<Q>(a.q, tq), dq = fe_sub<Q>(a.q, tq);
+    // multiplying by -tw swaps the two outputs
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        a.p.v[k] = neg_tw ? dp.v[k] : sp.v[k];
+        b.p.v[k] = neg_tw ? sp.v[k] : dp.v[k];
+        a.q.v[k] = neg_tw ? dq.v[k] : sq.v[k];
+        b.q.v[k] = neg_tw ? sq.v[k] : dq.v[k];
+    }
+}
+
+// Stages s and (if STAGES == 2) s+1 fused.  One thread: one column, rows base + {0, m2, 2*m2, 3*m2}.
+template <class Q, int STAGES>
+__global__ void __launch_bounds__(256)
+k_icc_stages(IccElem<Q>* __restrict__ work, const IccElem<Q>* __restrict__ tw, uint32_t n, uint32_t ncols, int s) {
+    const uint32_t m2 = 1u << (s - 1);
+    size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t groups = (size_t)(n >> STAGES) * ncols;
+    if (tid >= groups) return;
+    uint32_t col = (uint32_t)(tid % ncols);
+    uint32_t g = (uint32_t)(tid / ncols);
+    uint32_t low = g & (m2 - 1);
+    uint32_t high = g >> (s - 1);
+    uint32_t base = (high << (s - 1 + STAGES)) | low;   // STAGES zero bits inserted at position s-1
+    uint32_t j0 = low;                                   // = base mod m2
+    if (STAGES == 1) {
+        IccElem<Q>* pa = work + (size_t)base * ncols + col;
+        IccElem<Q>* pb = work + (size_t)(base + m2) * ncols + col;
+        IccElem<Q> a = ld_elem<Q>(pa), b = ld_elem<Q>(pb);
+        IccElem<Q> t1 = ld_elem<Q>(tw + (size_t)j0 * (n / m2) % n);
+        butterfly<Q>(a, b, t1, false);
+        st_elem<Q>(pa, a);
+        st_elem<Q>(pb, b);
+    } else {
+        IccElem<Q>* p0 = work + (size_t)base * ncols + col;
+        IccElem<Q>* p1 = work + (size_t)(base + m2) * ncols + col;
+        IccElem<Q>* p2 = work + (size_t)(base + 2 * m2) * ncols + col;
+        IccElem<Q>* p3 = work + (size_t)(base + 3 * m2) * ncols + col;
+        IccElem<Q> e0 = ld_elem<Q>(p0), e1 = ld_elem<Q>(p1), e2 = ld_elem<Q>(p2), e3 = ld_elem<Q>(p3);
+        // stage s: v = w^(N/m2), twiddle v^j0 for both pairs
+        IccElem<Q> t1 = ld_elem<Q>(tw + ((size_t)j0 * (n / m2)) % n);
+        butterfly<Q>(e0, e1, t1, false);
+        butterfly<Q>(e2, e3, t1, false);
+        // stage s+1: m2' = 2*m2, v' = w^(N/(2 m2)); pair (0,2): j = j0; pair (1,3): j = j0 + m2 -> exponent j0*N/m + N/2
+        // (the integer v'^(j0+m2) mod p_icc is what multiplies the q-residue, so it comes from the table:
+        //  "-v'^j0" would only be right for the p_icc residue)
+        const size_t e2i = ((size_t)j0 * (n / (2 * m2))) % n;
+        IccElem<Q> t2 = ld_elem<Q>(tw + e2i);
+        butterfly<Q>(e0, e2, t2, false);
+        IccElem<Q> t3 = ld_elem<Q>(tw + (e2i + n / 2) % n);
+        butterfly<Q>(e1, e3, t3, false);
+        st_elem<Q>(p0, e0); st_elem<Q>(p1, e1); st_elem<Q>(p2, e2); st_elem<Q>(p3, e3);
+    }
+}
+
+// residue pair -> (a) value in [0, LCM) as 64-byte LE, (b) value mod p_icc as 32-byte LE,
+// (c) alignment scalar c = (A mod p_icc - A) mod q (Server.hpp:535-538) as 32 bytes BE (or LE limbs)
+template <class Q>
+__global__ void k_icc_finish(const IccElem<Q>* __restrict__ work, size_t total, uint8_t* __restrict__ x_out,
+                             uint8_t* __restrict__ al_out, uint8_t* __restrict__ sc_out, int scalar_le) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    IccElem<Q> e = ld_elem<Q>(work + i);
+    Fe<IccFp> P = fe_from_mont<IccFp>(e.p);      // A mod p_icc, plain
+    if (al_out) st_fe<IccFp>(reinterpret_cast<uint32_t*>(al_out + 32 * i), P);
+    Fe<Q> pq;                                     // (A mod p_icc) mod q
+#pragma unroll
+    for (int k = 0; k < 8; k++) pq.v[k] = P.v[k];
+    fe_reduce_plain<Q>(pq.v, Q::MAX_Q_P + 1);
+    Fe<Q> pq_m = fe_to_mont<Q>(pq);
+    if (sc_out) {
+        Fe<Q> c = fe_from_mont<Q>(fe_sub<Q>(pq_m, e.q));
+        uint32_t* d = reinterpret_cast<uint32_t*>(sc_out + 32 * i);
+        if (scalar_le) {
+            st_fe<Q>(d, c);
+        } else {
+            uint4* q4 = reinterpret_cast<uint4*>(d);
+            q4[0] = make_uint4(__builtin_bswap32(c.v[7]), __builtin_bswap32(c.v[6]), __builtin_bswap32(c.v[5]), __builtin_bswap32(c.v[4]));
+            q4[1] = make_uint4(__builtin_bswap32(c.v[3]), __builtin_bswap32(c.v[2]), __builtin_bswap32(c.v[1]), __builtin_bswap32(c.v[0]));
+        }
+    }
+    if (x_out) {
+        // A = P + p_icc * t,  t = (a_q - P) * p_icc^-1 mod q;  p_icc * t = t + (207 t << 248)
+        Fe<Q> pinv;
+#pragma unroll
+        for (int k = 0; k < 8; k++) pinv.v[k] = Q::PINV[k];
+        Fe<Q> t = fe_mul<Q>(fe_sub<Q>(e.q, pq_m), pinv);   // Montgomery(d) * plain -> plain product
+        uint32_t u[9];
+        uint32_t carry = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            uint64_t x = (uint64_t)t.v[k] * 207u + carry;
+            u[k] = (uint32_t)x;
+            carry = (uint32_t)(x >> 32);
+        }
+        u[8] = carry;
+        uint32_t A[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) A[k] = 0;
+        // A = P + t
+        uint32_t c2 = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            uint64_t x = (uint64_t)P.v[k] + t.v[k] + c2;
+            A[k] = (uint32_t)x;
+            c2 = (uint32_t)(x >> 32);
+        }
+        A[8] = c2;
+        // A += u << 248   (248 = 7*32 + 24)
+        uint32_t c3 = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            uint32_t lo = u[k] << 24;
+            uint32_t hi = (k > 0) ? (u[k - 1] >> 8) : 0;
+            uint64_t x = (uint64_t)A[7 + k] + (lo | hi) + c3;
+            A[7 + k] = (uint32_t)x;
+            c3 = (uint32_t)(x >> 32);
+        }
+        // top word of (u << 248): u[8] >> 8 lands in A[16] which must be zero because A < LCM < 2^512
+        uint4* o = reinterpret_cast<uint4*>(x_out + 64 * i);
+        o[0] = make_uint4(A[0], A[1], A[2], A[3]);
+        o[1] = make_uint4(A[4], A[5], A[6], A[7]);
+        o[2] = make_uint4(A[8], A[9], A[10], A[11]);
+        o[3] = make_uint4(A[12], A[13], A[14], A[15]);
+    }
+}
+
+}  // namespace porla

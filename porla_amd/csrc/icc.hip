@@ -1,0 +1,174 @@
+// ICC encode launch logic + C ABI (include/porla_gpu.h: porla_icc_encode_device / _host).
+// Patch site in the reference (no function boundary exists there): Server::CRebuild_Cached,
+// porla/Server/Server.hpp:1544-1833; see INTEGRATION.md.
+#include "engine.hpp"
+#include "icc.cuh"
+
+#include <vector>
+
+namespace porla {
+
+struct IccWs {
+    int device = -1;
+    Buf work, tw, wpow, in, xo, al, sc;
+    uint32_t tw_n = 0;
+    int tw_curve = -1;
+};
+static std::mutex g_icc_mu;
+static std::vector<IccWs*> g_icc_ws;
+
+static int get_icc_ws(IccWs** out) {
+    int dev = 0;
+    PORLA_HIP(hipGetDevice(&dev));
+    for (auto* w : g_icc_ws) if (w->device == dev) { *out = w; return PORLA_OK; }
+    IccWs* w = new IccWs();
+    w->device = dev;
+    g_icc_ws.push_back(w);
+    *out = w;
+    return PORLA_OK;
+}
+
+static inline int ilog2u(size_t n) { int l = 0; while (n >>= 1) l++; return l; }
+static inline uint64_t rev_bits(uint64_t x, int n) { uint64_t r = 0; for (int i = 0; i < n; i++) { r = (r << 1) | (x & 1); x >>= 1; } return r; }
+
+// w = GENERATOR^((p_icc - 1)/(2N)) mod p_icc (Server.hpp:214-216), Montgomery form
+static Fe<IccFp> icc_root(size_t n) {
+    Fe<IccFp> g;
+    for (int i = 0; i < 8; i++) g.v[i] = IccGen::G[i];
+    g = fe_to_mont<IccFp>(g);
+    // (p-1)/(2N) = 207 * 2^(247 - log2 N)
+    int sh = 247 - ilog2u(n);
+    uint32_t e[8] = {0};
+    uint64_t v = 207;
+    int limb = sh >> 5, off = sh & 31;
+    uint64_t lo = v << off;
+    e[limb] = (uint32_t)lo;
+    if (limb + 1 < 8) e[limb + 1] = (uint32_t)(lo >> 32);
+    return h_fe_pow<IccFp>(g, e);
+}
+
+template <class Q>
+static int icc_encode_core(IccWs* ws, int curve, const uint8_t* d_rows, size_t n, size_t ncols, unsigned long long write_step,
+                           int part, uint8_t* d_x, uint8_t* d_al, uint8_t* d_sc, int scalar_le, hipStream_t stream) {
+    const int logn = ilog2u(n);
+    if (n < 2 || ((size_t)1 << logn) != n || n > (1u << 30) || ncols == 0) {
+        set_last_error("porla: ICC encode needs a power-of-two row count >= 2");
+        return PORLA_ERR_ARG;
+    }
+    const size_t total = n * ncols;
+    int rc;
+    if ((rc = ws->work.ensure(total * sizeof(IccElem<Q>)))) return rc;
+    // ---- twiddle table w^e, e < N (resident across calls with the same N and curve)
+    Fe<IccFp> w = icc_root(n);
+    if (ws->tw_n != n || ws->tw_curve != curve) {
+        if ((rc = ws->tw.ensure(n * sizeof(IccElem<Q>)))) return rc;
+        if ((rc = ws->wpow.ensure(64 * sizeof(Fe<IccFp>)))) return rc;
+        std::vector<Fe<IccFp>> wp(logn ? logn : 1);
+        Fe<IccFp> cur = w;
+        for (int i = 0; i < logn; i++) { wp[i] = cur; cur = fe_sqr<IccFp>(cur); }
+        PORLA_HIP(hipMemcpyAsync(ws->wpow.p, wp.data(), logn * sizeof(Fe<IccFp>), hipMemcpyHostToDevice, stream));
+        PORLA_HIP(hipStreamSynchronize(stream));  // wp is a host temporary
+        ProfScope ps("icc_twiddles", stream);
+        hipLaunchKernelGGL((k_icc_twiddles<Q>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (IccElem<Q>*)ws->tw.p,
+                           (uint32_t)n, (const Fe<IccFp>*)ws->wpow.p, logn);
+        ws->tw_n = (uint32_t)n;
+        ws->tw_curve = curve;
+    }
+    // ---- init scaling: wt = w^reverse_bits(write_step % N, height-1) for the Y part (Server.hpp:1494), 1 for X
+    IccElem<Q> wt;
+    wt.p = fe_one<IccFp>();
+    wt.q = fe_one<Q>();
+    int use_wt = 0;
+    if (part == 1) {
+        const int height = logn + 1;
+        uint64_t ex = rev_bits(write_step % n, height - 1);
+        uint32_t e[8] = {(uint32_t)ex, (uint32_t)(ex >> 32), 0, 0, 0, 0, 0, 0};
+        wt.p = h_fe_pow<IccFp>(w, e);
+        Fe<IccFp> plain = fe_from_mont<IccFp>(wt.p);
+        Fe<Q> tq;
+        for (int k = 0; k < 8; k++) tq.v[k] = plain.v[k];
+        fe_reduce_plain<Q>(tq.v, 8);
+        wt.q = fe_to_mont<Q>(tq);
+        use_wt = 1;
+    }
+    {
+        ProfScope ps("icc_load", stream);
+        hipLaunchKernelGGL((k_icc_load<Q>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, d_rows,
+                           (IccElem<Q>*)ws->work.p, total, wt, use_wt);
+    }
+    int s = 1;
+    while (s + 1 <= logn) {
+        ProfScope ps("icc_stages_r4", stream);
+        size_t groups = (n >> 2) * ncols;
+        hipLaunchKernelGGL((k_icc_stages<Q, 2>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream,
+                           (IccElem<Q>*)ws->work.p, (const IccElem<Q>*)ws->tw.p, (uint32_t)n, (uint32_t)ncols, s);
+        s += 2;
+    }
+    if (s <= logn) {
+        ProfScope ps("icc_stages_r2", stream);
+        size_t groups = (n >> 1) * ncols;
+        hipLaunchKernelGGL((k_icc_stages<Q, 1>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream,
+                           (IccElem<Q>*)ws->work.p, (const IccElem<Q>*)ws->tw.p, (uint32_t)n, (uint32_t)ncols, s);
+    }
+    {
+        ProfScope ps("icc_finish", stream);
+        hipLaunchKernelGGL((k_icc_finish<Q>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                           (const IccElem<Q>*)ws->work.p, total, d_x, d_al, d_sc, scalar_le);
+    }
+    PORLA_HIP(hipGetLastError());
+    return PORLA_OK;
+}
+
+static int icc_encode_dispatch(IccWs* ws, int curve, const uint8_t* d_rows, size_t n, size_t ncols, unsigned long long ws_step,
+                               int part, uint8_t* d_x, uint8_t* d_al, uint8_t* d_sc, int scalar_le, hipStream_t stream) {
+    if (curve == 0) return icc_encode_core<IccBn254Fr>(ws, 0, d_rows, n, ncols, ws_step, part, d_x, d_al, d_sc, scalar_le, stream);
+    if (curve == 1) return icc_encode_core<IccSecp256k1Fn>(ws, 1, d_rows, n, ncols, ws_step, part, d_x, d_al, d_sc, scalar_le, stream);
+    set_last_error("porla: curve must be 0 (BN254 / KZG) or 1 (secp256k1 / IPA)");
+    return PORLA_ERR_ARG;
+}
+
+}  // namespace porla
+
+using namespace porla;
+
+extern "C" {
+
+int porla_icc_encode_device(const void* d_rows_in, size_t n_rows, size_t n_cols, int curve, unsigned long long write_step,
+                            int part, void* d_x_out, void* d_aligned_out, void* d_scalars_out, int scalar_le, void* stream) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!d_rows_in) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    std::lock_guard<std::mutex> lk(g_icc_mu);
+    IccWs* ws;
+    if ((rc = get_icc_ws(&ws))) return rc;
+    return icc_encode_dispatch(ws, curve, (const uint8_t*)d_rows_in, n_rows, n_cols, write_step, part, (uint8_t*)d_x_out,
+                               (uint8_t*)d_aligned_out, (uint8_t*)d_scalars_out, scalar_le, (hipStream_t)stream);
+}
+
+int porla_icc_encode_host(const uint8_t* rows_in, size_t n_rows, size_t n_cols, int curve, unsigned long long write_step,
+                          int part, uint8_t* x_out, uint8_t* aligned_out, uint8_t* scalars_out, int scalar_le) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!rows_in) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    std::lock_guard<std::mutex> lk(g_icc_mu);
+    IccWs* ws;
+    if ((rc = get_icc_ws(&ws))) return rc;
+    const size_t total = n_rows * n_cols;
+    if ((rc = ws->in.ensure(total * 32))) return rc;
+    if (x_out && (rc = ws->xo.ensure(total * 64))) return rc;
+    if (aligned_out && (rc = ws->al.ensure(total * 32))) return rc;
+    if (scalars_out && (rc = ws->sc.ensure(total * 32))) return rc;
+    hipStream_t s = nullptr;
+    PORLA_HIP(hipMemcpyAsync(ws->in.p, rows_in, total * 32, hipMemcpyHostToDevice, s));
+    rc = icc_encode_dispatch(ws, curve, (const uint8_t*)ws->in.p, n_rows, n_cols, write_step, part,
+                             x_out ? (uint8_t*)ws->xo.p : nullptr, aligned_out ? (uint8_t*)ws->al.p : nullptr,
+                             scalars_out ? (uint8_t*)ws->sc.p : nullptr, scalar_le, s);
+    if (rc) return rc;
+    if (x_out) PORLA_HIP(hipMemcpyAsync(x_out, ws->xo.p, total * 64, hipMemcpyDeviceToHost, s));
+    if (aligned_out) PORLA_HIP(hipMemcpyAsync(aligned_out, ws->al.p, total * 32, hipMemcpyDeviceToHost, s));
+    if (scalars_out) PORLA_HIP(hipMemcpyAsync(scalars_out, ws->sc.p, total * 32, hipMemcpyDeviceToHost, s));
+    PORLA_HIP(hipStreamSynchronize(s));
+    return PORLA_OK;
+}
+
+}  // extern "C"

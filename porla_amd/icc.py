@@ -1,0 +1,37 @@
+"""Host-side mirror of the ICC encode step of the reference's Server (CRebuild_Cached data part,
+porla/Server/Server.hpp:1487-1833, and the scalar part of align_MAC, Server.hpp:531-541) over the engine's
+C ABI (include/porla_gpu.h: porla_icc_encode_*).  Rows are in the reference's own formats: 32-byte
+little-endian chunks in (utils.h:353-364), 64-byte little-endian values mod LCM out (utils.h:473-517)."""
+import ctypes
+
+from .loader import lib
+
+CURVE = {"bn254": 0, "secp256k1": 1}
+NUM_CHUNKS = 128  # config.hpp:22
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError("porla engine error %d: %s" % (rc, lib.porla_gpu_last_error().decode()))
+
+
+def crebuild_host(rows, n_rows, n_cols=NUM_CHUNKS, curve="bn254", write_step=0, part=0, want_x=True,
+                  want_aligned=True, want_scalars=True, scalar_le=False):
+    """rows: n_rows*n_cols*32 bytes.  Returns (x_rows, aligned_rows, scalars) as bytes (or None)."""
+    total = n_rows * n_cols
+    x = ctypes.create_string_buffer(64 * total) if want_x else None
+    al = ctypes.create_string_buffer(32 * total) if want_aligned else None
+    sc = ctypes.create_string_buffer(32 * total) if want_scalars else None
+    _check(lib.porla_icc_encode_host(bytes(rows), n_rows, n_cols, CURVE[curve], write_step, part,
+                                     ctypes.cast(x, ctypes.c_void_p) if x else None,
+                                     ctypes.cast(al, ctypes.c_void_p) if al else None,
+                                     ctypes.cast(sc, ctypes.c_void_p) if sc else None, 1 if scalar_le else 0))
+    return (x.raw if x else None, al.raw if al else None, sc.raw if sc else None)
+
+
+def crebuild_device(d_rows, n_rows, n_cols, curve, write_step, part, d_x=0, d_aligned=0, d_scalars=0, scalar_le=False,
+                    stream=0):
+    """device-pointer form (integers, e.g. torch tensor .data_ptr()); asynchronous on `stream`."""
+    _check(lib.porla_icc_encode_device(ctypes.c_void_p(d_rows), n_rows, n_cols, CURVE[curve], write_step, part,
+                                       ctypes.c_void_p(d_x or None), ctypes.c_void_p(d_aligned or None),
+                                       ctypes.c_void_p(d_scalars or None), 1 if scalar_le else 0, ctypes.c_void_p(stream)))

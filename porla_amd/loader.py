@@ -62,6 +62,10 @@ def _declare(L):
         f = getattr(L, "porla_%s_msm_device_partial" % curve); f.argtypes = [vp, vp, sz, u8p, vp]; f.restype = ctypes.c_int
         f = getattr(L, "porla_%s_msm_host" % curve); f.argtypes = [u8p, u8p, sz, u8p]; f.restype = ctypes.c_int
         f = getattr(L, "porla_%s_jac_sum" % curve); f.argtypes = [u8p, sz, u8p]; f.restype = ctypes.c_int
+    L.porla_icc_encode_device.argtypes = [vp, sz, sz, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_int, vp, vp, vp, ctypes.c_int, vp]
+    L.porla_icc_encode_device.restype = ctypes.c_int
+    L.porla_icc_encode_host.argtypes = [u8p, sz, sz, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_int, vp, vp, vp, ctypes.c_int]
+    L.porla_icc_encode_host.restype = ctypes.c_int
 
 
 class _LazyLib:

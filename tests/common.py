@@ -71,3 +71,35 @@ def cached_inputs(n):
     except OSError:
         pass
     return sc, pt
+
+
+# ---------------------------------------------------------------- secp256k1 (IPA path) inputs
+SECP_N = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+
+
+def secp_bench_scalars(n, start=0):
+    """generate_scalar of the reference's bench: SHA-256("ecmult" || LE32(i)) (bench_ecmult.c:233-247)"""
+    return b"".join(hashlib.sha256(b"ecmult" + (start + i).to_bytes(4, "little")).digest() for i in range(n))
+
+
+def secp_bench_points(n):
+    """P_i = 2^i * G, normalised (bench_ecmult.c:328-337), 64-byte x||y big-endian"""
+    out = ctypes.create_string_buffer(64 * n)
+    oracle().oracle_secp256k1_doubling_chain(ctypes.c_size_t(n), out)
+    return out.raw
+
+
+def secp_bench_expected(scalars, n):
+    """(sum s_i * 2^i) * G like the bench teardown (bench_ecmult.c:258-270) -- independent of any bucket method"""
+    acc = 0
+    for i in range(n):
+        acc = (acc + (int.from_bytes(scalars[32 * i:32 * i + 32], "big") % SECP_N) * pow(2, i, SECP_N)) % SECP_N
+    out = ctypes.create_string_buffer(64)
+    oracle().oracle_secp256k1_mul_g_batch(acc.to_bytes(32, "big"), ctypes.c_size_t(1), out, 1)
+    return out.raw
+
+
+def oracle_secp_msm(scalars, points, n, naive=False, threads=None):
+    out = ctypes.create_string_buffer(64)
+    oracle().oracle_secp256k1_multi(bytes(scalars), bytes(points), ctypes.c_size_t(n), out, threads or ncpu(), 1 if naive else 0)
+    return out.raw

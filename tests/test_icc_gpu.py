@@ -1,0 +1,90 @@
+"""Parity of the HIP ICC encode against the oracle (C restatement working directly in Z/LCM, itself pinned to the
+Python restatement of porla/Server/Server.hpp:1487-1833 + :531-541), through the C ABI.  Bit-exact."""
+import ctypes
+import hashlib
+
+import pytest
+
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+
+def rows_bytes(n, ncols, seed=0):
+    """uniform 256-bit chunks from a SHA-256 counter stream (SURVEY.md s8d cfg 5)"""
+    out = bytearray()
+    i = 0
+    while len(out) < 32 * n * ncols:
+        out += hashlib.sha256(b"porla-icc" + seed.to_bytes(4, "little") + i.to_bytes(8, "little")).digest()
+        i += 1
+    return bytes(out[:32 * n * ncols])
+
+
+def oracle_crebuild(rows, n, ncols, curve, part, write_step):
+    L = common.oracle()
+    x = ctypes.create_string_buffer(64 * n * ncols)
+    al = ctypes.create_string_buffer(32 * n * ncols)
+    sc = ctypes.create_string_buffer(32 * n * ncols)
+    L.oracle_icc_crebuild(rows, ctypes.c_size_t(n), ctypes.c_size_t(ncols), curve, part, ctypes.c_uint64(write_step), x, al, sc,
+                          common.ncpu())
+    return x.raw, al.raw, sc.raw
+
+
+@pytest.mark.parametrize("curve", ["bn254", "secp256k1"])
+@pytest.mark.parametrize("n,ncols", [(2, 128), (4, 5), (8, 128), (16, 3), (32, 128), (1024, 128), (2048, 16)])
+def test_crebuild_x_part(curve, n, ncols):
+    from porla_amd import icc
+    rows = rows_bytes(n, ncols, seed=n)
+    got = icc.crebuild_host(rows, n, ncols, curve, 0, 0)
+    want = oracle_crebuild(rows, n, ncols, icc.CURVE[curve], 0, 0)
+    assert got[0] == want[0]      # values mod LCM, 64-byte LE
+    assert got[1] == want[1]      # values mod p_icc
+    assert got[2] == want[2]      # alignment scalars, big-endian
+
+
+@pytest.mark.parametrize("curve", ["bn254", "secp256k1"])
+def test_crebuild_y_part_and_scalar_formats(curve):
+    """Y = X * wt with wt = w^reverse_bits(write_step % N, height-1) (Server.hpp:1494); at write_step % N == 0, Y == X"""
+    from porla_amd import icc
+    n, ncols = 64, 128
+    rows = rows_bytes(n, ncols, seed=9)
+    for ws in (0, 5, 37, 64 + 3):
+        got = icc.crebuild_host(rows, n, ncols, curve, ws, 1)
+        want = oracle_crebuild(rows, n, ncols, icc.CURVE[curve], 1, ws)
+        assert got == want
+    assert icc.crebuild_host(rows, n, ncols, curve, 0, 1)[0] == icc.crebuild_host(rows, n, ncols, curve, 0, 0)[0]
+    # little-endian limb form of the scalars (secp256k1_scalar layout)
+    be = icc.crebuild_host(rows, n, ncols, curve, 0, 0)[2]
+    le = icc.crebuild_host(rows, n, ncols, curve, 0, 0, scalar_le=True)[2]
+    assert all(be[32 * i:32 * i + 32] == le[32 * i:32 * i + 32][::-1] for i in range(n * ncols))
+
+
+@pytest.mark.parametrize("curve", ["bn254", "secp256k1"])
+def test_edge_values(curve):
+    """chunks equal to 0, 2^256-1, p_icc, p_icc-1, q, q-1 (unreduced inputs, Client.hpp:369-371 allows any 256-bit value)"""
+    from porla_amd import icc
+    import icc_py
+    n, ncols = 8, 6
+    vals = [0, 2**256 - 1, icc_py.P_ICC, icc_py.P_ICC - 1, icc_py.Q[curve], icc_py.Q[curve] - 1, 1, 2**255]
+    rows = b"".join(vals[(r + c) % len(vals)].to_bytes(32, "little") for r in range(n) for c in range(ncols))
+    got = icc.crebuild_host(rows, n, ncols, curve, 3, 1)
+    assert got == oracle_crebuild(rows, n, ncols, icc.CURVE[curve], 1, 3)
+
+
+def test_full_size_2_22_elements():
+    """BASELINE.json config 5: 2^22 elements = 2^15 rows x 128 columns, device-resident, vs the oracle"""
+    import torch
+    from porla_amd import icc
+    n, ncols = 1 << 15, 128
+    rows = rows_bytes(n, ncols, seed=22)
+    d_in = torch.frombuffer(bytearray(rows), dtype=torch.uint8).cuda()
+    d_x = torch.empty(64 * n * ncols, dtype=torch.uint8, device="cuda")
+    d_al = torch.empty(32 * n * ncols, dtype=torch.uint8, device="cuda")
+    d_sc = torch.empty(32 * n * ncols, dtype=torch.uint8, device="cuda")
+    icc.crebuild_device(d_in.data_ptr(), n, ncols, "bn254", 0, 0, d_x.data_ptr(), d_al.data_ptr(), d_sc.data_ptr(),
+                        stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want = oracle_crebuild(rows, n, ncols, 0, 0, 0)
+    assert d_x.cpu().numpy().tobytes() == want[0]
+    assert d_al.cpu().numpy().tobytes() == want[1]
+    assert d_sc.cpu().numpy().tobytes() == want[2]
