@@ -71,16 +71,12 @@ def main():
     d_sc = torch.frombuffer(bytearray(sc), dtype=torch.uint8).to(dev)
     d_pt = torch.frombuffer(bytearray(pt), dtype=torch.uint8).to(dev)
     stream = torch.cuda.current_stream().cuda_stream
-    gather = [torch.zeros(96, dtype=torch.uint8, device=dev) for _ in range(world)] if world > 1 else None
+    from porla_amd import sharded
 
     def step():
-        if world == 1:
-            return mx.msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n, stream)
-        part = mx.msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n, stream, partial=True)
-        mine = torch.frombuffer(bytearray(part), dtype=torch.uint8).to(dev)
-        dist.all_gather(gather, mine)                      # RCCL over xGMI: N x 96 bytes
-        parts = b"".join(bytes(g.cpu().numpy().tobytes()) for g in gather)
-        return mx.jac_sum("bn254", parts, world)           # N-1 group additions + one inversion (host)
+        # N == 1: one MSM -> 64-byte affine.  N > 1: per-rank partial Jacobian, ONE RCCL all_gather of N x 96 bytes,
+        # N-1 group additions + one inversion on the host (porla_amd/sharded.py)
+        return sharded.sharded_msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n, stream, dev)
 
     result = None
     for _ in range(args.warmup):
