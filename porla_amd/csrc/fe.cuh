@@ -152,9 +152,10 @@ PORLA_HD void mac96(uint64_t& acc, uint32_t& acc2, uint32_t a, uint32_t b) {
     acc = t;
 }
 
-// Montgomery product a*b*R^-1 mod P, product-scanning with interleaved reduction.
+// Montgomery product a*b*R^-1 mod P, product-scanning with interleaved reduction (portable form: host pass,
+// and the device pass when PORLA_NO_ASM_MUL is defined).
 template <class M>
-PORLA_HD Fe<M> fe_mul(const Fe<M>& a, const Fe<M>& b) {
+PORLA_HD Fe<M> fe_mul_generic(const Fe<M>& a, const Fe<M>& b) {
     uint32_t m[8], t[8], s[8];
     uint64_t acc = 0;
     uint32_t acc2 = 0;
@@ -185,6 +186,19 @@ PORLA_HD Fe<M> fe_mul(const Fe<M>& a, const Fe<M>& b) {
 #pragma unroll
     for (int i = 0; i < 8; i++) r.v[i] = ge ? s[i] : t[i];
     return r;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PORLA_NO_ASM_MUL)
+#include "fe_mul_gfx950.inc"
+#endif
+
+template <class M>
+PORLA_HD Fe<M> fe_mul(const Fe<M>& a, const Fe<M>& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PORLA_NO_ASM_MUL)
+    return fe_mul_gfx950<M>(a, b);
+#else
+    return fe_mul_generic<M>(a, b);
+#endif
 }
 
 template <class M>
