@@ -47,116 +47,102 @@ PORLA_HD XYZZ<M> xyzz_from_affine(const Affine<M>& a) {
 }
 
 // 2 * (affine a), a != infinity   (mdbl-2008-s-1, a = 0)
-template <class M>
+template <class M, bool CALL = false>
 PORLA_HD XYZZ<M> xyzz_double_affine(const Affine<M>& a) {
     XYZZ<M> r;
     if (fe_is_zero<M>(a.y)) return xyzz_inf<M>();  // order-2 point: cannot occur on prime-order curves
     Fe<M> U = fe_dbl<M>(a.y);
-    Fe<M> V = fe_sqr<M>(U);
-    Fe<M> W = fe_mul<M>(U, V);
-    Fe<M> S = fe_mul<M>(a.x, V);
-    Fe<M> XX = fe_sqr<M>(a.x);
+    Fe<M> V = fmul<M, CALL>(U, U);
+    Fe<M> W = fmul<M, CALL>(U, V);
+    Fe<M> S = fmul<M, CALL>(a.x, V);
+    Fe<M> XX = fmul<M, CALL>(a.x, a.x);
     Fe<M> Mm = fe_add<M>(fe_dbl<M>(XX), XX);
-    r.x = fe_sub<M>(fe_sub<M>(fe_sqr<M>(Mm), S), S);
-    r.y = fe_sub<M>(fe_mul<M>(Mm, fe_sub<M>(S, r.x)), fe_mul<M>(W, a.y));
+    r.x = fe_sub<M>(fe_sub<M>(fmul<M, CALL>(Mm, Mm), S), S);
+    r.y = fe_sub<M>(fmul<M, CALL>(Mm, fe_sub<M>(S, r.x)), fmul<M, CALL>(W, a.y));
     r.zz = V;
     r.zzz = W;
     return r;
 }
 
 // 2 * p   (dbl-2008-s-1, a = 0)
-template <class M>
+template <class M, bool CALL = false>
 PORLA_HD XYZZ<M> xyzz_double(const XYZZ<M>& p) {
     if (xyzz_is_inf<M>(p) || fe_is_zero<M>(p.y)) return xyzz_inf<M>();
     XYZZ<M> r;
     Fe<M> U = fe_dbl<M>(p.y);
-    Fe<M> V = fe_sqr<M>(U);
-    Fe<M> W = fe_mul<M>(U, V);
-    Fe<M> S = fe_mul<M>(p.x, V);
-    Fe<M> XX = fe_sqr<M>(p.x);
+    Fe<M> V = fmul<M, CALL>(U, U);
+    Fe<M> W = fmul<M, CALL>(U, V);
+    Fe<M> S = fmul<M, CALL>(p.x, V);
+    Fe<M> XX = fmul<M, CALL>(p.x, p.x);
     Fe<M> Mm = fe_add<M>(fe_dbl<M>(XX), XX);
-    r.x = fe_sub<M>(fe_sub<M>(fe_sqr<M>(Mm), S), S);
-    r.y = fe_sub<M>(fe_mul<M>(Mm, fe_sub<M>(S, r.x)), fe_mul<M>(W, p.y));
-    r.zz = fe_mul<M>(V, p.zz);
-    r.zzz = fe_mul<M>(W, p.zzz);
+    r.x = fe_sub<M>(fe_sub<M>(fmul<M, CALL>(Mm, Mm), S), S);
+    r.y = fe_sub<M>(fmul<M, CALL>(Mm, fe_sub<M>(S, r.x)), fmul<M, CALL>(W, p.y));
+    r.zz = fmul<M, CALL>(V, p.zz);
+    r.zzz = fmul<M, CALL>(W, p.zzz);
     return r;
 }
 
 // p += a   (madd-2008-s), all exceptional cases handled
-template <class M>
+template <class M, bool CALL = false>
 PORLA_HD void xyzz_madd(XYZZ<M>& p, const Affine<M>& a) {
     if (aff_is_inf<M>(a)) return;
     if (xyzz_is_inf<M>(p)) {
         p.x = a.x; p.y = a.y; p.zz = fe_one<M>(); p.zzz = fe_one<M>();
         return;
     }
-    Fe<M> U2 = fe_mul<M>(a.x, p.zz);
-    Fe<M> S2 = fe_mul<M>(a.y, p.zzz);
+    Fe<M> U2 = fmul<M, CALL>(a.x, p.zz);
+    Fe<M> S2 = fmul<M, CALL>(a.y, p.zzz);
     Fe<M> Pp = fe_sub<M>(U2, p.x);
     Fe<M> Rr = fe_sub<M>(S2, p.y);
     if (fe_is_zero<M>(Pp)) {
-        if (fe_is_zero<M>(Rr)) p = xyzz_double_affine<M>(a);
+        if (fe_is_zero<M>(Rr)) p = xyzz_double_affine<M, CALL>(a);
         else p = xyzz_inf<M>();
         return;
     }
-    Fe<M> PP = fe_sqr<M>(Pp);
-    Fe<M> PPP = fe_mul<M>(Pp, PP);
-    Fe<M> Q = fe_mul<M>(p.x, PP);
-    Fe<M> X3 = fe_sub<M>(fe_sub<M>(fe_sub<M>(fe_sqr<M>(Rr), PPP), Q), Q);
-    Fe<M> Y3 = fe_sub<M>(fe_mul<M>(Rr, fe_sub<M>(Q, X3)), fe_mul<M>(p.y, PPP));
+    Fe<M> PP = fmul<M, CALL>(Pp, Pp);
+    Fe<M> PPP = fmul<M, CALL>(Pp, PP);
+    Fe<M> Q = fmul<M, CALL>(p.x, PP);
+    Fe<M> X3 = fe_sub<M>(fe_sub<M>(fe_sub<M>(fmul<M, CALL>(Rr, Rr), PPP), Q), Q);
+    Fe<M> Y3 = fe_sub<M>(fmul<M, CALL>(Rr, fe_sub<M>(Q, X3)), fmul<M, CALL>(p.y, PPP));
     p.x = X3;
     p.y = Y3;
-    p.zz = fe_mul<M>(p.zz, PP);
-    p.zzz = fe_mul<M>(p.zzz, PPP);
+    p.zz = fmul<M, CALL>(p.zz, PP);
+    p.zzz = fmul<M, CALL>(p.zzz, PPP);
 }
 
 // p += q   (add-2008-s), all exceptional cases handled
-template <class M>
+template <class M, bool CALL = false>
 PORLA_HD void xyzz_add(XYZZ<M>& p, const XYZZ<M>& q) {
     if (xyzz_is_inf<M>(q)) return;
     if (xyzz_is_inf<M>(p)) { p = q; return; }
-    Fe<M> U1 = fe_mul<M>(p.x, q.zz);
-    Fe<M> U2 = fe_mul<M>(q.x, p.zz);
-    Fe<M> S1 = fe_mul<M>(p.y, q.zzz);
-    Fe<M> S2 = fe_mul<M>(q.y, p.zzz);
+    Fe<M> U1 = fmul<M, CALL>(p.x, q.zz);
+    Fe<M> U2 = fmul<M, CALL>(q.x, p.zz);
+    Fe<M> S1 = fmul<M, CALL>(p.y, q.zzz);
+    Fe<M> S2 = fmul<M, CALL>(q.y, p.zzz);
     Fe<M> Pp = fe_sub<M>(U2, U1);
     Fe<M> Rr = fe_sub<M>(S2, S1);
     if (fe_is_zero<M>(Pp)) {
-        if (fe_is_zero<M>(Rr)) p = xyzz_double<M>(p);
+        if (fe_is_zero<M>(Rr)) p = xyzz_double<M, CALL>(p);
         else p = xyzz_inf<M>();
         return;
     }
-    Fe<M> PP = fe_sqr<M>(Pp);
-    Fe<M> PPP = fe_mul<M>(Pp, PP);
-    Fe<M> Q = fe_mul<M>(U1, PP);
-    Fe<M> X3 = fe_sub<M>(fe_sub<M>(fe_sub<M>(fe_sqr<M>(Rr), PPP), Q), Q);
-    Fe<M> Y3 = fe_sub<M>(fe_mul<M>(Rr, fe_sub<M>(Q, X3)), fe_mul<M>(S1, PPP));
+    Fe<M> PP = fmul<M, CALL>(Pp, Pp);
+    Fe<M> PPP = fmul<M, CALL>(Pp, PP);
+    Fe<M> Q = fmul<M, CALL>(U1, PP);
+    Fe<M> X3 = fe_sub<M>(fe_sub<M>(fe_sub<M>(fmul<M, CALL>(Rr, Rr), PPP), Q), Q);
+    Fe<M> Y3 = fe_sub<M>(fmul<M, CALL>(Rr, fe_sub<M>(Q, X3)), fmul<M, CALL>(S1, PPP));
     p.x = X3;
     p.y = Y3;
-    p.zz = fe_mul<M>(fe_mul<M>(p.zz, q.zz), PP);
-    p.zzz = fe_mul<M>(fe_mul<M>(p.zzz, q.zzz), PPP);
+    p.zz = fmul<M, CALL>(fmul<M, CALL>(p.zz, q.zz), PP);
+    p.zzz = fmul<M, CALL>(fmul<M, CALL>(p.zzz, q.zzz), PPP);
 }
 
-// Out-of-line copies for the cold reduction kernels (keeps their code size and compile time bounded;
-// the hot bucket accumulation inlines everything).
-#if defined(__HIP_DEVICE_COMPILE__)
+// Cold-path forms for the reduction kernels: the group law is inlined but every field product is a call to one shared
+// out-of-line body (fe_mul_call), which keeps those kernels inside the instruction cache.
 template <class M>
-__device__ __noinline__ void xyzz_add_cold(XYZZ<M>* p, const XYZZ<M>* q) {
-    XYZZ<M> a = *p;
-    xyzz_add<M>(a, *q);
-    *p = a;
-}
+PORLA_HD void xyzz_add_cold(XYZZ<M>* p, const XYZZ<M>* q) { xyzz_add<M, true>(*p, *q); }
 template <class M>
-__device__ __noinline__ void xyzz_double_cold(XYZZ<M>* p) {
-    XYZZ<M> a = xyzz_double<M>(*p);
-    *p = a;
-}
-#else
-template <class M>
-__host__ __device__ inline void xyzz_add_cold(XYZZ<M>* p, const XYZZ<M>* q) { xyzz_add<M>(*p, *q); }
-template <class M>
-__host__ __device__ inline void xyzz_double_cold(XYZZ<M>* p) { *p = xyzz_double<M>(*p); }
-#endif
+PORLA_HD void xyzz_double_cold(XYZZ<M>* p) { *p = xyzz_double<M, true>(*p); }
 
 template <class M>
 PORLA_HD Affine<M> aff_neg_if(const Affine<M>& a, bool neg) {

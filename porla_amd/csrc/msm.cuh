@@ -11,7 +11,9 @@
 //   k_scalar_digits    32-B big-endian scalar -> reduce mod order -> signed c-bit digits; per-(window,bucket)
 //                      histogram with device-scope atomics
 //   k_bucket_offsets   one slot range per bucket (wave prefix + one cursor atomic per wave; bucket order in
-//                      memory is irrelevant, so no global scan is needed)
+//                      memory is irrelevant, so no global scan is needed) + per-block histogram of bucket sizes
+//   k_size_scan/order  counting sort of the buckets BY SIZE (descending): k_bucket_sum takes buckets in that order so
+//                      the 64 lanes of a wave run (almost) the same number of additions
 //   k_scatter          counting-sort scatter of point indices into their bucket's range
 //   k_bucket_sum       ONE THREAD PER BUCKET: walks its index list, gathers 64-B points (L2 / Infinity-Cache
 //                      resident: 2^20 points = 64 MiB) and accumulates with the 8M+2S mixed add
@@ -180,9 +182,15 @@ __global__ void k_scalar_digits(const uint8_t* __restrict__ scalars, uint32_t n,
     }
 }
 
-// one contiguous slot range per bucket; also resets the fill counters
-static __global__ void k_bucket_offsets(const uint32_t* __restrict__ counts, uint32_t* __restrict__ starts,
-                                 uint32_t* __restrict__ fill, uint32_t nb, uint32_t* __restrict__ cursor) {
+// one contiguous slot range per bucket; also resets the fill counters and emits, per 1024-bucket block, a
+// histogram of (clamped) bucket sizes used to schedule buckets by size (k_size_scan / k_size_order).
+constexpr int SIZE_BINS = 256;
+static __global__ void __launch_bounds__(1024)
+k_bucket_offsets(const uint32_t* __restrict__ counts, uint32_t* __restrict__ starts, uint32_t* __restrict__ fill,
+                 uint32_t nb, uint32_t* __restrict__ cursor, uint32_t* __restrict__ blk_hist, uint32_t nblocks) {
+    __shared__ uint32_t hist[SIZE_BINS];
+    if (threadIdx.x < SIZE_BINS) hist[threadIdx.x] = 0;
+    __syncthreads();
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t cnt = (i < nb) ? counts[i] : 0;
     // inclusive prefix over the 64-lane wave
@@ -200,6 +208,46 @@ static __global__ void k_bucket_offsets(const uint32_t* __restrict__ counts, uin
     if (i < nb) {
         starts[i] = base + incl - cnt;
         fill[i] = 0;
+        atomicAdd(&hist[cnt < SIZE_BINS ? cnt : SIZE_BINS - 1], 1u);
+    }
+    __syncthreads();
+    // bin-major layout, largest sizes first: row r = SIZE_BINS-1-bin
+    if (threadIdx.x < SIZE_BINS) blk_hist[(size_t)(SIZE_BINS - 1 - threadIdx.x) * nblocks + blockIdx.x] = hist[threadIdx.x];
+}
+
+// exclusive scan of blk_hist (SIZE_BINS * nblocks entries, already in descending-size order) -> blk_off; one block.
+static __global__ void __launch_bounds__(1024)
+k_size_scan(const uint32_t* __restrict__ blk_hist, uint32_t* __restrict__ blk_off, uint32_t total) {
+    __shared__ uint32_t part[1024];
+    uint32_t per = (total + 1023) / 1024;
+    uint32_t lo = threadIdx.x * per, hi = lo + per < total ? lo + per : total;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += blk_hist[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over 1024 partials
+    for (int d = 1; d < 1024; d <<= 1) {
+        uint32_t v = (threadIdx.x >= (uint32_t)d) ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (uint32_t i = lo; i < hi; i++) { uint32_t v = blk_hist[i]; blk_off[i] = run; run += v; }
+}
+
+// order[pos] = bucket id, buckets sorted by size (descending, clamped at SIZE_BINS-1); same block shape as k_bucket_offsets
+static __global__ void __launch_bounds__(1024)
+k_size_order(const uint32_t* __restrict__ counts, uint32_t nb, const uint32_t* __restrict__ blk_off, uint32_t nblocks,
+             uint32_t* __restrict__ order) {
+    __shared__ uint32_t next[SIZE_BINS];
+    if (threadIdx.x < SIZE_BINS) next[threadIdx.x] = blk_off[(size_t)(SIZE_BINS - 1 - threadIdx.x) * nblocks + blockIdx.x];
+    __syncthreads();
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nb) {
+        uint32_t cnt = counts[i];
+        uint32_t pos = atomicAdd(&next[cnt < SIZE_BINS ? cnt : SIZE_BINS - 1], 1u);
+        order[pos] = i;
     }
 }
 
@@ -217,22 +265,217 @@ static __global__ void k_scatter(const uint32_t* __restrict__ keys, uint32_t n, 
     entries[starts[b] + pos] = i | (key & 0x80000000u);
 }
 
-// ONE THREAD PER BUCKET.
+// ------------------------------------------------------------------------------------------------
+// Two-pass LDS counting sort of the (window, bucket) keys -- no global atomics on the data path.
+//
+// Pass A  k_digits_partition: a block owns a TILE of 4096 scalars.  It reduces them mod the group order once, keeps the
+//         limbs in registers, and for every window w emits the tile's non-zero digits grouped by PARTITION
+//         (= high bits of the bucket id) into tile_items[w][tile][*] together with the 129-entry offset table
+//         tile_off[w][tile][*].  An item is (bucket & lowmask) | sign << 8 | local_index << 9  (local_index < 4096).
+// Pass B  k_partition_sort: a block owns one (window, partition) = at most 256 buckets.  It walks that partition's run in
+//         every tile twice: first to count per bucket (-> counts, starts; the partition's slot range comes from ONE
+//         cursor atomic per block), then to place the point indices with LDS cursors.
+constexpr int TILE = 4096;
+constexpr int TILE_THREADS = 1024;
+constexpr int TILE_SPT = TILE / TILE_THREADS;  // scalars per thread
+constexpr int MAX_PARTS = 128;
+
+template <class C>
+__global__ void __launch_bounds__(TILE_THREADS)
+k_digits_partition(const uint8_t* __restrict__ scalars, uint32_t n, int c, int W, int lowbits,
+                   uint32_t* __restrict__ tile_items, uint16_t* __restrict__ tile_off) {
+    __shared__ uint32_t hist[MAX_PARTS];
+    __shared__ uint32_t cursor[MAX_PARTS];
+    __shared__ uint32_t stage[TILE];
+    const uint32_t tile = blockIdx.x, T = gridDim.x, tid = threadIdx.x;
+    const int P = 1 << (c - 1 - lowbits);
+    const uint32_t B = 1u << (c - 1);
+    const uint32_t mask = (1u << c) - 1;
+    const uint32_t lowmask = (1u << lowbits) - 1;
+    uint32_t t[TILE_SPT][8];
+    bool valid[TILE_SPT];
+#pragma unroll
+    for (int j = 0; j < TILE_SPT; j++) {
+        uint32_t i = tile * TILE + j * TILE_THREADS + tid;
+        valid[j] = i < n;
+#pragma unroll
+        for (int k = 0; k < 8; k++) t[j][k] = 0;
+        if (valid[j]) {
+            load_be256(t[j], scalars + (size_t)i * 32);
+            for (int q = 0; q < C::MAX_Q; q++) {
+                uint32_t s[8];
+                uint32_t br = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    uint64_t d = (uint64_t)t[j][k] - C::ORDER[k] - br;
+                    s[k] = (uint32_t)d;
+                    br = (uint32_t)(d >> 63);
+                }
+                if (br) break;
+#pragma unroll
+                for (int k = 0; k < 8; k++) t[j][k] = s[k];
+            }
+        }
+    }
+    uint32_t carry[TILE_SPT];
+#pragma unroll
+    for (int j = 0; j < TILE_SPT; j++) carry[j] = 0;
+
+    for (int w = 0; w < W; w++) {
+        if (tid < MAX_PARTS) hist[tid] = 0;
+        __syncthreads();
+        uint32_t key[TILE_SPT];
+        const int lo = w * c;
+        const int limb = lo >> 5, sh = lo & 31;
+#pragma unroll
+        for (int j = 0; j < TILE_SPT; j++) {
+            uint32_t raw = 0;
+            if (lo < 256) {
+                uint32_t a = 0, b = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    a = (k == limb) ? t[j][k] : a;
+                    b = (k == limb + 1) ? t[j][k] : b;
+                }
+                uint64_t v = ((uint64_t)b << 32) | a;
+                raw = (uint32_t)(v >> sh) & mask;
+            }
+            raw += carry[j];
+            if (raw > B) {
+                carry[j] = 1;
+                key[j] = (((1u << c) - raw) - 1) | 0x80000000u;
+            } else {
+                carry[j] = 0;
+                key[j] = raw ? (raw - 1) : KEY_NONE;
+            }
+            if (!valid[j]) key[j] = KEY_NONE;
+            if (key[j] != KEY_NONE) atomicAdd(&hist[(key[j] & 0x7fffffffu) >> lowbits], 1u);
+        }
+        __syncthreads();
+        // exclusive scan over P <= 128 partitions by the first two waves (Hillis-Steele in LDS)
+        if (tid < MAX_PARTS) {
+            uint32_t v = (tid < (uint32_t)P) ? hist[tid] : 0;
+            cursor[tid] = v;
+        }
+        __syncthreads();
+        for (int d = 1; d < MAX_PARTS; d <<= 1) {
+            uint32_t v = 0;
+            if (tid < MAX_PARTS && tid >= (uint32_t)d) v = cursor[tid - d];
+            __syncthreads();
+            if (tid < MAX_PARTS) cursor[tid] += v;
+            __syncthreads();
+        }
+        uint16_t* off = tile_off + ((size_t)w * T + tile) * (MAX_PARTS + 1);
+        uint32_t total = cursor[MAX_PARTS - 1];
+        if (tid < MAX_PARTS) {
+            uint32_t excl = cursor[tid] - ((tid < (uint32_t)P) ? hist[tid] : 0);
+            off[tid] = (uint16_t)excl;
+            if (tid == 0) off[MAX_PARTS] = (uint16_t)total;
+            hist[tid] = excl;  // becomes the running cursor
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TILE_SPT; j++) {
+            if (key[j] != KEY_NONE) {
+                uint32_t bkt = key[j] & 0x7fffffffu;
+                uint32_t pos = atomicAdd(&hist[bkt >> lowbits], 1u);
+                stage[pos] = (bkt & lowmask) | ((key[j] >> 31) << 8) | ((uint32_t)(j * TILE_THREADS + tid) << 9);
+            }
+        }
+        __syncthreads();
+        uint32_t* dst = tile_items + ((size_t)w * T + tile) * TILE;
+        for (uint32_t i = tid; i < total; i += TILE_THREADS) dst[i] = stage[i];
+        __syncthreads();
+    }
+}
+
+// grid = W * P blocks of 256 threads
+static __global__ void __launch_bounds__(256)
+k_partition_sort(const uint32_t* __restrict__ tile_items, const uint16_t* __restrict__ tile_off, uint32_t T, int c,
+                 int lowbits, uint32_t* __restrict__ counts, uint32_t* __restrict__ starts,
+                 uint32_t* __restrict__ entries, uint32_t* __restrict__ cursor) {
+    __shared__ uint32_t cnt[256];
+    __shared__ uint32_t scan[256];
+    __shared__ uint32_t base_sh;
+    const int P = 1 << (c - 1 - lowbits);
+    const uint32_t nlow = 1u << lowbits;
+    const uint32_t w = blockIdx.x / P, p = blockIdx.x % P;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lowmask = nlow - 1;
+    cnt[tid] = 0;
+    __syncthreads();
+    for (uint32_t t = tid; t < T; t += 256) {
+        const uint16_t* off = tile_off + ((size_t)w * T + t) * (MAX_PARTS + 1);
+        uint32_t lo = off[p], hi = (p + 1 < (uint32_t)P) ? off[p + 1] : off[MAX_PARTS];
+        const uint32_t* it = tile_items + ((size_t)w * T + t) * TILE;
+        for (uint32_t i = lo; i < hi; i++) atomicAdd(&cnt[it[i] & lowmask], 1u);
+    }
+    __syncthreads();
+    uint32_t mine = cnt[tid];
+    scan[tid] = mine;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        uint32_t v = (tid >= (uint32_t)d) ? scan[tid - d] : 0;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    if (tid == 255) base_sh = atomicAdd(cursor, scan[255]);
+    __syncthreads();
+    uint32_t start = base_sh + scan[tid] - mine;
+    if (tid < nlow) {
+        size_t b = ((size_t)w << (c - 1)) + (size_t)p * nlow + tid;
+        counts[b] = mine;
+        starts[b] = start;
+    }
+    cnt[tid] = start;  // running cursor per bucket
+    __syncthreads();
+    for (uint32_t t = tid; t < T; t += 256) {
+        const uint16_t* off = tile_off + ((size_t)w * T + t) * (MAX_PARTS + 1);
+        uint32_t lo = off[p], hi = (p + 1 < (uint32_t)P) ? off[p + 1] : off[MAX_PARTS];
+        const uint32_t* it = tile_items + ((size_t)w * T + t) * TILE;
+        for (uint32_t i = lo; i < hi; i++) {
+            uint32_t item = it[i];
+            uint32_t pos = atomicAdd(&cnt[item & lowmask], 1u);
+            entries[pos] = (t * TILE + (item >> 9)) | (((item >> 8) & 1u) << 31);
+        }
+    }
+}
+
+// per-1024-bucket block histogram of (clamped) bucket sizes for the size ordering
+static __global__ void __launch_bounds__(1024)
+k_size_hist(const uint32_t* __restrict__ counts, uint32_t nb, uint32_t* __restrict__ blk_hist, uint32_t nblocks) {
+    __shared__ uint32_t hist[SIZE_BINS];
+    if (threadIdx.x < SIZE_BINS) hist[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nb) {
+        uint32_t cnt = counts[i];
+        atomicAdd(&hist[cnt < SIZE_BINS ? cnt : SIZE_BINS - 1], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < SIZE_BINS) blk_hist[(size_t)(SIZE_BINS - 1 - threadIdx.x) * nblocks + blockIdx.x] = hist[threadIdx.x];
+}
+
+// ONE THREAD PER BUCKET, buckets taken in size order so that the 64 lanes of a wave run the same trip count.
 template <class C>
 __global__ void __launch_bounds__(256)
 k_bucket_sum(const Affine<typename C::Fp>* __restrict__ pts, const uint32_t* __restrict__ entries,
              const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
-             XYZZ<typename C::Fp>* __restrict__ buckets, uint32_t nb) {
+             const uint32_t* __restrict__ order, XYZZ<typename C::Fp>* __restrict__ buckets, uint32_t nb) {
     using M = typename C::Fp;
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
+    uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= nb) return;
+    uint32_t b = order[tid];
     uint32_t cnt = counts[b];
     const uint32_t* e = entries + starts[b];
     XYZZ<M> acc = xyzz_inf<M>();
+    uint32_t ent = cnt ? e[0] : 0;
     for (uint32_t k = 0; k < cnt; k++) {
-        uint32_t ent = e[k];
-        Affine<M> a = load_affine<M>(pts, ent & 0x7fffffffu);
-        a = aff_neg_if<M>(a, (ent >> 31) != 0);
+        uint32_t cur = ent;
+        if (k + 1 < cnt) ent = e[k + 1];          // next index is in flight while this point is accumulated
+        Affine<M> a = load_affine<M>(pts, cur & 0x7fffffffu);
+        a = aff_neg_if<M>(a, (cur >> 31) != 0);
         xyzz_madd<M>(acc, a);
     }
     store_xyzz<M>(buckets + b, acc);

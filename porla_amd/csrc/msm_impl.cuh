@@ -2,6 +2,7 @@
 // (msm_bn254.hip, msm_secp256k1.hip) so that the two instantiations compile in parallel.
 #pragma once
 #include "engine.hpp"
+#include <cstdlib>
 #include "../../include/porla_gpu.h"
 
 namespace porla {
@@ -26,7 +27,8 @@ static int msm_core(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_po
     const int c = choose_window(n);
     const int W = (C::SCALAR_BITS + 1 + c - 1) / c;
     const uint32_t B = 1u << (c - 1);
-    const uint32_t L = B < 8 ? B : 8;
+    static const uint32_t Lenv = getenv("PORLA_REDUCE_L") ? (uint32_t)atoi(getenv("PORLA_REDUCE_L")) : 8;
+    const uint32_t L = B < Lenv ? B : Lenv;
     const uint32_t T = B / L;
     const uint32_t wavesPerWindow = (T + 63) / 64;
     const size_t nb = (size_t)W * B;
@@ -34,12 +36,17 @@ static int msm_core(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_po
 
     int rc;
     if (!d_points_mont) { if ((rc = ws->pts.ensure(n * sizeof(Affine<M>)))) return rc; }
-    if ((rc = ws->keys.ensure((size_t)W * n * 4))) return rc;
+    const uint32_t T_tiles = (uint32_t)((n + TILE - 1) / TILE);
+    if ((rc = ws->keys.ensure((size_t)W * T_tiles * TILE * 4))) return rc;   // keys (legacy) / tile_items
+    if ((rc = ws->tile_off.ensure((size_t)W * T_tiles * (MAX_PARTS + 1) * 2))) return rc;
     if ((rc = ws->entries.ensure((size_t)W * n * 4))) return rc;
     if ((rc = ws->counts.ensure(nb * 4))) return rc;
     if ((rc = ws->starts.ensure(nb * 4))) return rc;
     if ((rc = ws->fill.ensure(nb * 4))) return rc;
     if ((rc = ws->cursor.ensure(256))) return rc;
+    if ((rc = ws->order.ensure(nb * 4))) return rc;
+    if ((rc = ws->blk_hist.ensure((size_t)SIZE_BINS * ((nb + 1023) / 1024) * 4))) return rc;
+    if ((rc = ws->blk_off.ensure((size_t)SIZE_BINS * ((nb + 1023) / 1024) * 4))) return rc;
     if ((rc = ws->buckets.ensure(nb * sizeof(XYZZ<M>)))) return rc;
     if ((rc = ws->partial.ensure((size_t)W * wavesPerWindow * sizeof(XYZZ<M>)))) return rc;
     if ((rc = ws->windows.ensure((size_t)W * sizeof(XYZZ<M>)))) return rc;
@@ -50,7 +57,7 @@ static int msm_core(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_po
     }
 
     const Affine<M>* pts = d_points_mont;
-    PORLA_HIP(hipMemsetAsync(ws->counts.p, 0, nb * 4, stream));
+    if (g_legacy_sort) PORLA_HIP(hipMemsetAsync(ws->counts.p, 0, nb * 4, stream));
     PORLA_HIP(hipMemsetAsync(ws->cursor.p, 0, 4, stream));
     if (!pts) {
         ProfScope ps("points_to_mont", stream);
@@ -58,29 +65,59 @@ static int msm_core(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_po
                            (Affine<M>*)ws->pts.p, n32);
         pts = (const Affine<M>*)ws->pts.p;
     }
-    {
-        ProfScope ps("scalar_digits", stream);
-        hipLaunchKernelGGL((k_scalar_digits<C>), dim3((n32 + 255) / 256), dim3(256), 0, stream, d_scalars, n32, c, W,
-                           (uint32_t*)ws->keys.p, (uint32_t*)ws->counts.p);
+    const uint32_t nblk = (uint32_t)((nb + 1023) / 1024);
+    if (g_legacy_sort) {
+        {
+            ProfScope ps("scalar_digits", stream);
+            hipLaunchKernelGGL((k_scalar_digits<C>), dim3((n32 + 255) / 256), dim3(256), 0, stream, d_scalars, n32, c, W,
+                               (uint32_t*)ws->keys.p, (uint32_t*)ws->counts.p);
+        }
+        {
+            ProfScope ps("bucket_offsets", stream);
+            hipLaunchKernelGGL(k_bucket_offsets, dim3(nblk), dim3(1024), 0, stream, (const uint32_t*)ws->counts.p,
+                               (uint32_t*)ws->starts.p, (uint32_t*)ws->fill.p, (uint32_t)nb, (uint32_t*)ws->cursor.p,
+                               (uint32_t*)ws->blk_hist.p, nblk);
+        }
+        {
+            ProfScope ps("scatter", stream);
+            size_t tot = (size_t)W * n;
+            hipLaunchKernelGGL(k_scatter, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream,
+                               (const uint32_t*)ws->keys.p, n32, W, B, (const uint32_t*)ws->starts.p,
+                               (uint32_t*)ws->fill.p, (uint32_t*)ws->entries.p);
+        }
+    } else {
+        const int lowbits = (c - 1) < 8 ? (c - 1) : 8;
+        const int P = 1 << (c - 1 - lowbits);
+        {
+            ProfScope ps("digits_partition", stream);
+            hipLaunchKernelGGL((k_digits_partition<C>), dim3(T_tiles), dim3(TILE_THREADS), 0, stream, d_scalars, n32, c, W,
+                               lowbits, (uint32_t*)ws->keys.p, (uint16_t*)ws->tile_off.p);
+        }
+        {
+            ProfScope ps("partition_sort", stream);
+            hipLaunchKernelGGL(k_partition_sort, dim3((unsigned)(W * P)), dim3(256), 0, stream, (const uint32_t*)ws->keys.p,
+                               (const uint16_t*)ws->tile_off.p, T_tiles, c, lowbits, (uint32_t*)ws->counts.p,
+                               (uint32_t*)ws->starts.p, (uint32_t*)ws->entries.p, (uint32_t*)ws->cursor.p);
+        }
+        {
+            ProfScope ps("size_hist", stream);
+            hipLaunchKernelGGL(k_size_hist, dim3(nblk), dim3(1024), 0, stream, (const uint32_t*)ws->counts.p, (uint32_t)nb,
+                               (uint32_t*)ws->blk_hist.p, nblk);
+        }
     }
     {
-        ProfScope ps("bucket_offsets", stream);
-        hipLaunchKernelGGL(k_bucket_offsets, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, stream,
-                           (const uint32_t*)ws->counts.p, (uint32_t*)ws->starts.p, (uint32_t*)ws->fill.p,
-                           (uint32_t)nb, (uint32_t*)ws->cursor.p);
-    }
-    {
-        ProfScope ps("scatter", stream);
-        size_t tot = (size_t)W * n;
-        hipLaunchKernelGGL(k_scatter, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream,
-                           (const uint32_t*)ws->keys.p, n32, W, B, (const uint32_t*)ws->starts.p,
-                           (uint32_t*)ws->fill.p, (uint32_t*)ws->entries.p);
+        ProfScope ps("size_order", stream);
+        hipLaunchKernelGGL(k_size_scan, dim3(1), dim3(1024), 0, stream, (const uint32_t*)ws->blk_hist.p,
+                           (uint32_t*)ws->blk_off.p, (uint32_t)(SIZE_BINS * nblk));
+        hipLaunchKernelGGL(k_size_order, dim3(nblk), dim3(1024), 0, stream, (const uint32_t*)ws->counts.p, (uint32_t)nb,
+                           (const uint32_t*)ws->blk_off.p, nblk, (uint32_t*)ws->order.p);
     }
     {
         ProfScope ps("bucket_sum", stream);
         hipLaunchKernelGGL((k_bucket_sum<C>), dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, stream, pts,
                            (const uint32_t*)ws->entries.p, (const uint32_t*)ws->starts.p,
-                           (const uint32_t*)ws->counts.p, (XYZZ<M>*)ws->buckets.p, (uint32_t)nb);
+                           (const uint32_t*)ws->counts.p, (const uint32_t*)ws->order.p, (XYZZ<M>*)ws->buckets.p,
+                           (uint32_t)nb);
     }
     {
         ProfScope ps("bucket_reduce", stream);
