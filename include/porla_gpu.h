@@ -10,8 +10,12 @@
  *                            keep the (scalar, point) arrays resident in HBM (bench, multi-GPU sharding)
  *   porla_bn254_jac_sum      the partial-sum fold of range-sharded MSMs; the reference does the same fold
  *                            across its 8 pool threads with gej_add_var, porla/Client/Client.hpp:761-787
- *   porla_kzg_commit_batch   compute_digest_from_srs (main.go:103-116) hoisted over many rows
- *                            (callers Server.hpp:550-560, 1077-1078, 2061-2062)
+ *   porla_kzg_commit_batch_* compute_digest_from_srs (main.go:103-116) hoisted over many rows
+ *                            (callers Server.hpp:550-560, 1077-1078, 2061-2062); uses the SRS loaded by
+ *                            init_SRS / init_SRS_from_data of libmultiexp.h
+ *   porla_fixed_base_*       the same batched commitment against any fixed base: the IPA twin is the Pedersen
+ *                            commitment over the fixed generators[] (compute_commitment, Client.hpp:374-406,
+ *                            Server.hpp:329-361 -> secp256k1_ecmult_multi_var over 128 fixed points)
  *   porla_secp256k1_msm_*    secp256k1_ecmult_multi_var with g_sc = 0,
  *                            porla/Utils/secp256k1_lib/ecmult_impl.h:814-860 (call sites Server.hpp:842-848,
  *                            Client.hpp:395,778), reached through the include shim in INTEGRATION.md
@@ -67,6 +71,26 @@ int porla_secp256k1_msm_device_partial(const void *d_scalars, const void *d_poin
                                        uint8_t out_jacobian[96], void *hip_stream);
 int porla_secp256k1_msm_host(const uint8_t *scalars, const uint8_t *points, size_t n, uint8_t out_affine[64]);
 int porla_secp256k1_jac_sum(const uint8_t *jacobians, size_t count, uint8_t out_affine[64]);
+
+/* ---- batched fixed-base commitments ----
+ * out[r] = sum_{i < n_coeffs} (row_r[i] mod order) * base[i] for every row r, as 64-byte X||Y big-endian affine points.
+ * rows: coefficient i of row r at rows + r*row_stride + 32*i, 32 bytes big-endian (bn254_scalar, utils.h:307-318).
+ * The base is expanded once into a table of window multiples resident in HBM (window_bits c, 0 = automatic:
+ * 16, i.e. 4.3 GB for 128 BN254 points; shrunk until it fits a quarter of the free HBM); a commitment is then
+ * n_coeffs * ceil((bits+1)/c) mixed additions.  curve: 0 = BN254 G1, 1 = secp256k1. */
+typedef struct porla_fixed_base porla_fixed_base;
+int  porla_fixed_base_create(int curve, const uint8_t *points, size_t n_points, int window_bits, porla_fixed_base **out);
+int  porla_fixed_base_info(const porla_fixed_base *fb, int *window_bits, int *windows, unsigned long long *table_bytes);
+int  porla_fixed_base_commit_device(porla_fixed_base *fb, const void *d_rows, size_t n_rows, size_t n_coeffs,
+                                    size_t row_stride, void *d_out, void *hip_stream);
+int  porla_fixed_base_commit_host(porla_fixed_base *fb, const uint8_t *rows, size_t n_rows, size_t n_coeffs,
+                                  size_t row_stride, uint8_t *out);
+void porla_fixed_base_destroy(porla_fixed_base *fb);
+/* KZG: rows of n_samples coefficients (4096 bytes per row for NUM_CHUNKS = 128) against the resident SRS */
+int  porla_kzg_commit_batch_device(const void *d_rows, size_t n_rows, void *d_out, void *hip_stream);
+int  porla_kzg_commit_batch_host(const uint8_t *rows, size_t n_rows, uint8_t *out);
+/* window bits used when the SRS table is (re)built; 0 = automatic */
+int  porla_kzg_set_commit_window(int window_bits);
 
 /* ---- ICC encode (CRebuild_Cached data part + align_MAC scalar part) ----
  * rows_in : n_rows * n_cols elements, 32 bytes little-endian each (8 x uint32 LE words, utils.h:353-364; the layout

@@ -105,6 +105,24 @@ void oracle_bn254_multi_exp(const uint8_t *scalars, const uint8_t *points, size_
     g1_marshal_jac(out, &r);
     free(k); free(pts);
 }
+/* kzg.Commit row by row (compute_digest_from_srs, main.go:103-116, called per row at Server.hpp:550-560): out[r] =
+ * sum_i (row_r[i] mod r) * base[i]; one MSM per row (naive != 0: double-and-add sum), rows split over threads */
+void oracle_bn254_commit_batch(const uint8_t *rows, size_t n_rows, size_t n_coeffs, size_t row_stride,
+                               const uint8_t *base, uint8_t *out, int threads, int naive) {
+    bn_init();
+    aff_t *pts = (aff_t *)malloc(sizeof(aff_t) * (n_coeffs ? n_coeffs : 1));
+    for (size_t i = 0; i < n_coeffs; i++) g1_unmarshal(&pts[i], base + 64 * i);
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 4)
+    for (size_t r = 0; r < n_rows; r++) {
+        u256 *k = (u256 *)malloc(sizeof(u256) * (n_coeffs ? n_coeffs : 1));
+        for (size_t i = 0; i < n_coeffs; i++) fr_set_bytes(&k[i], rows + r * row_stride + 32 * i);
+        jac_t j;
+        if (naive) msm_naive(&BN, &j, k, pts, n_coeffs); else msm_pippenger(&BN, &j, k, pts, n_coeffs, 254, 1);
+        g1_marshal_jac(out + 64 * r, &j);
+        free(k);
+    }
+    free(pts);
+}
 /* add_point, main.go:195-202 (in place on a) */
 void oracle_bn254_add_point(uint8_t a[64], const uint8_t b[64]) {
     bn_init();

@@ -69,6 +69,24 @@ void oracle_secp256k1_multi(const uint8_t *scalars, const uint8_t *points, size_
     sk_point_out(out, &r);
     free(k); free(pts);
 }
+/* Pedersen commitment row by row (compute_commitment, Client.hpp:374-406 / Server.hpp:329-361: ecmult_multi_var of the
+ * 128 chunks of a block against the fixed generators): out[r] = sum_i row_r[i] * base[i] */
+void oracle_secp256k1_commit_batch(const uint8_t *rows, size_t n_rows, size_t n_coeffs, size_t row_stride,
+                                   const uint8_t *base, uint8_t *out, int threads, int naive) {
+    sk_init();
+    aff_t *pts = (aff_t *)malloc(sizeof(aff_t) * (n_coeffs ? n_coeffs : 1));
+    for (size_t i = 0; i < n_coeffs; i++) sk_point_in(&pts[i], base + 64 * i);
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 4)
+    for (size_t r = 0; r < n_rows; r++) {
+        u256 *k = (u256 *)malloc(sizeof(u256) * (n_coeffs ? n_coeffs : 1));
+        for (size_t i = 0; i < n_coeffs; i++) sk_scalar_in(&k[i], rows + r * row_stride + 32 * i);
+        jac_t j;
+        if (naive) msm_naive(&SK, &j, k, pts, n_coeffs); else msm_pippenger(&SK, &j, k, pts, n_coeffs, 256, 1);
+        sk_point_out(out + 64 * r, &j);
+        free(k);
+    }
+    free(pts);
+}
 /* R = na * A + ng * G  (secp256k1_ecmult, ecmult_impl.h:335-349) */
 void oracle_secp256k1_ecmult(const uint8_t a[64], const uint8_t na[32], const uint8_t ng[32], uint8_t out[64]) {
     sk_init();

@@ -134,9 +134,22 @@ static int abi_jac_sum(const uint8_t* jacs, size_t count, uint8_t* out) {
     return PORLA_OK;
 }
 
+hipStream_t engine_stream() {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    Workspace* ws;
+    if (get_workspace(&ws)) return nullptr;
+    return ws->own_stream;
+}
+
 }  // namespace porla
 
 using namespace porla;
+
+struct porla_fixed_base {
+    int curve;
+    FixedBase<Bn254G1> bn;
+    FixedBase<Secp256k1G> secp;
+};
 
 extern "C" {
 
@@ -193,6 +206,56 @@ int porla_secp256k1_msm_host(const uint8_t* scalars, const uint8_t* points, size
 }
 int porla_secp256k1_jac_sum(const uint8_t* jacs, size_t count, uint8_t out_affine[64]) {
     return abi_jac_sum<Secp256k1G>(jacs, count, out_affine);
+}
+
+int porla_fixed_base_create(int curve, const uint8_t* points, size_t n_points, int window_bits, porla_fixed_base** out) {
+    if (!out || (n_points && !points) || (curve != 0 && curve != 1)) { set_last_error("porla: bad argument"); return PORLA_ERR_ARG; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    hipStream_t s = engine_stream();
+    porla_fixed_base* fb = new porla_fixed_base();
+    fb->curve = curve;
+    rc = curve == 0 ? fb->bn.build_from_host_bytes(points, n_points, window_bits, s)
+                    : fb->secp.build_from_host_bytes(points, n_points, window_bits, s);
+    if (rc) { porla_fixed_base_destroy(fb); return rc; }
+    *out = fb;
+    return PORLA_OK;
+}
+int porla_fixed_base_info(const porla_fixed_base* fb, int* window_bits, int* windows, unsigned long long* table_bytes) {
+    if (!fb) return PORLA_ERR_ARG;
+    int c = fb->curve == 0 ? fb->bn.c : fb->secp.c, W = fb->curve == 0 ? fb->bn.W : fb->secp.W;
+    size_t n = fb->curve == 0 ? fb->bn.n_points : fb->secp.n_points;
+    if (window_bits) *window_bits = c;
+    if (windows) *windows = W;
+    if (table_bytes) *table_bytes = c ? (unsigned long long)n * W * ((size_t)1 << (c - 1)) * 64 : 0;
+    return PORLA_OK;
+}
+int porla_fixed_base_commit_device(porla_fixed_base* fb, const void* d_rows, size_t n_rows, size_t n_coeffs,
+                                   size_t row_stride, void* d_out, void* stream) {
+    if (!fb || (n_rows && (!d_rows || !d_out))) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    if (fb->curve == 0) {
+        std::lock_guard<std::mutex> lk(fb->bn.mu);
+        return fb->bn.commit_device((const uint8_t*)d_rows, n_rows, n_coeffs, row_stride, (uint8_t*)d_out, (hipStream_t)stream);
+    }
+    std::lock_guard<std::mutex> lk(fb->secp.mu);
+    return fb->secp.commit_device((const uint8_t*)d_rows, n_rows, n_coeffs, row_stride, (uint8_t*)d_out, (hipStream_t)stream);
+}
+int porla_fixed_base_commit_host(porla_fixed_base* fb, const uint8_t* rows, size_t n_rows, size_t n_coeffs,
+                                 size_t row_stride, uint8_t* out) {
+    if (!fb || (n_rows && (!rows || !out))) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    hipStream_t s = engine_stream();
+    if (fb->curve == 0) {
+        std::lock_guard<std::mutex> lk(fb->bn.mu);
+        return fb->bn.commit_host(rows, n_rows, n_coeffs, row_stride, out, s);
+    }
+    std::lock_guard<std::mutex> lk(fb->secp.mu);
+    return fb->secp.commit_host(rows, n_rows, n_coeffs, row_stride, out, s);
+}
+void porla_fixed_base_destroy(porla_fixed_base* fb) {
+    if (!fb) return;
+    fb->bn.release();
+    fb->secp.release();
+    delete fb;
 }
 
 }  // extern "C"

@@ -75,9 +75,35 @@ struct Workspace {
     size_t h_windows_cap = 0;
     hipStream_t own_stream = nullptr;
 };
+// Batched fixed-base commitments (fixed_base.cuh): resident table of window multiples of one base.
+// Calls on one object are serialised by `mu`; the *_device form leaves its kernels in flight on the caller's stream
+// (one stream per object at a time: the slice-partial scratch is shared between calls).
+template <class C>
+struct FixedBase {
+    int device = -1;
+    int c = 0, W = 0;
+    size_t n_points = 0;
+    Affine<typename C::Fp>* table = nullptr;
+    XYZZ<typename C::Fp>* partial = nullptr;
+    size_t partial_cap = 0;
+    uint8_t* io_rows = nullptr;
+    size_t io_rows_cap = 0;
+    uint8_t* io_out = nullptr;
+    size_t io_out_cap = 0;
+    std::mutex mu;
+    void release();
+    int build(const Affine<typename C::Fp>* d_base, size_t n, int window_bits, hipStream_t stream);
+    int build_from_host_bytes(const uint8_t* points_be, size_t n, int window_bits, hipStream_t stream);
+    int commit_device(const uint8_t* d_rows, size_t n_rows, size_t n_coeffs, size_t row_stride, uint8_t* d_out,
+                      hipStream_t stream);
+    int commit_host(const uint8_t* rows, size_t n_rows, size_t n_coeffs, size_t row_stride, uint8_t* out,
+                    hipStream_t stream);
+};
+
 extern std::mutex g_ws_mu;
 extern int g_window_override;
 extern int g_legacy_sort;  // PORLA_LEGACY_SORT=1: global-atomic counting sort (kept for A/B timing)
 int get_workspace(Workspace** out);
+hipStream_t engine_stream();  // this device's engine-owned non-blocking stream
 
 }  // namespace porla

@@ -207,13 +207,14 @@ PORLA_HD Fe<M> fe_sqr(const Fe<M>& a) { return fe_mul<M>(a, a); }
 // Out-of-line product: one shared ~2.7 KB body per field instead of an inlined copy per use.  The cold reduction
 // kernels chain dozens of group operations of 9-14 products each; fully inlined they exceed the instruction cache
 // (64 KB per CU pair), called they fit in a few KB.
+template <class M>
+__host__ __device__
 #if defined(__HIP_DEVICE_COMPILE__)
-template <class M>
-__device__ __noinline__ Fe<M> fe_mul_call(Fe<M> a, Fe<M> b) { return fe_mul<M>(a, b); }
+__noinline__
 #else
-template <class M>
-inline Fe<M> fe_mul_call(Fe<M> a, Fe<M> b) { return fe_mul<M>(a, b); }
+inline
 #endif
+Fe<M> fe_mul_call(Fe<M> a, Fe<M> b) { return fe_mul<M>(a, b); }
 // CALL = true -> out-of-line product
 template <class M, bool CALL>
 PORLA_HD Fe<M> fmul(const Fe<M>& a, const Fe<M>& b) {

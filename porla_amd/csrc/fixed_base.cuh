@@ -1,0 +1,261 @@
+// Batched fixed-base commitments on gfx950 (MI355X): many rows of coefficients against ONE resident base.
+//
+// This is what a large Porla encode actually executes: `compute_digest_from_srs`
+// (porla/main.go:103-116, kzg.Commit = 128-point MSM against the fixed SRS) is called twice per last-stage butterfly
+// and per `mix` output row (porla/Server/Server.hpp:550-560, 1077-1078, 2061-2062); the IPA twin is the Pedersen
+// commitment over the fixed generators (`compute_commitment`, porla/Client/Client.hpp:374-406 ->
+// secp256k1_ecmult_multi_var over 128 fixed points).  The reference runs one 128-point Pippenger/Strauss per row.
+//
+// MI355X-first design: the base never changes, HBM is 288 GB, so trade memory for arithmetic.  For every base point
+// G_i and every c-bit window w the table holds the affine multiples (k+1) * 2^(c*w) * G_i, k < 2^(c-1) (signed
+// digits halve the table).  A commitment is then n_coeffs * W mixed additions and NO doublings and NO bucket
+// pass: c = 16 -> 16 windows -> 2048 additions per 128-coefficient row (a per-row Pippenger needs ~8000 group
+// operations), table = 128 * 16 * 2^15 * 64 B = 4.3 GB.  One lane owns one row (optionally one slice of a row), so
+// the 64 lanes of a wave walk (i, w) in lock-step and their gathers fall into the same 2 MiB sub-table.
+//
+//   k_fb_base_powers   thread per base point: 2^(c*w) * G_i for all w (c*W dependent doublings)
+//   k_fb_multiples     thread per (pair, chunk): (j*K+1)*B by double-and-add, then K-1 additions of B -> XYZZ scratch
+//   k_fb_normalize     XYZZ -> affine with one inversion per 8 entries (Montgomery's trick) -> table
+//   k_fb_commit        lane = row (x slice): scalar -> reduce mod order -> signed digits -> gather + 8M+2S mixed add
+//   k_fb_finish        G lanes per row: fold the slice partials (sequential + wave-shuffle tree), one inversion,
+//                      Montgomery -> big-endian X||Y (64 zero bytes = infinity)
+#pragma once
+#include "msm.cuh"
+
+namespace porla {
+
+// ---------------------------------------------------------------- device-side inversion (Fermat, a^(p-2))
+template <class M>
+__device__ __noinline__ Fe<M> fe_inv_dev(Fe<M> a) {
+    // exponent p - 2, scanned from the top bit
+    Fe<M> acc = fe_one<M>();
+#pragma unroll
+    for (int l = 7; l >= 0; l--) {
+        const uint32_t limb = (l == 0) ? M::P[0] - 2u : M::P[l];  // P is odd and P[0] >= 2: no borrow past limb 0
+#pragma unroll 1
+        for (int b = 31; b >= 0; b--) {
+            acc = fe_mul_call<M>(acc, acc);
+            if ((limb >> b) & 1) acc = fe_mul_call<M>(acc, a);
+        }
+    }
+    return acc;
+}
+
+// XYZZ -> affine on the device (cold path): x = X * (ZZ*I)^2, y = Y * I with I = 1/ZZZ  (ZZ^3 = ZZZ^2)
+template <class M>
+__device__ __forceinline__ Affine<M> xyzz_to_affine_with_inv(const XYZZ<M>& p, const Fe<M>& inv_zzz) {
+    Affine<M> r;
+    Fe<M> t = fe_mul_call<M>(p.zz, inv_zzz);     // ZZ/ZZZ = 1/Z
+    Fe<M> t2 = fe_mul_call<M>(t, t);             // 1/ZZ
+    r.x = fe_mul_call<M>(p.x, t2);
+    r.y = fe_mul_call<M>(p.y, inv_zzz);
+    return r;
+}
+
+template <class M>
+__device__ __forceinline__ void store_affine(Affine<M>* dst, const Affine<M>& a) {
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+    store_fe<M>(d, a.x);
+    store_fe<M>(d + 8, a.y);
+}
+
+// ---------------------------------------------------------------- table construction
+// pow[i*W + w] = 2^(c*w) * base[i]
+template <class C>
+__global__ void __launch_bounds__(64)
+k_fb_base_powers(const Affine<typename C::Fp>* __restrict__ base, uint32_t n_points, int c, int W,
+                 XYZZ<typename C::Fp>* __restrict__ pow) {
+    using M = typename C::Fp;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_points) return;
+    XYZZ<M> p = xyzz_from_affine<M>(load_affine<M>(base, i));
+    for (int w = 0; w < W; w++) {
+        store_xyzz<M>(pow + (size_t)i * W + w, p);
+        if (w + 1 < W)
+            for (int d = 0; d < c; d++) xyzz_double_cold<M>(&p);
+    }
+}
+
+// scratch[(pair - pair0) * H + k] = (k+1) * pow[pair], k < H; thread = (pair, chunk of K consecutive k)
+template <class C>
+__global__ void __launch_bounds__(64)
+k_fb_multiples(const XYZZ<typename C::Fp>* __restrict__ pow, uint32_t pair0, uint32_t n_pairs, uint32_t H, uint32_t K,
+               XYZZ<typename C::Fp>* __restrict__ scratch) {
+    using M = typename C::Fp;
+    const uint32_t chunks = H / K;
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_pairs * chunks) return;
+    uint32_t pair = t / chunks, j = t % chunks;
+    XYZZ<M> Bp = load_xyzz<M>(pow + pair0 + pair);
+    // first = (j*K + 1) * B by left-to-right double-and-add
+    uint32_t m = j * K + 1;
+    XYZZ<M> acc = xyzz_inf<M>();
+    for (int bit = 31 - __clz(m); bit >= 0; bit--) {
+        xyzz_double_cold<M>(&acc);
+        if ((m >> bit) & 1) xyzz_add_cold<M>(&acc, &Bp);
+    }
+    XYZZ<M>* dst = scratch + (size_t)pair * H + (size_t)j * K;
+    for (uint32_t k = 0; k < K; k++) {
+        store_xyzz<M>(dst + k, acc);
+        if (k + 1 < K) xyzz_add_cold<M>(&acc, &Bp);
+    }
+}
+
+// table[k] = affine(scratch[k]); one inversion per NB entries
+template <class C>
+__global__ void __launch_bounds__(64)
+k_fb_normalize(const XYZZ<typename C::Fp>* __restrict__ scratch, size_t n, Affine<typename C::Fp>* __restrict__ table) {
+    using M = typename C::Fp;
+    constexpr int NB = 8;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t k0 = t * NB;
+    if (k0 >= n) return;
+    Fe<M> prefix[NB];
+    Fe<M> run = fe_one<M>();
+#pragma unroll 1
+    for (int k = 0; k < NB; k++) {
+        Fe<M> z = fe_one<M>();
+        if (k0 + k < n) {
+            z = load_fe<M>(reinterpret_cast<const uint32_t*>(scratch + k0 + k) + 24);  // zzz
+            if (fe_is_zero<M>(z)) z = fe_one<M>();
+        }
+        prefix[k] = run;
+        run = fe_mul_call<M>(run, z);
+    }
+    Fe<M> inv = fe_inv_dev<M>(run);
+#pragma unroll 1
+    for (int k = NB - 1; k >= 0; k--) {
+        if (k0 + k >= n) continue;
+        XYZZ<M> p = load_xyzz<M>(scratch + k0 + k);
+        Affine<M> a;
+        if (xyzz_is_inf<M>(p)) {
+            a.x = fe_zero<M>(); a.y = fe_zero<M>();
+        } else {
+            Fe<M> iz = fe_mul_call<M>(inv, prefix[k]);
+            inv = fe_mul_call<M>(inv, p.zzz);
+            a = xyzz_to_affine_with_inv<M>(p, iz);
+        }
+        store_affine<M>(table + k0 + k, a);
+    }
+}
+
+// ---------------------------------------------------------------- the commitment kernel
+// rows: row r, coefficient i at rows + r*row_stride + 32*i, 32 bytes big-endian (bn254_scalar, utils.h:307-318;
+//       fr.SetBytes semantics: reduced mod the group order, porla/main.go:110).
+// grid.x covers rows (lane = row), grid.y = slice s of the coefficient range; partial[r*S + s] = slice sum.
+template <class C>
+__global__ void __launch_bounds__(256)
+k_fb_commit(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_coeffs, size_t row_stride,
+            const Affine<typename C::Fp>* __restrict__ table, int c, int W, uint32_t S,
+            XYZZ<typename C::Fp>* __restrict__ partial) {
+    using M = typename C::Fp;
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t s = blockIdx.y;
+    if (r >= n_rows) return;
+    const uint32_t per = (n_coeffs + S - 1) / S;
+    const uint32_t i0 = s * per;
+    const uint32_t i1 = (i0 + per < n_coeffs) ? i0 + per : n_coeffs;
+    const uint32_t Bh = 1u << (c - 1);
+    const uint32_t mask = (1u << c) - 1;
+    const uint8_t* row = rows + (size_t)r * row_stride;
+    XYZZ<M> acc = xyzz_inf<M>();
+    for (uint32_t i = i0; i < i1; i++) {
+        uint32_t t[8];
+        load_be256(t, row + (size_t)i * 32);
+        for (int q = 0; q < C::MAX_Q; q++) {
+            uint32_t d[8];
+            uint32_t br = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                uint64_t x = (uint64_t)t[k] - C::ORDER[k] - br;
+                d[k] = (uint32_t)x;
+                br = (uint32_t)(x >> 63);
+            }
+            if (br) break;
+#pragma unroll
+            for (int k = 0; k < 8; k++) t[k] = d[k];
+        }
+        const Affine<M>* tab_i = table + (size_t)i * W * Bh;
+        uint32_t carry = 0;
+        // software pipeline: the gather of window w+1 is issued before the addition of window w
+        Affine<M> cur;
+        bool cur_valid = false, cur_neg = false;
+        for (int w = 0; w <= W; w++) {
+            Affine<M> nxt;
+            bool nxt_valid = false, nxt_neg = false;
+            if (w < W) {
+                const int lo = w * c;
+                uint32_t raw = 0;
+                if (lo < 256) {
+                    const int limb = lo >> 5, sh = lo & 31;
+                    uint32_t a = 0, b = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        a = (k == limb) ? t[k] : a;
+                        b = (k == limb + 1) ? t[k] : b;
+                    }
+                    uint64_t v = ((uint64_t)b << 32) | a;
+                    raw = (uint32_t)(v >> sh) & mask;
+                }
+                raw += carry;
+                uint32_t mag;
+                if (raw > Bh) { carry = 1; mag = (1u << c) - raw; nxt_neg = true; }
+                else { carry = 0; mag = raw; }
+                if (mag) {
+                    nxt_valid = true;
+                    nxt = load_affine<M>(tab_i + (size_t)w * Bh, mag - 1);
+                }
+            }
+            if (cur_valid) {
+                Affine<M> a = aff_neg_if<M>(cur, cur_neg);
+                xyzz_madd<M>(acc, a);
+            }
+            if (nxt_valid) cur = nxt;
+            cur_valid = nxt_valid;
+            cur_neg = nxt_neg;
+        }
+    }
+    store_xyzz<M>(partial + (size_t)r * S + s, acc);
+}
+
+// G lanes per row (G a power of two <= 64, G <= S or G == 1): fold S partials, normalise, marshal.
+template <class C>
+__global__ void __launch_bounds__(64)
+k_fb_finish(const XYZZ<typename C::Fp>* __restrict__ partial, uint32_t n_rows, uint32_t S, uint32_t G,
+            uint8_t* __restrict__ out) {
+    using M = typename C::Fp;
+    const uint32_t rows_per_wave = 64 / G;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t row = blockIdx.x * rows_per_wave + lane / G;
+    const uint32_t sub = lane % G;
+    XYZZ<M> acc = xyzz_inf<M>();
+    if (row < n_rows) {
+        for (uint32_t s = sub; s < S; s += G) {
+            XYZZ<M> p = load_xyzz<M>(partial + (size_t)row * S + s);
+            xyzz_add_cold<M>(&acc, &p);
+        }
+    }
+#pragma unroll 1
+    for (uint32_t m = G >> 1; m >= 1; m >>= 1) {
+        XYZZ<M> o = xyzz_shfl_xor<M>(acc, (int)m);
+        xyzz_add_cold<M>(&acc, &o);
+    }
+    if (sub == 0 && row < n_rows) {
+        uint8_t* dst = out + (size_t)row * 64;
+        if (xyzz_is_inf<M>(acc)) {
+            uint4 z = make_uint4(0, 0, 0, 0);
+            uint4* q = reinterpret_cast<uint4*>(dst);
+            q[0] = z; q[1] = z; q[2] = z; q[3] = z;
+        } else {
+            Fe<M> inv = fe_inv_dev<M>(acc.zzz);
+            Affine<M> a = xyzz_to_affine_with_inv<M>(acc, inv);
+            Fe<M> one = fe_zero<M>();
+            one.v[0] = 1;
+            Fe<M> x = fe_mul_call<M>(a.x, one), y = fe_mul_call<M>(a.y, one);  // out of Montgomery form
+            store_be256(dst, x.v);
+            store_be256(dst + 32, y.v);
+        }
+    }
+}
+
+}  // namespace porla

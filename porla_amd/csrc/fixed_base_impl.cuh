@@ -1,0 +1,168 @@
+// Host-side launch logic of the batched fixed-base commitment (fixed_base.cuh); included by the per-curve TUs.
+#pragma once
+#include "engine.hpp"
+#include "fixed_base.cuh"
+#include <cstdlib>
+
+namespace porla {
+
+template <class C>
+void FixedBase<C>::release() {
+    if (table) (void)hipFree(table);
+    if (partial) (void)hipFree(partial);
+    if (io_rows) (void)hipFree(io_rows);
+    if (io_out) (void)hipFree(io_out);
+    table = nullptr; partial = nullptr; io_rows = nullptr; io_out = nullptr;
+    partial_cap = io_rows_cap = io_out_cap = 0;
+    n_points = 0;
+}
+
+// Builds the multiples table for `n` base points (Montgomery affine, device memory).  window_bits = 0 -> automatic:
+// the largest c <= 16 whose table fits the memory budget (PORLA_COMMIT_WINDOW overrides).
+template <class C>
+int FixedBase<C>::build(const Affine<typename C::Fp>* d_base, size_t n, int window_bits, hipStream_t stream) {
+    using M = typename C::Fp;
+    release();
+    if (n == 0) return PORLA_OK;
+    int cc = window_bits;
+    if (cc <= 0) {
+        const char* e = getenv("PORLA_COMMIT_WINDOW");
+        cc = e ? atoi(e) : 16;
+    }
+    if (cc < 2) cc = 2;
+    if (cc > 20) cc = 20;
+    PORLA_HIP(hipGetDevice(&device));
+    size_t free_b = 0, total_b = 0;
+    PORLA_HIP(hipMemGetInfo(&free_b, &total_b));
+    for (;; cc--) {  // shrink the window until the table (plus its construction scratch) fits in a quarter of free HBM
+        int Wc = (C::SCALAR_BITS + 1 + cc - 1) / cc;
+        size_t bytes = n * (size_t)Wc * ((size_t)1 << (cc - 1)) * sizeof(Affine<M>);
+        if (bytes <= free_b / 4 || cc <= 4) break;
+    }
+    c = cc;
+    W = (C::SCALAR_BITS + 1 + c - 1) / c;
+    const uint32_t H = 1u << (c - 1);
+    const size_t pairs = n * (size_t)W;
+    const size_t entries = pairs * H;
+    PORLA_HIP(hipMalloc((void**)&table, entries * sizeof(Affine<M>)));
+    XYZZ<M>* pow = nullptr;
+    PORLA_HIP(hipMalloc((void**)&pow, pairs * sizeof(XYZZ<M>)));
+    // scratch: at most 1 GiB of XYZZ entries per batch of (point, window) pairs
+    size_t batch_pairs = ((size_t)1 << 30) / ((size_t)H * sizeof(XYZZ<M>));
+    if (batch_pairs < 1) batch_pairs = 1;
+    if (batch_pairs > pairs) batch_pairs = pairs;
+    XYZZ<M>* scratch = nullptr;
+    hipError_t e = hipMalloc((void**)&scratch, batch_pairs * H * sizeof(XYZZ<M>));
+    if (e != hipSuccess) { (void)hipFree(pow); return hip_fail(e, "hipMalloc(scratch)", __FILE__, __LINE__); }
+    {
+        ProfScope ps("fb_base_powers", stream);
+        hipLaunchKernelGGL((k_fb_base_powers<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_base, (uint32_t)n, c, W, pow);
+    }
+    const uint32_t K = H < 64 ? H : 64;
+    for (size_t p0 = 0; p0 < pairs; p0 += batch_pairs) {
+        size_t np = pairs - p0 < batch_pairs ? pairs - p0 : batch_pairs;
+        size_t threads = np * (H / K);
+        {
+            ProfScope ps("fb_multiples", stream);
+            hipLaunchKernelGGL((k_fb_multiples<C>), dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, stream,
+                               (const XYZZ<M>*)pow, (uint32_t)p0, (uint32_t)np, H, K, scratch);
+        }
+        size_t cnt = np * H;
+        {
+            ProfScope ps("fb_normalize", stream);
+            hipLaunchKernelGGL((k_fb_normalize<C>), dim3((unsigned)((cnt / 8 + 1 + 63) / 64)), dim3(64), 0, stream,
+                               (const XYZZ<M>*)scratch, cnt, table + p0 * H);
+        }
+    }
+    hipError_t e2 = hipStreamSynchronize(stream);
+    (void)hipFree(scratch);
+    (void)hipFree(pow);
+    if (e2 != hipSuccess) return hip_fail(e2, "fixed-base table construction", __FILE__, __LINE__);
+    PORLA_HIP(hipGetLastError());
+    n_points = n;
+    return PORLA_OK;
+}
+
+template <class C>
+int FixedBase<C>::commit_device(const uint8_t* d_rows, size_t n_rows, size_t n_coeffs, size_t row_stride, uint8_t* d_out,
+                                hipStream_t stream) {
+    using M = typename C::Fp;
+    if (n_rows == 0) return PORLA_OK;
+    if (!table || n_coeffs > n_points) { set_last_error("porla: fixed base not built / too few base points"); return PORLA_ERR_STATE; }
+    if (n_rows > 0xfffffff0u || n_coeffs > 0xffffu) { set_last_error("porla: commit batch too large"); return PORLA_ERR_ARG; }
+    if (n_coeffs == 0) { PORLA_HIP(hipMemsetAsync(d_out, 0, n_rows * 64, stream)); return PORLA_OK; }
+    // slices per row: enough lanes to fill 256 CUs x 4 SIMDs x 3 waves
+    static const size_t target = getenv("PORLA_COMMIT_LANES") ? (size_t)atol(getenv("PORLA_COMMIT_LANES")) : (size_t)196608;
+    uint32_t S = 1;
+    while ((size_t)n_rows * S < target && S * 2 <= n_coeffs && S < 128) S *= 2;
+    uint32_t G = S < 64 ? S : 64;
+    size_t need = n_rows * (size_t)S * sizeof(XYZZ<M>);
+    if (need > partial_cap) {
+        if (partial) PORLA_HIP(hipFree(partial));
+        partial = nullptr; partial_cap = 0;
+        PORLA_HIP(hipMalloc((void**)&partial, need + need / 8));
+        partial_cap = need + need / 8;
+    }
+    {
+        ProfScope ps("fb_commit", stream);
+        hipLaunchKernelGGL((k_fb_commit<C>), dim3((unsigned)((n_rows + 255) / 256), S), dim3(256), 0, stream, d_rows,
+                           (uint32_t)n_rows, (uint32_t)n_coeffs, row_stride, (const Affine<M>*)table, c, W, S, partial);
+    }
+    {
+        ProfScope ps("fb_finish", stream);
+        uint32_t rows_per_wave = 64 / G;
+        hipLaunchKernelGGL((k_fb_finish<C>), dim3((unsigned)((n_rows + rows_per_wave - 1) / rows_per_wave)), dim3(64), 0,
+                           stream, (const XYZZ<M>*)partial, (uint32_t)n_rows, S, G, d_out);
+    }
+    PORLA_HIP(hipGetLastError());
+    return PORLA_OK;
+}
+
+template <class C>
+int FixedBase<C>::commit_host(const uint8_t* rows, size_t n_rows, size_t n_coeffs, size_t row_stride, uint8_t* out,
+                              hipStream_t stream) {
+    if (n_rows == 0) return PORLA_OK;
+    size_t in_bytes = (n_rows - 1) * row_stride + n_coeffs * 32;
+    if (in_bytes > io_rows_cap) {
+        if (io_rows) PORLA_HIP(hipFree(io_rows));
+        io_rows = nullptr; io_rows_cap = 0;
+        PORLA_HIP(hipMalloc((void**)&io_rows, in_bytes + 256));
+        io_rows_cap = in_bytes + 256;
+    }
+    if (n_rows * 64 > io_out_cap) {
+        if (io_out) PORLA_HIP(hipFree(io_out));
+        io_out = nullptr; io_out_cap = 0;
+        PORLA_HIP(hipMalloc((void**)&io_out, n_rows * 64 + 256));
+        io_out_cap = n_rows * 64 + 256;
+    }
+    if (in_bytes) PORLA_HIP(hipMemcpyAsync(io_rows, rows, in_bytes, hipMemcpyHostToDevice, stream));
+    int rc = commit_device(io_rows, n_rows, n_coeffs, row_stride, io_out, stream);
+    if (rc) return rc;
+    PORLA_HIP(hipMemcpyAsync(out, io_out, n_rows * 64, hipMemcpyDeviceToHost, stream));
+    PORLA_HIP(hipStreamSynchronize(stream));
+    return PORLA_OK;
+}
+
+// base given as 64-byte big-endian affine points on the host (the reference's wire format)
+template <class C>
+int FixedBase<C>::build_from_host_bytes(const uint8_t* points_be, size_t n, int window_bits, hipStream_t stream) {
+    using M = typename C::Fp;
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n == 0) { release(); return PORLA_OK; }
+    uint8_t* d_in = nullptr;
+    Affine<M>* d_mont = nullptr;
+    PORLA_HIP(hipMalloc((void**)&d_in, n * 64));
+    hipError_t e = hipMalloc((void**)&d_mont, n * sizeof(Affine<M>));
+    if (e != hipSuccess) { (void)hipFree(d_in); return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
+    (void)hipMemcpyAsync(d_in, points_be, n * 64, hipMemcpyHostToDevice, stream);
+    hipLaunchKernelGGL((k_points_to_mont<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const uint8_t*)d_in,
+                       d_mont, (uint32_t)n);
+    rc = build(d_mont, n, window_bits, stream);
+    (void)hipStreamSynchronize(stream);
+    (void)hipFree(d_in);
+    (void)hipFree(d_mont);
+    return rc;
+}
+
+}  // namespace porla

@@ -33,6 +33,8 @@ struct KzgState {
     size_t d_srs_cap = 0;
     int d_srs_device = -1;
     bool d_srs_dirty = true;      // host copy changed since the last upload
+    FixedBase<Bn254G1> fb;        // window-multiples table of the SRS (fixed_base.cuh), rebuilt when the SRS changes
+    int commit_window = 0;        // 0 = automatic
     bool have_g2 = false;
     G2Affine g2[2];               // SRS.G2[0], SRS.G2[1]
     Affine<Fp> h_mac;             // MAC hiding base (main.go:28,58-59)
@@ -77,25 +79,41 @@ int upload_srs() {
     return PORLA_OK;
 }
 
-// kzg.Commit(f, srs) (main.go:114,164): MSM of len coefficients (32-byte BE each) against SRS.G1[:len]
-Affine<Fp> commit_gpu(const uint8_t* coeffs_be, size_t len, const char* where) {
+// make the HBM copies (Montgomery SRS + its window-multiples table) current; g.mu held by the caller
+int refresh_srs_locked() {
+    if (!g.d_srs_dirty) return PORLA_OK;
+    if (g.srs.empty()) return PORLA_ERR_STATE;
+    int rc = upload_srs();
+    if (rc) return rc;
+    hipStream_t s = engine_stream();
+    {
+        std::lock_guard<std::mutex> lk(g.fb.mu);
+        rc = g.fb.build(g.d_srs, g.srs.size(), g.commit_window, s);
+    }
+    if (rc) return rc;
+    g.d_srs_dirty = false;
+    return PORLA_OK;
+}
+
+// kzg.Commit(f, srs) (main.go:114,164) for `n_rows` coefficient rows: fixed-base table path, len <= n_samples
+int commit_rows(const uint8_t* rows, bool device_ptrs, size_t n_rows, size_t len, uint8_t* out, hipStream_t stream) {
     {
         std::lock_guard<std::mutex> lk(g.mu);
-        if (g.d_srs_dirty && !g.srs.empty()) {
-            int rc = upload_srs();
-            if (rc) die(where, rc);
-            g.d_srs_dirty = false;
+        int rc = refresh_srs_locked();
+        if (rc) {
+            if (rc == PORLA_ERR_STATE) set_last_error("porla: SRS not initialised (call init_SRS / init_SRS_from_data first)");
+            return rc;
         }
+        if (len > g.srs.size()) { set_last_error("porla: more coefficients than SRS points"); return PORLA_ERR_STATE; }
     }
-    if (!g.d_srs || len > g.srs.size()) {
-        fprintf(stderr, "libmultiexp (MI355X): %s: SRS not initialised (need %zu points, have %zu)\n", where, len,
-                g.srs.size());
-        abort();
-    }
-    XYZZ<Fp> tot;
-    int rc = msm_host_scalars<Bn254G1>(coeffs_be, g.d_srs, len, &tot);
+    std::lock_guard<std::mutex> lk(g.fb.mu);
+    if (device_ptrs) return g.fb.commit_device(rows, n_rows, len, len * 32, out, stream);
+    return g.fb.commit_host(rows, n_rows, len, len * 32, out, engine_stream());
+}
+
+void commit_gpu(const uint8_t* coeffs_be, size_t len, const char* where, uint8_t out[64]) {
+    int rc = commit_rows(coeffs_be, false, 1, len, out, nullptr);
     if (rc) die(where, rc);
-    return h_xyzz_to_affine<Fp>(tot);
 }
 
 void copy_out(GoSlice* dst, const uint8_t* src, size_t n) {  // Go copy(): min(len(dst), len(src))
@@ -211,7 +229,7 @@ void compute_digest_complement(GoSlice* data_in, GoSlice* data_out) {
 // main.go:103-116: kzg.Commit -- GPU MSM against the resident SRS
 void compute_digest_from_srs(GoSlice* data_in, GoSlice* data_out) {
     uint8_t out[64];
-    h_affine_to_bytes<Fp>(out, commit_gpu((const uint8_t*)data_in->data, (size_t)g.n_samples, "compute_digest_from_srs"));
+    commit_gpu((const uint8_t*)data_in->data, (size_t)g.n_samples, "compute_digest_from_srs", out);
     copy_out(data_out, out, 64);
 }
 
@@ -241,7 +259,7 @@ void create_proof(GoUint64 random_point, GoSlice* data_in, GoSlice* commitment_o
     const uint8_t* d = (const uint8_t*)data_in->data;
     size_t n = (size_t)g.n_samples;
     uint8_t buf[64];
-    h_affine_to_bytes<Fp>(buf, commit_gpu(d, n, "create_proof (commit)"));
+    commit_gpu(d, n, "create_proof (commit)", buf);
     copy_out(commitment_out, buf, 64);
 
     uint8_t zb[32] = {0};
@@ -258,7 +276,7 @@ void create_proof(GoUint64 random_point, GoSlice* data_in, GoSlice* commitment_o
         carry = fe_add<Fr>(fe_mul<Fr>(carry, z), f[i]);
         fr_plain_be(&hb[32 * (i - 1)], carry);
     }
-    h_affine_to_bytes<Fp>(buf, commit_gpu(hb.data(), n ? n - 1 : 0, "create_proof (open)"));
+    commit_gpu(hb.data(), n ? n - 1 : 0, "create_proof (open)", buf);
     copy_out(proof_H, buf, 64);
     uint8_t t[32];
     fr_plain_be(t, z); copy_out(proof_point, t, 32);
@@ -332,6 +350,25 @@ void neg_point(GoSlice* point) {
 void set_inf_point(GoSlice* point) {
     uint8_t out[64] = {0};
     copy_out(point, out, 64);
+}
+
+// ---- batched form of compute_digest_from_srs (include/porla_gpu.h) ----
+int porla_kzg_commit_batch_device(const void* d_rows, size_t n_rows, void* d_out, void* hip_stream) {
+    if (n_rows && (!d_rows || !d_out)) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    return commit_rows((const uint8_t*)d_rows, true, n_rows, (size_t)g.n_samples, (uint8_t*)d_out, (hipStream_t)hip_stream);
+}
+int porla_kzg_commit_batch_host(const uint8_t* rows, size_t n_rows, uint8_t* out) {
+    if (n_rows && (!rows || !out)) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    return commit_rows(rows, false, n_rows, (size_t)g.n_samples, out, nullptr);
+}
+int porla_kzg_set_commit_window(int window_bits) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (window_bits != g.commit_window) { g.commit_window = window_bits; g.d_srs_dirty = true; }
+    return PORLA_OK;
 }
 
 }  // extern "C"

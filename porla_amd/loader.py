@@ -62,6 +62,17 @@ def _declare(L):
         f = getattr(L, "porla_%s_msm_device_partial" % curve); f.argtypes = [vp, vp, sz, u8p, vp]; f.restype = ctypes.c_int
         f = getattr(L, "porla_%s_msm_host" % curve); f.argtypes = [u8p, u8p, sz, u8p]; f.restype = ctypes.c_int
         f = getattr(L, "porla_%s_jac_sum" % curve); f.argtypes = [u8p, sz, u8p]; f.restype = ctypes.c_int
+    L.porla_fixed_base_create.argtypes = [ctypes.c_int, u8p, sz, ctypes.c_int, ctypes.POINTER(vp)]
+    L.porla_fixed_base_create.restype = ctypes.c_int
+    L.porla_fixed_base_info.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                        ctypes.POINTER(ctypes.c_ulonglong)]
+    L.porla_fixed_base_info.restype = ctypes.c_int
+    L.porla_fixed_base_commit_device.argtypes = [vp, vp, sz, sz, sz, vp, vp]; L.porla_fixed_base_commit_device.restype = ctypes.c_int
+    L.porla_fixed_base_commit_host.argtypes = [vp, u8p, sz, sz, sz, u8p]; L.porla_fixed_base_commit_host.restype = ctypes.c_int
+    L.porla_fixed_base_destroy.argtypes = [vp]; L.porla_fixed_base_destroy.restype = None
+    L.porla_kzg_commit_batch_device.argtypes = [vp, sz, vp, vp]; L.porla_kzg_commit_batch_device.restype = ctypes.c_int
+    L.porla_kzg_commit_batch_host.argtypes = [u8p, sz, u8p]; L.porla_kzg_commit_batch_host.restype = ctypes.c_int
+    L.porla_kzg_set_commit_window.argtypes = [ctypes.c_int]; L.porla_kzg_set_commit_window.restype = ctypes.c_int
     L.porla_icc_encode_device.argtypes = [vp, sz, sz, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_int, vp, vp, vp, ctypes.c_int, vp]
     L.porla_icc_encode_device.restype = ctypes.c_int
     L.porla_icc_encode_host.argtypes = [u8p, sz, sz, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_int, vp, vp, vp, ctypes.c_int]

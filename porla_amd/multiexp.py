@@ -161,6 +161,55 @@ def jac_sum(curve, jacobians, count):
     return out.raw
 
 
+# ---- batched fixed-base commitments (include/porla_gpu.h) ------------------------------------------
+CURVES = {"bn254": 0, "secp256k1": 1}
+
+
+class FixedBase:
+    """Resident window-multiples table of a fixed base; commit() = compute_digest_from_srs / compute_commitment
+    hoisted over many rows (Server.hpp:550-560, Client.hpp:374-406)."""
+
+    def __init__(self, curve, points, n_points, window_bits=0):
+        self.h = ctypes.c_void_p()
+        _check(lib.porla_fixed_base_create(CURVES[curve], bytes(points), n_points, window_bits, ctypes.byref(self.h)))
+
+    def info(self):
+        c, w, b = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_ulonglong(0)
+        _check(lib.porla_fixed_base_info(self.h, ctypes.byref(c), ctypes.byref(w), ctypes.byref(b)))
+        return {"window_bits": c.value, "windows": w.value, "table_bytes": b.value}
+
+    def commit_host(self, rows, n_rows, n_coeffs, row_stride=None):
+        out = ctypes.create_string_buffer(64 * max(n_rows, 1))
+        _check(lib.porla_fixed_base_commit_host(self.h, bytes(rows), n_rows, n_coeffs, row_stride or 32 * n_coeffs, out))
+        return out.raw[:64 * n_rows]
+
+    def commit_device(self, d_rows, n_rows, n_coeffs, d_out, stream=0, row_stride=None):
+        _check(lib.porla_fixed_base_commit_device(self.h, ctypes.c_void_p(d_rows), n_rows, n_coeffs,
+                                                  row_stride or 32 * n_coeffs, ctypes.c_void_p(d_out),
+                                                  ctypes.c_void_p(stream)))
+
+    def close(self):
+        if self.h:
+            lib.porla_fixed_base_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def kzg_commit_batch_host(rows, n_rows):
+    out = ctypes.create_string_buffer(64 * max(n_rows, 1))
+    _check(lib.porla_kzg_commit_batch_host(bytes(rows), n_rows, out))
+    return out.raw[:64 * n_rows]
+
+
+def kzg_commit_batch_device(d_rows, n_rows, d_out, stream=0):
+    _check(lib.porla_kzg_commit_batch_device(ctypes.c_void_p(d_rows), n_rows, ctypes.c_void_p(d_out), ctypes.c_void_p(stream)))
+
+
 def profile_enable(on=True):
     lib.porla_gpu_profile_enable(1 if on else 0)
 

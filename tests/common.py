@@ -103,3 +103,12 @@ def oracle_secp_msm(scalars, points, n, naive=False, threads=None):
     out = ctypes.create_string_buffer(64)
     oracle().oracle_secp256k1_multi(bytes(scalars), bytes(points), ctypes.c_size_t(n), out, threads or ncpu(), 1 if naive else 0)
     return out.raw
+
+
+def oracle_commit_batch(curve, rows, n_rows, n_coeffs, base, row_stride=None, naive=False, threads=None):
+    """row-by-row commitments against a fixed base (compute_digest_from_srs / compute_commitment restatement)"""
+    out = ctypes.create_string_buffer(64 * max(n_rows, 1))
+    fn = getattr(oracle(), "oracle_%s_commit_batch" % curve)
+    fn(bytes(rows), ctypes.c_size_t(n_rows), ctypes.c_size_t(n_coeffs), ctypes.c_size_t(row_stride or 32 * n_coeffs),
+       bytes(base), out, threads or ncpu(), 1 if naive else 0)
+    return out.raw[:64 * n_rows]

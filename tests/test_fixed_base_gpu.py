@@ -1,0 +1,163 @@
+"""Parity of the batched fixed-base commitment kernels (porla_amd/csrc/fixed_base.cuh) against the oracle, through the
+C ABI (GPU box only).
+
+What the reference does row by row: compute_digest_from_srs (porla/main.go:103-116; callers
+porla/Server/Server.hpp:550-560, 1077-1078, 2061-2062) and, for IPA, compute_commitment
+(porla/Client/Client.hpp:374-406 -> secp256k1_ecmult_multi_var over the fixed generators).  Bar: bit-exact 64-byte
+points for every row.
+"""
+import hashlib
+
+import pytest
+
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+R = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+TAU = bytes.fromhex("ffeeddccbbaa99887766554433221100")     # TAU_KEY, config.hpp:39
+ALPHA = bytes.fromhex("00112233445566778899aabbccddeeff")   # SECRET_KEY, config.hpp:38
+
+
+@pytest.fixture(scope="module")
+def mx():
+    from porla_amd import multiexp
+    return multiexp
+
+
+def rows_bytes(n_rows, n_coeffs, seed=b"porla-row"):
+    return b"".join(hashlib.sha256(seed + i.to_bytes(4, "little")).digest() for i in range(n_rows * n_coeffs))
+
+
+@pytest.fixture(scope="module")
+def srs128(mx):
+    """the Porla SRS (n = NUM_CHUNKS = 128) as raw 64-byte points, from the oracle's KZG state"""
+    import ctypes
+    o = common.oracle()
+    o.oracle_kzg_init_key(TAU, ctypes.c_size_t(len(TAU)), ALPHA, ctypes.c_size_t(len(ALPHA)))
+    o.oracle_kzg_init_srs(ctypes.c_size_t(128), (1).to_bytes(32, "big"))
+    raw = ctypes.create_string_buffer(64 * 128)
+    o.oracle_kzg_srs_g1_raw(raw)
+    return raw.raw
+
+
+@pytest.mark.parametrize("c", [4, 8, 11, 13])
+@pytest.mark.parametrize("n_rows", [1, 3, 70])
+def test_bn254_commit_matches_oracle_every_window(mx, srs128, c, n_rows):
+    """every table window width x the slice/lane configurations (1 row -> 128 slices, 70 rows -> 128 slices, ...)"""
+    fb = mx.FixedBase("bn254", srs128, 128, window_bits=c)
+    assert fb.info()["window_bits"] == c
+    rows = rows_bytes(n_rows, 128, b"w%d" % c)
+    got = fb.commit_host(rows, n_rows, 128)
+    assert got == common.oracle_commit_batch("bn254", rows, n_rows, 128, srs128)
+    fb.close()
+
+
+def test_bn254_commit_edge_scalars_and_short_rows(mx, srs128):
+    """zero / r-1 / r / 2^256-1 coefficients (SetBytes reduction, main.go:110), all-zero row -> 64 zero bytes,
+    n_coeffs < n_points (the 127-coefficient quotient of create_proof, main.go:164-170), padded row stride"""
+    fb = mx.FixedBase("bn254", srs128, 128, window_bits=9)
+    vals = [0, 1, 2, R - 1, R, R + 1, (1 << 256) - 1, 1 << 128, (1 << 255) + 12345, 5 * R, 5 * R + 7, 1 << 253]
+    row0 = b"".join(vals[i % len(vals)].to_bytes(32, "big") for i in range(128))
+    row1 = bytes(32 * 128)
+    row2 = (R - 1).to_bytes(32, "big") * 128
+    rows = row0 + row1 + row2
+    got = fb.commit_host(rows, 3, 128)
+    assert got == common.oracle_commit_batch("bn254", rows, 3, 128, srs128, naive=True)
+    assert got[64:128] == bytes(64)
+    got127 = fb.commit_host(rows, 3, 127, row_stride=4096)
+    assert got127 == common.oracle_commit_batch("bn254", rows, 3, 127, srs128, row_stride=4096)
+    assert got127 != got
+    fb.close()
+
+
+def test_bn254_base_with_infinity_and_repeats(mx, srs128):
+    """a base holding the point at infinity and a repeated point (tau = 0 would give G1[i>0] = O)"""
+    base = srs128[:64] + bytes(64) + srs128[:64] + srs128[64:128]
+    fb = mx.FixedBase("bn254", base, 4, window_bits=6)
+    rows = rows_bytes(5, 4, b"inf")
+    assert fb.commit_host(rows, 5, 4) == common.oracle_commit_batch("bn254", rows, 5, 4, base, naive=True)
+    fb.close()
+
+
+def test_kzg_batch_equals_per_row_calls(mx, srs128):
+    """porla_kzg_commit_batch_host over R rows == R calls of the reference symbol compute_digest_from_srs"""
+    mx.init_key(TAU, ALPHA)
+    blob = mx.init_SRS(128)
+    mx.init_SRS_from_data(128, blob)
+    n_rows = 9
+    rows = rows_bytes(n_rows, 128, b"kzg")
+    got = mx.kzg_commit_batch_host(rows, n_rows)
+    want = common.oracle_commit_batch("bn254", rows, n_rows, 128, srs128)
+    assert got == want
+    for r in (0, 4, 8):
+        assert mx.compute_digest_from_srs(rows[4096 * r:4096 * r + 4096]) == want[64 * r:64 * r + 64]
+
+
+def test_bn254_device_rows_large_batch_default_window(mx, srs128):
+    """device-resident rows, default (largest) window, 4096 rows; spot rows against the naive oracle too"""
+    import torch
+    fb = mx.FixedBase("bn254", srs128, 128)
+    info = fb.info()
+    assert info["window_bits"] >= 8
+    n_rows = 4096
+    rows = rows_bytes(n_rows, 128, b"big")
+    d_rows = torch.frombuffer(bytearray(rows), dtype=torch.uint8).cuda()
+    d_out = torch.empty(64 * n_rows, dtype=torch.uint8, device="cuda")
+    fb.commit_device(d_rows.data_ptr(), n_rows, 128, d_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = bytes(d_out.cpu().numpy())
+    want = common.oracle_commit_batch("bn254", rows, n_rows, 128, srs128)
+    assert got == want
+    assert got[:128] == common.oracle_commit_batch("bn254", rows, 2, 128, srs128, naive=True)
+    fb.close()
+
+
+def test_linearity_at_full_row_count(mx, srs128):
+    """size-independent property at a batch the oracle cannot finish in seconds: Commit(a) + Commit(b) == Commit(a + b
+    mod r) row-wise, checked by a second commitment and the engine's own add_point on sampled rows"""
+    import torch
+    fb = mx.FixedBase("bn254", srs128, 128)
+    n_rows = 1 << 15
+    a = rows_bytes(n_rows, 128, b"lin-a")
+    b = rows_bytes(n_rows, 128, b"lin-b")
+    d_a = torch.frombuffer(bytearray(a), dtype=torch.uint8).cuda()
+    d_b = torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda()
+    d_oa = torch.empty(64 * n_rows, dtype=torch.uint8, device="cuda")
+    d_ob = torch.empty(64 * n_rows, dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    fb.commit_device(d_a.data_ptr(), n_rows, 128, d_oa.data_ptr(), s)
+    fb.commit_device(d_b.data_ptr(), n_rows, 128, d_ob.data_ptr(), s)
+    torch.cuda.synchronize()
+    oa, ob = bytes(d_oa.cpu().numpy()), bytes(d_ob.cpu().numpy())
+    sample = [0, 1, 777, n_rows // 2, n_rows - 1]
+    srows = b""
+    for r in sample:
+        for i in range(128):
+            x = int.from_bytes(a[4096 * r + 32 * i:4096 * r + 32 * i + 32], "big")
+            y = int.from_bytes(b[4096 * r + 32 * i:4096 * r + 32 * i + 32], "big")
+            srows += ((x + y) % R).to_bytes(32, "big")
+    sums = fb.commit_host(srows, len(sample), 128)
+    for k, r in enumerate(sample):
+        assert mx.bn254_add(oa[64 * r:64 * r + 64], ob[64 * r:64 * r + 64]) == sums[64 * k:64 * k + 64]
+    # and the sampled rows themselves against the oracle
+    for r in sample:
+        assert oa[64 * r:64 * r + 64] == common.oracle_commit_batch("bn254", a[4096 * r:4096 * r + 4096], 1, 128, srs128)
+    fb.close()
+
+
+@pytest.mark.parametrize("c", [5, 12])
+def test_secp256k1_pedersen_commit(mx, c):
+    """IPA twin: 128 fixed generators (here 2^i * G as in bench_ecmult.c:328-337), rows of 256-bit chunks incl. values >= n"""
+    base = common.secp_bench_points(128)
+    fb = mx.FixedBase("secp256k1", base, 128, window_bits=c)
+    n_rows = 6
+    rows = bytearray(rows_bytes(n_rows, 128, b"secp"))
+    rows[0:32] = (common.SECP_N + 5).to_bytes(32, "big")
+    rows[32:64] = ((1 << 256) - 1).to_bytes(32, "big")
+    rows[64:96] = bytes(32)
+    rows[96:128] = (common.SECP_N - 1).to_bytes(32, "big")
+    got = fb.commit_host(bytes(rows), n_rows, 128)
+    assert got == common.oracle_commit_batch("secp256k1", bytes(rows), n_rows, 128, base)
+    assert got[:64] == common.oracle_commit_batch("secp256k1", bytes(rows), 1, 128, base, naive=True)
+    fb.close()
