@@ -85,7 +85,6 @@ void prof_flush() {
 std::mutex g_ws_mu;  // serialises MSM calls (compute_digest_from_srs may be called from 8 threads)
 static std::vector<Workspace*> g_ws;
 int g_window_override = 0;
-int g_legacy_sort = getenv("PORLA_LEGACY_SORT") && getenv("PORLA_LEGACY_SORT")[0] == '1';
 
 int get_workspace(Workspace** out) {
     int dev = 0;

@@ -70,7 +70,7 @@ struct Buf {
 struct Workspace {
     int device = -1;
     Buf pts, keys, entries, counts, starts, fill, cursor, buckets, partial, windows, in_scalars, in_points;
-    Buf order, blk_hist, blk_off, tile_off;
+    Buf order, blk_hist, blk_off, tile_off, heavy, chunk_out;
     void* h_windows = nullptr;  // pinned
     size_t h_windows_cap = 0;
     hipStream_t own_stream = nullptr;
@@ -102,7 +102,6 @@ struct FixedBase {
 
 extern std::mutex g_ws_mu;
 extern int g_window_override;
-extern int g_legacy_sort;  // PORLA_LEGACY_SORT=1: global-atomic counting sort (kept for A/B timing)
 int get_workspace(Workspace** out);
 hipStream_t engine_stream();  // this device's engine-owned non-blocking stream
 

@@ -1,0 +1,133 @@
+// Host tail of the MSM in 4 x 64-bit limbs: the Horner fold of the W window sums (W*c dependent doublings + W additions)
+// is a purely sequential chain, so it runs on one host core -- with 64x64->128 products it costs ~60 us instead of the
+// ~270 us of the portable 8 x 32-bit code shared with the device.  Same Montgomery radix (R = 2^256) as fe.cuh, so
+// elements convert by repacking limbs.  The reference does this fold inside gnark's MultiExp / at the end of
+// secp256k1_ecmult_pippenger_wnaf (porla/Utils/secp256k1_lib/ecmult_impl.h:544-564).
+#pragma once
+#include "ec.cuh"
+
+namespace porla {
+
+template <class M>
+struct Fp64 {
+    typedef unsigned __int128 u128;
+    uint64_t p[4];
+    uint64_t inv;  // -p^-1 mod 2^64
+    Fp64() {
+        for (int i = 0; i < 4; i++) p[i] = ((uint64_t)M::P[2 * i + 1] << 32) | M::P[2 * i];
+        uint64_t x = 1;  // Newton: x <- x * (2 - p0 * x), doubles the number of correct low bits
+        for (int i = 0; i < 6; i++) x *= 2 - p[0] * x;
+        inv = 0 - x;
+    }
+    struct E { uint64_t v[4]; };
+
+    static E from(const Fe<M>& a) {
+        E r;
+        for (int i = 0; i < 4; i++) r.v[i] = ((uint64_t)a.v[2 * i + 1] << 32) | a.v[2 * i];
+        return r;
+    }
+    static Fe<M> to(const E& a) {
+        Fe<M> r;
+        for (int i = 0; i < 4; i++) { r.v[2 * i] = (uint32_t)a.v[i]; r.v[2 * i + 1] = (uint32_t)(a.v[i] >> 32); }
+        return r;
+    }
+    static bool is_zero(const E& a) { return (a.v[0] | a.v[1] | a.v[2] | a.v[3]) == 0; }
+
+    // t - p if t >= p (t given with an extra carry word)
+    E cond_sub(const uint64_t t[4], uint64_t carry) const {
+        uint64_t s[4];
+        u128 br = 0;
+        for (int i = 0; i < 4; i++) {
+            u128 d = (u128)t[i] - p[i] - (uint64_t)br;
+            s[i] = (uint64_t)d;
+            br = (d >> 64) & 1;
+        }
+        E r;
+        bool ge = carry != 0 || br == 0;
+        for (int i = 0; i < 4; i++) r.v[i] = ge ? s[i] : t[i];
+        return r;
+    }
+    E add(const E& a, const E& b) const {
+        uint64_t t[4];
+        u128 c = 0;
+        for (int i = 0; i < 4; i++) { c += (u128)a.v[i] + b.v[i]; t[i] = (uint64_t)c; c >>= 64; }
+        return cond_sub(t, (uint64_t)c);
+    }
+    E sub(const E& a, const E& b) const {
+        uint64_t t[4];
+        u128 br = 0;
+        for (int i = 0; i < 4; i++) {
+            u128 d = (u128)a.v[i] - b.v[i] - (uint64_t)br;
+            t[i] = (uint64_t)d;
+            br = (d >> 64) & 1;
+        }
+        E r;
+        u128 c = 0;
+        uint64_t mask = 0 - (uint64_t)br;
+        for (int i = 0; i < 4; i++) { c += (u128)t[i] + (p[i] & mask); r.v[i] = (uint64_t)c; c >>= 64; }
+        return r;
+    }
+    // CIOS Montgomery product
+    E mul(const E& a, const E& b) const {
+        uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 4; i++) {
+            u128 c = 0;
+            for (int j = 0; j < 4; j++) { c += (u128)a.v[j] * b.v[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+            c += t[4]; t[4] = (uint64_t)c; t[5] = (uint64_t)(c >> 64);
+            uint64_t m = t[0] * inv;
+            c = (u128)m * p[0] + t[0];
+            c >>= 64;
+            for (int j = 1; j < 4; j++) { c += (u128)m * p[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+            c += t[4]; t[3] = (uint64_t)c; t[4] = t[5] + (uint64_t)(c >> 64);
+        }
+        return cond_sub(t, t[4]);
+    }
+
+    struct Pt { E x, y, zz, zzz; };
+    Pt from(const XYZZ<M>& q) const { Pt r; r.x = from(q.x); r.y = from(q.y); r.zz = from(q.zz); r.zzz = from(q.zzz); return r; }
+    XYZZ<M> to(const Pt& q) const { XYZZ<M> r; r.x = to(q.x); r.y = to(q.y); r.zz = to(q.zz); r.zzz = to(q.zzz); return r; }
+    Pt inf() const { Pt r; r.x = from(fe_one<M>()); r.y = r.x; r.zz = from(fe_zero<M>()); r.zzz = r.zz; return r; }
+
+    // dbl-2008-s-1 (a = 0), same formulas as xyzz_double in ec.cuh
+    Pt dbl(const Pt& q) const {
+        if (is_zero(q.zz) || is_zero(q.y)) return inf();
+        Pt r;
+        E U = add(q.y, q.y), V = mul(U, U), W = mul(U, V), S = mul(q.x, V), XX = mul(q.x, q.x);
+        E Mm = add(add(XX, XX), XX);
+        r.x = sub(sub(mul(Mm, Mm), S), S);
+        r.y = sub(mul(Mm, sub(S, r.x)), mul(W, q.y));
+        r.zz = mul(V, q.zz);
+        r.zzz = mul(W, q.zzz);
+        return r;
+    }
+    // add-2008-s, all exceptional cases as xyzz_add in ec.cuh
+    Pt padd(const Pt& a, const Pt& b) const {
+        if (is_zero(b.zz)) return a;
+        if (is_zero(a.zz)) return b;
+        E U1 = mul(a.x, b.zz), U2 = mul(b.x, a.zz), S1 = mul(a.y, b.zzz), S2 = mul(b.y, a.zzz);
+        E Pp = sub(U2, U1), Rr = sub(S2, S1);
+        if (is_zero(Pp)) return is_zero(Rr) ? dbl(a) : inf();
+        E PP = mul(Pp, Pp), PPP = mul(Pp, PP), Q = mul(U1, PP);
+        Pt r;
+        r.x = sub(sub(sub(mul(Rr, Rr), PPP), Q), Q);
+        r.y = sub(mul(Rr, sub(Q, r.x)), mul(S1, PPP));
+        r.zz = mul(mul(a.zz, b.zz), PP);
+        r.zzz = mul(mul(a.zzz, b.zzz), PPP);
+        return r;
+    }
+};
+
+// total = sum_w 2^(c*w) * win[w]
+template <class M>
+inline XYZZ<M> h_fold_windows64(const XYZZ<M>* win, int W, int c) {
+    static const Fp64<M> F;
+    typename Fp64<M>::Pt acc = F.inf();
+    for (int w = W - 1; w >= 0; w--) {
+        if (!Fp64<M>::is_zero(acc.zz))
+            for (int d = 0; d < c; d++) acc = F.dbl(acc);
+        acc = F.padd(acc, F.from(win[w]));
+    }
+    return F.to(acc);
+}
+
+}  // namespace porla

@@ -7,20 +7,20 @@
 // per window; libsecp256k1: GLV + wNAF + buckets, single thread) fix WHAT is computed
 // (sum (s_i mod order) * P_i); the decomposition below is designed for 256 CUs:
 //
-//   k_points_to_mont   64-B big-endian affine -> Montgomery limbs (one coalesced pass, 64 B in / 64 B out)
-//   k_scalar_digits    32-B big-endian scalar -> reduce mod order -> signed c-bit digits; per-(window,bucket)
-//                      histogram with device-scope atomics
-//   k_bucket_offsets   one slot range per bucket (wave prefix + one cursor atomic per wave; bucket order in
-//                      memory is irrelevant, so no global scan is needed) + per-block histogram of bucket sizes
-//   k_size_scan/order  counting sort of the buckets BY SIZE (descending): k_bucket_sum takes buckets in that order so
-//                      the 64 lanes of a wave run (almost) the same number of additions
-//   k_scatter          counting-sort scatter of point indices into their bucket's range
-//   k_bucket_sum       ONE THREAD PER BUCKET: walks its index list, gathers 64-B points (L2 / Infinity-Cache
-//                      resident: 2^20 points = 64 MiB) and accumulates with the 8M+2S mixed add
-//   k_bucket_reduce    per window sum_b (b+1)*B_b: per-thread running sums over L buckets, small scalar
-//                      multiple for the segment offset, wave-shuffle tree
-//   k_window_reduce    one wave per window folds the per-wave partials
-//   host               Horner over the W window sums (W*c doublings), affine normalisation, marshal
+//   k_points_to_mont    64-B big-endian affine -> Montgomery limbs (one coalesced pass, 64 B in / 64 B out)
+//   k_digits_partition  32-B big-endian scalar -> reduce mod order -> signed c-bit digits, grouped per 4096-scalar tile
+//                       by bucket partition in LDS (no global atomics)
+//   k_partition_sort    block per (window, partition): LDS counting sort -> counts/starts per bucket + point indices
+//                       grouped by bucket (coalesced reads of the tile runs)
+//   k_size_hist/scan/order  work items (<= CHUNK entries of one bucket) counting-sorted BY SIZE, largest first, so the 64
+//                       lanes of a wave run the same trip count; a heavy bucket becomes many items (skew-proof)
+//   k_bucket_sum        ONE THREAD PER WORK ITEM: walks its index list, gathers 64-B points (L2 / Infinity-Cache
+//                       resident: 2^20 points = 64 MiB) and accumulates with the 8M+2S mixed add
+//   k_bucket_combine    wave per multi-item bucket: folds that bucket's item sums (no-op for uniform scalars)
+//   k_bucket_reduce     per window sum_b (b+1)*B_b: per-thread running sums over L buckets, small scalar
+//                       multiple for the segment offset, wave-shuffle tree
+//   k_window_reduce     one wave per window folds the per-wave partials
+//   host                Horner over the W window sums (W*c doublings), affine normalisation, marshal
 //
 // HBM traffic per pair (c = 16, W = 16): 96 B input + 64 B converted point + 2*W*4 B keys + W*4 B index
 // + W * 64 B gathers (cache-resident) -- the kernel is VALU (integer multiply) bound, see DESIGN.md.
@@ -126,159 +126,53 @@ __global__ void k_points_to_mont(const uint8_t* __restrict__ in, Affine<typename
     store_fe<M>(d + 8, y);
 }
 
-// fr.Element.SetBytes (main.go:127): big-endian, reduced mod the group order; then signed c-bit digits.
-// keys[w*n + i] = bucket | sign<<31, or KEY_NONE for a zero digit; counts[w*B + bucket]++.
-template <class C>
-__global__ void k_scalar_digits(const uint8_t* __restrict__ scalars, uint32_t n, int c, int W,
-                                uint32_t* __restrict__ keys, uint32_t* __restrict__ counts) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t t[8];
-    load_be256(t, scalars + (size_t)i * 32);
-    // reduce mod order: at most MAX_Q subtractions
-    for (int q = 0; q < C::MAX_Q; q++) {
-        uint32_t s[8];
-        uint32_t br = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            uint64_t d = (uint64_t)t[k] - C::ORDER[k] - br;
-            s[k] = (uint32_t)d;
-            br = (uint32_t)(d >> 63);
-        }
-        if (br) break;
-#pragma unroll
-        for (int k = 0; k < 8; k++) t[k] = s[k];
-    }
-    const uint32_t B = 1u << (c - 1);
-    const uint32_t mask = (1u << c) - 1;
-    uint32_t carry = 0;
-    for (int w = 0; w < W; w++) {
-        int lo = w * c;
-        uint32_t raw = 0;
-        if (lo < 256) {
-            int limb = lo >> 5, sh = lo & 31;
-            // dynamic limb index into registers -> select chain (8 limbs)
-            uint32_t a = 0, b = 0;
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                a = (k == limb) ? t[k] : a;
-                b = (k == limb + 1) ? t[k] : b;
-            }
-            uint64_t v = ((uint64_t)b << 32) | a;
-            raw = (uint32_t)(v >> sh) & mask;
-        }
-        raw += carry;
-        uint32_t key;
-        if (raw > B) {           // negative digit: raw - 2^c
-            uint32_t mag = (1u << c) - raw;  // 1 .. B-1
-            carry = 1;
-            key = (mag - 1) | 0x80000000u;
-        } else {
-            carry = 0;
-            key = raw ? (raw - 1) : KEY_NONE;
-        }
-        keys[(size_t)w * n + i] = key;
-        if (key != KEY_NONE) atomicAdd(&counts[(size_t)w * B + (key & 0x7fffffffu)], 1u);
-    }
+// ------------------------------------------------------------------------------------------------
+// Two-pass LDS counting sort of the (window, bucket) keys -- no global atomics on the data path.
+//
+// Pass A  k_digits_partition: a block owns a TILE of 4096 scalars.  It reduces them mod the group order once
+//         (fr.Element.SetBytes, main.go:127), keeps the limbs in registers, and for every window w emits the tile's
+//         non-zero signed digits grouped by PARTITION (= high bits of the bucket id) into tile_items[w][tile][*] together
+//         with the offset table tile_off[w][tile][*].
+//         An item is (bucket & lowmask) | sign << lowbits | local_index << (lowbits + 1)   (local_index < 4096).
+// Pass B  k_partition_sort: a block owns one (window, partition) = 2^lowbits buckets (1024 for c <= 18).  Its waves walk
+//         that partition's run in every tile with COALESCED loads (a run is ~TILE / P items = 512 B at c = 16), twice:
+//         first to count per bucket in LDS (-> counts, starts; the partition's slot range comes from ONE cursor atomic
+//         per block), then to place the point indices with LDS cursors.
+constexpr int TILE = 4096;
+constexpr int TILE_THREADS = 1024;
+constexpr int TILE_SPT = TILE / TILE_THREADS;  // scalars per thread
+constexpr int MAX_PARTS = 128;                 // partitions per window
+constexpr int SORT_LOWBITS = 10;               // buckets per partition = 2^10 unless that needs more than MAX_PARTS partitions
+constexpr int SORT_MAX_LOW = 4096;             // LDS counters of k_partition_sort (lowbits <= 12)
+
+static inline int sort_lowbits(int c) {
+    int lb = (c - 1) < SORT_LOWBITS ? (c - 1) : SORT_LOWBITS;
+    if (c - 1 - lb > 7) lb = c - 1 - 7;  // at most MAX_PARTS = 2^7 partitions
+    return lb;
 }
 
-// one contiguous slot range per bucket; also resets the fill counters and emits, per 1024-bucket block, a
-// histogram of (clamped) bucket sizes used to schedule buckets by size (k_size_scan / k_size_order).
-constexpr int SIZE_BINS = 256;
-static __global__ void __launch_bounds__(1024)
-k_bucket_offsets(const uint32_t* __restrict__ counts, uint32_t* __restrict__ starts, uint32_t* __restrict__ fill,
-                 uint32_t nb, uint32_t* __restrict__ cursor, uint32_t* __restrict__ blk_hist, uint32_t nblocks) {
-    __shared__ uint32_t hist[SIZE_BINS];
-    if (threadIdx.x < SIZE_BINS) hist[threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t cnt = (i < nb) ? counts[i] : 0;
-    // inclusive prefix over the 64-lane wave
-    uint32_t lane = threadIdx.x & 63;
-    uint32_t incl = cnt;
+// exclusive scan of one value per thread over a 1024-thread block; returns the exclusive prefix, *total = block sum
+__device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* wsum /* 16 */, uint32_t* total) {
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t incl = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         uint32_t o = __shfl_up(incl, d, 64);
         if (lane >= (uint32_t)d) incl += o;
     }
-    uint32_t total = __shfl(incl, 63, 64);
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(cursor, total);
-    base = __shfl(base, 0, 64);
-    if (i < nb) {
-        starts[i] = base + incl - cnt;
-        fill[i] = 0;
-        atomicAdd(&hist[cnt < SIZE_BINS ? cnt : SIZE_BINS - 1], 1u);
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        uint32_t s = wsum[k];
+        if ((uint32_t)k < wv) base += s;
+        tot += s;
     }
     __syncthreads();
-    // bin-major layout, largest sizes first: row r = SIZE_BINS-1-bin
-    if (threadIdx.x < SIZE_BINS) blk_hist[(size_t)(SIZE_BINS - 1 - threadIdx.x) * nblocks + blockIdx.x] = hist[threadIdx.x];
+    *total = tot;
+    return base + incl - v;
 }
-
-// exclusive scan of blk_hist (SIZE_BINS * nblocks entries, already in descending-size order) -> blk_off; one block.
-static __global__ void __launch_bounds__(1024)
-k_size_scan(const uint32_t* __restrict__ blk_hist, uint32_t* __restrict__ blk_off, uint32_t total) {
-    __shared__ uint32_t part[1024];
-    uint32_t per = (total + 1023) / 1024;
-    uint32_t lo = threadIdx.x * per, hi = lo + per < total ? lo + per : total;
-    uint32_t sum = 0;
-    for (uint32_t i = lo; i < hi; i++) sum += blk_hist[i];
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 partials
-    for (int d = 1; d < 1024; d <<= 1) {
-        uint32_t v = (threadIdx.x >= (uint32_t)d) ? part[threadIdx.x - d] : 0;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t run = part[threadIdx.x] - sum;
-    for (uint32_t i = lo; i < hi; i++) { uint32_t v = blk_hist[i]; blk_off[i] = run; run += v; }
-}
-
-// order[pos] = bucket id, buckets sorted by size (descending, clamped at SIZE_BINS-1); same block shape as k_bucket_offsets
-static __global__ void __launch_bounds__(1024)
-k_size_order(const uint32_t* __restrict__ counts, uint32_t nb, const uint32_t* __restrict__ blk_off, uint32_t nblocks,
-             uint32_t* __restrict__ order) {
-    __shared__ uint32_t next[SIZE_BINS];
-    if (threadIdx.x < SIZE_BINS) next[threadIdx.x] = blk_off[(size_t)(SIZE_BINS - 1 - threadIdx.x) * nblocks + blockIdx.x];
-    __syncthreads();
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nb) {
-        uint32_t cnt = counts[i];
-        uint32_t pos = atomicAdd(&next[cnt < SIZE_BINS ? cnt : SIZE_BINS - 1], 1u);
-        order[pos] = i;
-    }
-}
-
-static __global__ void k_scatter(const uint32_t* __restrict__ keys, uint32_t n, int W, uint32_t B,
-                          const uint32_t* __restrict__ starts, uint32_t* __restrict__ fill,
-                          uint32_t* __restrict__ entries) {
-    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= (size_t)W * n) return;
-    uint32_t key = keys[g];
-    if (key == KEY_NONE) return;
-    uint32_t w = (uint32_t)(g / n);
-    uint32_t i = (uint32_t)(g - (size_t)w * n);
-    uint32_t b = w * B + (key & 0x7fffffffu);
-    uint32_t pos = atomicAdd(&fill[b], 1u);
-    entries[starts[b] + pos] = i | (key & 0x80000000u);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Two-pass LDS counting sort of the (window, bucket) keys -- no global atomics on the data path.
-//
-// Pass A  k_digits_partition: a block owns a TILE of 4096 scalars.  It reduces them mod the group order once, keeps the
-//         limbs in registers, and for every window w emits the tile's non-zero digits grouped by PARTITION
-//         (= high bits of the bucket id) into tile_items[w][tile][*] together with the 129-entry offset table
-//         tile_off[w][tile][*].  An item is (bucket & lowmask) | sign << 8 | local_index << 9  (local_index < 4096).
-// Pass B  k_partition_sort: a block owns one (window, partition) = at most 256 buckets.  It walks that partition's run in
-//         every tile twice: first to count per bucket (-> counts, starts; the partition's slot range comes from ONE
-//         cursor atomic per block), then to place the point indices with LDS cursors.
-constexpr int TILE = 4096;
-constexpr int TILE_THREADS = 1024;
-constexpr int TILE_SPT = TILE / TILE_THREADS;  // scalars per thread
-constexpr int MAX_PARTS = 128;
 
 template <class C>
 __global__ void __launch_bounds__(TILE_THREADS)
@@ -341,7 +235,7 @@ k_digits_partition(const uint8_t* __restrict__ scalars, uint32_t n, int c, int W
                 raw = (uint32_t)(v >> sh) & mask;
             }
             raw += carry[j];
-            if (raw > B) {
+            if (raw > B) {  // negative digit raw - 2^c, magnitude 1 .. B-1
                 carry[j] = 1;
                 key[j] = (((1u << c) - raw) - 1) | 0x80000000u;
             } else {
@@ -352,7 +246,7 @@ k_digits_partition(const uint8_t* __restrict__ scalars, uint32_t n, int c, int W
             if (key[j] != KEY_NONE) atomicAdd(&hist[(key[j] & 0x7fffffffu) >> lowbits], 1u);
         }
         __syncthreads();
-        // exclusive scan over P <= 128 partitions by the first two waves (Hillis-Steele in LDS)
+        // exclusive scan over P <= 128 partitions (Hillis-Steele in LDS)
         if (tid < MAX_PARTS) {
             uint32_t v = (tid < (uint32_t)P) ? hist[tid] : 0;
             cursor[tid] = v;
@@ -379,7 +273,7 @@ k_digits_partition(const uint8_t* __restrict__ scalars, uint32_t n, int c, int W
             if (key[j] != KEY_NONE) {
                 uint32_t bkt = key[j] & 0x7fffffffu;
                 uint32_t pos = atomicAdd(&hist[bkt >> lowbits], 1u);
-                stage[pos] = (bkt & lowmask) | ((key[j] >> 31) << 8) | ((uint32_t)(j * TILE_THREADS + tid) << 9);
+                stage[pos] = (bkt & lowmask) | ((key[j] >> 31) << lowbits) | ((uint32_t)(j * TILE_THREADS + tid) << (lowbits + 1));
             }
         }
         __syncthreads();
@@ -389,88 +283,173 @@ k_digits_partition(const uint8_t* __restrict__ scalars, uint32_t n, int c, int W
     }
 }
 
-// grid = W * P blocks of 256 threads
-static __global__ void __launch_bounds__(256)
+// grid = W * P blocks of 1024 threads (16 waves; wave v takes tiles v, v+16, ...)
+static __global__ void __launch_bounds__(1024)
 k_partition_sort(const uint32_t* __restrict__ tile_items, const uint16_t* __restrict__ tile_off, uint32_t T, int c,
                  int lowbits, uint32_t* __restrict__ counts, uint32_t* __restrict__ starts,
                  uint32_t* __restrict__ entries, uint32_t* __restrict__ cursor) {
-    __shared__ uint32_t cnt[256];
-    __shared__ uint32_t scan[256];
+    __shared__ uint32_t cnt[SORT_MAX_LOW];
+    __shared__ uint32_t wsum[16];
     __shared__ uint32_t base_sh;
     const int P = 1 << (c - 1 - lowbits);
     const uint32_t nlow = 1u << lowbits;
     const uint32_t w = blockIdx.x / P, p = blockIdx.x % P;
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t lowmask = nlow - 1;
-    cnt[tid] = 0;
+    for (uint32_t i = tid; i < nlow; i += 1024) cnt[i] = 0;
     __syncthreads();
-    for (uint32_t t = tid; t < T; t += 256) {
+    for (uint32_t t = wv; t < T; t += 16) {
         const uint16_t* off = tile_off + ((size_t)w * T + t) * (MAX_PARTS + 1);
-        uint32_t lo = off[p], hi = (p + 1 < (uint32_t)P) ? off[p + 1] : off[MAX_PARTS];
+        const uint32_t lo = off[p], hi = (p + 1 < (uint32_t)P) ? off[p + 1] : off[MAX_PARTS];
         const uint32_t* it = tile_items + ((size_t)w * T + t) * TILE;
-        for (uint32_t i = lo; i < hi; i++) atomicAdd(&cnt[it[i] & lowmask], 1u);
+        for (uint32_t i = lo + lane; i < hi; i += 64) atomicAdd(&cnt[it[i] & lowmask], 1u);
     }
     __syncthreads();
-    uint32_t mine = cnt[tid];
-    scan[tid] = mine;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-        uint32_t v = (tid >= (uint32_t)d) ? scan[tid - d] : 0;
-        __syncthreads();
-        scan[tid] += v;
-        __syncthreads();
+    // exclusive scan over the nlow counters: thread owns `per` consecutive ones
+    const uint32_t per = nlow > 1024 ? nlow / 1024 : 1;
+    const uint32_t first = tid * per;
+    uint32_t mine[4] = {0, 0, 0, 0};
+    uint32_t sum = 0;
+    if (first < nlow) {
+        for (uint32_t k = 0; k < per; k++) { mine[k] = cnt[first + k]; sum += mine[k]; }
     }
-    if (tid == 255) base_sh = atomicAdd(cursor, scan[255]);
+    uint32_t total;
+    uint32_t excl = block_scan_1024(sum, wsum, &total);
+    if (tid == 0) base_sh = atomicAdd(cursor, total);
     __syncthreads();
-    uint32_t start = base_sh + scan[tid] - mine;
-    if (tid < nlow) {
-        size_t b = ((size_t)w << (c - 1)) + (size_t)p * nlow + tid;
-        counts[b] = mine;
-        starts[b] = start;
+    if (first < nlow) {
+        uint32_t run = base_sh + excl;
+        for (uint32_t k = 0; k < per; k++) {
+            size_t b = ((size_t)w << (c - 1)) + (size_t)p * nlow + first + k;
+            counts[b] = mine[k];
+            starts[b] = run;
+            cnt[first + k] = run;  // running cursor per bucket
+            run += mine[k];
+        }
     }
-    cnt[tid] = start;  // running cursor per bucket
     __syncthreads();
-    for (uint32_t t = tid; t < T; t += 256) {
+    for (uint32_t t = wv; t < T; t += 16) {
         const uint16_t* off = tile_off + ((size_t)w * T + t) * (MAX_PARTS + 1);
-        uint32_t lo = off[p], hi = (p + 1 < (uint32_t)P) ? off[p + 1] : off[MAX_PARTS];
+        const uint32_t lo = off[p], hi = (p + 1 < (uint32_t)P) ? off[p + 1] : off[MAX_PARTS];
         const uint32_t* it = tile_items + ((size_t)w * T + t) * TILE;
-        for (uint32_t i = lo; i < hi; i++) {
+        for (uint32_t i = lo + lane; i < hi; i += 64) {
             uint32_t item = it[i];
             uint32_t pos = atomicAdd(&cnt[item & lowmask], 1u);
-            entries[pos] = (t * TILE + (item >> 9)) | (((item >> 8) & 1u) << 31);
+            entries[pos] = (t * TILE + (item >> (lowbits + 1))) | (((item >> lowbits) & 1u) << 31);
         }
     }
 }
 
-// per-1024-bucket block histogram of (clamped) bucket sizes for the size ordering
+// ------------------------------------------------------------------------------------------------
+// Scheduling of the bucket accumulation.  A WORK ITEM is at most CHUNK consecutive entries of one bucket: a bucket with
+// cnt entries yields cnt / CHUNK full items and one remainder item, so a skewed input (all scalars equal, or the few
+// occupied buckets of a partially filled top window) becomes many items instead of one 2^20-long dependent chain.  Items
+// are counting-sorted by size, largest first, so that the 64 lanes of a wave run (almost) the same trip count.
+//   ctrl[0] entries cursor   ctrl[1] chunk-output cursor   ctrl[2] number of multi-item buckets   ctrl[3] number of items
+//   ctrl[4 .. 4+CHUNK)  items per size row (row r <-> size CHUNK - r)
+constexpr int CHUNK = 128;
+constexpr int CTRL_WORDS = 4 + CHUNK;
+constexpr uint32_t NO_CHUNK = 0xffffffffu;
+
+// per-1024-bucket block: histogram of item sizes; layout row-major [row][block], row = CHUNK - size
 static __global__ void __launch_bounds__(1024)
-k_size_hist(const uint32_t* __restrict__ counts, uint32_t nb, uint32_t* __restrict__ blk_hist, uint32_t nblocks) {
-    __shared__ uint32_t hist[SIZE_BINS];
-    if (threadIdx.x < SIZE_BINS) hist[threadIdx.x] = 0;
+k_size_hist(const uint32_t* __restrict__ counts, uint32_t nb, uint32_t* __restrict__ blk_hist, uint32_t nblocks,
+            uint32_t* __restrict__ ctrl) {
+    __shared__ uint32_t hist[CHUNK];
+    if (threadIdx.x < CHUNK) hist[threadIdx.x] = 0;
     __syncthreads();
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nb) {
         uint32_t cnt = counts[i];
-        atomicAdd(&hist[cnt < SIZE_BINS ? cnt : SIZE_BINS - 1], 1u);
+        uint32_t full = cnt / CHUNK, rem = cnt % CHUNK;
+        if (full) atomicAdd(&hist[0], full);
+        if (rem) atomicAdd(&hist[CHUNK - rem], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < SIZE_BINS) blk_hist[(size_t)(SIZE_BINS - 1 - threadIdx.x) * nblocks + blockIdx.x] = hist[threadIdx.x];
+    if (threadIdx.x < CHUNK) {
+        uint32_t v = hist[threadIdx.x];
+        blk_hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = v;
+        if (v) atomicAdd(&ctrl[4 + threadIdx.x], v);
+    }
 }
 
-// ONE THREAD PER BUCKET, buckets taken in size order so that the 64 lanes of a wave run the same trip count.
+// grid = CHUNK blocks (one per size row): blk_off[row][blk] = items of larger sizes + items of this size in earlier blocks
+static __global__ void __launch_bounds__(1024)
+k_size_scan(const uint32_t* __restrict__ blk_hist, uint32_t* __restrict__ blk_off, uint32_t nblocks,
+            uint32_t* __restrict__ ctrl) {
+    __shared__ uint32_t wsum[16];
+    const uint32_t row = blockIdx.x, tid = threadIdx.x;
+    uint32_t total;
+    uint32_t v = (tid < CHUNK) ? ctrl[4 + tid] : 0;
+    uint32_t excl = block_scan_1024(v, wsum, &total);
+    __shared__ uint32_t row_base;
+    if (tid == row) row_base = excl;
+    if (row == 0 && tid == 0) ctrl[3] = total;
+    __syncthreads();
+    uint32_t run = row_base;
+    for (uint32_t b0 = 0; b0 < nblocks; b0 += 1024) {
+        uint32_t x = (b0 + tid < nblocks) ? blk_hist[(size_t)row * nblocks + b0 + tid] : 0;
+        uint32_t tot;
+        uint32_t e = block_scan_1024(x, wsum, &tot);
+        if (b0 + tid < nblocks) blk_off[(size_t)row * nblocks + b0 + tid] = run + e;
+        run += tot;
+    }
+}
+
+// order[pos] = (bucket, item index inside the bucket); empty buckets are written as infinity (zz = 0) here.
+static __global__ void __launch_bounds__(1024)
+k_size_order(const uint32_t* __restrict__ counts, uint32_t nb, const uint32_t* __restrict__ blk_off, uint32_t nblocks,
+             uint2* __restrict__ order, uint32_t* __restrict__ chunk_base, uint32_t* __restrict__ heavy_list,
+             uint32_t* __restrict__ ctrl, uint4* __restrict__ buckets_raw) {
+    __shared__ uint32_t next[CHUNK];
+    if (threadIdx.x < CHUNK) next[threadIdx.x] = blk_off[(size_t)threadIdx.x * nblocks + blockIdx.x];
+    __syncthreads();
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb) return;
+    uint32_t cnt = counts[i];
+    uint32_t full = cnt / CHUNK, rem = cnt % CHUNK;
+    uint32_t items = full + (rem ? 1u : 0u);
+    if (items == 0) {
+        uint4 z = make_uint4(0, 0, 0, 0);
+        uint4* d = buckets_raw + (size_t)i * 8;
+#pragma unroll
+        for (int k = 0; k < 8; k++) d[k] = z;
+    }
+    if (full) {
+        uint32_t pos = atomicAdd(&next[0], full);
+        for (uint32_t j = 0; j < full; j++) order[pos + j] = make_uint2(i, j);
+    }
+    if (rem) {
+        uint32_t pos = atomicAdd(&next[CHUNK - rem], 1u);
+        order[pos] = make_uint2(i, full);
+    }
+    if (items > 1) {
+        chunk_base[i] = atomicAdd(&ctrl[1], items);
+        heavy_list[atomicAdd(&ctrl[2], 1u)] = i;
+    } else {
+        chunk_base[i] = NO_CHUNK;
+    }
+}
+
+// ONE THREAD PER WORK ITEM, items taken in size order.
 template <class C>
 __global__ void __launch_bounds__(256)
 k_bucket_sum(const Affine<typename C::Fp>* __restrict__ pts, const uint32_t* __restrict__ entries,
              const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
-             const uint32_t* __restrict__ order, XYZZ<typename C::Fp>* __restrict__ buckets, uint32_t nb) {
+             const uint2* __restrict__ order, const uint32_t* __restrict__ chunk_base,
+             const uint32_t* __restrict__ ctrl, XYZZ<typename C::Fp>* __restrict__ buckets,
+             XYZZ<typename C::Fp>* __restrict__ chunk_out) {
     using M = typename C::Fp;
     uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= nb) return;
-    uint32_t b = order[tid];
-    uint32_t cnt = counts[b];
-    const uint32_t* e = entries + starts[b];
+    if (tid >= ctrl[3]) return;
+    uint2 item = order[tid];
+    const uint32_t b = item.x;
+    const uint32_t first = item.y * CHUNK;
+    uint32_t cnt = counts[b] - first;
+    if (cnt > CHUNK) cnt = CHUNK;
+    const uint32_t* e = entries + starts[b] + first;
     XYZZ<M> acc = xyzz_inf<M>();
-    uint32_t ent = cnt ? e[0] : 0;
+    uint32_t ent = e[0];
     for (uint32_t k = 0; k < cnt; k++) {
         uint32_t cur = ent;
         if (k + 1 < cnt) ent = e[k + 1];          // next index is in flight while this point is accumulated
@@ -478,8 +457,11 @@ k_bucket_sum(const Affine<typename C::Fp>* __restrict__ pts, const uint32_t* __r
         a = aff_neg_if<M>(a, (cur >> 31) != 0);
         xyzz_madd<M>(acc, a);
     }
-    store_xyzz<M>(buckets + b, acc);
+    const uint32_t cb = chunk_base[b];
+    if (cb == NO_CHUNK) store_xyzz<M>(buckets + b, acc);
+    else store_xyzz<M>(chunk_out + cb + item.y, acc);
 }
+
 
 template <class M>
 __device__ __forceinline__ XYZZ<M> xyzz_shfl_xor(const XYZZ<M>& p, int mask) {
@@ -551,6 +533,28 @@ k_window_reduce(const XYZZ<typename C::Fp>* __restrict__ partial, uint32_t perWi
     }
     acc = wave_sum<M>(acc);
     if (threadIdx.x == 0) store_xyzz<M>(out + w, acc);
+}
+
+// wave per multi-item bucket: buckets[b] = sum of its item sums (ctrl[2] buckets listed in heavy_list)
+template <class C>
+__global__ void __launch_bounds__(64)
+k_bucket_combine(const uint32_t* __restrict__ heavy_list, const uint32_t* __restrict__ chunk_base,
+                 const uint32_t* __restrict__ counts, const uint32_t* __restrict__ ctrl,
+                 const XYZZ<typename C::Fp>* __restrict__ chunk_out, XYZZ<typename C::Fp>* __restrict__ buckets) {
+    using M = typename C::Fp;
+    const uint32_t n_heavy = ctrl[2];
+    for (uint32_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {
+        const uint32_t b = heavy_list[h];
+        const uint32_t items = (counts[b] + CHUNK - 1) / CHUNK;
+        const XYZZ<M>* src = chunk_out + chunk_base[b];
+        XYZZ<M> acc = xyzz_inf<M>();
+        for (uint32_t k = threadIdx.x; k < items; k += 64) {
+            XYZZ<M> p = load_xyzz<M>(src + k);
+            xyzz_add_cold<M>(&acc, &p);
+        }
+        acc = wave_sum<M>(acc);
+        if (threadIdx.x == 0) store_xyzz<M>(buckets + b, acc);
+    }
 }
 
 }  // namespace porla

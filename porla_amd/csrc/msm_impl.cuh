@@ -2,6 +2,7 @@
 // (msm_bn254.hip, msm_secp256k1.hip) so that the two instantiations compile in parallel.
 #pragma once
 #include "engine.hpp"
+#include "host_fold64.hpp"
 #include <cstdlib>
 #include "../../include/porla_gpu.h"
 
@@ -37,16 +38,22 @@ static int msm_core(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_po
     int rc;
     if (!d_points_mont) { if ((rc = ws->pts.ensure(n * sizeof(Affine<M>)))) return rc; }
     const uint32_t T_tiles = (uint32_t)((n + TILE - 1) / TILE);
-    if ((rc = ws->keys.ensure((size_t)W * T_tiles * TILE * 4))) return rc;   // keys (legacy) / tile_items
+    const uint32_t nblk = (uint32_t)((nb + 1023) / 1024);
+    const size_t max_entries = (size_t)W * n;
+    const size_t max_items = nb + max_entries / CHUNK;          // every bucket: <= cnt/CHUNK full items + 1 remainder
+    const size_t max_chunk_out = 2 * (max_entries / CHUNK) + 2; // multi-item buckets only: ceil(cnt/CHUNK) <= 2 cnt/CHUNK
+    if ((rc = ws->keys.ensure((size_t)W * T_tiles * TILE * 4))) return rc;   // tile_items
     if ((rc = ws->tile_off.ensure((size_t)W * T_tiles * (MAX_PARTS + 1) * 2))) return rc;
-    if ((rc = ws->entries.ensure((size_t)W * n * 4))) return rc;
+    if ((rc = ws->entries.ensure(max_entries * 4))) return rc;
     if ((rc = ws->counts.ensure(nb * 4))) return rc;
     if ((rc = ws->starts.ensure(nb * 4))) return rc;
-    if ((rc = ws->fill.ensure(nb * 4))) return rc;
-    if ((rc = ws->cursor.ensure(256))) return rc;
-    if ((rc = ws->order.ensure(nb * 4))) return rc;
-    if ((rc = ws->blk_hist.ensure((size_t)SIZE_BINS * ((nb + 1023) / 1024) * 4))) return rc;
-    if ((rc = ws->blk_off.ensure((size_t)SIZE_BINS * ((nb + 1023) / 1024) * 4))) return rc;
+    if ((rc = ws->fill.ensure(nb * 4))) return rc;                            // chunk_base
+    if ((rc = ws->cursor.ensure(CTRL_WORDS * 4))) return rc;                  // ctrl
+    if ((rc = ws->order.ensure(max_items * sizeof(uint2)))) return rc;
+    if ((rc = ws->heavy.ensure((max_entries / CHUNK + 2) * 4))) return rc;
+    if ((rc = ws->chunk_out.ensure(max_chunk_out * sizeof(XYZZ<M>)))) return rc;
+    if ((rc = ws->blk_hist.ensure((size_t)CHUNK * nblk * 4))) return rc;
+    if ((rc = ws->blk_off.ensure((size_t)CHUNK * nblk * 4))) return rc;
     if ((rc = ws->buckets.ensure(nb * sizeof(XYZZ<M>)))) return rc;
     if ((rc = ws->partial.ensure((size_t)W * wavesPerWindow * sizeof(XYZZ<M>)))) return rc;
     if ((rc = ws->windows.ensure((size_t)W * sizeof(XYZZ<M>)))) return rc;
@@ -57,67 +64,49 @@ static int msm_core(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_po
     }
 
     const Affine<M>* pts = d_points_mont;
-    if (g_legacy_sort) PORLA_HIP(hipMemsetAsync(ws->counts.p, 0, nb * 4, stream));
-    PORLA_HIP(hipMemsetAsync(ws->cursor.p, 0, 4, stream));
+    uint32_t* ctrl = (uint32_t*)ws->cursor.p;
+    PORLA_HIP(hipMemsetAsync(ctrl, 0, CTRL_WORDS * 4, stream));
     if (!pts) {
         ProfScope ps("points_to_mont", stream);
         hipLaunchKernelGGL((k_points_to_mont<C>), dim3((n32 + 255) / 256), dim3(256), 0, stream, d_points_be,
                            (Affine<M>*)ws->pts.p, n32);
         pts = (const Affine<M>*)ws->pts.p;
     }
-    const uint32_t nblk = (uint32_t)((nb + 1023) / 1024);
-    if (g_legacy_sort) {
-        {
-            ProfScope ps("scalar_digits", stream);
-            hipLaunchKernelGGL((k_scalar_digits<C>), dim3((n32 + 255) / 256), dim3(256), 0, stream, d_scalars, n32, c, W,
-                               (uint32_t*)ws->keys.p, (uint32_t*)ws->counts.p);
-        }
-        {
-            ProfScope ps("bucket_offsets", stream);
-            hipLaunchKernelGGL(k_bucket_offsets, dim3(nblk), dim3(1024), 0, stream, (const uint32_t*)ws->counts.p,
-                               (uint32_t*)ws->starts.p, (uint32_t*)ws->fill.p, (uint32_t)nb, (uint32_t*)ws->cursor.p,
-                               (uint32_t*)ws->blk_hist.p, nblk);
-        }
-        {
-            ProfScope ps("scatter", stream);
-            size_t tot = (size_t)W * n;
-            hipLaunchKernelGGL(k_scatter, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream,
-                               (const uint32_t*)ws->keys.p, n32, W, B, (const uint32_t*)ws->starts.p,
-                               (uint32_t*)ws->fill.p, (uint32_t*)ws->entries.p);
-        }
-    } else {
-        const int lowbits = (c - 1) < 8 ? (c - 1) : 8;
-        const int P = 1 << (c - 1 - lowbits);
-        {
-            ProfScope ps("digits_partition", stream);
-            hipLaunchKernelGGL((k_digits_partition<C>), dim3(T_tiles), dim3(TILE_THREADS), 0, stream, d_scalars, n32, c, W,
-                               lowbits, (uint32_t*)ws->keys.p, (uint16_t*)ws->tile_off.p);
-        }
-        {
-            ProfScope ps("partition_sort", stream);
-            hipLaunchKernelGGL(k_partition_sort, dim3((unsigned)(W * P)), dim3(256), 0, stream, (const uint32_t*)ws->keys.p,
-                               (const uint16_t*)ws->tile_off.p, T_tiles, c, lowbits, (uint32_t*)ws->counts.p,
-                               (uint32_t*)ws->starts.p, (uint32_t*)ws->entries.p, (uint32_t*)ws->cursor.p);
-        }
-        {
-            ProfScope ps("size_hist", stream);
-            hipLaunchKernelGGL(k_size_hist, dim3(nblk), dim3(1024), 0, stream, (const uint32_t*)ws->counts.p, (uint32_t)nb,
-                               (uint32_t*)ws->blk_hist.p, nblk);
-        }
+    const int lowbits = sort_lowbits(c);
+    const int P = 1 << (c - 1 - lowbits);
+    {
+        ProfScope ps("digits_partition", stream);
+        hipLaunchKernelGGL((k_digits_partition<C>), dim3(T_tiles), dim3(TILE_THREADS), 0, stream, d_scalars, n32, c, W,
+                           lowbits, (uint32_t*)ws->keys.p, (uint16_t*)ws->tile_off.p);
+    }
+    {
+        ProfScope ps("partition_sort", stream);
+        hipLaunchKernelGGL(k_partition_sort, dim3((unsigned)(W * P)), dim3(1024), 0, stream, (const uint32_t*)ws->keys.p,
+                           (const uint16_t*)ws->tile_off.p, T_tiles, c, lowbits, (uint32_t*)ws->counts.p,
+                           (uint32_t*)ws->starts.p, (uint32_t*)ws->entries.p, ctrl);
     }
     {
         ProfScope ps("size_order", stream);
-        hipLaunchKernelGGL(k_size_scan, dim3(1), dim3(1024), 0, stream, (const uint32_t*)ws->blk_hist.p,
-                           (uint32_t*)ws->blk_off.p, (uint32_t)(SIZE_BINS * nblk));
+        hipLaunchKernelGGL(k_size_hist, dim3(nblk), dim3(1024), 0, stream, (const uint32_t*)ws->counts.p, (uint32_t)nb,
+                           (uint32_t*)ws->blk_hist.p, nblk, ctrl);
+        hipLaunchKernelGGL(k_size_scan, dim3(CHUNK), dim3(1024), 0, stream, (const uint32_t*)ws->blk_hist.p,
+                           (uint32_t*)ws->blk_off.p, nblk, ctrl);
         hipLaunchKernelGGL(k_size_order, dim3(nblk), dim3(1024), 0, stream, (const uint32_t*)ws->counts.p, (uint32_t)nb,
-                           (const uint32_t*)ws->blk_off.p, nblk, (uint32_t*)ws->order.p);
+                           (const uint32_t*)ws->blk_off.p, nblk, (uint2*)ws->order.p, (uint32_t*)ws->fill.p,
+                           (uint32_t*)ws->heavy.p, ctrl, (uint4*)ws->buckets.p);
     }
     {
         ProfScope ps("bucket_sum", stream);
-        hipLaunchKernelGGL((k_bucket_sum<C>), dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, stream, pts,
+        hipLaunchKernelGGL((k_bucket_sum<C>), dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, stream, pts,
                            (const uint32_t*)ws->entries.p, (const uint32_t*)ws->starts.p,
-                           (const uint32_t*)ws->counts.p, (const uint32_t*)ws->order.p, (XYZZ<M>*)ws->buckets.p,
-                           (uint32_t)nb);
+                           (const uint32_t*)ws->counts.p, (const uint2*)ws->order.p, (const uint32_t*)ws->fill.p,
+                           (const uint32_t*)ctrl, (XYZZ<M>*)ws->buckets.p, (XYZZ<M>*)ws->chunk_out.p);
+    }
+    {
+        ProfScope ps("bucket_combine", stream);
+        hipLaunchKernelGGL((k_bucket_combine<C>), dim3(2048), dim3(64), 0, stream, (const uint32_t*)ws->heavy.p,
+                           (const uint32_t*)ws->fill.p, (const uint32_t*)ws->counts.p, (const uint32_t*)ctrl,
+                           (const XYZZ<M>*)ws->chunk_out.p, (XYZZ<M>*)ws->buckets.p);
     }
     {
         ProfScope ps("bucket_reduce", stream);
@@ -132,7 +121,7 @@ static int msm_core(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_po
     PORLA_HIP(hipGetLastError());
     PORLA_HIP(hipMemcpyAsync(ws->h_windows, ws->windows.p, (size_t)W * sizeof(XYZZ<M>), hipMemcpyDeviceToHost, stream));
     PORLA_HIP(hipStreamSynchronize(stream));
-    *total = h_fold_windows<M>((const XYZZ<M>*)ws->h_windows, W, c);
+    *total = h_fold_windows64<M>((const XYZZ<M>*)ws->h_windows, W, c);
     return PORLA_OK;
 }
 

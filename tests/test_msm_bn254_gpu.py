@@ -34,7 +34,7 @@ def test_multi_exp_matches_oracle(mx, inputs, n):
     assert got == common.oracle_msm(sc, pt, n)
 
 
-@pytest.mark.parametrize("c", [2, 3, 5, 8, 11, 13, 16])
+@pytest.mark.parametrize("c", [2, 3, 5, 8, 11, 12, 13, 16, 17, 18, 20])
 def test_every_window_width(mx, inputs, c):
     """forces the window width (bucket count, segment length, carries into the top window)"""
     from porla_amd import lib
@@ -93,6 +93,23 @@ def test_all_same_point_same_scalar(mx, inputs):
     n = 512
     got = mx.bn254_multi_exp(pt[:64] * n, sc[:32] * n, n)
     assert got == common.oracle_msm(sc[:32] * n, pt[:64] * n, n)
+
+
+@pytest.mark.parametrize("n,c", [(20000, 0), (20000, 9), (1 << 14, 13), (1 << 14, 16)])
+def test_heavy_buckets_are_split_into_work_items(mx, inputs, n, c):
+    """skewed inputs: one scalar for all pairs (every window has ONE bucket of n entries), and windows whose top
+    digit has 1-2 bits (n = 2^14 -> c = 11: the top window holds all pairs in <= 2 buckets).  The bucket
+    accumulation must split such buckets into <= 128-entry work items (k_bucket_sum / k_bucket_combine)."""
+    from porla_amd import lib
+    sc, pt = inputs
+    scs = sc[:32] * n if c in (0, 9) else sc[:32 * n]
+    pts = (pt[:64 * 200] * (n // 200 + 1))[:64 * n] if c in (0, 9) else pt[:64 * n]
+    lib.porla_gpu_set_msm_window(c)
+    try:
+        got = mx.msm_host("bn254", scs, pts, n)
+    finally:
+        lib.porla_gpu_set_msm_window(0)
+    assert got == common.oracle_msm(scs, pts, n)
 
 
 def test_device_pointer_api_and_partials(mx, inputs):
