@@ -1,13 +1,14 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): GPU parity tests, the default bench line, the rocprofv3 kernel-trace summary of
 # the same bench command, and two separate PMC passes (FETCH_SIZE / WRITE_SIZE cannot share a pass on gfx950).
-# Usage: tools/gpu_profile.sh <tag>        outputs under gpurun_out/<tag>/
+# Usage: [WORKLOAD=bn254_msm|kzg_commit|secp256k1_msm|icc] [SKIP_TESTS=1] tools/gpu_profile.sh <tag>     outputs under gpurun_out/<tag>/
 set -u
 TAG=${1:-run}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --steps 10 --warmup 2"
+WORKLOAD=${WORKLOAD:-bn254_msm}
+BENCH="python3 $PWD/bench.py --steps 10 --warmup 2 --workload $WORKLOAD"
 if [ "${SKIP_TESTS:-0}" != 1 ]; then (timeout 900 python3 -m pytest tests -m gpu -x -q 2>&1 | tail -5) > "$OUT/pytest.txt"; fi
 (timeout 600 $BENCH 2>/dev/null | grep '^{') > "$OUT/bench_n1.json"
 cd /tmp
