@@ -109,6 +109,20 @@ int porla_icc_encode_device(const void *d_rows_in, size_t n_rows, size_t n_cols,
 int porla_icc_encode_host(const uint8_t *rows_in, size_t n_rows, size_t n_cols, int curve, unsigned long long write_step,
                           int part, uint8_t *x_out, uint8_t *aligned_out, uint8_t *scalars_out, int scalar_le);
 
+/* ---- MAC-side ICC encode ("FFT in the exponent": the MAC halves of CRebuild_Cached, Server.hpp:1523-1536 init
+ * scaling, :1590-1609 / :1658-1676 butterflies tm = v^j * MAC[k+m2]; MAC[k] = um + tm; MAC[k+m2] = um - tm; client twin
+ * Client.hpp:1040-1453) ----
+ * macs_in / macs_out : n_rows points, 64 bytes X||Y big-endian affine each (KZG MAC_Block, utils.h:65; for IPA the
+ *           include shim converts secp256k1_gej <-> this canonical form), n_rows a power of two >= 2
+ * curve, write_step, part : as for porla_icc_encode_* (part 1 = Y: inputs pre-multiplied by wt) */
+int porla_icc_mac_encode_device(const void *d_macs_in, size_t n_rows, int curve, unsigned long long write_step, int part,
+                                void *d_macs_out, void *hip_stream);
+int porla_icc_mac_encode_host(const uint8_t *macs_in, size_t n_rows, int curve, unsigned long long write_step, int part,
+                              uint8_t *macs_out);
+/* tuning: row counts <= n_rows use the matrix form (N commitments against the per-call base, throughput-bound), larger
+ * ones the stage-by-stage ladder form (default 2048; 0 = always ladder).  Both are bit-exact. */
+int porla_icc_mac_set_matrix_max(size_t n_rows);
+
 #ifdef __cplusplus
 }
 #endif

@@ -118,3 +118,64 @@ def linear_network_matrix(n):
         return out
 
     return transform
+
+
+# ---------------------------------------------------------------- MAC halves of CRebuild_Cached ("FFT in the exponent")
+# Server.hpp:1523-1536 (X = MAC_U, Y = wt * MAC_U) and :1590-1609 / :1658-1676 (tm = vi*MAC[k+m2]; MAC[k] = um + tm;
+# MAC[k+m2] = um - tm), vi = v^j mod p_icc handed to the group as an integer and reduced mod the group order there.
+CURVE_P = {"bn254": 21888242871839275222246405745257275088696311157297823662689037894645226208583,
+           "secp256k1": 2**256 - 2**32 - 977}
+
+
+def ec_add(curve, a, b):
+    """affine addition on y^2 = x^3 + b (a = 0); None = infinity"""
+    p = CURVE_P[curve]
+    if a is None:
+        return b
+    if b is None:
+        return a
+    if a[0] == b[0]:
+        if (a[1] + b[1]) % p == 0:
+            return None
+        lam = 3 * a[0] * a[0] * pow(2 * a[1], -1, p) % p
+    else:
+        lam = (b[1] - a[1]) * pow(b[0] - a[0], -1, p) % p
+    x = (lam * lam - a[0] - b[0]) % p
+    return (x, (lam * (a[0] - x) - a[1]) % p)
+
+
+def ec_neg(curve, a):
+    return None if a is None else (a[0], (-a[1]) % CURVE_P[curve])
+
+
+def ec_mul(curve, a, k):
+    k %= Q[curve]
+    acc = None
+    for bit in bin(k)[2:] if k else "":
+        acc = ec_add(curve, acc, acc)
+        if bit == "1":
+            acc = ec_add(curve, acc, a)
+    return acc
+
+
+def mac_crebuild(macs, curve="bn254", write_step=0):
+    """macs: N affine points (x, y) or None.  Returns (X, Y) MAC arrays after the butterfly network."""
+    n = len(macs)
+    h = height_of(n)
+    w = root_w(n)
+    wt = pow(w, reverse_bits(write_step % n, h - 1), P_ICC)
+    X = list(macs)
+    Y = [ec_mul(curve, m, wt) for m in macs]
+    for part in (X, Y):
+        for s in range(1, h):
+            m, m2 = 1 << s, 1 << (s - 1)
+            v = pow(w, n // m2, P_ICC)
+            vi = 1
+            for j in range(m2):
+                for k in range(j, n, m):
+                    tm = ec_mul(curve, part[k + m2], vi)
+                    um = part[k]
+                    part[k] = ec_add(curve, um, tm)
+                    part[k + m2] = ec_add(curve, um, ec_neg(curve, tm))
+                vi = vi * v % P_ICC
+    return X, Y

@@ -84,6 +84,12 @@ struct FixedBase {
     int c = 0, W = 0;
     size_t n_points = 0;
     Affine<typename C::Fp>* table = nullptr;
+    size_t table_cap = 0;                     // bytes
+    XYZZ<typename C::Fp>* pow_buf = nullptr;  // construction buffers, kept between builds when keep_build_buffers
+    size_t pow_cap = 0;
+    XYZZ<typename C::Fp>* scratch_buf = nullptr;
+    size_t scratch_cap = 0;
+    bool keep_build_buffers = false;          // true: a base that changes per call (mac_fft.hip); false: one-off (SRS)
     XYZZ<typename C::Fp>* partial = nullptr;
     size_t partial_cap = 0;
     uint8_t* io_rows = nullptr;
@@ -104,5 +110,9 @@ extern std::mutex g_ws_mu;
 extern int g_window_override;
 int get_workspace(Workspace** out);
 hipStream_t engine_stream();  // this device's engine-owned non-blocking stream
+
+// icc.hip: the ICC butterfly network as an n x n matrix of 32-byte big-endian coefficients mod the group order
+int icc_network_matrix_device(int curve, size_t n, unsigned long long write_step, int part, uint8_t* d_rows_out,
+                              hipStream_t stream);
 
 }  // namespace porla

@@ -15,10 +15,10 @@
 //
 //   k_fb_base_powers   thread per base point: 2^(c*w) * G_i for all w (c*W dependent doublings)
 //   k_fb_multiples     thread per (pair, chunk): (j*K+1)*B by double-and-add, then K-1 additions of B -> XYZZ scratch
-//   k_fb_normalize     XYZZ -> affine with one inversion per 8 entries (Montgomery's trick) -> table
+//   k_fb_normalize     XYZZ -> affine with one inversion per 32 entries (Montgomery's trick) -> table
 //   k_fb_commit        lane = row (x slice): scalar -> reduce mod order -> signed digits -> gather + 8M+2S mixed add
-//   k_fb_finish        G lanes per row: fold the slice partials (sequential + wave-shuffle tree), one inversion,
-//                      Montgomery -> big-endian X||Y (64 zero bytes = infinity)
+//   k_fb_fold          G lanes per row: fold the slice partials (sequential + wave-shuffle tree)
+//   k_fb_finish        lane = row: one inversion, Montgomery -> big-endian X||Y (64 zero bytes = infinity)
 #pragma once
 #include "msm.cuh"
 
@@ -101,37 +101,35 @@ k_fb_multiples(const XYZZ<typename C::Fp>* __restrict__ pow, uint32_t pair0, uin
     }
 }
 
-// table[k] = affine(scratch[k]); one inversion per NB entries
+// table[k] = affine(scratch[k]); one inversion per NB entries (Montgomery's trick; the running prefix products are staged in
+// the x half of the thread's own output slots, which are overwritten by the result in the second pass)
 template <class C>
 __global__ void __launch_bounds__(64)
 k_fb_normalize(const XYZZ<typename C::Fp>* __restrict__ scratch, size_t n, Affine<typename C::Fp>* __restrict__ table) {
     using M = typename C::Fp;
-    constexpr int NB = 8;
+    constexpr int NB = 32;
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t k0 = t * NB;
     if (k0 >= n) return;
-    Fe<M> prefix[NB];
+    const int cnt = (n - k0 < (size_t)NB) ? (int)(n - k0) : NB;
     Fe<M> run = fe_one<M>();
 #pragma unroll 1
-    for (int k = 0; k < NB; k++) {
-        Fe<M> z = fe_one<M>();
-        if (k0 + k < n) {
-            z = load_fe<M>(reinterpret_cast<const uint32_t*>(scratch + k0 + k) + 24);  // zzz
-            if (fe_is_zero<M>(z)) z = fe_one<M>();
-        }
-        prefix[k] = run;
+    for (int k = 0; k < cnt; k++) {
+        Fe<M> z = load_fe<M>(reinterpret_cast<const uint32_t*>(scratch + k0 + k) + 24);  // zzz
+        if (fe_is_zero<M>(z)) z = fe_one<M>();
+        store_fe<M>(reinterpret_cast<uint32_t*>(table + k0 + k), run);
         run = fe_mul_call<M>(run, z);
     }
     Fe<M> inv = fe_inv_dev<M>(run);
 #pragma unroll 1
-    for (int k = NB - 1; k >= 0; k--) {
-        if (k0 + k >= n) continue;
+    for (int k = cnt - 1; k >= 0; k--) {
         XYZZ<M> p = load_xyzz<M>(scratch + k0 + k);
         Affine<M> a;
         if (xyzz_is_inf<M>(p)) {
             a.x = fe_zero<M>(); a.y = fe_zero<M>();
         } else {
-            Fe<M> iz = fe_mul_call<M>(inv, prefix[k]);
+            Fe<M> prefix = load_fe<M>(reinterpret_cast<const uint32_t*>(table + k0 + k));
+            Fe<M> iz = fe_mul_call<M>(inv, prefix);
             inv = fe_mul_call<M>(inv, p.zzz);
             a = xyzz_to_affine_with_inv<M>(p, iz);
         }
@@ -218,11 +216,10 @@ k_fb_commit(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_coeffs
     store_xyzz<M>(partial + (size_t)r * S + s, acc);
 }
 
-// G lanes per row (G a power of two <= 64, G <= S or G == 1): fold S partials, normalise, marshal.
+// G lanes per row (G a power of two, 2 <= G <= 64, G <= S): fold the S slice partials of a row into partial[row * S]
 template <class C>
 __global__ void __launch_bounds__(64)
-k_fb_finish(const XYZZ<typename C::Fp>* __restrict__ partial, uint32_t n_rows, uint32_t S, uint32_t G,
-            uint8_t* __restrict__ out) {
+k_fb_fold(XYZZ<typename C::Fp>* __restrict__ partial, uint32_t n_rows, uint32_t S, uint32_t G) {
     using M = typename C::Fp;
     const uint32_t rows_per_wave = 64 / G;
     const uint32_t lane = threadIdx.x;
@@ -240,22 +237,31 @@ k_fb_finish(const XYZZ<typename C::Fp>* __restrict__ partial, uint32_t n_rows, u
         XYZZ<M> o = xyzz_shfl_xor<M>(acc, (int)m);
         xyzz_add_cold<M>(&acc, &o);
     }
-    if (sub == 0 && row < n_rows) {
-        uint8_t* dst = out + (size_t)row * 64;
-        if (xyzz_is_inf<M>(acc)) {
-            uint4 z = make_uint4(0, 0, 0, 0);
-            uint4* q = reinterpret_cast<uint4*>(dst);
-            q[0] = z; q[1] = z; q[2] = z; q[3] = z;
-        } else {
-            Fe<M> inv = fe_inv_dev<M>(acc.zzz);
-            Affine<M> a = xyzz_to_affine_with_inv<M>(acc, inv);
-            Fe<M> one = fe_zero<M>();
-            one.v[0] = 1;
-            Fe<M> x = fe_mul_call<M>(a.x, one), y = fe_mul_call<M>(a.y, one);  // out of Montgomery form
-            store_be256(dst, x.v);
-            store_be256(dst + 32, y.v);
-        }
+    if (sub == 0 && row < n_rows) store_xyzz<M>(partial + (size_t)row * S, acc);
+}
+
+// one lane per row: partial[row * S] -> affine (one inversion), Montgomery -> big-endian X||Y (64 zero bytes = infinity)
+template <class C>
+__global__ void __launch_bounds__(64)
+k_fb_finish(const XYZZ<typename C::Fp>* __restrict__ partial, uint32_t n_rows, uint32_t S, uint8_t* __restrict__ out) {
+    using M = typename C::Fp;
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    XYZZ<M> acc = load_xyzz<M>(partial + (size_t)row * S);
+    uint8_t* dst = out + (size_t)row * 64;
+    if (xyzz_is_inf<M>(acc)) {
+        uint4 z = make_uint4(0, 0, 0, 0);
+        uint4* q = reinterpret_cast<uint4*>(dst);
+        q[0] = z; q[1] = z; q[2] = z; q[3] = z;
+        return;
     }
+    Fe<M> inv = fe_inv_dev<M>(acc.zzz);
+    Affine<M> a = xyzz_to_affine_with_inv<M>(acc, inv);
+    Fe<M> one = fe_zero<M>();
+    one.v[0] = 1;
+    Fe<M> x = fe_mul_call<M>(a.x, one), y = fe_mul_call<M>(a.y, one);  // out of Montgomery form
+    store_be256(dst, x.v);
+    store_be256(dst + 32, y.v);
 }
 
 }  // namespace porla

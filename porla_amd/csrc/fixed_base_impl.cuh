@@ -9,6 +9,9 @@ namespace porla {
 template <class C>
 void FixedBase<C>::release() {
     if (table) (void)hipFree(table);
+    if (pow_buf) (void)hipFree(pow_buf);
+    if (scratch_buf) (void)hipFree(scratch_buf);
+    pow_buf = nullptr; scratch_buf = nullptr; table_cap = pow_cap = scratch_cap = 0;
     if (partial) (void)hipFree(partial);
     if (io_rows) (void)hipFree(io_rows);
     if (io_out) (void)hipFree(io_out);
@@ -22,7 +25,7 @@ void FixedBase<C>::release() {
 template <class C>
 int FixedBase<C>::build(const Affine<typename C::Fp>* d_base, size_t n, int window_bits, hipStream_t stream) {
     using M = typename C::Fp;
-    release();
+    n_points = 0;
     if (n == 0) return PORLA_OK;
     int cc = window_bits;
     if (cc <= 0) {
@@ -34,6 +37,7 @@ int FixedBase<C>::build(const Affine<typename C::Fp>* d_base, size_t n, int wind
     PORLA_HIP(hipGetDevice(&device));
     size_t free_b = 0, total_b = 0;
     PORLA_HIP(hipMemGetInfo(&free_b, &total_b));
+    free_b += table_cap;
     for (;; cc--) {  // shrink the window until the table (plus its construction scratch) fits in a quarter of free HBM
         int Wc = (C::SCALAR_BITS + 1 + cc - 1) / cc;
         size_t bytes = n * (size_t)Wc * ((size_t)1 << (cc - 1)) * sizeof(Affine<M>);
@@ -44,16 +48,24 @@ int FixedBase<C>::build(const Affine<typename C::Fp>* d_base, size_t n, int wind
     const uint32_t H = 1u << (c - 1);
     const size_t pairs = n * (size_t)W;
     const size_t entries = pairs * H;
-    PORLA_HIP(hipMalloc((void**)&table, entries * sizeof(Affine<M>)));
-    XYZZ<M>* pow = nullptr;
-    PORLA_HIP(hipMalloc((void**)&pow, pairs * sizeof(XYZZ<M>)));
     // scratch: at most 1 GiB of XYZZ entries per batch of (point, window) pairs
     size_t batch_pairs = ((size_t)1 << 30) / ((size_t)H * sizeof(XYZZ<M>));
     if (batch_pairs < 1) batch_pairs = 1;
     if (batch_pairs > pairs) batch_pairs = pairs;
-    XYZZ<M>* scratch = nullptr;
-    hipError_t e = hipMalloc((void**)&scratch, batch_pairs * H * sizeof(XYZZ<M>));
-    if (e != hipSuccess) { (void)hipFree(pow); return hip_fail(e, "hipMalloc(scratch)", __FILE__, __LINE__); }
+    auto ensure = [](void** ptr, size_t* cap, size_t bytes) -> hipError_t {
+        if (bytes <= *cap) return hipSuccess;
+        if (*ptr) (void)hipFree(*ptr);
+        *ptr = nullptr; *cap = 0;
+        hipError_t e = hipMalloc(ptr, bytes);
+        if (e == hipSuccess) *cap = bytes;
+        return e;
+    };
+    hipError_t e;
+    if ((e = ensure((void**)&table, &table_cap, entries * sizeof(Affine<M>))) != hipSuccess) return hip_fail(e, "hipMalloc(table)", __FILE__, __LINE__);
+    if ((e = ensure((void**)&pow_buf, &pow_cap, pairs * sizeof(XYZZ<M>))) != hipSuccess) return hip_fail(e, "hipMalloc(pow)", __FILE__, __LINE__);
+    if ((e = ensure((void**)&scratch_buf, &scratch_cap, batch_pairs * H * sizeof(XYZZ<M>))) != hipSuccess) return hip_fail(e, "hipMalloc(scratch)", __FILE__, __LINE__);
+    XYZZ<M>* pow = pow_buf;
+    XYZZ<M>* scratch = scratch_buf;
     {
         ProfScope ps("fb_base_powers", stream);
         hipLaunchKernelGGL((k_fb_base_powers<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_base, (uint32_t)n, c, W, pow);
@@ -70,14 +82,16 @@ int FixedBase<C>::build(const Affine<typename C::Fp>* d_base, size_t n, int wind
         size_t cnt = np * H;
         {
             ProfScope ps("fb_normalize", stream);
-            hipLaunchKernelGGL((k_fb_normalize<C>), dim3((unsigned)((cnt / 8 + 1 + 63) / 64)), dim3(64), 0, stream,
+            hipLaunchKernelGGL((k_fb_normalize<C>), dim3((unsigned)((cnt / 32 + 1 + 63) / 64)), dim3(64), 0, stream,
                                (const XYZZ<M>*)scratch, cnt, table + p0 * H);
         }
     }
-    hipError_t e2 = hipStreamSynchronize(stream);
-    (void)hipFree(scratch);
-    (void)hipFree(pow);
-    if (e2 != hipSuccess) return hip_fail(e2, "fixed-base table construction", __FILE__, __LINE__);
+    if (!keep_build_buffers) {
+        hipError_t e2 = hipStreamSynchronize(stream);
+        (void)hipFree(scratch_buf); (void)hipFree(pow_buf);
+        scratch_buf = nullptr; pow_buf = nullptr; scratch_cap = pow_cap = 0;
+        if (e2 != hipSuccess) return hip_fail(e2, "fixed-base table construction", __FILE__, __LINE__);
+    }
     PORLA_HIP(hipGetLastError());
     n_points = n;
     return PORLA_OK;
@@ -108,11 +122,16 @@ int FixedBase<C>::commit_device(const uint8_t* d_rows, size_t n_rows, size_t n_c
         hipLaunchKernelGGL((k_fb_commit<C>), dim3((unsigned)((n_rows + 255) / 256), S), dim3(256), 0, stream, d_rows,
                            (uint32_t)n_rows, (uint32_t)n_coeffs, row_stride, (const Affine<M>*)table, c, W, S, partial);
     }
+    if (S > 1) {
+        ProfScope ps("fb_fold", stream);
+        uint32_t rows_per_wave = 64 / G;
+        hipLaunchKernelGGL((k_fb_fold<C>), dim3((unsigned)((n_rows + rows_per_wave - 1) / rows_per_wave)), dim3(64), 0,
+                           stream, partial, (uint32_t)n_rows, S, G);
+    }
     {
         ProfScope ps("fb_finish", stream);
-        uint32_t rows_per_wave = 64 / G;
-        hipLaunchKernelGGL((k_fb_finish<C>), dim3((unsigned)((n_rows + rows_per_wave - 1) / rows_per_wave)), dim3(64), 0,
-                           stream, (const XYZZ<M>*)partial, (uint32_t)n_rows, S, G, d_out);
+        hipLaunchKernelGGL((k_fb_finish<C>), dim3((unsigned)((n_rows + 63) / 64)), dim3(64), 0, stream,
+                           (const XYZZ<M>*)partial, (uint32_t)n_rows, S, d_out);
     }
     PORLA_HIP(hipGetLastError());
     return PORLA_OK;

@@ -199,13 +199,22 @@ k_icc_stages(IccElem<Q>* __restrict__ work, const IccElem<Q>* __restrict__ tw, u
 }
 
 // residue pair -> (a) value in [0, LCM) as 64-byte LE, (b) value mod p_icc as 32-byte LE,
-// (c) alignment scalar c = (A mod p_icc - A) mod q (Server.hpp:535-538) as 32 bytes BE (or LE limbs)
+// (c) alignment scalar c = (A mod p_icc - A) mod q (Server.hpp:535-538) as 32 bytes BE (or LE limbs),
+// (d) A mod q as 32 bytes BE (the coefficient the MAC side sees, mac_fft.hip)
 template <class Q>
 __global__ void k_icc_finish(const IccElem<Q>* __restrict__ work, size_t total, uint8_t* __restrict__ x_out,
-                             uint8_t* __restrict__ al_out, uint8_t* __restrict__ sc_out, int scalar_le) {
+                             uint8_t* __restrict__ al_out, uint8_t* __restrict__ sc_out, int scalar_le,
+                             uint8_t* __restrict__ qres_out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     IccElem<Q> e = ld_elem<Q>(work + i);
+    if (qres_out) {
+        Fe<Q> a = fe_from_mont<Q>(e.q);
+        uint4* q4 = reinterpret_cast<uint4*>(qres_out + 32 * i);
+        q4[0] = make_uint4(__builtin_bswap32(a.v[7]), __builtin_bswap32(a.v[6]), __builtin_bswap32(a.v[5]), __builtin_bswap32(a.v[4]));
+        q4[1] = make_uint4(__builtin_bswap32(a.v[3]), __builtin_bswap32(a.v[2]), __builtin_bswap32(a.v[1]), __builtin_bswap32(a.v[0]));
+        if (!x_out && !al_out && !sc_out) return;
+    }
     Fe<IccFp> P = fe_from_mont<IccFp>(e.p);      // A mod p_icc, plain
     if (al_out) st_fe<IccFp>(reinterpret_cast<uint32_t*>(al_out + 32 * i), P);
     Fe<Q> pq;                                     // (A mod p_icc) mod q
@@ -268,6 +277,12 @@ __global__ void k_icc_finish(const IccElem<Q>* __restrict__ work, size_t total, 
         o[2] = make_uint4(A[8], A[9], A[10], A[11]);
         o[3] = make_uint4(A[12], A[13], A[14], A[15]);
     }
+}
+
+// rows_in = N x N identity (32-byte LE chunks): entry (i, i) = 1
+static __global__ void k_icc_identity(uint8_t* __restrict__ rows, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rows[((size_t)i * n + i) * 32] = 1;
 }
 
 }  // namespace porla

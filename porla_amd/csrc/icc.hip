@@ -3,6 +3,7 @@
 // porla/Server/Server.hpp:1544-1833; see INTEGRATION.md.
 #include "engine.hpp"
 #include "icc.cuh"
+#include "icc_host.hpp"
 
 #include <vector>
 
@@ -28,28 +29,10 @@ static int get_icc_ws(IccWs** out) {
     return PORLA_OK;
 }
 
-static inline int ilog2u(size_t n) { int l = 0; while (n >>= 1) l++; return l; }
-static inline uint64_t rev_bits(uint64_t x, int n) { uint64_t r = 0; for (int i = 0; i < n; i++) { r = (r << 1) | (x & 1); x >>= 1; } return r; }
-
-// w = GENERATOR^((p_icc - 1)/(2N)) mod p_icc (Server.hpp:214-216), Montgomery form
-static Fe<IccFp> icc_root(size_t n) {
-    Fe<IccFp> g;
-    for (int i = 0; i < 8; i++) g.v[i] = IccGen::G[i];
-    g = fe_to_mont<IccFp>(g);
-    // (p-1)/(2N) = 207 * 2^(247 - log2 N)
-    int sh = 247 - ilog2u(n);
-    uint32_t e[8] = {0};
-    uint64_t v = 207;
-    int limb = sh >> 5, off = sh & 31;
-    uint64_t lo = v << off;
-    e[limb] = (uint32_t)lo;
-    if (limb + 1 < 8) e[limb + 1] = (uint32_t)(lo >> 32);
-    return h_fe_pow<IccFp>(g, e);
-}
-
 template <class Q>
 static int icc_encode_core(IccWs* ws, int curve, const uint8_t* d_rows, size_t n, size_t ncols, unsigned long long write_step,
-                           int part, uint8_t* d_x, uint8_t* d_al, uint8_t* d_sc, int scalar_le, hipStream_t stream) {
+                           int part, uint8_t* d_x, uint8_t* d_al, uint8_t* d_sc, int scalar_le, hipStream_t stream,
+                           uint8_t* d_qres = nullptr) {
     const int logn = ilog2u(n);
     if (n < 2 || ((size_t)1 << logn) != n || n > (1u << 30) || ncols == 0) {
         set_last_error("porla: ICC encode needs a power-of-two row count >= 2");
@@ -113,18 +96,35 @@ static int icc_encode_core(IccWs* ws, int curve, const uint8_t* d_rows, size_t n
     {
         ProfScope ps("icc_finish", stream);
         hipLaunchKernelGGL((k_icc_finish<Q>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
-                           (const IccElem<Q>*)ws->work.p, total, d_x, d_al, d_sc, scalar_le);
+                           (const IccElem<Q>*)ws->work.p, total, d_x, d_al, d_sc, scalar_le, d_qres);
     }
     PORLA_HIP(hipGetLastError());
     return PORLA_OK;
 }
 
 static int icc_encode_dispatch(IccWs* ws, int curve, const uint8_t* d_rows, size_t n, size_t ncols, unsigned long long ws_step,
-                               int part, uint8_t* d_x, uint8_t* d_al, uint8_t* d_sc, int scalar_le, hipStream_t stream) {
-    if (curve == 0) return icc_encode_core<IccBn254Fr>(ws, 0, d_rows, n, ncols, ws_step, part, d_x, d_al, d_sc, scalar_le, stream);
-    if (curve == 1) return icc_encode_core<IccSecp256k1Fn>(ws, 1, d_rows, n, ncols, ws_step, part, d_x, d_al, d_sc, scalar_le, stream);
+                               int part, uint8_t* d_x, uint8_t* d_al, uint8_t* d_sc, int scalar_le, hipStream_t stream,
+                               uint8_t* d_qres = nullptr) {
+    if (curve == 0) return icc_encode_core<IccBn254Fr>(ws, 0, d_rows, n, ncols, ws_step, part, d_x, d_al, d_sc, scalar_le, stream, d_qres);
+    if (curve == 1) return icc_encode_core<IccSecp256k1Fn>(ws, 1, d_rows, n, ncols, ws_step, part, d_x, d_al, d_sc, scalar_le, stream, d_qres);
     set_last_error("porla: curve must be 0 (BN254 / KZG) or 1 (secp256k1 / IPA)");
     return PORLA_ERR_ARG;
+}
+
+// The butterfly network as a matrix over Z_q: row k = the coefficients F[k][0..n) with out_k = sum_i F[k][i] * in_i
+// (part 1: inputs pre-scaled by wt), 32-byte big-endian each -- the data-side encode applied to the N x N identity.
+int icc_network_matrix_device(int curve, size_t n, unsigned long long write_step, int part, uint8_t* d_rows_out,
+                              hipStream_t stream) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_icc_mu);
+    IccWs* ws;
+    if ((rc = get_icc_ws(&ws))) return rc;
+    if ((rc = ws->in.ensure(n * n * 32))) return rc;
+    PORLA_HIP(hipMemsetAsync(ws->in.p, 0, n * n * 32, stream));
+    hipLaunchKernelGGL(k_icc_identity, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (uint8_t*)ws->in.p, (uint32_t)n);
+    return icc_encode_dispatch(ws, curve, (const uint8_t*)ws->in.p, n, n, write_step, part, nullptr, nullptr, nullptr, 0,
+                               stream, d_rows_out);
 }
 
 }  // namespace porla

@@ -1,0 +1,167 @@
+// MAC-side ICC encode ("FFT in the exponent") on gfx950: the butterfly network of icc.cuh applied to group elements.
+//
+// Reference: Server::CRebuild_Cached interleaves, with every data butterfly, the same butterfly on the block MACs
+//   tm = v^j * MAC[k+m2];  MAC[k] = um + tm;  MAC[k+m2] = um - tm
+// (porla/Server/Server.hpp:1590-1609 and :1658-1676, KZG branch: bn254_mult / bn254_add / bn254_neg = one cgo call
+// each; IPA branch: secp256k1_ecmult + gej_add_var), after the init scaling X = MAC_U, Y = wt * MAC_U
+// (Server.hpp:1523-1536).  The client runs the same network on the MAC complements (porla/Client/Client.hpp:1040-1453).
+// The multiplier is the INTEGER v^j mod p_icc handed to the group as a scalar (convert_ZZ_to_scalar, utils.h:307-318),
+// i.e. reduced mod the group order by fr.SetBytes (main.go:209) / the secp256k1 scalar.
+//
+// MI355X: N/2 independent scalar multiplications per stage, log2 N dependent stages.  One lane owns one butterfly; the
+// scalar multiplication is a signed fixed-window (4-bit) ladder over extended-Jacobian points kept in HBM between
+// stages (128 B per MAC), so a stage is N/2 * (256 doublings + ~64 additions) and is VALU (integer multiply) bound;
+// HBM traffic is 2 * 128 B per MAC per stage.  Stage twiddles with value 1 (j = 0) skip the ladder.
+#pragma once
+#include "fixed_base.cuh"
+#include "icc.cuh"
+
+namespace porla {
+
+// plain little-endian limbs of (w^e mod p_icc) mod q for e in [0, n)   (cf. k_icc_twiddles in icc.cuh)
+template <class Q>
+__global__ void k_mac_twiddles(uint32_t* __restrict__ tws, uint32_t n, const Fe<IccFp>* __restrict__ wpow, int logn) {
+    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    Fe<IccFp> acc = fe_one<IccFp>();
+    for (int i = 0; i < logn; i++) {
+        if ((e >> i) & 1) acc = fe_mul_call<IccFp>(acc, wpow[i]);
+    }
+    Fe<IccFp> plain = fe_from_mont<IccFp>(acc);
+    uint32_t t[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) t[k] = plain.v[k];
+    fe_reduce_plain<Q>(t, Q::MAX_Q_P + 1);
+    uint4* d = reinterpret_cast<uint4*>(tws + (size_t)e * 8);
+    d[0] = make_uint4(t[0], t[1], t[2], t[3]);
+    d[1] = make_uint4(t[4], t[5], t[6], t[7]);
+}
+
+template <class M>
+__device__ __forceinline__ XYZZ<M> xyzz_neg(const XYZZ<M>& p) {
+    XYZZ<M> r = p;
+    r.y = fe_neg<M>(p.y);
+    return r;
+}
+
+// k * P, k < 2^256 plain limbs: signed 4-bit fixed windows, most significant first (65 digits cover the carry)
+template <class M>
+__device__ __noinline__ XYZZ<M> xyzz_scalar_mul(XYZZ<M> P, const uint32_t k[8]) {
+    uint32_t nz = 0;
+#pragma unroll
+    for (int i = 1; i < 8; i++) nz |= k[i];
+    if (nz == 0 && k[0] == 1) return P;
+    if (nz == 0 && k[0] == 0) return xyzz_inf<M>();
+    XYZZ<M> tbl[8];
+    tbl[0] = P;
+#pragma unroll 1
+    for (int i = 1; i < 8; i++) {
+        tbl[i] = tbl[i - 1];
+        xyzz_add_cold<M>(&tbl[i], &P);
+    }
+    // signed digits, least significant first: d in [-8, 8]
+    int8_t dig[65];
+    uint32_t carry = 0;
+#pragma unroll 1
+    for (int i = 0; i < 64; i++) {
+        uint32_t limb = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) limb = (j == (i >> 3)) ? k[j] : limb;
+        uint32_t d = ((limb >> ((i & 7) * 4)) & 15u) + carry;
+        if (d > 8) { dig[i] = (int8_t)((int)d - 16); carry = 1; }
+        else { dig[i] = (int8_t)d; carry = 0; }
+    }
+    dig[64] = (int8_t)carry;
+    XYZZ<M> acc = xyzz_inf<M>();
+#pragma unroll 1
+    for (int i = 64; i >= 0; i--) {
+        if (!xyzz_is_inf<M>(acc)) {
+#pragma unroll 1
+            for (int d = 0; d < 4; d++) xyzz_double_cold<M>(&acc);
+        }
+        int d = dig[i];
+        if (d != 0) {
+            XYZZ<M> t = tbl[(d < 0 ? -d : d) - 1];
+            if (d < 0) t.y = fe_neg<M>(t.y);
+            xyzz_add_cold<M>(&acc, &t);
+        }
+    }
+    return acc;
+}
+
+// 64-byte big-endian affine MACs -> XYZZ work array; part 1 (Y): times wt (Server.hpp:1528-1536)
+template <class C>
+__global__ void __launch_bounds__(64)
+k_mac_load(const uint8_t* __restrict__ in, uint32_t n, XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restrict__ wt,
+           int use_wt) {
+    using M = typename C::Fp;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<M> a;
+    load_be256(a.x.v, in + (size_t)i * 64);
+    load_be256(a.y.v, in + (size_t)i * 64 + 32);
+    fe_reduce_plain<M>(a.x.v, 6);
+    fe_reduce_plain<M>(a.y.v, 6);
+    a.x = fe_to_mont<M>(a.x);
+    a.y = fe_to_mont<M>(a.y);
+    XYZZ<M> p = xyzz_from_affine<M>(a);
+    if (use_wt) {
+        uint32_t k[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) k[j] = wt[j];
+        p = xyzz_scalar_mul<M>(p, k);
+    }
+    store_xyzz<M>(work + i, p);
+}
+
+// stage s: m = 2^s, m2 = m/2; butterfly t <-> (j = t % m2, k = (t / m2) * m + j); twiddle exponent e = j * (n / m2)
+template <class C>
+__global__ void __launch_bounds__(64)
+k_mac_stage(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restrict__ tws, uint32_t n, int s) {
+    using M = typename C::Fp;
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n / 2) return;
+    const uint32_t m2 = 1u << (s - 1);
+    const uint32_t j = t & (m2 - 1);
+    const uint32_t k = ((t >> (s - 1)) << s) + j;
+    const uint32_t e = j * (n >> (s - 1));
+    uint32_t sc[8];
+    const uint4* q = reinterpret_cast<const uint4*>(tws + (size_t)e * 8);
+    uint4 a = q[0], b = q[1];
+    sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
+    XYZZ<M> hi = load_xyzz<M>(work + k + m2);
+    XYZZ<M> tm = xyzz_scalar_mul<M>(hi, sc);
+    XYZZ<M> um = load_xyzz<M>(work + k);
+    XYZZ<M> sum = um;
+    xyzz_add_cold<M>(&sum, &tm);
+    XYZZ<M> ntm = xyzz_neg<M>(tm);
+    xyzz_add_cold<M>(&um, &ntm);
+    store_xyzz<M>(work + k, sum);
+    store_xyzz<M>(work + k + m2, um);
+}
+
+// XYZZ work array -> 64-byte big-endian affine MACs (infinity = 64 zero bytes, main.go:224-230)
+template <class C>
+__global__ void __launch_bounds__(64)
+k_mac_finish(const XYZZ<typename C::Fp>* __restrict__ work, uint32_t n, uint8_t* __restrict__ out) {
+    using M = typename C::Fp;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    XYZZ<M> p = load_xyzz<M>(work + i);
+    uint8_t* dst = out + (size_t)i * 64;
+    if (xyzz_is_inf<M>(p)) {
+        uint4 z = make_uint4(0, 0, 0, 0);
+        uint4* q = reinterpret_cast<uint4*>(dst);
+        q[0] = z; q[1] = z; q[2] = z; q[3] = z;
+        return;
+    }
+    Fe<M> inv = fe_inv_dev<M>(p.zzz);
+    Affine<M> a = xyzz_to_affine_with_inv<M>(p, inv);
+    Fe<M> one = fe_zero<M>();
+    one.v[0] = 1;
+    Fe<M> x = fe_mul_call<M>(a.x, one), y = fe_mul_call<M>(a.y, one);
+    store_be256(dst, x.v);
+    store_be256(dst + 32, y.v);
+}
+
+}  // namespace porla

@@ -1,0 +1,176 @@
+// MAC-side ICC encode: launch logic + C ABI (include/porla_gpu.h: porla_icc_mac_encode_device / _host).
+//
+// Two forms of the same linear map over the group (bit-exact on the affine result):
+//   ladder (N > PORLA_MAC_MATRIX_MAX, default 2048): stage by stage, one lane per butterfly (mac_fft.cuh); a stage costs
+//          one 256-bit scalar multiplication of LATENCY (~2.9 ms for a lone wave), so small N is latency-bound;
+//   matrix (N <= 2048): out_k = sum_i F[k][i] * MAC_i with F = the butterfly network as an N x N matrix over Z_q (the
+//          data-side encode applied to the identity, cached per (N, curve, part, wt)); evaluated as N commitments
+//          against the per-call base {MAC_i} with the batched fixed-base kernels (fixed_base.cuh, 8-bit windows):
+//          N^2 * 32 independent mixed additions instead of log2(N) dependent ladders -- throughput- not latency-bound.
+// Patch site in the reference (no function boundary exists there): the MAC halves of Server::CRebuild_Cached,
+// porla/Server/Server.hpp:1523-1536, 1590-1609, 1658-1676 and the Y-part twins; see INTEGRATION.md.
+#include "engine.hpp"
+#include "mac_fft.cuh"
+#include "icc_host.hpp"
+
+#include <cstdlib>
+#include <vector>
+
+namespace porla {
+
+struct MacWs {
+    int device = -1;
+    Buf work, tws, wpow, wt, in, out;
+    uint32_t tw_n = 0;
+    int tw_curve = -1;
+    // matrix form
+    Buf F, mont;
+    size_t F_n = 0;
+    int F_curve = -1, F_part = -1;
+    unsigned long long F_wt_exp = 0;
+    FixedBase<Bn254G1> fb_bn;
+    FixedBase<Secp256k1G> fb_secp;
+};
+template <class C> struct FbOf;
+template <> struct FbOf<Bn254G1> { static FixedBase<Bn254G1>& get(MacWs* w) { return w->fb_bn; } };
+template <> struct FbOf<Secp256k1G> { static FixedBase<Secp256k1G>& get(MacWs* w) { return w->fb_secp; } };
+static std::mutex g_mac_mu;
+static size_t g_matrix_max = getenv("PORLA_MAC_MATRIX_MAX") ? (size_t)atol(getenv("PORLA_MAC_MATRIX_MAX")) : 2048;
+static std::vector<MacWs*> g_mac_ws;
+
+static int get_mac_ws(MacWs** out) {
+    int dev = 0;
+    PORLA_HIP(hipGetDevice(&dev));
+    for (auto* w : g_mac_ws) if (w->device == dev) { *out = w; return PORLA_OK; }
+    MacWs* w = new MacWs();
+    w->device = dev;
+    g_mac_ws.push_back(w);
+    *out = w;
+    return PORLA_OK;
+}
+
+template <class C, class Q>
+static int mac_encode_core(MacWs* ws, int curve, const uint8_t* d_in, size_t n, unsigned long long write_step, int part,
+                           uint8_t* d_out, hipStream_t stream) {
+    using M = typename C::Fp;
+    const int logn = ilog2u(n);
+    if (n < 2 || ((size_t)1 << logn) != n || n > (1u << 30)) {
+        set_last_error("porla: MAC encode needs a power-of-two row count >= 2");
+        return PORLA_ERR_ARG;
+    }
+    int rc;
+    if (n <= g_matrix_max) {
+        // ---- matrix form
+        const unsigned long long wt_exp = part == 1 ? rev_bits(write_step % n, logn) : 0;
+        if (ws->F_n != n || ws->F_curve != curve || ws->F_part != part || ws->F_wt_exp != wt_exp) {
+            if ((rc = ws->F.ensure(n * n * 32))) return rc;
+            ProfScope ps("mac_matrix", stream);
+            if ((rc = icc_network_matrix_device(curve, n, write_step, part, (uint8_t*)ws->F.p, stream))) return rc;
+            ws->F_n = n; ws->F_curve = curve; ws->F_part = part; ws->F_wt_exp = wt_exp;
+        }
+        if ((rc = ws->mont.ensure(n * sizeof(Affine<M>)))) return rc;
+        FixedBase<C>& fb = FbOf<C>::get(ws);
+        fb.keep_build_buffers = true;
+        hipLaunchKernelGGL((k_points_to_mont<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_in,
+                           (Affine<M>*)ws->mont.p, (uint32_t)n);
+        static const int mw = getenv("PORLA_MAC_MATRIX_WINDOW") ? atoi(getenv("PORLA_MAC_MATRIX_WINDOW")) : 8;
+        if ((rc = fb.build((const Affine<M>*)ws->mont.p, n, mw, stream))) return rc;
+        return fb.commit_device((const uint8_t*)ws->F.p, n, n, n * 32, d_out, stream);
+    }
+    if ((rc = ws->work.ensure(n * sizeof(XYZZ<M>)))) return rc;
+    if ((rc = ws->wt.ensure(64))) return rc;
+    if (ws->tw_n != n || ws->tw_curve != curve) {
+        if ((rc = ws->tws.ensure(n * 32))) return rc;
+        if ((rc = ws->wpow.ensure(64 * sizeof(Fe<IccFp>)))) return rc;
+        std::vector<Fe<IccFp>> wp(logn ? logn : 1);
+        Fe<IccFp> cur = icc_root(n);
+        for (int i = 0; i < logn; i++) { wp[i] = cur; cur = fe_sqr<IccFp>(cur); }
+        PORLA_HIP(hipMemcpyAsync(ws->wpow.p, wp.data(), logn * sizeof(Fe<IccFp>), hipMemcpyHostToDevice, stream));
+        PORLA_HIP(hipStreamSynchronize(stream));  // wp is a host temporary
+        ProfScope ps("mac_twiddles", stream);
+        hipLaunchKernelGGL((k_mac_twiddles<Q>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (uint32_t*)ws->tws.p,
+                           (uint32_t)n, (const Fe<IccFp>*)ws->wpow.p, logn);
+        ws->tw_n = (uint32_t)n;
+        ws->tw_curve = curve;
+    }
+    int use_wt = 0;
+    if (part == 1) {
+        // wt as the group sees it: the integer (wt mod p_icc) reduced mod the group order (Server.hpp:1494-1503)
+        Fe<IccFp> plain = fe_from_mont<IccFp>(icc_wt(n, write_step));
+        uint32_t k[8];
+        for (int i = 0; i < 8; i++) k[i] = plain.v[i];
+        fe_reduce_plain<Q>(k, 8);
+        PORLA_HIP(hipMemcpyAsync(ws->wt.p, k, 32, hipMemcpyHostToDevice, stream));
+        PORLA_HIP(hipStreamSynchronize(stream));
+        use_wt = 1;
+    }
+    {
+        ProfScope ps("mac_load", stream);
+        hipLaunchKernelGGL((k_mac_load<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_in, (uint32_t)n,
+                           (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->wt.p, use_wt);
+    }
+    for (int s = 1; s <= logn; s++) {
+        ProfScope ps("mac_stage", stream);
+        hipLaunchKernelGGL((k_mac_stage<C>), dim3((unsigned)((n / 2 + 63) / 64)), dim3(64), 0, stream, (XYZZ<M>*)ws->work.p,
+                           (const uint32_t*)ws->tws.p, (uint32_t)n, s);
+    }
+    {
+        ProfScope ps("mac_finish", stream);
+        hipLaunchKernelGGL((k_mac_finish<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, (const XYZZ<M>*)ws->work.p,
+                           (uint32_t)n, d_out);
+    }
+    PORLA_HIP(hipGetLastError());
+    return PORLA_OK;
+}
+
+static int mac_dispatch(MacWs* ws, int curve, const uint8_t* d_in, size_t n, unsigned long long write_step, int part,
+                        uint8_t* d_out, hipStream_t stream) {
+    if (curve == 0) return mac_encode_core<Bn254G1, IccBn254Fr>(ws, 0, d_in, n, write_step, part, d_out, stream);
+    if (curve == 1) return mac_encode_core<Secp256k1G, IccSecp256k1Fn>(ws, 1, d_in, n, write_step, part, d_out, stream);
+    set_last_error("porla: curve must be 0 (BN254) or 1 (secp256k1)");
+    return PORLA_ERR_ARG;
+}
+
+}  // namespace porla
+
+using namespace porla;
+
+extern "C" {
+
+int porla_icc_mac_set_matrix_max(size_t n_rows) {
+    std::lock_guard<std::mutex> lk(g_mac_mu);
+    g_matrix_max = n_rows;
+    return PORLA_OK;
+}
+
+int porla_icc_mac_encode_device(const void* d_macs_in, size_t n_rows, int curve, unsigned long long write_step, int part,
+                                void* d_macs_out, void* hip_stream) {
+    if (!d_macs_in || !d_macs_out) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mac_mu);
+    MacWs* ws;
+    if ((rc = get_mac_ws(&ws))) return rc;
+    return mac_dispatch(ws, curve, (const uint8_t*)d_macs_in, n_rows, write_step, part, (uint8_t*)d_macs_out, (hipStream_t)hip_stream);
+}
+
+int porla_icc_mac_encode_host(const uint8_t* macs_in, size_t n_rows, int curve, unsigned long long write_step, int part,
+                              uint8_t* macs_out) {
+    if (!macs_in || !macs_out) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mac_mu);
+    MacWs* ws;
+    if ((rc = get_mac_ws(&ws))) return rc;
+    if ((rc = ws->in.ensure(n_rows * 64))) return rc;
+    if ((rc = ws->out.ensure(n_rows * 64))) return rc;
+    hipStream_t s = engine_stream();
+    PORLA_HIP(hipMemcpyAsync(ws->in.p, macs_in, n_rows * 64, hipMemcpyHostToDevice, s));
+    rc = mac_dispatch(ws, curve, (const uint8_t*)ws->in.p, n_rows, write_step, part, (uint8_t*)ws->out.p, s);
+    if (rc) return rc;
+    PORLA_HIP(hipMemcpyAsync(macs_out, ws->out.p, n_rows * 64, hipMemcpyDeviceToHost, s));
+    PORLA_HIP(hipStreamSynchronize(s));
+    return PORLA_OK;
+}
+
+}  // extern "C"

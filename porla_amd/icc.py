@@ -35,3 +35,15 @@ def crebuild_device(d_rows, n_rows, n_cols, curve, write_step, part, d_x=0, d_al
     _check(lib.porla_icc_encode_device(ctypes.c_void_p(d_rows), n_rows, n_cols, CURVE[curve], write_step, part,
                                        ctypes.c_void_p(d_x or None), ctypes.c_void_p(d_aligned or None),
                                        ctypes.c_void_p(d_scalars or None), 1 if scalar_le else 0, ctypes.c_void_p(stream)))
+
+
+def mac_crebuild_host(macs, n_rows, curve="bn254", write_step=0, part=0):
+    """MAC halves of CRebuild_Cached (Server.hpp:1523-1536, 1590-1609, 1658-1676): n_rows 64-byte affine MACs in/out."""
+    out = ctypes.create_string_buffer(64 * n_rows)
+    _check(lib.porla_icc_mac_encode_host(bytes(macs), n_rows, CURVE[curve], write_step, part, out))
+    return out.raw
+
+
+def mac_crebuild_device(d_macs, n_rows, curve, write_step, part, d_out, stream=0):
+    _check(lib.porla_icc_mac_encode_device(ctypes.c_void_p(d_macs), n_rows, CURVE[curve], write_step, part,
+                                           ctypes.c_void_p(d_out), ctypes.c_void_p(stream)))

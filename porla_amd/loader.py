@@ -73,6 +73,11 @@ def _declare(L):
     L.porla_kzg_commit_batch_device.argtypes = [vp, sz, vp, vp]; L.porla_kzg_commit_batch_device.restype = ctypes.c_int
     L.porla_kzg_commit_batch_host.argtypes = [u8p, sz, u8p]; L.porla_kzg_commit_batch_host.restype = ctypes.c_int
     L.porla_kzg_set_commit_window.argtypes = [ctypes.c_int]; L.porla_kzg_set_commit_window.restype = ctypes.c_int
+    L.porla_icc_mac_encode_device.argtypes = [vp, sz, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_int, vp, vp]
+    L.porla_icc_mac_encode_device.restype = ctypes.c_int
+    L.porla_icc_mac_encode_host.argtypes = [u8p, sz, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_int, u8p]
+    L.porla_icc_mac_encode_host.restype = ctypes.c_int
+    L.porla_icc_mac_set_matrix_max.argtypes = [sz]; L.porla_icc_mac_set_matrix_max.restype = ctypes.c_int
     L.porla_icc_encode_device.argtypes = [vp, sz, sz, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_int, vp, vp, vp, ctypes.c_int, vp]
     L.porla_icc_encode_device.restype = ctypes.c_int
     L.porla_icc_encode_host.argtypes = [u8p, sz, sz, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_int, vp, vp, vp, ctypes.c_int]
