@@ -123,6 +123,19 @@ int porla_icc_mac_encode_host(const uint8_t *macs_in, size_t n_rows, int curve, 
  * ones the stage-by-stage ladder form (default 2048; 0 = always ladder).  Both are bit-exact. */
 int porla_icc_mac_set_matrix_max(size_t n_rows);
 
+/* ---- audit row combine (Server::audit, Server.hpp:790-828) + the scalar part of align_MAC on the result (:531-541) ----
+ * B_j = sum_i coeff_i * row_i[j] (exact integer), then aligned_j = B_j mod p_icc, c_j = (aligned_j - B_j) mod q.
+ * The challenged rows are addressed inside row stores resident in HBM:
+ *   d_rows64 : store of 512-bit rows, n_cols * 64 bytes per row, little-endian values < LCM (utils.h:473-517, cached levels)
+ *   d_rows32 : store of 256-bit rows, n_cols * 32 bytes per row, little-endian (levels kept aligned)
+ *   d_idx*   : row numbers inside the store (uint64), d_coef* : abs(int32) coefficients (Server.hpp:617-621), n* : counts
+ * outputs (each may be NULL): exact 80 bytes/column LE (the unreduced B_j), aligned 32 B LE, aligned_be 32 B BE (the
+ * coefficient format of create_proof / compute_digest_from_srs), scalars c_j 32 B BE.  curve selects q as for the ICC encode. */
+int porla_audit_combine_device(const void *d_rows64, const uint64_t *d_idx64, const uint32_t *d_coef64, size_t n64,
+                               const void *d_rows32, const uint64_t *d_idx32, const uint32_t *d_coef32, size_t n32,
+                               size_t n_cols, int curve, void *d_exact_out, void *d_aligned_out, void *d_aligned_be_out,
+                               void *d_scalars_out, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -179,3 +179,15 @@ def mac_crebuild(macs, curve="bn254", write_step=0):
                     part[k + m2] = ec_add(curve, um, ec_neg(curve, tm))
                 vi = vi * v % P_ICC
     return X, Y
+
+
+def audit_combine(rows, coeffs, curve="bn254"):
+    """Server::audit row combine (Server.hpp:790-828): B_j = sum_i coeff_i * rows[i][j] (exact), then the scalar part of
+    align_MAC on B (Server.hpp:531-541).  Returns (B, B mod p_icc, alignment scalars)."""
+    ncols = len(rows[0]) if rows else 0
+    B = [0] * ncols
+    for r, c in zip(rows, coeffs):
+        for j in range(ncols):
+            B[j] += c * r[j]
+    mods, cs = align(B, curve)
+    return B, mods, cs

@@ -47,3 +47,13 @@ def mac_crebuild_host(macs, n_rows, curve="bn254", write_step=0, part=0):
 def mac_crebuild_device(d_macs, n_rows, curve, write_step, part, d_out, stream=0):
     _check(lib.porla_icc_mac_encode_device(ctypes.c_void_p(d_macs), n_rows, CURVE[curve], write_step, part,
                                            ctypes.c_void_p(d_out), ctypes.c_void_p(stream)))
+
+
+def audit_combine_device(d_rows64, d_idx64, d_coef64, n64, d_rows32, d_idx32, d_coef32, n32, n_cols, curve,
+                         d_exact=0, d_aligned=0, d_aligned_be=0, d_scalars=0, stream=0):
+    """Server::audit row combine + align_MAC scalar part (Server.hpp:790-828, 531-541); all arguments device addresses."""
+    vp = ctypes.c_void_p
+    _check(lib.porla_audit_combine_device(vp(d_rows64 or None), vp(d_idx64 or None), vp(d_coef64 or None), n64,
+                                          vp(d_rows32 or None), vp(d_idx32 or None), vp(d_coef32 or None), n32, n_cols,
+                                          CURVE[curve], vp(d_exact or None), vp(d_aligned or None), vp(d_aligned_be or None),
+                                          vp(d_scalars or None), vp(stream)))
