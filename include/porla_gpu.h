@@ -55,6 +55,13 @@ int         porla_gpu_profile_enable(int enable);
 int         porla_gpu_profile_get(int slot, char *name, size_t name_cap, double *total_ms, long long *launches);
 /* MSM tuning override (0 = automatic): window bits c */
 int         porla_gpu_set_msm_window(int c);
+/* 1: split every scalar with the curve endomorphism (half the windows); 0: plain windows over the full scalar;
+ * -1 (default): per curve -- secp256k1 on (as the reference does, ecmult_impl.h:621-634), BN254 off (measured slower) */
+int         porla_gpu_set_msm_glv(int on);
+/* diagnostic: the scalar split the digit kernel applies (host execution of the same code): scalar mod n = k1 + lambda*k2,
+ * magnitudes as 16-byte big-endian, signs as 0/1.  curve: 0 = BN254, 1 = secp256k1. */
+int         porla_glv_split(int curve, const uint8_t scalar_be[32], uint8_t k1_mag_be[16], int *k1_neg,
+                            uint8_t k2_mag_be[16], int *k2_neg);
 
 /* ---- BN254 G1 MSM ---- */
 int porla_bn254_msm_device(const void *d_scalars, const void *d_points, size_t n, uint8_t out_affine[64],

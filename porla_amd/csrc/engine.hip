@@ -85,6 +85,7 @@ void prof_flush() {
 std::mutex g_ws_mu;  // serialises MSM calls (compute_digest_from_srs may be called from 8 threads)
 static std::vector<Workspace*> g_ws;
 int g_window_override = 0;
+int g_use_glv = getenv("PORLA_MSM_GLV") ? (getenv("PORLA_MSM_GLV")[0] == '1' ? 1 : 0) : -1;  // -1: per-curve default
 
 int get_workspace(Workspace** out) {
     int dev = 0;
@@ -144,6 +145,12 @@ hipStream_t engine_stream() {
 
 using namespace porla;
 
+namespace {
+struct IccSecp256k1FnHost {  // secp256k1 group order, only P is needed (fe_reduce_plain)
+    static constexpr uint32_t P[8] = {0xd0364141u, 0xbfd25e8cu, 0xaf48a03bu, 0xbaaedce6u, 0xfffffffeu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+};
+}  // namespace
+
 struct porla_fixed_base {
     int curve;
     FixedBase<Bn254G1> bn;
@@ -180,6 +187,26 @@ int porla_gpu_profile_get(int slot, char* name, size_t name_cap, double* total_m
     return PORLA_OK;
 }
 int porla_gpu_set_msm_window(int c) { g_window_override = c; return PORLA_OK; }
+int porla_gpu_set_msm_glv(int on) { g_use_glv = on < 0 ? -1 : (on != 0); return PORLA_OK; }
+
+// host execution of the very code the digit kernel runs (glv.cuh is __host__ __device__): lets the CPU tests pin the
+// split against the Python model of tools/gen_glv.py
+int porla_glv_split(int curve, const uint8_t scalar_be[32], uint8_t k1_mag_be[16], int* k1_neg, uint8_t k2_mag_be[16], int* k2_neg) {
+    if (!scalar_be || !k1_mag_be || !k2_mag_be || !k1_neg || !k2_neg || (curve != 0 && curve != 1)) return PORLA_ERR_ARG;
+    uint32_t k[8], m1[4], m2[4];
+    bool n1, n2;
+    h_load_be(k, scalar_be);
+    if (curve == 0) { fe_reduce_plain<Bn254Fr>(k, 8); glv_split<GlvBn254>(k, m1, n1, m2, n2); }
+    else { fe_reduce_plain<IccSecp256k1FnHost>(k, 2); glv_split<GlvSecp256k1>(k, m1, n1, m2, n2); }
+    for (int i = 0; i < 4; i++) {
+        for (int b = 0; b < 4; b++) {
+            k1_mag_be[15 - (4 * i + b)] = (uint8_t)(m1[i] >> (8 * b));
+            k2_mag_be[15 - (4 * i + b)] = (uint8_t)(m2[i] >> (8 * b));
+        }
+    }
+    *k1_neg = n1; *k2_neg = n2;
+    return PORLA_OK;
+}
 
 int porla_bn254_msm_device(const void* d_scalars, const void* d_points, size_t n, uint8_t out_affine[64], void* s) {
     return abi_msm_device<Bn254G1>(d_scalars, d_points, n, out_affine, s, false);

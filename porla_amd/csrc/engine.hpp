@@ -37,16 +37,6 @@ template <class C>
 int msm_device(const uint8_t* d_scalars, const uint8_t* d_points, size_t n, hipStream_t stream,
                XYZZ<typename C::Fp>* total);
 
-// Same, but the points are already Montgomery limbs in HBM (resident fixed base, e.g. the SRS).
-template <class C>
-int msm_device_mont(const uint8_t* d_scalars, const Affine<typename C::Fp>* d_points_mont, size_t n,
-                    hipStream_t stream, XYZZ<typename C::Fp>* total);
-
-// host scalars (n*32 B big-endian) against a resident Montgomery-form base in HBM
-template <class C>
-int msm_host_scalars(const uint8_t* scalars, const Affine<typename C::Fp>* d_points_mont, size_t n,
-                     XYZZ<typename C::Fp>* total);
-
 // host buffers -> device -> msm
 template <class C>
 int msm_host(const uint8_t* scalars, const uint8_t* points, size_t n, XYZZ<typename C::Fp>* total);
@@ -108,6 +98,7 @@ struct FixedBase {
 
 extern std::mutex g_ws_mu;
 extern int g_window_override;
+extern int g_use_glv;  // 1: GLV split of every scalar; 0: plain signed windows over the full scalar; -1: the curve's default
 int get_workspace(Workspace** out);
 hipStream_t engine_stream();  // this device's engine-owned non-blocking stream
 

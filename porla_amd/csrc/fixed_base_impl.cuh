@@ -175,7 +175,7 @@ int FixedBase<C>::build_from_host_bytes(const uint8_t* points_be, size_t n, int 
     hipError_t e = hipMalloc((void**)&d_mont, n * sizeof(Affine<M>));
     if (e != hipSuccess) { (void)hipFree(d_in); return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
     (void)hipMemcpyAsync(d_in, points_be, n * 64, hipMemcpyHostToDevice, stream);
-    hipLaunchKernelGGL((k_points_to_mont<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const uint8_t*)d_in,
+    hipLaunchKernelGGL((k_points_to_mont<C, false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const uint8_t*)d_in,
                        d_mont, (uint32_t)n);
     rc = build(d_mont, n, window_bits, stream);
     (void)hipStreamSynchronize(stream);

@@ -71,7 +71,7 @@ static int mac_encode_core(MacWs* ws, int curve, const uint8_t* d_in, size_t n, 
         if ((rc = ws->mont.ensure(n * sizeof(Affine<M>)))) return rc;
         FixedBase<C>& fb = FbOf<C>::get(ws);
         fb.keep_build_buffers = true;
-        hipLaunchKernelGGL((k_points_to_mont<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_in,
+        hipLaunchKernelGGL((k_points_to_mont<C, false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_in,
                            (Affine<M>*)ws->mont.p, (uint32_t)n);
         static const int mw = getenv("PORLA_MAC_MATRIX_WINDOW") ? atoi(getenv("PORLA_MAC_MATRIX_WINDOW")) : 8;
         if ((rc = fb.build((const Affine<M>*)ws->mont.p, n, mw, stream))) return rc;

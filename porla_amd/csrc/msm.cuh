@@ -26,6 +26,7 @@
 // + W * 64 B gathers (cache-resident) -- the kernel is VALU (integer multiply) bound, see DESIGN.md.
 #pragma once
 #include "ec.cuh"
+#include "glv.cuh"
 
 namespace porla {
 
@@ -36,6 +37,10 @@ struct Bn254G1 {
                                           0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
     static constexpr int SCALAR_BITS = 254;
     static constexpr int MAX_Q = 5;  // floor((2^256-1)/r)
+    using Glv = GlvBn254;
+    // 254-bit scalars fill 16 windows of 16 bits exactly; the GLV split would halve the windows but double the entries per
+    // bucket and the gathered point set (measured: 3.31 ms vs 2.85 ms at 2^20) -- off by default, on with porla_gpu_set_msm_glv(1)
+    static constexpr bool GLV_DEFAULT = false;
 };
 struct Secp256k1G {
     using Fp = Secp256k1Fp;
@@ -43,6 +48,10 @@ struct Secp256k1G {
                                           0xfffffffeu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
     static constexpr int SCALAR_BITS = 256;
     static constexpr int MAX_Q = 1;
+    using Glv = GlvSecp256k1;
+    // 256-bit scalars need a carry-only 17th window at c = 16 (one bucket with half of all entries); the GLV split (which
+    // the reference's secp256k1 path also applies, ecmult_impl.h:621-634) gives 8 windows of 17 bits instead
+    static constexpr bool GLV_DEFAULT = true;
 };
 
 constexpr uint32_t KEY_NONE = 0xffffffffu;
@@ -109,7 +118,7 @@ __device__ __forceinline__ XYZZ<M> load_xyzz(const XYZZ<M>* src) {
 // ------------------------------------------------------------------------------------------------
 // G1Affine.Unmarshal semantics for the uncompressed form (main.go:130): X, Y <- SetBytes (reduced
 // mod p); (0,0) stays (0,0) = infinity.  Output: Montgomery limbs, 64 B per point.
-template <class C>
+template <class C, bool GLV>
 __global__ void k_points_to_mont(const uint8_t* __restrict__ in, Affine<typename C::Fp>* __restrict__ out, uint32_t n) {
     using M = typename C::Fp;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -121,9 +130,22 @@ __global__ void k_points_to_mont(const uint8_t* __restrict__ in, Affine<typename
     fe_reduce_plain<M>(y.v, 6);
     x = fe_to_mont<M>(x);
     y = fe_to_mont<M>(y);
-    uint32_t* d = reinterpret_cast<uint32_t*>(out + i);
-    store_fe<M>(d, x);
-    store_fe<M>(d + 8, y);
+    if (GLV) {
+        // P at 2i, phi(P) = (beta * x, y) at 2i + 1; infinity (0, 0) stays (0, 0)
+        Fe<M> beta;
+#pragma unroll
+        for (int k = 0; k < 8; k++) beta.v[k] = C::Glv::BETA[k];
+        Fe<M> bx = fe_mul<M>(x, fe_to_mont<M>(beta));
+        uint32_t* d = reinterpret_cast<uint32_t*>(out + 2 * (size_t)i);
+        store_fe<M>(d, x);
+        store_fe<M>(d + 8, y);
+        store_fe<M>(d + 16, bx);
+        store_fe<M>(d + 24, y);
+    } else {
+        uint32_t* d = reinterpret_cast<uint32_t*>(out + i);
+        store_fe<M>(d, x);
+        store_fe<M>(d + 8, y);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -131,9 +153,9 @@ __global__ void k_points_to_mont(const uint8_t* __restrict__ in, Affine<typename
 //
 // Pass A  k_digits_partition: a block owns a TILE of 4096 scalars.  It reduces them mod the group order once
 //         (fr.Element.SetBytes, main.go:127), keeps the limbs in registers, and for every window w emits the tile's
-//         non-zero signed digits grouped by PARTITION (= high bits of the bucket id) into tile_items[w][tile][*] together
-//         with the offset table tile_off[w][tile][*].
-//         An item is (bucket & lowmask) | sign << lowbits | local_index << (lowbits + 1)   (local_index < 4096).
+//         non-zero signed digits grouped by PARTITION (= LOW bits of the bucket id, so that a sparsely filled top window
+//         still spreads over all partitions) into tile_items[w][tile][*] together with the offset table tile_off[w][tile][*].
+//         An item is (bucket >> log2 P) | sign << lowbits | local_index << (lowbits + 1)   (local_index < 8192).
 // Pass B  k_partition_sort: a block owns one (window, partition) = 2^lowbits buckets (1024 for c <= 18).  Its waves walk
 //         that partition's run in every tile with COALESCED loads (a run is ~TILE / P items = 512 B at c = 16), twice:
 //         first to count per bucket in LDS (-> counts, starts; the partition's slot range comes from ONE cursor atomic
@@ -174,76 +196,97 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* wsum /
     return base + incl - v;
 }
 
-template <class C>
+// SUBS = 2 with GLV: every scalar k contributes the sub-scalars |k1| (point 2i) and |k2| (point 2i+1 = phi(P_i)), signs
+// folded into the entry's sign bit; SUBS = 1: the scalar itself (point i).  An item's local index is j * SUBS + e.
+template <class C, bool GLV>
 __global__ void __launch_bounds__(TILE_THREADS)
 k_digits_partition(const uint8_t* __restrict__ scalars, uint32_t n, int c, int W, int lowbits,
                    uint32_t* __restrict__ tile_items, uint16_t* __restrict__ tile_off) {
+    constexpr int SUBS = GLV ? 2 : 1;
+    constexpr int LIMBS = GLV ? 4 : 8;
+    constexpr int NSUB = TILE_SPT * SUBS;
     __shared__ uint32_t hist[MAX_PARTS];
     __shared__ uint32_t cursor[MAX_PARTS];
-    __shared__ uint32_t stage[TILE];
+    __shared__ uint32_t stage[TILE * SUBS];
     const uint32_t tile = blockIdx.x, T = gridDim.x, tid = threadIdx.x;
     const int P = 1 << (c - 1 - lowbits);
     const uint32_t B = 1u << (c - 1);
     const uint32_t mask = (1u << c) - 1;
-    const uint32_t lowmask = (1u << lowbits) - 1;
-    uint32_t t[TILE_SPT][8];
+    uint32_t t[NSUB][LIMBS];
     bool valid[TILE_SPT];
+    uint32_t sneg = 0;  // bit u: sub-scalar u is negative
 #pragma unroll
     for (int j = 0; j < TILE_SPT; j++) {
         uint32_t i = tile * TILE + j * TILE_THREADS + tid;
         valid[j] = i < n;
+        uint32_t k[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) t[j][k] = 0;
+        for (int q = 0; q < 8; q++) k[q] = 0;
         if (valid[j]) {
-            load_be256(t[j], scalars + (size_t)i * 32);
+            load_be256(k, scalars + (size_t)i * 32);
             for (int q = 0; q < C::MAX_Q; q++) {
                 uint32_t s[8];
                 uint32_t br = 0;
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    uint64_t d = (uint64_t)t[j][k] - C::ORDER[k] - br;
-                    s[k] = (uint32_t)d;
+                for (int q2 = 0; q2 < 8; q2++) {
+                    uint64_t d = (uint64_t)k[q2] - C::ORDER[q2] - br;
+                    s[q2] = (uint32_t)d;
                     br = (uint32_t)(d >> 63);
                 }
                 if (br) break;
 #pragma unroll
-                for (int k = 0; k < 8; k++) t[j][k] = s[k];
+                for (int q2 = 0; q2 < 8; q2++) k[q2] = s[q2];
             }
         }
-    }
-    uint32_t carry[TILE_SPT];
+        if (GLV) {
+            uint32_t m1[4], m2[4];
+            bool n1, n2;
+            glv_split<typename C::Glv>(k, m1, n1, m2, n2);
 #pragma unroll
-    for (int j = 0; j < TILE_SPT; j++) carry[j] = 0;
+            for (int q = 0; q < 4; q++) { t[j * SUBS][q] = m1[q]; t[j * SUBS + (SUBS - 1)][q] = m2[q]; }
+            sneg |= (n1 ? 1u : 0u) << (j * SUBS);
+            sneg |= (n2 ? 1u : 0u) << (j * SUBS + (SUBS - 1));
+        } else {
+#pragma unroll
+            for (int q = 0; q < LIMBS; q++) t[j][q] = k[q];
+        }
+    }
+    uint32_t carry = 0;  // bit u: carry into the next window of sub-scalar u
 
     for (int w = 0; w < W; w++) {
         if (tid < MAX_PARTS) hist[tid] = 0;
         __syncthreads();
-        uint32_t key[TILE_SPT];
+        uint32_t key[NSUB];
         const int lo = w * c;
         const int limb = lo >> 5, sh = lo & 31;
 #pragma unroll
-        for (int j = 0; j < TILE_SPT; j++) {
+        for (int u = 0; u < NSUB; u++) {
             uint32_t raw = 0;
-            if (lo < 256) {
+            if (lo < 32 * LIMBS) {
                 uint32_t a = 0, b = 0;
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    a = (k == limb) ? t[j][k] : a;
-                    b = (k == limb + 1) ? t[j][k] : b;
+                for (int q = 0; q < LIMBS; q++) {
+                    a = (q == limb) ? t[u][q] : a;
+                    b = (q == limb + 1) ? t[u][q] : b;
                 }
                 uint64_t v = ((uint64_t)b << 32) | a;
                 raw = (uint32_t)(v >> sh) & mask;
             }
-            raw += carry[j];
+            raw += (carry >> u) & 1u;
+            uint32_t dneg = 0;
             if (raw > B) {  // negative digit raw - 2^c, magnitude 1 .. B-1
-                carry[j] = 1;
-                key[j] = (((1u << c) - raw) - 1) | 0x80000000u;
+                carry |= 1u << u;
+                key[u] = ((1u << c) - raw) - 1;
+                dneg = 1;
             } else {
-                carry[j] = 0;
-                key[j] = raw ? (raw - 1) : KEY_NONE;
+                carry &= ~(1u << u);
+                key[u] = raw ? (raw - 1) : KEY_NONE;
             }
-            if (!valid[j]) key[j] = KEY_NONE;
-            if (key[j] != KEY_NONE) atomicAdd(&hist[(key[j] & 0x7fffffffu) >> lowbits], 1u);
+            if (!valid[u / SUBS]) key[u] = KEY_NONE;
+            if (key[u] != KEY_NONE) {
+                key[u] |= (dneg ^ ((sneg >> u) & 1u)) << 31;
+                atomicAdd(&hist[(key[u] & 0x7fffffffu) & (uint32_t)(P - 1)], 1u);
+            }
         }
         __syncthreads();
         // exclusive scan over P <= 128 partitions (Hillis-Steele in LDS)
@@ -269,15 +312,16 @@ k_digits_partition(const uint8_t* __restrict__ scalars, uint32_t n, int c, int W
         }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < TILE_SPT; j++) {
-            if (key[j] != KEY_NONE) {
-                uint32_t bkt = key[j] & 0x7fffffffu;
-                uint32_t pos = atomicAdd(&hist[bkt >> lowbits], 1u);
-                stage[pos] = (bkt & lowmask) | ((key[j] >> 31) << lowbits) | ((uint32_t)(j * TILE_THREADS + tid) << (lowbits + 1));
+        for (int u = 0; u < NSUB; u++) {
+            if (key[u] != KEY_NONE) {
+                uint32_t bkt = key[u] & 0x7fffffffu;
+                uint32_t pos = atomicAdd(&hist[bkt & (uint32_t)(P - 1)], 1u);
+                uint32_t local = (uint32_t)((u / SUBS) * TILE_THREADS + tid) * SUBS + (u % SUBS);
+                stage[pos] = (bkt >> (c - 1 - lowbits)) | ((key[u] >> 31) << lowbits) | (local << (lowbits + 1));
             }
         }
         __syncthreads();
-        uint32_t* dst = tile_items + ((size_t)w * T + tile) * TILE;
+        uint32_t* dst = tile_items + ((size_t)w * T + tile) * (TILE * SUBS);
         for (uint32_t i = tid; i < total; i += TILE_THREADS) dst[i] = stage[i];
         __syncthreads();
     }
@@ -285,8 +329,8 @@ k_digits_partition(const uint8_t* __restrict__ scalars, uint32_t n, int c, int W
 
 // grid = W * P blocks of 1024 threads (16 waves; wave v takes tiles v, v+16, ...)
 static __global__ void __launch_bounds__(1024)
-k_partition_sort(const uint32_t* __restrict__ tile_items, const uint16_t* __restrict__ tile_off, uint32_t T, int c,
-                 int lowbits, uint32_t* __restrict__ counts, uint32_t* __restrict__ starts,
+k_partition_sort(const uint32_t* __restrict__ tile_items, const uint16_t* __restrict__ tile_off, uint32_t T, uint32_t tile_cap,
+                 int c, int lowbits, uint32_t* __restrict__ counts, uint32_t* __restrict__ starts,
                  uint32_t* __restrict__ entries, uint32_t* __restrict__ cursor) {
     __shared__ uint32_t cnt[SORT_MAX_LOW];
     __shared__ uint32_t wsum[16];
@@ -301,8 +345,20 @@ k_partition_sort(const uint32_t* __restrict__ tile_items, const uint16_t* __rest
     for (uint32_t t = wv; t < T; t += 16) {
         const uint16_t* off = tile_off + ((size_t)w * T + t) * (MAX_PARTS + 1);
         const uint32_t lo = off[p], hi = (p + 1 < (uint32_t)P) ? off[p + 1] : off[MAX_PARTS];
-        const uint32_t* it = tile_items + ((size_t)w * T + t) * TILE;
-        for (uint32_t i = lo + lane; i < hi; i += 64) atomicAdd(&cnt[it[i] & lowmask], 1u);
+        const uint32_t* it = tile_items + ((size_t)w * T + t) * tile_cap;
+        for (uint32_t i0 = lo; i0 < hi; i0 += 64) {
+            const bool active = i0 + lane < hi;
+            const uint32_t low = active ? (it[i0 + lane] & lowmask) : 0xffffffffu;
+            // skewed digits (a sparsely populated top window): lanes that hit the first lane's bucket share one atomic
+            const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)low);
+            const unsigned long long same = __ballot(low == first);
+            if (__popcll(same) >= 8) {
+                if (lane == (uint32_t)(__ffsll((long long)same) - 1)) atomicAdd(&cnt[first], (uint32_t)__popcll(same));
+                if (active && low != first) atomicAdd(&cnt[low], 1u);
+            } else if (active) {
+                atomicAdd(&cnt[low], 1u);
+            }
+        }
     }
     __syncthreads();
     // exclusive scan over the nlow counters: thread owns `per` consecutive ones
@@ -320,7 +376,7 @@ k_partition_sort(const uint32_t* __restrict__ tile_items, const uint16_t* __rest
     if (first < nlow) {
         uint32_t run = base_sh + excl;
         for (uint32_t k = 0; k < per; k++) {
-            size_t b = ((size_t)w << (c - 1)) + (size_t)p * nlow + first + k;
+            size_t b = ((size_t)w << (c - 1)) + ((size_t)(first + k) << (c - 1 - lowbits)) + p;
             counts[b] = mine[k];
             starts[b] = run;
             cnt[first + k] = run;  // running cursor per bucket
@@ -331,11 +387,25 @@ k_partition_sort(const uint32_t* __restrict__ tile_items, const uint16_t* __rest
     for (uint32_t t = wv; t < T; t += 16) {
         const uint16_t* off = tile_off + ((size_t)w * T + t) * (MAX_PARTS + 1);
         const uint32_t lo = off[p], hi = (p + 1 < (uint32_t)P) ? off[p + 1] : off[MAX_PARTS];
-        const uint32_t* it = tile_items + ((size_t)w * T + t) * TILE;
-        for (uint32_t i = lo + lane; i < hi; i += 64) {
-            uint32_t item = it[i];
-            uint32_t pos = atomicAdd(&cnt[item & lowmask], 1u);
-            entries[pos] = (t * TILE + (item >> (lowbits + 1))) | (((item >> lowbits) & 1u) << 31);
+        const uint32_t* it = tile_items + ((size_t)w * T + t) * tile_cap;
+        for (uint32_t i0 = lo; i0 < hi; i0 += 64) {
+            const bool active = i0 + lane < hi;
+            const uint32_t item = active ? it[i0 + lane] : 0u;
+            const uint32_t low = active ? (item & lowmask) : 0xffffffffu;
+            const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)low);
+            const unsigned long long same = __ballot(low == first);
+            uint32_t pos = 0;
+            if (__popcll(same) >= 8) {
+                const uint32_t leader = (uint32_t)(__ffsll((long long)same) - 1);
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(&cnt[first], (uint32_t)__popcll(same));
+                base = __shfl(base, (int)leader, 64);
+                if (low == first) pos = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+                else if (active) pos = atomicAdd(&cnt[low], 1u);
+            } else if (active) {
+                pos = atomicAdd(&cnt[low], 1u);
+            }
+            if (active) entries[pos] = (t * tile_cap + (item >> (lowbits + 1))) | (((item >> lowbits) & 1u) << 31);
         }
     }
 }

@@ -4,8 +4,6 @@
 
 namespace porla {
 template int msm_device<Bn254G1>(const uint8_t*, const uint8_t*, size_t, hipStream_t, XYZZ<Bn254Fp>*);
-template int msm_device_mont<Bn254G1>(const uint8_t*, const Affine<Bn254Fp>*, size_t, hipStream_t, XYZZ<Bn254Fp>*);
-template int msm_host_scalars<Bn254G1>(const uint8_t*, const Affine<Bn254Fp>*, size_t, XYZZ<Bn254Fp>*);
 template int msm_host<Bn254G1>(const uint8_t*, const uint8_t*, size_t, XYZZ<Bn254Fp>*);
 template struct FixedBase<Bn254G1>;
 }  // namespace porla

@@ -10,23 +10,38 @@ namespace porla {
 
 static inline int ilog2(size_t n) { int l = 0; while (n >>= 1) l++; return l; }
 
-static inline int choose_window(size_t n) {
+// Window width for m sub-scalars of `bits` bits: minimise  W*m (bucket additions) + 3*W*2^(c-1) (bucket reduction: the
+// weight is fitted to the 2^20 sweeps in profiles/ -- the reduction is latency-bound, so it grows slower than its work).  Widths are skipped when the average bucket (m / 2^(c-1) entries) would
+// not fit one work item, or when the top window (holding only `top` bits) would crowd all entries into a few buckets of
+// more than 64 work items each -- both still work (heavy buckets are split and combined) but cost time.
+static inline int choose_window(size_t m, int bits) {
     if (g_window_override >= 2 && g_window_override <= 20) return g_window_override;
-    int c = ilog2(n) - 3;
-    if (c < 2) c = 2;
-    if (c > 16) c = 16;
-    return c;
+    int best = 2;
+    double best_cost = 1e300;
+    for (int c = 2; c <= 20; c++) {
+        const int W = (bits + 1 + c - 1) / c;
+        const int top = bits + 1 - c * (W - 1);                       // bits left for the top window, 1 .. c
+        const double load = (double)m / (double)((size_t)1 << (c - 1));
+        const double top_load = (double)m / (double)((size_t)1 << (top > 1 ? top - 1 : 0));
+        const bool crowded = (load > 0.75 * CHUNK || (W > 1 && top_load > 64.0 * CHUNK)) && c < 20;
+        const double cost = (double)W * (double)m + 3.0 * W * (double)((size_t)1 << (c - 1)) + (crowded ? 1e18 : 0.0);
+        if (cost < best_cost) { best_cost = cost; best = c; }
+    }
+    return best;
 }
 
 template <class C>
-static int msm_core(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_points_be,
-                    const Affine<typename C::Fp>* d_points_mont, size_t n, hipStream_t stream,
+static int msm_core(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_points_be, size_t n, hipStream_t stream,
                     XYZZ<typename C::Fp>* total) {
     using M = typename C::Fp;
     if (n == 0) { *total = xyzz_inf<M>(); return PORLA_OK; }
-    if (n >= (1ull << 31)) { set_last_error("porla: MSM length must be < 2^31"); return PORLA_ERR_ARG; }
-    const int c = choose_window(n);
-    const int W = (C::SCALAR_BITS + 1 + c - 1) / c;
+    if (n >= (1ull << 30)) { set_last_error("porla: MSM length must be < 2^30"); return PORLA_ERR_ARG; }
+    const bool glv = g_use_glv < 0 ? C::GLV_DEFAULT : g_use_glv != 0;
+    const int bits = glv ? C::Glv::BITS : C::SCALAR_BITS;
+    const size_t n_sub = glv ? 2 * n : n;                 // sub-scalars = entries per window at most
+    const uint32_t tile_cap = glv ? 2 * TILE : TILE;
+    const int c = choose_window(n_sub, bits);
+    const int W = (bits + 1 + c - 1) / c;
     const uint32_t B = 1u << (c - 1);
     static const uint32_t Lenv = getenv("PORLA_REDUCE_L") ? (uint32_t)atoi(getenv("PORLA_REDUCE_L")) : 8;
     const uint32_t L = B < Lenv ? B : Lenv;
@@ -36,13 +51,13 @@ static int msm_core(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_po
     const uint32_t n32 = (uint32_t)n;
 
     int rc;
-    if (!d_points_mont) { if ((rc = ws->pts.ensure(n * sizeof(Affine<M>)))) return rc; }
+    if ((rc = ws->pts.ensure(n_sub * sizeof(Affine<M>)))) return rc;
     const uint32_t T_tiles = (uint32_t)((n + TILE - 1) / TILE);
     const uint32_t nblk = (uint32_t)((nb + 1023) / 1024);
-    const size_t max_entries = (size_t)W * n;
+    const size_t max_entries = (size_t)W * n_sub;
     const size_t max_items = nb + max_entries / CHUNK;          // every bucket: <= cnt/CHUNK full items + 1 remainder
     const size_t max_chunk_out = 2 * (max_entries / CHUNK) + 2; // multi-item buckets only: ceil(cnt/CHUNK) <= 2 cnt/CHUNK
-    if ((rc = ws->keys.ensure((size_t)W * T_tiles * TILE * 4))) return rc;   // tile_items
+    if ((rc = ws->keys.ensure((size_t)W * T_tiles * tile_cap * 4))) return rc;   // tile_items
     if ((rc = ws->tile_off.ensure((size_t)W * T_tiles * (MAX_PARTS + 1) * 2))) return rc;
     if ((rc = ws->entries.ensure(max_entries * 4))) return rc;
     if ((rc = ws->counts.ensure(nb * 4))) return rc;
@@ -63,26 +78,33 @@ static int msm_core(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_po
         PORLA_HIP(hipHostMalloc(&ws->h_windows, ws->h_windows_cap, hipHostMallocDefault));
     }
 
-    const Affine<M>* pts = d_points_mont;
     uint32_t* ctrl = (uint32_t*)ws->cursor.p;
     PORLA_HIP(hipMemsetAsync(ctrl, 0, CTRL_WORDS * 4, stream));
-    if (!pts) {
+    const Affine<M>* pts = (const Affine<M>*)ws->pts.p;
+    {
         ProfScope ps("points_to_mont", stream);
-        hipLaunchKernelGGL((k_points_to_mont<C>), dim3((n32 + 255) / 256), dim3(256), 0, stream, d_points_be,
-                           (Affine<M>*)ws->pts.p, n32);
-        pts = (const Affine<M>*)ws->pts.p;
+        if (glv)
+            hipLaunchKernelGGL((k_points_to_mont<C, true>), dim3((n32 + 255) / 256), dim3(256), 0, stream, d_points_be,
+                               (Affine<M>*)ws->pts.p, n32);
+        else
+            hipLaunchKernelGGL((k_points_to_mont<C, false>), dim3((n32 + 255) / 256), dim3(256), 0, stream, d_points_be,
+                               (Affine<M>*)ws->pts.p, n32);
     }
     const int lowbits = sort_lowbits(c);
     const int P = 1 << (c - 1 - lowbits);
     {
         ProfScope ps("digits_partition", stream);
-        hipLaunchKernelGGL((k_digits_partition<C>), dim3(T_tiles), dim3(TILE_THREADS), 0, stream, d_scalars, n32, c, W,
-                           lowbits, (uint32_t*)ws->keys.p, (uint16_t*)ws->tile_off.p);
+        if (glv)
+            hipLaunchKernelGGL((k_digits_partition<C, true>), dim3(T_tiles), dim3(TILE_THREADS), 0, stream, d_scalars, n32, c, W,
+                               lowbits, (uint32_t*)ws->keys.p, (uint16_t*)ws->tile_off.p);
+        else
+            hipLaunchKernelGGL((k_digits_partition<C, false>), dim3(T_tiles), dim3(TILE_THREADS), 0, stream, d_scalars, n32, c, W,
+                               lowbits, (uint32_t*)ws->keys.p, (uint16_t*)ws->tile_off.p);
     }
     {
         ProfScope ps("partition_sort", stream);
         hipLaunchKernelGGL(k_partition_sort, dim3((unsigned)(W * P)), dim3(1024), 0, stream, (const uint32_t*)ws->keys.p,
-                           (const uint16_t*)ws->tile_off.p, T_tiles, c, lowbits, (uint32_t*)ws->counts.p,
+                           (const uint16_t*)ws->tile_off.p, T_tiles, tile_cap, c, lowbits, (uint32_t*)ws->counts.p,
                            (uint32_t*)ws->starts.p, (uint32_t*)ws->entries.p, ctrl);
     }
     {
@@ -133,17 +155,7 @@ int msm_device(const uint8_t* d_scalars, const uint8_t* d_points, size_t n, hipS
     std::lock_guard<std::mutex> lk(g_ws_mu);
     Workspace* ws;
     if ((rc = get_workspace(&ws))) return rc;
-    return msm_core<C>(ws, d_scalars, d_points, nullptr, n, stream, total);
-}
-template <class C>
-int msm_device_mont(const uint8_t* d_scalars, const Affine<typename C::Fp>* d_points_mont, size_t n,
-                    hipStream_t stream, XYZZ<typename C::Fp>* total) {
-    int rc = ensure_device();
-    if (rc) return rc;
-    std::lock_guard<std::mutex> lk(g_ws_mu);
-    Workspace* ws;
-    if ((rc = get_workspace(&ws))) return rc;
-    return msm_core<C>(ws, d_scalars, nullptr, d_points_mont, n, stream, total);
+    return msm_core<C>(ws, d_scalars, d_points, n, stream, total);
 }
 template <class C>
 int msm_host(const uint8_t* scalars, const uint8_t* points, size_t n, XYZZ<typename C::Fp>* total) {
@@ -158,24 +170,8 @@ int msm_host(const uint8_t* scalars, const uint8_t* points, size_t n, XYZZ<typen
     hipStream_t s = ws->own_stream;
     PORLA_HIP(hipMemcpyAsync(ws->in_scalars.p, scalars, n * 32, hipMemcpyHostToDevice, s));
     PORLA_HIP(hipMemcpyAsync(ws->in_points.p, points, n * 64, hipMemcpyHostToDevice, s));
-    return msm_core<C>(ws, (const uint8_t*)ws->in_scalars.p, (const uint8_t*)ws->in_points.p, nullptr, n, s, total);
+    return msm_core<C>(ws, (const uint8_t*)ws->in_scalars.p, (const uint8_t*)ws->in_points.p, n, s, total);
 }
-
-template <class C>
-int msm_host_scalars(const uint8_t* scalars, const Affine<typename C::Fp>* d_points_mont, size_t n,
-                     XYZZ<typename C::Fp>* total) {
-    int rc = ensure_device();
-    if (rc) return rc;
-    std::lock_guard<std::mutex> lk(g_ws_mu);
-    Workspace* ws;
-    if ((rc = get_workspace(&ws))) return rc;
-    if (n == 0) { *total = xyzz_inf<typename C::Fp>(); return PORLA_OK; }
-    if ((rc = ws->in_scalars.ensure(n * 32))) return rc;
-    hipStream_t s = ws->own_stream;
-    PORLA_HIP(hipMemcpyAsync(ws->in_scalars.p, scalars, n * 32, hipMemcpyHostToDevice, s));
-    return msm_core<C>(ws, (const uint8_t*)ws->in_scalars.p, nullptr, d_points_mont, n, s, total);
-}
-
 
 
 }  // namespace porla

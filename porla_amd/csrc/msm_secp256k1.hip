@@ -4,8 +4,6 @@
 
 namespace porla {
 template int msm_device<Secp256k1G>(const uint8_t*, const uint8_t*, size_t, hipStream_t, XYZZ<Secp256k1Fp>*);
-template int msm_device_mont<Secp256k1G>(const uint8_t*, const Affine<Secp256k1Fp>*, size_t, hipStream_t, XYZZ<Secp256k1Fp>*);
-template int msm_host_scalars<Secp256k1G>(const uint8_t*, const Affine<Secp256k1Fp>*, size_t, XYZZ<Secp256k1Fp>*);
 template int msm_host<Secp256k1G>(const uint8_t*, const uint8_t*, size_t, XYZZ<Secp256k1Fp>*);
 template struct FixedBase<Secp256k1G>;
 }  // namespace porla

@@ -12,6 +12,17 @@ from tests import common
 
 pytestmark = pytest.mark.gpu
 
+LAMBDA = 0x30644e72e131a029048b6e193fd84104cc37a73fec2bc5e9b8ca0b2d36636f23  # the curve endomorphism's eigenvalue (tools/gen_glv.py); scalars around it stress the GLV split
+
+
+@pytest.fixture(autouse=True, params=["glv", "plain"])
+def scalar_split(request):
+    """every test runs with the GLV scalar split (default) and with plain full-width windows"""
+    from porla_amd import lib
+    lib.porla_gpu_set_msm_glv(1 if request.param == "glv" else 0)
+    yield request.param
+    lib.porla_gpu_set_msm_glv(-1)
+
 R = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
 
 
@@ -51,7 +62,9 @@ def test_every_window_width(mx, inputs, c):
 def test_edge_scalars(mx, inputs):
     """zero, one, r-1, r, r+1, 2^256-1 (SetBytes reduction), 2^128: main.go:127"""
     _, pt = inputs
-    vals = [0, 1, 2, R - 1, R, R + 1, (1 << 256) - 1, 1 << 128, (1 << 255) + 12345, 5 * R, 5 * R + 7]
+    vals = [0, 1, 2, R - 1, R, R + 1, (1 << 256) - 1, 1 << 128, (1 << 255) + 12345, 5 * R, 5 * R + 7,
+            LAMBDA, LAMBDA + 1, LAMBDA - 1, R - LAMBDA, LAMBDA * LAMBDA % R, (R - 1) // 2, (R + 1) // 2, (1 << 126) - 1, 1 << 127,
+            147946756881789319000765030803803410728, 9931322734385697763, 3 * LAMBDA % R]
     n = len(vals)
     sc = b"".join(v.to_bytes(32, "big") for v in vals)
     got = mx.bn254_multi_exp(pt[:64 * n], sc, n)

@@ -8,6 +8,17 @@ import pytest
 from tests import common
 
 pytestmark = pytest.mark.gpu
+
+LAMBDA = 0x5363ad4cc05c30e0a5261c028812645a122e22ea20816678df02967c1b23bd72  # the curve endomorphism's eigenvalue (tools/gen_glv.py); scalars around it stress the GLV split
+
+
+@pytest.fixture(autouse=True, params=["glv", "plain"])
+def scalar_split(request):
+    """every test runs with the GLV scalar split (default) and with plain full-width windows"""
+    from porla_amd import lib
+    lib.porla_gpu_set_msm_glv(1 if request.param == "glv" else 0)
+    yield request.param
+    lib.porla_gpu_set_msm_glv(-1)
 P = 2**256 - 2**32 - 977
 
 
@@ -33,7 +44,7 @@ def test_bench_inputs_match_oracle_and_closed_form(mx, inputs, n):
         assert got == common.oracle_secp_msm(sc, pt, n, naive=True)
 
 
-@pytest.mark.parametrize("c", [2, 4, 7, 12, 16])
+@pytest.mark.parametrize("c", [2, 4, 7, 12, 15, 16, 17])
 def test_every_window_width(mx, inputs, c):
     from porla_amd import lib
     sc, pt = inputs
@@ -52,8 +63,10 @@ def test_edge_cases(mx, inputs):
     N = common.SECP_N
     p0 = pt[:64]
     neg0 = p0[:32] + (P - int.from_bytes(p0[32:], "big")).to_bytes(32, "big")
-    vals = [0, 1, N - 1, N, N + 5, 2**256 - 1, 7, 7, 9, 9]
-    pts = [pt[64 * i:64 * i + 64] for i in range(6)] + [p0, neg0, p0, p0]
+    vals = [0, 1, N - 1, N, N + 5, 2**256 - 1, 7, 7, 9, 9, LAMBDA, LAMBDA + 1, N - LAMBDA, LAMBDA * LAMBDA % N,
+            (N - 1) // 2, (N + 1) // 2, (1 << 128) - 1, 1 << 128, 0x3086d221a7d46bcde86c90e49284eb15,
+            0xe4437ed6010e88286f547fa90abfe4c3, 0x114ca50f7a8e2f3f657c1108d9d44cfd8]
+    pts = [pt[64 * i:64 * i + 64] for i in range(6)] + [p0, neg0, p0, p0] + [pt[64 * i:64 * i + 64] for i in range(6, 17)]
     scs = b"".join(v.to_bytes(32, "big") for v in vals) + sc[:32]
     ptb = b"".join(pts) + bytes(64)
     n = len(vals) + 1
