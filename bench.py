@@ -42,7 +42,7 @@ ICC_BYTES_PER_ELEMENT = 64    # 32 B in + 32 B out
 KERNEL_SYMBOL = {  # profile slot -> substring of the kernel symbol in the rocprofv3 output
     "bucket_sum": "k_bucket_sum", "bucket_reduce": "k_bucket_reduce", "partition_sort": "k_partition_sort",
     "fb_commit": "k_fb_commit", "digits_partition": "k_digits_partition", "points_to_mont": "k_points_to_mont",
-    "icc_stages_r4": "k_icc_stages", "icc_stages_r2": "k_icc_stages", "icc_load": "k_icc_load", "icc_finish": "k_icc_finish",
+    "icc_fused": "k_icc_fused", "icc_stages_r4": "k_icc_stages", "icc_stages_r2": "k_icc_stages", "icc_load": "k_icc_load", "icc_finish": "k_icc_finish",
 }
 
 

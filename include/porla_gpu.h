@@ -130,6 +130,17 @@ int porla_icc_mac_encode_host(const uint8_t *macs_in, size_t n_rows, int curve, 
  * ones the stage-by-stage ladder form (default 2048; 0 = always ladder).  Both are bit-exact. */
 int porla_icc_mac_set_matrix_max(size_t n_rows);
 
+/* ---- Server::mix, the incremental form of one butterfly stage between two sub-levels (Server.hpp:1209-1328) ----
+ * data part (Server.hpp:1269-1278): out[i] = (A0[i] + v^i A1[i]) % LCM, out[i+len] = (A0[i] - v^i A1[i]) % LCM, v = w^(n_total/len)
+ *   a0, a1 : len x n_cols symbols, 64 bytes little-endian each, values < LCM (512-bit rows, utils.h:473-517); out : 2*len rows
+ * MAC part (Server.hpp:1281-1318, used for the MACs and for the alignments): the same on 64-byte big-endian affine points.
+ * len and n_total (= num_blocks, which fixes w) are powers of two, len <= n_total. */
+int porla_icc_mix_device(const void *d_a0, const void *d_a1, size_t len, size_t n_cols, size_t n_total, int curve, void *d_out,
+                         void *hip_stream);
+int porla_icc_mix_host(const uint8_t *a0, const uint8_t *a1, size_t len, size_t n_cols, size_t n_total, int curve, uint8_t *out);
+int porla_icc_mac_mix_device(const void *d_a0, const void *d_a1, size_t len, size_t n_total, int curve, void *d_out, void *hip_stream);
+int porla_icc_mac_mix_host(const uint8_t *a0, const uint8_t *a1, size_t len, size_t n_total, int curve, uint8_t *out);
+
 /* ---- audit row combine (Server::audit, Server.hpp:790-828) + the scalar part of align_MAC on the result (:531-541) ----
  * B_j = sum_i coeff_i * row_i[j] (exact integer), then aligned_j = B_j mod p_icc, c_j = (aligned_j - B_j) mod q.
  * The challenged rows are addressed inside row stores resident in HBM:

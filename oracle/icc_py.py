@@ -191,3 +191,17 @@ def audit_combine(rows, coeffs, curve="bn254"):
             B[j] += c * r[j]
     mods, cs = align(B, curve)
     return B, mods, cs
+
+
+def mac_mix(a0, a1, n_total, curve="bn254"):
+    """Server::mix MAC part (Server.hpp:1281-1318): A[i] = A0[i] + v^i*A1[i], A[i+len] = A0[i] - v^i*A1[i], v = w^(N/len)."""
+    length = len(a0)
+    v = pow(root_w(n_total), n_total // length, P_ICC)
+    out = [None] * (2 * length)
+    vi = 1
+    for i in range(length):
+        tm = ec_mul(curve, a1[i], vi)
+        out[i] = ec_add(curve, a0[i], tm)
+        out[i + length] = ec_add(curve, a0[i], ec_neg(curve, tm))
+        vi = vi * v % P_ICC
+    return out

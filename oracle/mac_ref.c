@@ -90,3 +90,22 @@ void oracle_icc_mac_crebuild(const uint8_t *macs_in, size_t n, int curve, int is
     for (size_t i = 0; i < n; i++) mac_out(&X, macs_out + 64 * i, &M[i]);
     free(M);
 }
+
+/* MAC part of Server::mix (Server.hpp:1281-1318; the same lines serve the alignment MACs :1300-1318):
+ * out[i] = A0[i] + v^i * A1[i], out[i+len] = A0[i] - v^i * A1[i], v = w^(n_total/len) with w of n_total blocks */
+void oracle_icc_mac_mix(const uint8_t *a0, const uint8_t *a1, size_t len, size_t n_total, int curve, uint8_t *out, int threads) {
+    mac_ctx X; mac_init(&X, curve, n_total);
+    u256 v_m, e = {{n_total / len, 0, 0, 0}}; mod_pow(&X.PI, &v_m, &X.w_m, &e);
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 1)
+    for (size_t i = 0; i < len; i++) {
+        u256 vi_m, vi, ei = {{i, 0, 0, 0}};
+        mod_pow(&X.PI, &vi_m, &v_m, &ei); mod_from_mont(&X.PI, &vi, &vi_m);
+        aff_t p0, p1; mac_in(&X, &p0, a0 + 64 * i); mac_in(&X, &p1, a1 + 64 * i);
+        jac_t j0, j1, tm, ntm, r;
+        jac_from_aff(&X.C, &j0, &p0); jac_from_aff(&X.C, &j1, &p1);
+        mac_mul(&X, &tm, &j1, &vi);
+        jac_add(&X.C, &r, &j0, &tm); mac_out(&X, out + 64 * i, &r);
+        jac_neg(&X.C, &ntm, &tm);
+        jac_add(&X.C, &r, &j0, &ntm); mac_out(&X, out + 64 * (i + len), &r);
+    }
+}

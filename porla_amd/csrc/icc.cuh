@@ -198,6 +198,119 @@ k_icc_stages(IccElem<Q>* __restrict__ work, const IccElem<Q>* __restrict__ tw, u
     }
 }
 
+// LDS-fused stages s0 .. s0+ns-1 (ns <= 8).  A block owns a TILE: 2^ns rows {row_base + mid * 2^(s0-1)} (all values of the
+// ns row-index bits these stages pair up; the lower s0-1 bits `lo` and the upper bits `hi` are fixed per tile) x 2^cc_log
+// columns = 512 symbols = 32 KiB of LDS (4 blocks per CU).  The tile is read from HBM once, goes through ns butterfly stages in LDS and is
+// written back once: 15 stages cost 2 passes over the working set instead of 8.
+#ifndef PORLA_ICC_TILE
+#define PORLA_ICC_TILE 512
+#endif
+constexpr int ICC_TILE_ELEMS = PORLA_ICC_TILE;
+constexpr int ICC_TILE_LOG = PORLA_ICC_TILE == 1024 ? 10 : (PORLA_ICC_TILE == 512 ? 9 : 8);
+template <class Q>
+__global__ void __launch_bounds__(256)
+k_icc_fused(IccElem<Q>* __restrict__ work, const IccElem<Q>* __restrict__ tw, uint32_t n, uint32_t ncols, int s0, int ns,
+            int cc_log) {
+    __shared__ uint4 lds[ICC_TILE_ELEMS * 4];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t Cc = 1u << cc_log;
+    const uint32_t elems = (1u << ns) << cc_log;            // <= ICC_TILE_ELEMS
+    const uint32_t lo_bits = (uint32_t)(s0 - 1);
+    const uint32_t col_tiles = (ncols + Cc - 1) >> cc_log;
+    uint32_t tile = blockIdx.x;
+    const uint32_t ct = tile % col_tiles;
+    tile /= col_tiles;
+    const uint32_t lo = tile & ((1u << lo_bits) - 1u);
+    const uint32_t hi = tile >> lo_bits;
+    const uint32_t row_base = (hi << (lo_bits + ns)) + lo;
+    const uint32_t c0 = ct << cc_log;
+    for (uint32_t e = tid; e < elems; e += 256) {
+        const uint32_t mid = e >> cc_log, col = e & (Cc - 1);
+        if (c0 + col < ncols) {
+            const uint4* src = reinterpret_cast<const uint4*>(work + (size_t)(row_base + (mid << lo_bits)) * ncols + c0 + col);
+            uint4 a = src[0], b = src[1], c = src[2], d = src[3];
+            lds[e * 4 + 0] = a; lds[e * 4 + 1] = b; lds[e * 4 + 2] = c; lds[e * 4 + 3] = d;
+        }
+    }
+    __syncthreads();
+    for (int d = 0; d < ns; d++) {
+        const int s = s0 + d;
+        const uint32_t tw_step = n >> (s - 1);               // N / m2
+        for (uint32_t bf = tid; bf < elems / 2; bf += 256) {
+            const uint32_t col = bf & (Cc - 1), q = bf >> cc_log;
+            const uint32_t mid0 = ((q >> d) << (d + 1)) | (q & ((1u << d) - 1u));
+            const uint32_t mid1 = mid0 | (1u << d);
+            if (c0 + col < ncols) {
+                const uint32_t j = ((mid0 & ((1u << d) - 1u)) << lo_bits) + lo;    // row index mod m2
+                IccElem<Q> t1 = ld_elem<Q>(tw + (size_t)j * tw_step);
+                uint32_t* pa = reinterpret_cast<uint32_t*>(&lds[((mid0 << cc_log) + col) * 4]);
+                uint32_t* pb = reinterpret_cast<uint32_t*>(&lds[((mid1 << cc_log) + col) * 4]);
+                IccElem<Q> a, b;
+                a.p = ld_fe<IccFp>(pa); a.q = ld_fe<Q>(pa + 8);
+                b.p = ld_fe<IccFp>(pb); b.q = ld_fe<Q>(pb + 8);
+                butterfly<Q>(a, b, t1, false);
+                st_fe<IccFp>(pa, a.p); st_fe<Q>(pa + 8, a.q);
+                st_fe<IccFp>(pb, b.p); st_fe<Q>(pb + 8, b.q);
+            }
+        }
+        __syncthreads();
+    }
+    for (uint32_t e = tid; e < elems; e += 256) {
+        const uint32_t mid = e >> cc_log, col = e & (Cc - 1);
+        if (c0 + col < ncols) {
+            uint4* dst = reinterpret_cast<uint4*>(work + (size_t)(row_base + (mid << lo_bits)) * ncols + c0 + col);
+            dst[0] = lds[e * 4 + 0]; dst[1] = lds[e * 4 + 1]; dst[2] = lds[e * 4 + 2]; dst[3] = lds[e * 4 + 3];
+        }
+    }
+}
+
+// value in [0, LCM) as 64 bytes little-endian from the residue pair: P = A mod p_icc (plain), pq_m = P mod q (Montgomery)
+template <class Q>
+__device__ __forceinline__ void icc_store_lcm(const IccElem<Q>& e, const Fe<IccFp>& P, const Fe<Q>& pq_m, uint8_t* dst) {
+        // A = P + p_icc * t,  t = (a_q - P) * p_icc^-1 mod q;  p_icc * t = t + (207 t << 248)
+    Fe<Q> pinv;
+#pragma unroll
+    for (int k = 0; k < 8; k++) pinv.v[k] = Q::PINV[k];
+    Fe<Q> t = fe_mul<Q>(fe_sub<Q>(e.q, pq_m), pinv);   // Montgomery(d) * plain -> plain product
+    uint32_t u[9];
+    uint32_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        uint64_t x = (uint64_t)t.v[k] * 207u + carry;
+        u[k] = (uint32_t)x;
+        carry = (uint32_t)(x >> 32);
+    }
+    u[8] = carry;
+    uint32_t A[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) A[k] = 0;
+    // A = P + t
+    uint32_t c2 = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        uint64_t x = (uint64_t)P.v[k] + t.v[k] + c2;
+        A[k] = (uint32_t)x;
+        c2 = (uint32_t)(x >> 32);
+    }
+    A[8] = c2;
+    // A += u << 248   (248 = 7*32 + 24)
+    uint32_t c3 = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        uint32_t lo = u[k] << 24;
+        uint32_t hi = (k > 0) ? (u[k - 1] >> 8) : 0;
+        uint64_t x = (uint64_t)A[7 + k] + (lo | hi) + c3;
+        A[7 + k] = (uint32_t)x;
+        c3 = (uint32_t)(x >> 32);
+    }
+    // top word of (u << 248): u[8] >> 8 lands in A[16] which must be zero because A < LCM < 2^512
+    uint4* o = reinterpret_cast<uint4*>(dst);
+    o[0] = make_uint4(A[0], A[1], A[2], A[3]);
+    o[1] = make_uint4(A[4], A[5], A[6], A[7]);
+    o[2] = make_uint4(A[8], A[9], A[10], A[11]);
+    o[3] = make_uint4(A[12], A[13], A[14], A[15]);
+}
+
 // residue pair -> (a) value in [0, LCM) as 64-byte LE, (b) value mod p_icc as 32-byte LE,
 // (c) alignment scalar c = (A mod p_icc - A) mod q (Server.hpp:535-538) as 32 bytes BE (or LE limbs),
 // (d) A mod q as 32 bytes BE (the coefficient the MAC side sees, mac_fft.hip)
@@ -233,49 +346,52 @@ __global__ void k_icc_finish(const IccElem<Q>* __restrict__ work, size_t total, 
             q4[1] = make_uint4(__builtin_bswap32(c.v[3]), __builtin_bswap32(c.v[2]), __builtin_bswap32(c.v[1]), __builtin_bswap32(c.v[0]));
         }
     }
-    if (x_out) {
-        // A = P + p_icc * t,  t = (a_q - P) * p_icc^-1 mod q;  p_icc * t = t + (207 t << 248)
-        Fe<Q> pinv;
+    if (x_out) icc_store_lcm<Q>(e, P, pq_m, x_out + 64 * i);
+}
+
+// 512-bit little-endian value (< LCM, a stored code symbol) -> residue pair: Horner over the two 256-bit halves, R = 2^256
+template <class M>
+__device__ __forceinline__ Fe<M> icc_reduce512(const uint32_t a[16]) {
+    Fe<M> r2, d1, d0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) pinv.v[k] = Q::PINV[k];
-        Fe<Q> t = fe_mul<Q>(fe_sub<Q>(e.q, pq_m), pinv);   // Montgomery(d) * plain -> plain product
-        uint32_t u[9];
-        uint32_t carry = 0;
+    for (int k = 0; k < 8; k++) { r2.v[k] = M::R2[k]; d0.v[k] = a[k]; d1.v[k] = a[8 + k]; }
+    // Montgomery product with R2 takes any 256-bit operand: x -> x * R mod M
+    Fe<M> acc = fe_mul<M>(d1, r2);
+    return fe_add<M>(fe_mul<M>(acc, r2), fe_mul<M>(d0, r2));
+}
+
+// Server::mix data part (Server.hpp:1269-1278): out[i] = (A0[i] + v^i A1[i]) % LCM, out[i+len] = (A0[i] - v^i A1[i]) % LCM,
+// v = w^(N/len); symbols in and out are 64-byte little-endian values < LCM.  One thread: one (row i, column).
+template <class Q>
+__global__ void __launch_bounds__(256)
+k_icc_mix(const uint8_t* __restrict__ a0, const uint8_t* __restrict__ a1, uint32_t len, uint32_t ncols,
+          const IccElem<Q>* __restrict__ tw, uint32_t tw_step, uint8_t* __restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)len * ncols) return;
+    const uint32_t i = (uint32_t)(t / ncols);
+    uint32_t va[16], vb[16];
+    const uint4* pa = reinterpret_cast<const uint4*>(a0 + 64 * t);
+    const uint4* pb = reinterpret_cast<const uint4*>(a1 + 64 * t);
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            uint64_t x = (uint64_t)t.v[k] * 207u + carry;
-            u[k] = (uint32_t)x;
-            carry = (uint32_t)(x >> 32);
-        }
-        u[8] = carry;
-        uint32_t A[16];
+    for (int k = 0; k < 4; k++) {
+        uint4 x = pa[k], y = pb[k];
+        va[4 * k] = x.x; va[4 * k + 1] = x.y; va[4 * k + 2] = x.z; va[4 * k + 3] = x.w;
+        vb[4 * k] = y.x; vb[4 * k + 1] = y.y; vb[4 * k + 2] = y.z; vb[4 * k + 3] = y.w;
+    }
+    IccElem<Q> ea, eb;
+    ea.p = icc_reduce512<IccFp>(va); ea.q = icc_reduce512<Q>(va);
+    eb.p = icc_reduce512<IccFp>(vb); eb.q = icc_reduce512<Q>(vb);
+    IccElem<Q> twi = ld_elem<Q>(tw + (size_t)i * tw_step);
+    butterfly<Q>(ea, eb, twi, false);
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {
+        const IccElem<Q>& e = h ? eb : ea;
+        Fe<IccFp> P = fe_from_mont<IccFp>(e.p);
+        Fe<Q> pq;
 #pragma unroll
-        for (int k = 0; k < 16; k++) A[k] = 0;
-        // A = P + t
-        uint32_t c2 = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            uint64_t x = (uint64_t)P.v[k] + t.v[k] + c2;
-            A[k] = (uint32_t)x;
-            c2 = (uint32_t)(x >> 32);
-        }
-        A[8] = c2;
-        // A += u << 248   (248 = 7*32 + 24)
-        uint32_t c3 = 0;
-#pragma unroll
-        for (int k = 0; k < 9; k++) {
-            uint32_t lo = u[k] << 24;
-            uint32_t hi = (k > 0) ? (u[k - 1] >> 8) : 0;
-            uint64_t x = (uint64_t)A[7 + k] + (lo | hi) + c3;
-            A[7 + k] = (uint32_t)x;
-            c3 = (uint32_t)(x >> 32);
-        }
-        // top word of (u << 248): u[8] >> 8 lands in A[16] which must be zero because A < LCM < 2^512
-        uint4* o = reinterpret_cast<uint4*>(x_out + 64 * i);
-        o[0] = make_uint4(A[0], A[1], A[2], A[3]);
-        o[1] = make_uint4(A[4], A[5], A[6], A[7]);
-        o[2] = make_uint4(A[8], A[9], A[10], A[11]);
-        o[3] = make_uint4(A[12], A[13], A[14], A[15]);
+        for (int k = 0; k < 8; k++) pq.v[k] = P.v[k];
+        fe_reduce_plain<Q>(pq.v, Q::MAX_Q_P + 1);
+        icc_store_lcm<Q>(e, P, fe_to_mont<Q>(pq), out + 64 * (t + (size_t)h * len * ncols));
     }
 }
 

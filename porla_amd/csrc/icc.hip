@@ -5,6 +5,7 @@
 #include "icc.cuh"
 #include "icc_host.hpp"
 
+#include <cstdlib>
 #include <vector>
 
 namespace porla {
@@ -29,6 +30,40 @@ static int get_icc_ws(IccWs** out) {
     return PORLA_OK;
 }
 
+// twiddle table w^e, e < N (resident across calls with the same N and curve)
+template <class Q>
+static int ensure_twiddles(IccWs* ws, int curve, size_t n, hipStream_t stream) {
+    if (ws->tw_n == n && ws->tw_curve == curve) return PORLA_OK;
+    const int logn = ilog2u(n);
+    int rc;
+    if ((rc = ws->tw.ensure(n * sizeof(IccElem<Q>)))) return rc;
+    if ((rc = ws->wpow.ensure(64 * sizeof(Fe<IccFp>)))) return rc;
+    std::vector<Fe<IccFp>> wp(logn ? logn : 1);
+    Fe<IccFp> cur = icc_root(n);
+    for (int i = 0; i < logn; i++) { wp[i] = cur; cur = fe_sqr<IccFp>(cur); }
+    PORLA_HIP(hipMemcpyAsync(ws->wpow.p, wp.data(), logn * sizeof(Fe<IccFp>), hipMemcpyHostToDevice, stream));
+    PORLA_HIP(hipStreamSynchronize(stream));  // wp is a host temporary
+    ProfScope ps("icc_twiddles", stream);
+    hipLaunchKernelGGL((k_icc_twiddles<Q>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (IccElem<Q>*)ws->tw.p,
+                       (uint32_t)n, (const Fe<IccFp>*)ws->wpow.p, logn);
+    ws->tw_n = (uint32_t)n;
+    ws->tw_curve = curve;
+    return PORLA_OK;
+}
+
+template <class Q>
+static int icc_mix_core(IccWs* ws, int curve, const uint8_t* d_a0, const uint8_t* d_a1, size_t len, size_t ncols, size_t n_total,
+                        uint8_t* d_out, hipStream_t stream) {
+    int rc;
+    if ((rc = ensure_twiddles<Q>(ws, curve, n_total, stream))) return rc;
+    const size_t total = len * ncols;
+    ProfScope ps("icc_mix", stream);
+    hipLaunchKernelGGL((k_icc_mix<Q>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, d_a0, d_a1, (uint32_t)len,
+                       (uint32_t)ncols, (const IccElem<Q>*)ws->tw.p, (uint32_t)(n_total / len), d_out);
+    PORLA_HIP(hipGetLastError());
+    return PORLA_OK;
+}
+
 template <class Q>
 static int icc_encode_core(IccWs* ws, int curve, const uint8_t* d_rows, size_t n, size_t ncols, unsigned long long write_step,
                            int part, uint8_t* d_x, uint8_t* d_al, uint8_t* d_sc, int scalar_le, hipStream_t stream,
@@ -41,22 +76,8 @@ static int icc_encode_core(IccWs* ws, int curve, const uint8_t* d_rows, size_t n
     const size_t total = n * ncols;
     int rc;
     if ((rc = ws->work.ensure(total * sizeof(IccElem<Q>)))) return rc;
-    // ---- twiddle table w^e, e < N (resident across calls with the same N and curve)
+    if ((rc = ensure_twiddles<Q>(ws, curve, n, stream))) return rc;
     Fe<IccFp> w = icc_root(n);
-    if (ws->tw_n != n || ws->tw_curve != curve) {
-        if ((rc = ws->tw.ensure(n * sizeof(IccElem<Q>)))) return rc;
-        if ((rc = ws->wpow.ensure(64 * sizeof(Fe<IccFp>)))) return rc;
-        std::vector<Fe<IccFp>> wp(logn ? logn : 1);
-        Fe<IccFp> cur = w;
-        for (int i = 0; i < logn; i++) { wp[i] = cur; cur = fe_sqr<IccFp>(cur); }
-        PORLA_HIP(hipMemcpyAsync(ws->wpow.p, wp.data(), logn * sizeof(Fe<IccFp>), hipMemcpyHostToDevice, stream));
-        PORLA_HIP(hipStreamSynchronize(stream));  // wp is a host temporary
-        ProfScope ps("icc_twiddles", stream);
-        hipLaunchKernelGGL((k_icc_twiddles<Q>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (IccElem<Q>*)ws->tw.p,
-                           (uint32_t)n, (const Fe<IccFp>*)ws->wpow.p, logn);
-        ws->tw_n = (uint32_t)n;
-        ws->tw_curve = curve;
-    }
     // ---- init scaling: wt = w^reverse_bits(write_step % N, height-1) for the Y part (Server.hpp:1494), 1 for X
     IccElem<Q> wt;
     wt.p = fe_one<IccFp>();
@@ -79,19 +100,37 @@ static int icc_encode_core(IccWs* ws, int curve, const uint8_t* d_rows, size_t n
         hipLaunchKernelGGL((k_icc_load<Q>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, d_rows,
                            (IccElem<Q>*)ws->work.p, total, wt, use_wt);
     }
-    int s = 1;
-    while (s + 1 <= logn) {
-        ProfScope ps("icc_stages_r4", stream);
-        size_t groups = (n >> 2) * ncols;
-        hipLaunchKernelGGL((k_icc_stages<Q, 2>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream,
-                           (IccElem<Q>*)ws->work.p, (const IccElem<Q>*)ws->tw.p, (uint32_t)n, (uint32_t)ncols, s);
-        s += 2;
-    }
-    if (s <= logn) {
-        ProfScope ps("icc_stages_r2", stream);
-        size_t groups = (n >> 1) * ncols;
-        hipLaunchKernelGGL((k_icc_stages<Q, 1>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream,
-                           (IccElem<Q>*)ws->work.p, (const IccElem<Q>*)ws->tw.p, (uint32_t)n, (uint32_t)ncols, s);
+    static const int fused = !(getenv("PORLA_ICC_FUSED") && getenv("PORLA_ICC_FUSED")[0] == '0');
+    if (fused) {
+        // ceil(logn / 8) passes of (almost) equal stage counts, each through LDS tiles of 512 symbols
+        const int passes = (logn + 7) / 8;
+        int s = 1;
+        for (int pz = 0; pz < passes; pz++) {
+            const int ns = (logn - (s - 1) + (passes - pz) - 1) / (passes - pz);
+            int cc_log = ICC_TILE_LOG - ns;                                    // 2^ns rows x 2^cc_log columns = 512 symbols
+            while (cc_log > 0 && ((size_t)1 << (cc_log - 1)) >= ncols) cc_log--;   // no wider than the row
+            const size_t col_tiles = (ncols + ((size_t)1 << cc_log) - 1) >> cc_log;
+            const size_t tiles = col_tiles * (n >> ns);
+            ProfScope ps("icc_fused", stream);
+            hipLaunchKernelGGL((k_icc_fused<Q>), dim3((unsigned)tiles), dim3(256), 0, stream, (IccElem<Q>*)ws->work.p,
+                               (const IccElem<Q>*)ws->tw.p, (uint32_t)n, (uint32_t)ncols, s, ns, cc_log);
+            s += ns;
+        }
+    } else {
+        int s = 1;
+        while (s + 1 <= logn) {
+            ProfScope ps("icc_stages_r4", stream);
+            size_t groups = (n >> 2) * ncols;
+            hipLaunchKernelGGL((k_icc_stages<Q, 2>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream,
+                               (IccElem<Q>*)ws->work.p, (const IccElem<Q>*)ws->tw.p, (uint32_t)n, (uint32_t)ncols, s);
+            s += 2;
+        }
+        if (s <= logn) {
+            ProfScope ps("icc_stages_r2", stream);
+            size_t groups = (n >> 1) * ncols;
+            hipLaunchKernelGGL((k_icc_stages<Q, 1>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream,
+                               (IccElem<Q>*)ws->work.p, (const IccElem<Q>*)ws->tw.p, (uint32_t)n, (uint32_t)ncols, s);
+        }
     }
     {
         ProfScope ps("icc_finish", stream);
@@ -168,6 +207,42 @@ int porla_icc_encode_host(const uint8_t* rows_in, size_t n_rows, size_t n_cols, 
     if (aligned_out) PORLA_HIP(hipMemcpyAsync(aligned_out, ws->al.p, total * 32, hipMemcpyDeviceToHost, s));
     if (scalars_out) PORLA_HIP(hipMemcpyAsync(scalars_out, ws->sc.p, total * 32, hipMemcpyDeviceToHost, s));
     PORLA_HIP(hipStreamSynchronize(s));
+    return PORLA_OK;
+}
+
+int porla_icc_mix_device(const void* d_a0, const void* d_a1, size_t len, size_t n_cols, size_t n_total, int curve, void* d_out,
+                         void* hip_stream) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    const int ll = ilog2u(len), ln = ilog2u(n_total);
+    if (!d_a0 || !d_a1 || !d_out || len == 0 || n_cols == 0 || ((size_t)1 << ll) != len || ((size_t)1 << ln) != n_total ||
+        len > n_total || n_total < 2 || (curve != 0 && curve != 1)) {
+        set_last_error("porla: bad argument to porla_icc_mix_device (len and n_total must be powers of two, len <= n_total)");
+        return PORLA_ERR_ARG;
+    }
+    std::lock_guard<std::mutex> lk(g_icc_mu);
+    IccWs* ws;
+    if ((rc = get_icc_ws(&ws))) return rc;
+    if (curve == 0) return icc_mix_core<IccBn254Fr>(ws, 0, (const uint8_t*)d_a0, (const uint8_t*)d_a1, len, n_cols, n_total, (uint8_t*)d_out, (hipStream_t)hip_stream);
+    return icc_mix_core<IccSecp256k1Fn>(ws, 1, (const uint8_t*)d_a0, (const uint8_t*)d_a1, len, n_cols, n_total, (uint8_t*)d_out, (hipStream_t)hip_stream);
+}
+
+int porla_icc_mix_host(const uint8_t* a0, const uint8_t* a1, size_t len, size_t n_cols, size_t n_total, int curve, uint8_t* out) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!a0 || !a1 || !out) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    const size_t bytes = len * n_cols * 64;
+    void *d0 = nullptr, *d1 = nullptr, *dout = nullptr;
+    PORLA_HIP(hipMalloc(&d0, bytes));
+    hipError_t e1 = hipMalloc(&d1, bytes), e2 = hipMalloc(&dout, 2 * bytes);
+    if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipFree(d0); (void)hipFree(d1); (void)hipFree(dout); return hip_fail(e1 != hipSuccess ? e1 : e2, "hipMalloc", __FILE__, __LINE__); }
+    (void)hipMemcpy(d0, a0, bytes, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d1, a1, bytes, hipMemcpyHostToDevice);
+    rc = porla_icc_mix_device(d0, d1, len, n_cols, n_total, curve, dout, nullptr);
+    hipError_t e3 = hipMemcpy(out, dout, 2 * bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(d0); (void)hipFree(d1); (void)hipFree(dout);
+    if (rc) return rc;
+    if (e3 != hipSuccess) return hip_fail(e3, "hipMemcpy", __FILE__, __LINE__);
     return PORLA_OK;
 }
 

@@ -140,6 +140,58 @@ k_mac_stage(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restrict_
     store_xyzz<M>(work + k + m2, um);
 }
 
+template <class M>
+__device__ __forceinline__ void store_affine_be(uint8_t* dst, const XYZZ<M>& p) {
+    if (xyzz_is_inf<M>(p)) {
+        uint4 z = make_uint4(0, 0, 0, 0);
+        uint4* q = reinterpret_cast<uint4*>(dst);
+        q[0] = z; q[1] = z; q[2] = z; q[3] = z;
+        return;
+    }
+    Fe<M> inv = fe_inv_dev<M>(p.zzz);
+    Affine<M> a = xyzz_to_affine_with_inv<M>(p, inv);
+    Fe<M> one = fe_zero<M>();
+    one.v[0] = 1;
+    Fe<M> x = fe_mul_call<M>(a.x, one), y = fe_mul_call<M>(a.y, one);
+    store_be256(dst, x.v);
+    store_be256(dst + 32, y.v);
+}
+
+template <class M>
+__device__ __forceinline__ XYZZ<M> load_affine_be(const uint8_t* src) {
+    Affine<M> a;
+    load_be256(a.x.v, src);
+    load_be256(a.y.v, src + 32);
+    fe_reduce_plain<M>(a.x.v, 6);
+    fe_reduce_plain<M>(a.y.v, 6);
+    a.x = fe_to_mont<M>(a.x);
+    a.y = fe_to_mont<M>(a.y);
+    return xyzz_from_affine<M>(a);
+}
+
+// MAC part of Server::mix (Server.hpp:1281-1318): out[i] = A0[i] + v^i * A1[i], out[i+len] = A0[i] - v^i * A1[i], v = w^(N/len);
+// 64-byte big-endian affine points in and out.  One lane per i.
+template <class C>
+__global__ void __launch_bounds__(64)
+k_mac_mix(const uint8_t* __restrict__ a0, const uint8_t* __restrict__ a1, uint32_t len, const uint32_t* __restrict__ tws,
+          uint32_t tw_step, uint8_t* __restrict__ out) {
+    using M = typename C::Fp;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    uint32_t sc[8];
+    const uint4* q = reinterpret_cast<const uint4*>(tws + (size_t)i * tw_step * 8);
+    uint4 a = q[0], b = q[1];
+    sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
+    XYZZ<M> tm = xyzz_scalar_mul<M>(load_affine_be<M>(a1 + (size_t)i * 64), sc);
+    XYZZ<M> um = load_affine_be<M>(a0 + (size_t)i * 64);
+    XYZZ<M> sum = um;
+    xyzz_add_cold<M>(&sum, &tm);
+    XYZZ<M> ntm = xyzz_neg<M>(tm);
+    xyzz_add_cold<M>(&um, &ntm);
+    store_affine_be<M>(out + (size_t)i * 64, sum);
+    store_affine_be<M>(out + ((size_t)i + len) * 64, um);
+}
+
 // XYZZ work array -> 64-byte big-endian affine MACs (infinity = 64 zero bytes, main.go:224-230)
 template <class C>
 __global__ void __launch_bounds__(64)

@@ -49,6 +49,39 @@ static int get_mac_ws(MacWs** out) {
     return PORLA_OK;
 }
 
+// plain scalars (w^e mod p_icc) mod q for e < N, resident across calls with the same N and curve
+template <class Q>
+static int ensure_mac_twiddles(MacWs* ws, int curve, size_t n, hipStream_t stream) {
+    if (ws->tw_n == n && ws->tw_curve == curve) return PORLA_OK;
+    const int logn = ilog2u(n);
+    int rc;
+    if ((rc = ws->tws.ensure(n * 32))) return rc;
+    if ((rc = ws->wpow.ensure(64 * sizeof(Fe<IccFp>)))) return rc;
+    std::vector<Fe<IccFp>> wp(logn ? logn : 1);
+    Fe<IccFp> cur = icc_root(n);
+    for (int i = 0; i < logn; i++) { wp[i] = cur; cur = fe_sqr<IccFp>(cur); }
+    PORLA_HIP(hipMemcpyAsync(ws->wpow.p, wp.data(), logn * sizeof(Fe<IccFp>), hipMemcpyHostToDevice, stream));
+    PORLA_HIP(hipStreamSynchronize(stream));  // wp is a host temporary
+    ProfScope ps("mac_twiddles", stream);
+    hipLaunchKernelGGL((k_mac_twiddles<Q>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (uint32_t*)ws->tws.p,
+                       (uint32_t)n, (const Fe<IccFp>*)ws->wpow.p, logn);
+    ws->tw_n = (uint32_t)n;
+    ws->tw_curve = curve;
+    return PORLA_OK;
+}
+
+template <class C, class Q>
+static int mac_mix_core(MacWs* ws, int curve, const uint8_t* d_a0, const uint8_t* d_a1, size_t len, size_t n_total, uint8_t* d_out,
+                        hipStream_t stream) {
+    int rc;
+    if ((rc = ensure_mac_twiddles<Q>(ws, curve, n_total, stream))) return rc;
+    ProfScope ps("mac_mix", stream);
+    hipLaunchKernelGGL((k_mac_mix<C>), dim3((unsigned)((len + 63) / 64)), dim3(64), 0, stream, d_a0, d_a1, (uint32_t)len,
+                       (const uint32_t*)ws->tws.p, (uint32_t)(n_total / len), d_out);
+    PORLA_HIP(hipGetLastError());
+    return PORLA_OK;
+}
+
 template <class C, class Q>
 static int mac_encode_core(MacWs* ws, int curve, const uint8_t* d_in, size_t n, unsigned long long write_step, int part,
                            uint8_t* d_out, hipStream_t stream) {
@@ -79,20 +112,7 @@ static int mac_encode_core(MacWs* ws, int curve, const uint8_t* d_in, size_t n, 
     }
     if ((rc = ws->work.ensure(n * sizeof(XYZZ<M>)))) return rc;
     if ((rc = ws->wt.ensure(64))) return rc;
-    if (ws->tw_n != n || ws->tw_curve != curve) {
-        if ((rc = ws->tws.ensure(n * 32))) return rc;
-        if ((rc = ws->wpow.ensure(64 * sizeof(Fe<IccFp>)))) return rc;
-        std::vector<Fe<IccFp>> wp(logn ? logn : 1);
-        Fe<IccFp> cur = icc_root(n);
-        for (int i = 0; i < logn; i++) { wp[i] = cur; cur = fe_sqr<IccFp>(cur); }
-        PORLA_HIP(hipMemcpyAsync(ws->wpow.p, wp.data(), logn * sizeof(Fe<IccFp>), hipMemcpyHostToDevice, stream));
-        PORLA_HIP(hipStreamSynchronize(stream));  // wp is a host temporary
-        ProfScope ps("mac_twiddles", stream);
-        hipLaunchKernelGGL((k_mac_twiddles<Q>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (uint32_t*)ws->tws.p,
-                           (uint32_t)n, (const Fe<IccFp>*)ws->wpow.p, logn);
-        ws->tw_n = (uint32_t)n;
-        ws->tw_curve = curve;
-    }
+    if ((rc = ensure_mac_twiddles<Q>(ws, curve, n, stream))) return rc;
     int use_wt = 0;
     if (part == 1) {
         // wt as the group sees it: the integer (wt mod p_icc) reduced mod the group order (Server.hpp:1494-1503)
@@ -152,6 +172,41 @@ int porla_icc_mac_encode_device(const void* d_macs_in, size_t n_rows, int curve,
     MacWs* ws;
     if ((rc = get_mac_ws(&ws))) return rc;
     return mac_dispatch(ws, curve, (const uint8_t*)d_macs_in, n_rows, write_step, part, (uint8_t*)d_macs_out, (hipStream_t)hip_stream);
+}
+
+int porla_icc_mac_mix_device(const void* d_a0, const void* d_a1, size_t len, size_t n_total, int curve, void* d_out, void* hip_stream) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    const int ll = ilog2u(len), ln = ilog2u(n_total);
+    if (!d_a0 || !d_a1 || !d_out || len == 0 || ((size_t)1 << ll) != len || ((size_t)1 << ln) != n_total || len > n_total ||
+        n_total < 2 || (curve != 0 && curve != 1)) {
+        set_last_error("porla: bad argument to porla_icc_mac_mix_device (len and n_total must be powers of two, len <= n_total)");
+        return PORLA_ERR_ARG;
+    }
+    std::lock_guard<std::mutex> lk(g_mac_mu);
+    MacWs* ws;
+    if ((rc = get_mac_ws(&ws))) return rc;
+    if (curve == 0) return mac_mix_core<Bn254G1, IccBn254Fr>(ws, 0, (const uint8_t*)d_a0, (const uint8_t*)d_a1, len, n_total, (uint8_t*)d_out, (hipStream_t)hip_stream);
+    return mac_mix_core<Secp256k1G, IccSecp256k1Fn>(ws, 1, (const uint8_t*)d_a0, (const uint8_t*)d_a1, len, n_total, (uint8_t*)d_out, (hipStream_t)hip_stream);
+}
+
+int porla_icc_mac_mix_host(const uint8_t* a0, const uint8_t* a1, size_t len, size_t n_total, int curve, uint8_t* out) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!a0 || !a1 || !out) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    const size_t bytes = len * 64;
+    void *d0 = nullptr, *d1 = nullptr, *dout = nullptr;
+    PORLA_HIP(hipMalloc(&d0, bytes));
+    hipError_t e1 = hipMalloc(&d1, bytes), e2 = hipMalloc(&dout, 2 * bytes);
+    if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipFree(d0); (void)hipFree(d1); (void)hipFree(dout); return hip_fail(e1 != hipSuccess ? e1 : e2, "hipMalloc", __FILE__, __LINE__); }
+    (void)hipMemcpy(d0, a0, bytes, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d1, a1, bytes, hipMemcpyHostToDevice);
+    rc = porla_icc_mac_mix_device(d0, d1, len, n_total, curve, dout, nullptr);
+    hipError_t e3 = hipMemcpy(out, dout, 2 * bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(d0); (void)hipFree(d1); (void)hipFree(dout);
+    if (rc) return rc;
+    if (e3 != hipSuccess) return hip_fail(e3, "hipMemcpy", __FILE__, __LINE__);
+    return PORLA_OK;
 }
 
 int porla_icc_mac_encode_host(const uint8_t* macs_in, size_t n_rows, int curve, unsigned long long write_step, int part,

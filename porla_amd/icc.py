@@ -57,3 +57,17 @@ def audit_combine_device(d_rows64, d_idx64, d_coef64, n64, d_rows32, d_idx32, d_
                                           vp(d_rows32 or None), vp(d_idx32 or None), vp(d_coef32 or None), n32, n_cols,
                                           CURVE[curve], vp(d_exact or None), vp(d_aligned or None), vp(d_aligned_be or None),
                                           vp(d_scalars or None), vp(stream)))
+
+
+def mix_host(a0, a1, length, n_cols, n_total, curve="bn254"):
+    """Server::mix data part (Server.hpp:1269-1278): two blocks of `length` rows of 64-byte symbols -> 2*length rows."""
+    out = ctypes.create_string_buffer(2 * length * n_cols * 64)
+    _check(lib.porla_icc_mix_host(bytes(a0), bytes(a1), length, n_cols, n_total, CURVE[curve], out))
+    return out.raw
+
+
+def mac_mix_host(a0, a1, length, n_total, curve="bn254"):
+    """Server::mix MAC part (Server.hpp:1281-1318): two blocks of `length` 64-byte affine MACs -> 2*length MACs."""
+    out = ctypes.create_string_buffer(2 * length * 64)
+    _check(lib.porla_icc_mac_mix_host(bytes(a0), bytes(a1), length, n_total, CURVE[curve], out))
+    return out.raw

@@ -1,0 +1,63 @@
+"""Parity of the HIP Server::mix kernels (data part porla_icc_mix_*, MAC part porla_icc_mac_mix_*) against the oracle
+(oracle/icc_ref.c:oracle_icc_mix, oracle/mac_ref.c:oracle_icc_mac_mix, both pinned to the Python restatements of
+porla/Server/Server.hpp:1209-1328).  Bit-exact."""
+import ctypes
+import random
+
+import pytest
+
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("curve", ["bn254", "secp256k1"])
+@pytest.mark.parametrize("length,ncols,n_total", [(1, 128, 2), (4, 5, 64), (256, 128, 1024), (1024, 16, 1024)])
+def test_data_mix(curve, length, ncols, n_total):
+    import icc_py
+    from porla_amd import icc
+    rnd = random.Random(length * 131 + ncols)
+    lcm = icc_py.LCM[curve]
+    vals0 = [rnd.randrange(lcm) for _ in range(length * ncols)]
+    vals1 = [rnd.randrange(lcm) for _ in range(length * ncols)]
+    vals0[0], vals1[0] = lcm - 1, lcm - 1
+    vals0[-1], vals1[-1] = 0, 0
+    a0 = b"".join(v.to_bytes(64, "little") for v in vals0)
+    a1 = b"".join(v.to_bytes(64, "little") for v in vals1)
+    got = icc.mix_host(a0, a1, length, ncols, n_total, curve)
+    want = ctypes.create_string_buffer(2 * length * ncols * 64)
+    common.oracle().oracle_icc_mix(a0, a1, ctypes.c_size_t(length), ctypes.c_size_t(ncols), ctypes.c_size_t(n_total),
+                                   icc.CURVE[curve], want)
+    assert got == want.raw
+    if length <= 4:     # and directly against the Python restatement
+        rows0 = [vals0[i * ncols:(i + 1) * ncols] for i in range(length)]
+        rows1 = [vals1[i * ncols:(i + 1) * ncols] for i in range(length)]
+        py = icc_py.mix(rows0, rows1, n_total, curve)
+        assert got == b"".join(v.to_bytes(64, "little") for r in py for v in r)
+
+
+@pytest.mark.parametrize("curve", ["bn254", "secp256k1"])
+@pytest.mark.parametrize("length,n_total", [(1, 2), (8, 64), (512, 1024)])
+def test_mac_mix(curve, length, n_total):
+    from porla_amd import icc
+    from tests.test_mac_fft_gpu import macs_for
+    macs = bytearray(macs_for(curve, 2 * length))
+    if length >= 8:
+        macs[64 * 2:64 * 3] = bytes(64)                                    # infinity in A0
+        macs[64 * (length + 3):64 * (length + 4)] = bytes(64)              # infinity in A1
+    a0, a1 = bytes(macs[:64 * length]), bytes(macs[64 * length:])
+    got = icc.mac_mix_host(a0, a1, length, n_total, curve)
+    want = ctypes.create_string_buffer(2 * length * 64)
+    common.oracle().oracle_icc_mac_mix(a0, a1, ctypes.c_size_t(length), ctypes.c_size_t(n_total), icc.CURVE[curve], want,
+                                       common.ncpu())
+    assert got == want.raw
+
+
+def test_mac_mix_with_an_empty_upper_block():
+    """algebraic identity: mixing A0 with a block of infinity MACs (a fresh level, Server.hpp:1533-1534) returns A0 twice"""
+    from porla_amd import icc
+    from tests.test_mac_fft_gpu import macs_for
+    length = 16
+    a0 = macs_for("bn254", length)
+    got = icc.mac_mix_host(a0, bytes(64 * length), length, 64, "bn254")
+    assert got == a0 + a0

@@ -60,3 +60,20 @@ def test_c_oracle_matches_committed_golden():
         raw = bytes.fromhex("".join(c["macs"]))
         assert c_mac_crebuild(raw, c["n"], c["curve"], 0, c["write_step"]).hex() == "".join(c["X"])
         assert c_mac_crebuild(raw, c["n"], c["curve"], 1, c["write_step"]).hex() == "".join(c["Y"])
+
+
+@pytest.mark.parametrize("curve", ["bn254", "secp256k1"])
+def test_c_mac_mix_vs_python_and_vs_crebuild_last_stage(curve):
+    """oracle_icc_mac_mix vs icc_py.mac_mix; and mix of the two half-size transforms == the full CRebuild network
+    (the incremental construction the code is named for: Server.hpp:1209-1328 vs :1548-1687)"""
+    import icc_py
+    n = 8
+    macs = [icc_py.ec_mul(curve, GX[curve], 555 + 31 * i) for i in range(n)]
+    macs[5] = None
+    half = n // 2
+    a0, a1 = macs[:half], macs[half:]
+    want = icc_py.mac_mix(a0, a1, n, curve)
+    out = ctypes.create_string_buffer(64 * n)
+    common.oracle().oracle_icc_mac_mix(b"".join(pt_bytes(p) for p in a0), b"".join(pt_bytes(p) for p in a1), ctypes.c_size_t(half),
+                                       ctypes.c_size_t(n), 0 if curve == "bn254" else 1, out, 2)
+    assert out.raw == b"".join(pt_bytes(p) for p in want)
