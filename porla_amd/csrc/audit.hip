@@ -72,19 +72,6 @@ k_audit_accumulate(const uint8_t* __restrict__ rows64, const uint64_t* __restric
     for (int k = 0; k < ACC_LIMBS; k++) partial[((size_t)blockIdx.x * ACC_LIMBS + k) * n_cols + col] = acc[k];
 }
 
-// value of up to 19 limbs reduced into Montgomery form mod M: Horner over 256-bit digits with R = 2^256
-template <class M>
-__device__ __forceinline__ Fe<M> reduce_wide(const uint32_t a[ACC_LIMBS]) {
-    Fe<M> r2, d2, d1, d0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) { r2.v[k] = M::R2[k]; d0.v[k] = a[k]; d1.v[k] = a[8 + k]; d2.v[k] = (k < ACC_LIMBS - 16) ? a[16 + k] : 0; }
-    // Montgomery product with R2 takes any 256-bit operand: x -> x * R mod M
-    Fe<M> acc = fe_mul<M>(d2, r2);
-    acc = fe_add<M>(fe_mul<M>(acc, r2), fe_mul<M>(d1, r2));
-    acc = fe_add<M>(fe_mul<M>(acc, r2), fe_mul<M>(d0, r2));
-    return acc;
-}
-
 template <class Q>
 static __global__ void __launch_bounds__(128)
 k_audit_finish(const uint32_t* __restrict__ partial, uint32_t n_blocks, uint32_t n_cols, uint8_t* __restrict__ exact_out,
@@ -108,8 +95,8 @@ k_audit_finish(const uint32_t* __restrict__ partial, uint32_t n_blocks, uint32_t
 #pragma unroll
         for (int k = 0; k < 20; k++) d[k] = k < ACC_LIMBS ? acc[k] : 0;
     }
-    Fe<IccFp> P = fe_from_mont<IccFp>(reduce_wide<IccFp>(acc));   // B mod p_icc, plain
-    Fe<Q> bq = reduce_wide<Q>(acc);                                 // B mod q, Montgomery
+    Fe<IccFp> P = fe_from_mont<IccFp>(icc_reduce_wide<IccFp, ACC_LIMBS>(acc));   // B mod p_icc, plain
+    Fe<Q> bq = icc_reduce_wide<Q, ACC_LIMBS>(acc);                                 // B mod q, Montgomery
     if (al_out) st_fe<IccFp>(reinterpret_cast<uint32_t*>(al_out + 32 * (size_t)col), P);
     if (al_be_out) {
         uint4* q4 = reinterpret_cast<uint4*>(al_be_out + 32 * (size_t)col);

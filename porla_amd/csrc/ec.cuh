@@ -52,12 +52,12 @@ PORLA_HD XYZZ<M> xyzz_double_affine(const Affine<M>& a) {
     XYZZ<M> r;
     if (fe_is_zero<M>(a.y)) return xyzz_inf<M>();  // order-2 point: cannot occur on prime-order curves
     Fe<M> U = fe_dbl<M>(a.y);
-    Fe<M> V = fmul<M, CALL>(U, U);
+    Fe<M> V = fsqr<M, CALL>(U);
     Fe<M> W = fmul<M, CALL>(U, V);
     Fe<M> S = fmul<M, CALL>(a.x, V);
-    Fe<M> XX = fmul<M, CALL>(a.x, a.x);
+    Fe<M> XX = fsqr<M, CALL>(a.x);
     Fe<M> Mm = fe_add<M>(fe_dbl<M>(XX), XX);
-    r.x = fe_sub<M>(fe_sub<M>(fmul<M, CALL>(Mm, Mm), S), S);
+    r.x = fe_sub<M>(fe_sub<M>(fsqr<M, CALL>(Mm), S), S);
     r.y = fe_sub<M>(fmul<M, CALL>(Mm, fe_sub<M>(S, r.x)), fmul<M, CALL>(W, a.y));
     r.zz = V;
     r.zzz = W;
@@ -70,12 +70,12 @@ PORLA_HD XYZZ<M> xyzz_double(const XYZZ<M>& p) {
     if (xyzz_is_inf<M>(p) || fe_is_zero<M>(p.y)) return xyzz_inf<M>();
     XYZZ<M> r;
     Fe<M> U = fe_dbl<M>(p.y);
-    Fe<M> V = fmul<M, CALL>(U, U);
+    Fe<M> V = fsqr<M, CALL>(U);
     Fe<M> W = fmul<M, CALL>(U, V);
     Fe<M> S = fmul<M, CALL>(p.x, V);
-    Fe<M> XX = fmul<M, CALL>(p.x, p.x);
+    Fe<M> XX = fsqr<M, CALL>(p.x);
     Fe<M> Mm = fe_add<M>(fe_dbl<M>(XX), XX);
-    r.x = fe_sub<M>(fe_sub<M>(fmul<M, CALL>(Mm, Mm), S), S);
+    r.x = fe_sub<M>(fe_sub<M>(fsqr<M, CALL>(Mm), S), S);
     r.y = fe_sub<M>(fmul<M, CALL>(Mm, fe_sub<M>(S, r.x)), fmul<M, CALL>(W, p.y));
     r.zz = fmul<M, CALL>(V, p.zz);
     r.zzz = fmul<M, CALL>(W, p.zzz);
@@ -99,10 +99,10 @@ PORLA_HD void xyzz_madd(XYZZ<M>& p, const Affine<M>& a) {
         else p = xyzz_inf<M>();
         return;
     }
-    Fe<M> PP = fmul<M, CALL>(Pp, Pp);
+    Fe<M> PP = fsqr<M, CALL>(Pp);
     Fe<M> PPP = fmul<M, CALL>(Pp, PP);
     Fe<M> Q = fmul<M, CALL>(p.x, PP);
-    Fe<M> X3 = fe_sub<M>(fe_sub<M>(fe_sub<M>(fmul<M, CALL>(Rr, Rr), PPP), Q), Q);
+    Fe<M> X3 = fe_sub<M>(fe_sub<M>(fe_sub<M>(fsqr<M, CALL>(Rr), PPP), Q), Q);
     Fe<M> Y3 = fe_sub<M>(fmul<M, CALL>(Rr, fe_sub<M>(Q, X3)), fmul<M, CALL>(p.y, PPP));
     p.x = X3;
     p.y = Y3;
@@ -126,10 +126,10 @@ PORLA_HD void xyzz_add(XYZZ<M>& p, const XYZZ<M>& q) {
         else p = xyzz_inf<M>();
         return;
     }
-    Fe<M> PP = fmul<M, CALL>(Pp, Pp);
+    Fe<M> PP = fsqr<M, CALL>(Pp);
     Fe<M> PPP = fmul<M, CALL>(Pp, PP);
     Fe<M> Q = fmul<M, CALL>(U1, PP);
-    Fe<M> X3 = fe_sub<M>(fe_sub<M>(fe_sub<M>(fmul<M, CALL>(Rr, Rr), PPP), Q), Q);
+    Fe<M> X3 = fe_sub<M>(fe_sub<M>(fe_sub<M>(fsqr<M, CALL>(Rr), PPP), Q), Q);
     Fe<M> Y3 = fe_sub<M>(fmul<M, CALL>(Rr, fe_sub<M>(Q, X3)), fmul<M, CALL>(S1, PPP));
     p.x = X3;
     p.y = Y3;

@@ -34,7 +34,7 @@ __device__ __noinline__ Fe<M> fe_inv_dev(Fe<M> a) {
         const uint32_t limb = (l == 0) ? M::P[0] - 2u : M::P[l];  // P is odd and P[0] >= 2: no borrow past limb 0
 #pragma unroll 1
         for (int b = 31; b >= 0; b--) {
-            acc = fe_mul_call<M>(acc, acc);
+            acc = fe_sqr_call<M>(acc);
             if ((limb >> b) & 1) acc = fe_mul_call<M>(acc, a);
         }
     }
@@ -46,7 +46,7 @@ template <class M>
 __device__ __forceinline__ Affine<M> xyzz_to_affine_with_inv(const XYZZ<M>& p, const Fe<M>& inv_zzz) {
     Affine<M> r;
     Fe<M> t = fe_mul_call<M>(p.zz, inv_zzz);     // ZZ/ZZZ = 1/Z
-    Fe<M> t2 = fe_mul_call<M>(t, t);             // 1/ZZ
+    Fe<M> t2 = fe_sqr_call<M>(t);                // 1/ZZ
     r.x = fe_mul_call<M>(p.x, t2);
     r.y = fe_mul_call<M>(p.y, inv_zzz);
     return r;

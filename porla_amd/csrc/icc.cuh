@@ -349,6 +349,19 @@ __global__ void k_icc_finish(const IccElem<Q>* __restrict__ work, size_t total, 
     if (x_out) icc_store_lcm<Q>(e, P, pq_m, x_out + 64 * i);
 }
 
+// value of LIMBS (17..24) 32-bit limbs reduced into Montgomery form mod M: Horner over 256-bit digits with R = 2^256
+template <class M, int LIMBS>
+PORLA_HD Fe<M> icc_reduce_wide(const uint32_t* a) {
+    Fe<M> r2, d2, d1, d0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { r2.v[k] = M::R2[k]; d0.v[k] = a[k]; d1.v[k] = a[8 + k]; d2.v[k] = (k < LIMBS - 16) ? a[16 + k] : 0; }
+    // Montgomery product with R2 takes any 256-bit operand: x -> x * R mod M
+    Fe<M> acc = fe_mul<M>(d2, r2);
+    acc = fe_add<M>(fe_mul<M>(acc, r2), fe_mul<M>(d1, r2));
+    acc = fe_add<M>(fe_mul<M>(acc, r2), fe_mul<M>(d0, r2));
+    return acc;
+}
+
 // 512-bit little-endian value (< LCM, a stored code symbol) -> residue pair: Horner over the two 256-bit halves, R = 2^256
 template <class M>
 __device__ __forceinline__ Fe<M> icc_reduce512(const uint32_t a[16]) {

@@ -181,3 +181,23 @@ def test_full_size_2_20(mx, dist):
     d_pt = torch.frombuffer(bytearray(pt), dtype=torch.uint8).cuda()
     got = mx.msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
     assert got == common.oracle_msm(sc, pt, n)
+
+
+def test_all_ones_limbs_in_montgomery_form(mx):
+    """Points whose Montgomery x-coordinate is 0x0ffffffe ffffffff ... ffffffff: in P + P (two equal points in one bucket)
+    the doubling squares that coordinate, and every column of the product starts with 0xffffffff * 0xffffffff on top of a
+    non-zero incoming accumulator -- the case in which a dropped carry-out of the first v_mad_u64_u32 of a column would
+    corrupt the field product (fe_mul_gfx950.inc folds every carry).  The points are on the curve (tools: x = x_mont / R)."""
+    pts = [(0x22673664f672e901666cf81e3dcd006df9ca723b2f9061e646da650d1918dddd, 0x249117a44372fa51695e0427975f8c2137758ddab44ad63cb206c1b1b74cefa6),
+           (0x2cca58ea976932f57213e21fd33bf2d94a2b2eb52d3f68ab53b289f3e959f687, 0x19d1fe9404fd0b17af06463513e9afaea9dfb1f6ed93892ebc13216977b1ca7d),
+           (0x1979bba86b2b7c5bf97116a1c7213b15ada2260c3a521809dfe105078fd8595, 0x1d030e3b5a4b70c13187459682f544b1fc4486820b39f12bcbeb3884c77d476)]
+    for x, y in pts:
+        P = x.to_bytes(32, "big") + y.to_bytes(32, "big")
+        assert common.oracle().oracle_bn254_on_curve(P) == 1
+        one = (1).to_bytes(32, "big")
+        for k in (2, 3, 7):
+            got = mx.bn254_multi_exp(P * k, one * k, k)                 # k equal points, scalar 1: P + P + ...
+            assert got == common.oracle_msm(one * k, P * k, k, naive=True)
+        sc = (0x1234567).to_bytes(32, "big") * 2
+        assert mx.bn254_multi_exp(P * 2, sc, 2) == common.oracle_msm(sc, P * 2, 2, naive=True)
+        assert mx.bn254_mult(P, (2).to_bytes(32, "big")) == common.oracle_msm(one * 2, P * 2, 2, naive=True)
