@@ -97,11 +97,8 @@ __device__ __forceinline__ void st_elem(IccElem<Q>* p, const IccElem<Q>& e) {
 
 // raw 256-bit little-endian chunk (utils.h:353-364) -> residue pair, optionally times wt (the Y part)
 template <class Q>
-__global__ void k_icc_load(const uint8_t* __restrict__ in, IccElem<Q>* __restrict__ work, size_t total,
-                           IccElem<Q> wt, int use_wt) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    Fe<IccFp> xp = ld_fe<IccFp>(reinterpret_cast<const uint32_t*>(in + 32 * i));
+__device__ __forceinline__ IccElem<Q> icc_load_elem(const uint8_t* src, const IccElem<Q>& wt, int use_wt) {
+    Fe<IccFp> xp = ld_fe<IccFp>(reinterpret_cast<const uint32_t*>(src));
     Fe<Q> xq;
 #pragma unroll
     for (int k = 0; k < 8; k++) xq.v[k] = xp.v[k];
@@ -114,7 +111,14 @@ __global__ void k_icc_load(const uint8_t* __restrict__ in, IccElem<Q>* __restric
         e.p = fe_mul<IccFp>(e.p, wt.p);
         e.q = fe_mul<Q>(e.q, wt.q);
     }
-    st_elem<Q>(work + i, e);
+    return e;
+}
+template <class Q>
+__global__ void k_icc_load(const uint8_t* __restrict__ in, IccElem<Q>* __restrict__ work, size_t total,
+                           IccElem<Q> wt, int use_wt) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    st_elem<Q>(work + i, icc_load_elem<Q>(in + 32 * i, wt, use_wt));
 }
 
 // tw[e] = w^e for e in [0, n): residue pair of the INTEGER (w^e mod p_icc), as the reference multiplies by the
@@ -198,72 +202,6 @@ k_icc_stages(IccElem<Q>* __restrict__ work, const IccElem<Q>* __restrict__ tw, u
     }
 }
 
-// LDS-fused stages s0 .. s0+ns-1 (ns <= 8).  A block owns a TILE: 2^ns rows {row_base + mid * 2^(s0-1)} (all values of the
-// ns row-index bits these stages pair up; the lower s0-1 bits `lo` and the upper bits `hi` are fixed per tile) x 2^cc_log
-// columns = 512 symbols = 32 KiB of LDS (4 blocks per CU).  The tile is read from HBM once, goes through ns butterfly stages in LDS and is
-// written back once: 15 stages cost 2 passes over the working set instead of 8.
-#ifndef PORLA_ICC_TILE
-#define PORLA_ICC_TILE 512
-#endif
-constexpr int ICC_TILE_ELEMS = PORLA_ICC_TILE;
-constexpr int ICC_TILE_LOG = PORLA_ICC_TILE == 1024 ? 10 : (PORLA_ICC_TILE == 512 ? 9 : 8);
-template <class Q>
-__global__ void __launch_bounds__(256)
-k_icc_fused(IccElem<Q>* __restrict__ work, const IccElem<Q>* __restrict__ tw, uint32_t n, uint32_t ncols, int s0, int ns,
-            int cc_log) {
-    __shared__ uint4 lds[ICC_TILE_ELEMS * 4];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t Cc = 1u << cc_log;
-    const uint32_t elems = (1u << ns) << cc_log;            // <= ICC_TILE_ELEMS
-    const uint32_t lo_bits = (uint32_t)(s0 - 1);
-    const uint32_t col_tiles = (ncols + Cc - 1) >> cc_log;
-    uint32_t tile = blockIdx.x;
-    const uint32_t ct = tile % col_tiles;
-    tile /= col_tiles;
-    const uint32_t lo = tile & ((1u << lo_bits) - 1u);
-    const uint32_t hi = tile >> lo_bits;
-    const uint32_t row_base = (hi << (lo_bits + ns)) + lo;
-    const uint32_t c0 = ct << cc_log;
-    for (uint32_t e = tid; e < elems; e += 256) {
-        const uint32_t mid = e >> cc_log, col = e & (Cc - 1);
-        if (c0 + col < ncols) {
-            const uint4* src = reinterpret_cast<const uint4*>(work + (size_t)(row_base + (mid << lo_bits)) * ncols + c0 + col);
-            uint4 a = src[0], b = src[1], c = src[2], d = src[3];
-            lds[e * 4 + 0] = a; lds[e * 4 + 1] = b; lds[e * 4 + 2] = c; lds[e * 4 + 3] = d;
-        }
-    }
-    __syncthreads();
-    for (int d = 0; d < ns; d++) {
-        const int s = s0 + d;
-        const uint32_t tw_step = n >> (s - 1);               // N / m2
-        for (uint32_t bf = tid; bf < elems / 2; bf += 256) {
-            const uint32_t col = bf & (Cc - 1), q = bf >> cc_log;
-            const uint32_t mid0 = ((q >> d) << (d + 1)) | (q & ((1u << d) - 1u));
-            const uint32_t mid1 = mid0 | (1u << d);
-            if (c0 + col < ncols) {
-                const uint32_t j = ((mid0 & ((1u << d) - 1u)) << lo_bits) + lo;    // row index mod m2
-                IccElem<Q> t1 = ld_elem<Q>(tw + (size_t)j * tw_step);
-                uint32_t* pa = reinterpret_cast<uint32_t*>(&lds[((mid0 << cc_log) + col) * 4]);
-                uint32_t* pb = reinterpret_cast<uint32_t*>(&lds[((mid1 << cc_log) + col) * 4]);
-                IccElem<Q> a, b;
-                a.p = ld_fe<IccFp>(pa); a.q = ld_fe<Q>(pa + 8);
-                b.p = ld_fe<IccFp>(pb); b.q = ld_fe<Q>(pb + 8);
-                butterfly<Q>(a, b, t1, false);
-                st_fe<IccFp>(pa, a.p); st_fe<Q>(pa + 8, a.q);
-                st_fe<IccFp>(pb, b.p); st_fe<Q>(pb + 8, b.q);
-            }
-        }
-        __syncthreads();
-    }
-    for (uint32_t e = tid; e < elems; e += 256) {
-        const uint32_t mid = e >> cc_log, col = e & (Cc - 1);
-        if (c0 + col < ncols) {
-            uint4* dst = reinterpret_cast<uint4*>(work + (size_t)(row_base + (mid << lo_bits)) * ncols + c0 + col);
-            dst[0] = lds[e * 4 + 0]; dst[1] = lds[e * 4 + 1]; dst[2] = lds[e * 4 + 2]; dst[3] = lds[e * 4 + 3];
-        }
-    }
-}
-
 // value in [0, LCM) as 64 bytes little-endian from the residue pair: P = A mod p_icc (plain), pq_m = P mod q (Montgomery)
 template <class Q>
 __device__ __forceinline__ void icc_store_lcm(const IccElem<Q>& e, const Fe<IccFp>& P, const Fe<Q>& pq_m, uint8_t* dst) {
@@ -314,13 +252,17 @@ __device__ __forceinline__ void icc_store_lcm(const IccElem<Q>& e, const Fe<IccF
 // residue pair -> (a) value in [0, LCM) as 64-byte LE, (b) value mod p_icc as 32-byte LE,
 // (c) alignment scalar c = (A mod p_icc - A) mod q (Server.hpp:535-538) as 32 bytes BE (or LE limbs),
 // (d) A mod q as 32 bytes BE (the coefficient the MAC side sees, mac_fft.hip)
+struct IccOut {   // output pointers of the finish step (each may be null)
+    uint8_t* x;      // 64 B LE, value mod LCM
+    uint8_t* al;     // 32 B LE, value mod p_icc
+    uint8_t* sc;     // 32 B alignment scalar (BE, or LE limbs with scalar_le)
+    uint8_t* qres;   // 32 B BE, value mod q
+    int scalar_le;
+};
 template <class Q>
-__global__ void k_icc_finish(const IccElem<Q>* __restrict__ work, size_t total, uint8_t* __restrict__ x_out,
-                             uint8_t* __restrict__ al_out, uint8_t* __restrict__ sc_out, int scalar_le,
-                             uint8_t* __restrict__ qres_out) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    IccElem<Q> e = ld_elem<Q>(work + i);
+__device__ __forceinline__ void icc_finish_elem(const IccElem<Q>& e, size_t i, const IccOut& o) {
+    uint8_t* const x_out = o.x; uint8_t* const al_out = o.al; uint8_t* const sc_out = o.sc; uint8_t* const qres_out = o.qres;
+    const int scalar_le = o.scalar_le;
     if (qres_out) {
         Fe<Q> a = fe_from_mont<Q>(e.q);
         uint4* q4 = reinterpret_cast<uint4*>(qres_out + 32 * i);
@@ -347,6 +289,94 @@ __global__ void k_icc_finish(const IccElem<Q>* __restrict__ work, size_t total, 
         }
     }
     if (x_out) icc_store_lcm<Q>(e, P, pq_m, x_out + 64 * i);
+}
+template <class Q>
+__global__ void k_icc_finish(const IccElem<Q>* __restrict__ work, size_t total, IccOut o) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    icc_finish_elem<Q>(ld_elem<Q>(work + i), i, o);
+}
+
+// LDS-fused stages s0 .. s0+ns-1 (ns <= 8).  A block owns a TILE: 2^ns rows {row_base + mid * 2^(s0-1)} (all values of the
+// ns row-index bits these stages pair up; the lower s0-1 bits `lo` and the upper bits `hi` are fixed per tile) x 2^cc_log
+// columns = 512 symbols = 32 KiB of LDS (4 blocks per CU).  The tile is read from HBM once, goes through ns butterfly stages in LDS and is
+// written back once: 15 stages cost 2 passes over the working set instead of 8.  FIRST fuses the conversion of the raw
+// 32-byte chunks (k_icc_load) into the first pass, LAST the CRT recombination / alignment outputs (k_icc_finish) into the last.
+#ifndef PORLA_ICC_TILE
+#define PORLA_ICC_TILE 512
+#endif
+constexpr int ICC_TILE_ELEMS = PORLA_ICC_TILE;
+constexpr int ICC_TILE_LOG = PORLA_ICC_TILE == 1024 ? 10 : (PORLA_ICC_TILE == 512 ? 9 : 8);
+template <class Q, bool FIRST, bool LAST>
+__global__ void __launch_bounds__(256)
+k_icc_fused(IccElem<Q>* __restrict__ work, const IccElem<Q>* __restrict__ tw, uint32_t n, uint32_t ncols, int s0, int ns,
+            int cc_log, const uint8_t* __restrict__ raw, IccElem<Q> wt, int use_wt, IccOut out) {
+    __shared__ uint4 lds[ICC_TILE_ELEMS * 4];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t Cc = 1u << cc_log;
+    const uint32_t elems = (1u << ns) << cc_log;            // <= ICC_TILE_ELEMS
+    const uint32_t lo_bits = (uint32_t)(s0 - 1);
+    const uint32_t col_tiles = (ncols + Cc - 1) >> cc_log;
+    uint32_t tile = blockIdx.x;
+    const uint32_t ct = tile % col_tiles;
+    tile /= col_tiles;
+    const uint32_t lo = tile & ((1u << lo_bits) - 1u);
+    const uint32_t hi = tile >> lo_bits;
+    const uint32_t row_base = (hi << (lo_bits + ns)) + lo;
+    const uint32_t c0 = ct << cc_log;
+    for (uint32_t e = tid; e < elems; e += 256) {
+        const uint32_t mid = e >> cc_log, col = e & (Cc - 1);
+        if (c0 + col < ncols) {
+            const size_t gi = (size_t)(row_base + (mid << lo_bits)) * ncols + c0 + col;
+            if (FIRST) {   // the 32-byte chunk of the block file, converted on the way in (k_icc_load fused)
+                IccElem<Q> el = icc_load_elem<Q>(raw + 32 * gi, wt, use_wt);
+                uint32_t* pe = reinterpret_cast<uint32_t*>(&lds[e * 4]);
+                st_fe<IccFp>(pe, el.p); st_fe<Q>(pe + 8, el.q);
+            } else {
+                const uint4* src = reinterpret_cast<const uint4*>(work + gi);
+                uint4 a = src[0], b = src[1], c = src[2], d = src[3];
+                lds[e * 4 + 0] = a; lds[e * 4 + 1] = b; lds[e * 4 + 2] = c; lds[e * 4 + 3] = d;
+            }
+        }
+    }
+    __syncthreads();
+    for (int d = 0; d < ns; d++) {
+        const int s = s0 + d;
+        const uint32_t tw_step = n >> (s - 1);               // N / m2
+        for (uint32_t bf = tid; bf < elems / 2; bf += 256) {
+            const uint32_t col = bf & (Cc - 1), q = bf >> cc_log;
+            const uint32_t mid0 = ((q >> d) << (d + 1)) | (q & ((1u << d) - 1u));
+            const uint32_t mid1 = mid0 | (1u << d);
+            if (c0 + col < ncols) {
+                const uint32_t j = ((mid0 & ((1u << d) - 1u)) << lo_bits) + lo;    // row index mod m2
+                IccElem<Q> t1 = ld_elem<Q>(tw + (size_t)j * tw_step);
+                uint32_t* pa = reinterpret_cast<uint32_t*>(&lds[((mid0 << cc_log) + col) * 4]);
+                uint32_t* pb = reinterpret_cast<uint32_t*>(&lds[((mid1 << cc_log) + col) * 4]);
+                IccElem<Q> a, b;
+                a.p = ld_fe<IccFp>(pa); a.q = ld_fe<Q>(pa + 8);
+                b.p = ld_fe<IccFp>(pb); b.q = ld_fe<Q>(pb + 8);
+                butterfly<Q>(a, b, t1, false);
+                st_fe<IccFp>(pa, a.p); st_fe<Q>(pa + 8, a.q);
+                st_fe<IccFp>(pb, b.p); st_fe<Q>(pb + 8, b.q);
+            }
+        }
+        __syncthreads();
+    }
+    for (uint32_t e = tid; e < elems; e += 256) {
+        const uint32_t mid = e >> cc_log, col = e & (Cc - 1);
+        if (c0 + col < ncols) {
+            const size_t gi = (size_t)(row_base + (mid << lo_bits)) * ncols + c0 + col;
+            if (LAST) {    // k_icc_finish fused: outputs straight from the tile
+                const uint32_t* pe = reinterpret_cast<const uint32_t*>(&lds[e * 4]);
+                IccElem<Q> el;
+                el.p = ld_fe<IccFp>(pe); el.q = ld_fe<Q>(pe + 8);
+                icc_finish_elem<Q>(el, gi, out);
+            } else {
+                uint4* dst = reinterpret_cast<uint4*>(work + gi);
+                dst[0] = lds[e * 4 + 0]; dst[1] = lds[e * 4 + 1]; dst[2] = lds[e * 4 + 2]; dst[3] = lds[e * 4 + 3];
+            }
+        }
+    }
 }
 
 // value of LIMBS (17..24) 32-bit limbs reduced into Montgomery form mod M: Horner over 256-bit digits with R = 2^256

@@ -95,14 +95,11 @@ static int icc_encode_core(IccWs* ws, int curve, const uint8_t* d_rows, size_t n
         wt.q = fe_to_mont<Q>(tq);
         use_wt = 1;
     }
-    {
-        ProfScope ps("icc_load", stream);
-        hipLaunchKernelGGL((k_icc_load<Q>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, d_rows,
-                           (IccElem<Q>*)ws->work.p, total, wt, use_wt);
-    }
     static const int fused = !(getenv("PORLA_ICC_FUSED") && getenv("PORLA_ICC_FUSED")[0] == '0');
+    IccOut out{d_x, d_al, d_sc, d_qres, scalar_le};
     if (fused) {
-        // ceil(logn / 8) passes of (almost) equal stage counts, each through LDS tiles of 512 symbols
+        // ceil(logn / 8) passes of (almost) equal stage counts, each through LDS tiles of 512 symbols; the first pass reads
+        // the raw chunks, the last one writes the outputs: the residue-pair working set only travels between passes
         const int passes = (logn + 7) / 8;
         int s = 1;
         for (int pz = 0; pz < passes; pz++) {
@@ -110,13 +107,25 @@ static int icc_encode_core(IccWs* ws, int curve, const uint8_t* d_rows, size_t n
             int cc_log = ICC_TILE_LOG - ns;                                    // 2^ns rows x 2^cc_log columns = 512 symbols
             while (cc_log > 0 && ((size_t)1 << (cc_log - 1)) >= ncols) cc_log--;   // no wider than the row
             const size_t col_tiles = (ncols + ((size_t)1 << cc_log) - 1) >> cc_log;
-            const size_t tiles = col_tiles * (n >> ns);
+            const dim3 grid((unsigned)(col_tiles * (n >> ns)));
+            const bool first = pz == 0, last = pz == passes - 1;
             ProfScope ps("icc_fused", stream);
-            hipLaunchKernelGGL((k_icc_fused<Q>), dim3((unsigned)tiles), dim3(256), 0, stream, (IccElem<Q>*)ws->work.p,
-                               (const IccElem<Q>*)ws->tw.p, (uint32_t)n, (uint32_t)ncols, s, ns, cc_log);
+#define PORLA_ICC_LAUNCH(F, L)                                                                                              \
+    hipLaunchKernelGGL((k_icc_fused<Q, F, L>), grid, dim3(256), 0, stream, (IccElem<Q>*)ws->work.p,                         \
+                       (const IccElem<Q>*)ws->tw.p, (uint32_t)n, (uint32_t)ncols, s, ns, cc_log, d_rows, wt, use_wt, out)
+            if (first && last) PORLA_ICC_LAUNCH(true, true);
+            else if (first) PORLA_ICC_LAUNCH(true, false);
+            else if (last) PORLA_ICC_LAUNCH(false, true);
+            else PORLA_ICC_LAUNCH(false, false);
+#undef PORLA_ICC_LAUNCH
             s += ns;
         }
     } else {
+        {
+            ProfScope ps("icc_load", stream);
+            hipLaunchKernelGGL((k_icc_load<Q>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, d_rows,
+                               (IccElem<Q>*)ws->work.p, total, wt, use_wt);
+        }
         int s = 1;
         while (s + 1 <= logn) {
             ProfScope ps("icc_stages_r4", stream);
@@ -131,11 +140,11 @@ static int icc_encode_core(IccWs* ws, int curve, const uint8_t* d_rows, size_t n
             hipLaunchKernelGGL((k_icc_stages<Q, 1>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream,
                                (IccElem<Q>*)ws->work.p, (const IccElem<Q>*)ws->tw.p, (uint32_t)n, (uint32_t)ncols, s);
         }
-    }
-    {
-        ProfScope ps("icc_finish", stream);
-        hipLaunchKernelGGL((k_icc_finish<Q>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
-                           (const IccElem<Q>*)ws->work.p, total, d_x, d_al, d_sc, scalar_le, d_qres);
+        {
+            ProfScope ps("icc_finish", stream);
+            hipLaunchKernelGGL((k_icc_finish<Q>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                               (const IccElem<Q>*)ws->work.p, total, out);
+        }
     }
     PORLA_HIP(hipGetLastError());
     return PORLA_OK;
