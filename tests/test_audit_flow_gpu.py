@@ -1,0 +1,81 @@
+"""End-to-end KZG audit over the engine's kernels (GPU box only): the consistency the protocol itself checks.
+
+Server side of porla/Server/Server.hpp:564-931 with every arithmetic step on the engine:
+  blocks --(porla_icc_encode: CRebuild data part)--> encoded rows X            Server.hpp:1548-1687
+  Commit(block_i) --(porla_icc_mac_encode: CRebuild MAC part)--> encoded MACs   Server.hpp:1590-1609
+  challenge (idx, coeff) --(porla_audit_combine_device)--> B mod p_icc, alignment scalars c    :790-828, :531-541
+  combined_MAC = compute_multi_exp(coeffs, MACs[idx])                          Server.hpp:900
+  align_value  = compute_digest_from_srs(c)                                    Server.hpp:550-560
+  proof        = create_proof(z, B)                                            Server.hpp:907 -> main.go:153-175
+What must hold (Client::audit, porla/Client/Client.hpp:849-876, without the client's secret alpha / complements):
+  proof.commitment == combined_MAC + align_value      and      verify_proof(proof) == 1
+because the commitment is linear over Z_q and the code is linear: Commit(X_k mod q) = encoded MAC_k."""
+import ctypes
+import hashlib
+import random
+
+import pytest
+
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+TAU = bytes.fromhex("ffeeddccbbaa99887766554433221100")     # TAU_KEY, config.hpp:39
+ALPHA = bytes.fromhex("00112233445566778899aabbccddeeff")   # SECRET_KEY, config.hpp:38
+R = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+
+
+@pytest.mark.parametrize("n_blocks,write_step,part", [(64, 0, 0), (256, 37, 1)])
+def test_kzg_audit_is_consistent_end_to_end(n_blocks, write_step, part):
+    import numpy as np
+    import torch
+    from porla_amd import icc, multiexp as mx
+    ncols = 128
+    mx.init_key(TAU, ALPHA)
+    blob = mx.init_SRS(ncols)
+    mx.init_SRS_from_data(ncols, blob)
+    # blocks: chunk 0 = block id, the rest random 256-bit values (Client.hpp:367-372); 32-byte little-endian chunks
+    rows = b""
+    for i in range(n_blocks):
+        rows += i.to_bytes(32, "little")
+        rows += b"".join(hashlib.sha256(b"blk" + i.to_bytes(4, "little") + j.to_bytes(4, "little")).digest() for j in range(ncols - 1))
+    # per-block commitments (the MAC without the client's alpha / complement): coefficients = chunks as big-endian scalars
+    rows_be = b"".join(rows[32 * k:32 * k + 32][::-1] for k in range(n_blocks * ncols))
+    macs_u = mx.kzg_commit_batch_host(rows_be, n_blocks)
+    # encode data and MACs
+    x_rows = icc.crebuild_host(rows, n_blocks, ncols, "bn254", write_step, part, want_aligned=False, want_scalars=False)[0]
+    macs_h = icc.mac_crebuild_host(macs_u, n_blocks, "bn254", write_step, part)
+    # spot check of the linearity the audit relies on: Commit(X_k mod q) == encoded MAC_k
+    for k in (0, 1, n_blocks - 1):
+        coeffs = b"".join((int.from_bytes(x_rows[64 * (k * ncols + j):64 * (k * ncols + j) + 64], "little") % R).to_bytes(32, "big")
+                          for j in range(ncols))
+        assert mx.compute_digest_from_srs(coeffs) == macs_h[64 * k:64 * k + 64]
+    # challenge: NUM_CHECK_AUDIT-style random rows with abs(int32) coefficients (Server.hpp:604-621)
+    rnd = random.Random(n_blocks)
+    n_points = 128
+    idx = [rnd.randrange(n_blocks) for _ in range(n_points)]
+    coef = [rnd.getrandbits(31) for _ in range(n_points)]
+    d_rows = torch.frombuffer(bytearray(x_rows), dtype=torch.uint8).cuda()
+    d_idx = torch.tensor(idx, dtype=torch.int64).cuda()
+    d_coef = torch.tensor(np.array(coef, dtype=np.uint32).view(np.int32)).cuda()
+    d_b_be = torch.empty(32 * ncols, dtype=torch.uint8, device="cuda")
+    d_c = torch.empty(32 * ncols, dtype=torch.uint8, device="cuda")
+    icc.audit_combine_device(d_rows.data_ptr(), d_idx.data_ptr(), d_coef.data_ptr(), n_points, 0, 0, 0, 0, ncols, "bn254",
+                             d_aligned_be=d_b_be.data_ptr(), d_scalars=d_c.data_ptr(),
+                             stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    b_be, c_be = bytes(d_b_be.cpu().numpy()), bytes(d_c.cpu().numpy())
+    # the two MSMs of the audit (Server.hpp:900-901; the alignment MACs of a fresh level are infinity)
+    scalars = b"".join(mx.bn254_scalar_set_int(v) for v in coef)
+    points = b"".join(macs_h[64 * i:64 * i + 64] for i in idx)
+    combined_mac = mx.bn254_multi_exp(points, scalars, n_points)
+    align_value = mx.compute_digest_from_srs(c_be)              # align_MAC, Server.hpp:550-560
+    z = 0x0123456789abcdef
+    commitment, proof_h, point, claim = mx.create_proof(z, b_be)
+    assert commitment == mx.bn254_add(combined_mac, align_value)
+    assert mx.verify_proof(commitment, proof_h, point, claim)
+    # a tampered row breaks it
+    bad = bytearray(b_be)
+    bad[31] ^= 1
+    c2, h2, p2, y2 = mx.create_proof(z, bytes(bad))
+    assert c2 != mx.bn254_add(combined_mac, align_value)
