@@ -201,3 +201,23 @@ def test_all_ones_limbs_in_montgomery_form(mx):
         sc = (0x1234567).to_bytes(32, "big") * 2
         assert mx.bn254_multi_exp(P * 2, sc, 2) == common.oracle_msm(sc, P * 2, 2, naive=True)
         assert mx.bn254_mult(P, (2).to_bytes(32, "big")) == common.oracle_msm(one * 2, P * 2, 2, naive=True)
+
+
+def test_scale_2_22_pairs_and_range_partition_invariance(mx):
+    """4 Mi pairs (a quarter of BASELINE.json config 3's per-GPU share): random 256-bit scalars over 2^14 distinct points
+    repeated 256 times; the result equals the oracle, and folding 4 range-sharded partial sums (the multi-GPU decomposition,
+    porla_amd/sharded.py) gives the same point."""
+    import torch
+    n, distinct = 1 << 22, 1 << 14
+    pt = common.synth_points(distinct) * (n // distinct)
+    g = torch.Generator(device="cuda").manual_seed(2022)
+    d_sc = torch.randint(0, 256, (32 * n,), dtype=torch.uint8, device="cuda", generator=g)
+    d_pt = torch.frombuffer(bytearray(pt), dtype=torch.uint8).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    got = mx.msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n, stream)
+    parts = b""
+    for s in range(4):
+        lo = s * (n // 4)
+        parts += mx.msm_device("bn254", d_sc.data_ptr() + 32 * lo, d_pt.data_ptr() + 64 * lo, n // 4, stream, partial=True)
+    assert mx.jac_sum("bn254", parts, 4) == got
+    assert got == common.oracle_msm(bytes(d_sc.cpu().numpy()), pt, n)
