@@ -36,16 +36,23 @@ struct Bn254Fp {
     static constexpr uint32_t R2[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u,
                                        0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};  // R^2 mod p
     static constexpr int SPARE_BITS = 2;            // p < 2^254
+    static constexpr bool PSEUDO_MERSENNE = false;
+    static constexpr uint32_t FOLD = 0;
 };
 
-// secp256k1 base field p = 2^256 - 2^32 - 977 (field_5x52.h:13-15 of the vendored tree).
+// secp256k1 base field p = 2^256 - 2^32 - 977 (field_5x52.h:13-15 of the vendored tree).  Like the reference's own field
+// code this uses the special form of p: elements are PLAIN residues (the "Montgomery" radix is 1, so fe_to_mont /
+// fe_from_mont are the identity and R1 = R2 = 1) and a product is a 512-bit product folded twice with 2^256 = 2^32 + 977
+// (mod p) -- 64 + 10 multiply-adds instead of the 128 of a Montgomery product.
 struct Secp256k1Fp {
     static constexpr uint32_t P[8]  = {0xfffffc2fu, 0xfffffffeu, 0xffffffffu, 0xffffffffu,
                                        0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-    static constexpr uint32_t INV   = 0xd2253531u;  // -p^-1 mod 2^32
-    static constexpr uint32_t R1[8] = {0x000003d1u, 0x00000001u, 0, 0, 0, 0, 0, 0};          // 2^256 mod p
-    static constexpr uint32_t R2[8] = {0x000e90a1u, 0x000007a2u, 0x00000001u, 0, 0, 0, 0, 0}; // (2^32+977)^2
+    static constexpr uint32_t INV   = 0xd2253531u;  // -p^-1 mod 2^32 (unused by the special-form product)
+    static constexpr uint32_t R1[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+    static constexpr uint32_t R2[8] = {1, 0, 0, 0, 0, 0, 0, 0};
     static constexpr int SPARE_BITS = 0;
+    static constexpr bool PSEUDO_MERSENNE = true;   // p = 2^256 - (2^32 + FOLD)
+    static constexpr uint32_t FOLD = 977;
 };
 
 // ---------------------------------------------------------------- element type
@@ -192,8 +199,82 @@ PORLA_HD Fe<M> fe_mul_generic(const Fe<M>& a, const Fe<M>& b) {
 #include "fe_mul_gfx950.inc"
 #endif
 
+// Product for p = 2^256 - 2^32 - FOLD on plain residues: t = a*b (16 limbs), then 2^256 = 2^32 + FOLD (mod p) twice.
+template <class M>
+PORLA_HD Fe<M> fe_mul_pseudo_mersenne(const Fe<M>& a, const Fe<M>& b) {
+    uint32_t t[16];
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PORLA_NO_ASM_MUL)
+    fe_product_gfx950(a.v, b.v, t);
+#else
+    {
+        uint64_t acc = 0;
+        uint32_t acc2 = 0;
+#pragma unroll
+        for (int k = 0; k < 15; k++) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int j = k - i;
+                if (j >= 0 && j < 8) mac96(acc, acc2, a.v[i], b.v[j]);
+            }
+            t[k] = (uint32_t)acc;
+            acc = (acc >> 32) | ((uint64_t)acc2 << 32);
+            acc2 = 0;
+        }
+        t[15] = (uint32_t)acc;
+    }
+#endif
+    // s = L + H * FOLD + (H << 32),  H = t[8..15], L = t[0..7]:  10 limbs
+    uint32_t s[10];
+    uint64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t x = (uint64_t)t[8 + i] * M::FOLD + t[i] + carry;      // < 2^42 + 2^32 + 2^33
+        if (i > 0) x += t[8 + i - 1];                                     // the (H << 32) term
+        s[i] = (uint32_t)x;
+        carry = x >> 32;
+    }
+    {
+        uint64_t x = (uint64_t)t[15] + carry;
+        s[8] = (uint32_t)x;
+        s[9] = (uint32_t)(x >> 32);
+    }
+    // second fold: hi = s[8] + s[9] * 2^32 (< 2^34); r = s[0..7] + hi * FOLD + (hi << 32)
+    const uint64_t hi = ((uint64_t)s[9] << 32) | s[8];
+    const uint64_t hf = hi * M::FOLD;                                     // < 2^44
+    uint32_t r[8];
+    uint64_t x = (uint64_t)s[0] + (uint32_t)hf;
+    r[0] = (uint32_t)x;
+    x = (x >> 32) + s[1] + (uint32_t)(hf >> 32) + (uint32_t)hi;
+    r[1] = (uint32_t)x;
+    x = (x >> 32) + s[2] + (uint32_t)(hi >> 32);
+    r[2] = (uint32_t)x;
+#pragma unroll
+    for (int i = 3; i < 8; i++) {
+        x = (x >> 32) + s[i];
+        r[i] = (uint32_t)x;
+    }
+    // a carry out of 2^256 is worth 2^32 + FOLD once more; the low limbs are then tiny, so this cannot carry again
+    const uint32_t over = (uint32_t)(x >> 32);
+    x = (uint64_t)r[0] + (over ? M::FOLD : 0u);
+    r[0] = (uint32_t)x;
+    x = (x >> 32) + r[1] + over;
+    r[1] = (uint32_t)x;
+#pragma unroll
+    for (int i = 2; i < 8; i++) {
+        x = (x >> 32) + r[i];
+        r[i] = (uint32_t)x;
+    }
+    uint32_t d[8];
+    uint32_t br = sub_p<M>(d, r);
+    Fe<M> out;
+#pragma unroll
+    for (int i = 0; i < 8; i++) out.v[i] = br ? r[i] : d[i];
+    return out;
+}
+
 template <class M>
 PORLA_HD Fe<M> fe_mul(const Fe<M>& a, const Fe<M>& b) {
+    if (M::PSEUDO_MERSENNE) return fe_mul_pseudo_mersenne<M>(a, b);
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(PORLA_NO_ASM_MUL)
     return fe_mul_gfx950<M>(a, b);
 #else

@@ -19,6 +19,8 @@ struct Bn254Fr {  // scalar field of BN254 (group order r), for KZG polynomial a
     static constexpr uint32_t R2[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u,
                                        0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
     static constexpr int SPARE_BITS = 2;
+    static constexpr bool PSEUDO_MERSENNE = false;
+    static constexpr uint32_t FOLD = 0;
 };
 
 // 32 big-endian bytes -> plain limbs (not reduced)

@@ -67,8 +67,33 @@ struct Fp64 {
         for (int i = 0; i < 4; i++) { c += (u128)t[i] + (p[i] & mask); r.v[i] = (uint64_t)c; c >>= 64; }
         return r;
     }
+    // special-form product for p = 2^256 - 2^32 - FOLD on plain residues (fe_mul_pseudo_mersenne in fe.cuh)
+    E mul_pseudo_mersenne(const E& a, const E& b) const {
+        const uint64_t c = ((uint64_t)1 << 32) + M::FOLD;
+        uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 4; i++) {
+            u128 carry = 0;
+            for (int j = 0; j < 4; j++) { carry += (u128)a.v[i] * b.v[j] + t[i + j]; t[i + j] = (uint64_t)carry; carry >>= 64; }
+            t[i + 4] = (uint64_t)carry;
+        }
+        uint64_t s[5];
+        u128 carry = 0;
+        for (int i = 0; i < 4; i++) { carry += (u128)t[4 + i] * c + t[i]; s[i] = (uint64_t)carry; carry >>= 64; }
+        s[4] = (uint64_t)carry;                               // < 2^34
+        u128 x = (u128)s[4] * c + s[0];
+        uint64_t r[4];
+        r[0] = (uint64_t)x; x >>= 64;
+        for (int i = 1; i < 4; i++) { x += s[i]; r[i] = (uint64_t)x; x >>= 64; }
+        if ((uint64_t)x) {                                    // 2^256 = c (mod p) once more; cannot carry again
+            u128 y = (u128)r[0] + c;
+            r[0] = (uint64_t)y; y >>= 64;
+            for (int i = 1; i < 4; i++) { y += r[i]; r[i] = (uint64_t)y; y >>= 64; }
+        }
+        return cond_sub(r, 0);
+    }
     // CIOS Montgomery product
     E mul(const E& a, const E& b) const {
+        if (M::PSEUDO_MERSENNE) return mul_pseudo_mersenne(a, b);
         uint64_t t[6] = {0, 0, 0, 0, 0, 0};
         for (int i = 0; i < 4; i++) {
             u128 c = 0;

@@ -26,6 +26,8 @@ struct IccFp {  // p_icc = 207 * 2^248 + 1 (utils.h:31-32)
     static constexpr uint32_t R2[8] = {0xe1150631u, 0xfb0d9a96u, 0x845418bbu, 0xec366a5bu,
                                        0x115062efu, 0xb0d9a96eu, 0x45418bbfu, 0x6266a5b8u};
     static constexpr int SPARE_BITS = 0;
+    static constexpr bool PSEUDO_MERSENNE = false;
+    static constexpr uint32_t FOLD = 0;
 };
 struct IccBn254Fr {  // q = BN254 group order (utils.h:36), with the CRT constant p_icc^-1 mod q
     static constexpr uint32_t P[8]  = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u,
@@ -40,6 +42,8 @@ struct IccBn254Fr {  // q = BN254 group order (utils.h:36), with the CRT constan
                                          0xdaf96adbu, 0xe53d9858u, 0x7d59bd98u, 0x2d305e1eu};  // p_icc^-1 mod q (plain)
     static constexpr int MAX_Q_IN = 5;   // floor((2^256-1)/q): subtractions to reduce a raw 256-bit chunk
     static constexpr int MAX_Q_P  = 4;   // floor((p_icc-1)/q)
+    static constexpr bool PSEUDO_MERSENNE = false;
+    static constexpr uint32_t FOLD = 0;
 };
 struct IccSecp256k1Fn {  // q = secp256k1 group order (utils.h:27)
     static constexpr uint32_t P[8]  = {0xd0364141u, 0xbfd25e8cu, 0xaf48a03bu, 0xbaaedce6u,
@@ -53,6 +57,8 @@ struct IccSecp256k1Fn {  // q = secp256k1 group order (utils.h:27)
                                          0x74f03b2fu, 0x43030579u, 0xeb08b927u, 0x8d224d74u};
     static constexpr int MAX_Q_IN = 1;
     static constexpr int MAX_Q_P  = 0;
+    static constexpr bool PSEUDO_MERSENNE = false;
+    static constexpr uint32_t FOLD = 0;
 };
 // GENERATOR (utils.h:29-30), plain little-endian limbs
 struct IccGen {

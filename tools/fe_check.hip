@@ -1,5 +1,6 @@
-// Device-vs-host check of the gfx950 assembly Montgomery product (fe_mul_gfx950.inc) against the portable C++ form
-// (fe_mul_generic) for every field of the engine, on random, unreduced and all-ones-limb operands.
+// Device-vs-host check of the gfx950 assembly field products (fe_mul_gfx950.inc) against portable references -- the C++
+// Montgomery product fe_mul_generic, and for the special-form secp256k1 field a schoolbook product with binary long
+// division -- for every field of the engine, on random, unreduced and all-ones-limb operands.
 // Built by porla_amd/csrc/Makefile as porla_amd/fe_check; run by tests/test_fe_gpu.py on the GPU box.
 #include "host_curve.hpp"
 #include "icc.cuh"
@@ -7,6 +8,35 @@
 #include <random>
 #include <vector>
 using namespace porla;
+
+// independent reference for the special-form field (plain residues): schoolbook product, then binary long division by p
+template <class M>
+Fe<M> ref_mulmod(const Fe<M>& a, const Fe<M>& b) {
+    uint32_t t[16] = {0};
+    for (int i = 0; i < 8; i++) {
+        uint64_t c = 0;
+        for (int j = 0; j < 8; j++) { c += (uint64_t)a.v[i] * b.v[j] + t[i + j]; t[i + j] = (uint32_t)c; c >>= 32; }
+        t[i + 8] = (uint32_t)c;
+    }
+    uint32_t r[9] = {0};   // remainder, < 2p < 2^257
+    for (int bit = 511; bit >= 0; bit--) {
+        for (int k = 8; k > 0; k--) r[k] = (r[k] << 1) | (r[k - 1] >> 31);
+        r[0] = (r[0] << 1) | ((t[bit >> 5] >> (bit & 31)) & 1u);
+        uint32_t d[9];
+        uint64_t br = 0;
+        for (int k = 0; k < 9; k++) {
+            uint64_t x = (uint64_t)r[k] - (k < 8 ? M::P[k] : 0u) - br;
+            d[k] = (uint32_t)x;
+            br = (x >> 63) & 1;
+        }
+        if (!br) for (int k = 0; k < 9; k++) r[k] = d[k];
+    }
+    Fe<M> o;
+    for (int k = 0; k < 8; k++) o.v[k] = r[k];
+    return o;
+}
+template <class M>
+Fe<M> ref_mul(const Fe<M>& a, const Fe<M>& b) { return M::PSEUDO_MERSENNE ? ref_mulmod<M>(a, b) : fe_mul_generic<M>(a, b); }
 
 template <class M>
 __global__ void k_mul(const Fe<M>* a, const Fe<M>* b, Fe<M>* out, int n) {
@@ -30,7 +60,7 @@ int check(const char* name) {
         if (mode == 6) for (int k = 0; k < 8; k++) b[i].v[k] = M::R2[k];                            // x * R2 with x reduced
         if (mode == 0) for (int k = 0; k < 8; k++) b[i].v[k] = M::R2[k];                            // x * R2 with x unreduced
         if (mode == 2 || mode == 3) fe_reduce_plain<M>(b[i].v, 8);                                   // one operand < p
-        want[i] = fe_mul_generic<M>(a[i], b[i]);
+        want[i] = ref_mul<M>(a[i], b[i]);
     }
     Fe<M>*da, *db, *dout;
     hipMalloc(&da, n * sizeof(Fe<M>)); hipMalloc(&db, n * sizeof(Fe<M>)); hipMalloc(&dout, n * sizeof(Fe<M>));
@@ -39,7 +69,14 @@ int check(const char* name) {
     hipLaunchKernelGGL((k_mul<M>), dim3(n / 256), dim3(256), 0, 0, da, db, dout, n);
     hipMemcpy(got.data(), dout, n * sizeof(Fe<M>), hipMemcpyDeviceToHost);
     int bad = 0, bad_mode[8] = {0};
-    for (int i = 0; i < n; i++) if (!fe_eq<M>(got[i], want[i])) { bad++; bad_mode[i & 7]++; }
+    for (int i = 0; i < n; i++) if (!fe_eq<M>(got[i], want[i])) {
+        if (!bad) {
+            auto pr = [](const char* t, const Fe<M>& f) { printf("  %s ", t); for (int k = 7; k >= 0; k--) printf("%08x", f.v[k]); printf("\n"); };
+            printf("  first mismatch (operand mode %d):\n", i & 7);
+            pr("a   ", a[i]); pr("b   ", b[i]); pr("want", want[i]); pr("got ", got[i]);
+        }
+        bad++; bad_mode[i & 7]++;
+    }
     printf("%-16s %d mismatches of %d  (by operand mode:", name, bad, n);
     for (int m = 0; m < 8; m++) printf(" %d", bad_mode[m]);
     printf(")\n");
@@ -78,9 +115,9 @@ int check_const(const char* name) {
         fe_reduce_plain<M>(b[i].v, 8);
         Fe<M> x;
         for (int k = 0; k < 8; k++) x.v[k] = k < 3 ? a[i].v[k] : 0;
-        w1[i] = fe_mul_generic<M>(x, b[i]);
+        w1[i] = ref_mul<M>(x, b[i]);
         Fe<M> one = fe_zero<M>(); one.v[0] = 1;
-        w2[i] = fe_mul_generic<M>(fe_mul_generic<M>(a[i], r2), one);
+        w2[i] = ref_mul<M>(ref_mul<M>(a[i], r2), one);
     }
     Fe<M>*da, *db, *dout;
     hipMalloc(&da, n * sizeof(Fe<M>)); hipMalloc(&db, n * sizeof(Fe<M>)); hipMalloc(&dout, n * sizeof(Fe<M>));
