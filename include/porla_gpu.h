@@ -82,9 +82,9 @@ int porla_secp256k1_jac_sum(const uint8_t *jacobians, size_t count, uint8_t out_
 /* ---- batched fixed-base commitments ----
  * out[r] = sum_{i < n_coeffs} (row_r[i] mod order) * base[i] for every row r, as 64-byte X||Y big-endian affine points.
  * rows: coefficient i of row r at rows + r*row_stride + 32*i, 32 bytes big-endian (bn254_scalar, utils.h:307-318).
- * The base is expanded once into a table of window multiples resident in HBM (window_bits c, 0 = automatic:
- * 16, i.e. 4.3 GB for 128 BN254 points; shrunk until it fits a quarter of the free HBM); a commitment is then
- * n_coeffs * ceil((bits+1)/c) mixed additions.  curve: 0 = BN254 G1, 1 = secp256k1. */
+ * The base is expanded once into a table of window multiples resident in HBM (window_bits c, 0 = automatic: the
+ * widest c <= 20 whose table fits min(a quarter of the free HBM, PORLA_COMMIT_TABLE_GB = 20 GB): 18 bits = 16 GB for
+ * 128 BN254 points); a commitment is then n_coeffs * ceil((bits+1)/c) mixed additions.  curve: 0 = BN254 G1, 1 = secp256k1. */
 typedef struct porla_fixed_base porla_fixed_base;
 int  porla_fixed_base_create(int curve, const uint8_t *points, size_t n_points, int window_bits, porla_fixed_base **out);
 int  porla_fixed_base_info(const porla_fixed_base *fb, int *window_bits, int *windows, unsigned long long *table_bytes);

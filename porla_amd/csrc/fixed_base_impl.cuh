@@ -20,17 +20,20 @@ void FixedBase<C>::release() {
     n_points = 0;
 }
 
-// Builds the multiples table for `n` base points (Montgomery affine, device memory).  window_bits = 0 -> automatic:
-// the largest c <= 16 whose table fits the memory budget (PORLA_COMMIT_WINDOW overrides).
+// Builds the multiples table for `n` base points (Montgomery affine, device memory).
 template <class C>
 int FixedBase<C>::build(const Affine<typename C::Fp>* d_base, size_t n, int window_bits, hipStream_t stream) {
     using M = typename C::Fp;
     n_points = 0;
     if (n == 0) return PORLA_OK;
+    // window_bits = 0 -> automatic: the widest window (<= 20 bits) whose table fits min(a quarter of the free HBM,
+    // PORLA_COMMIT_TABLE_GB, default 20 GB) -- 18 bits = 16 GB for the 128-point BN254 SRS.  Wider is faster (fewer
+    // additions per row: 20 bits = 56 GB gives +15 % over 18 bits) and HBM is 288 GB, but the table build grows with it.
     int cc = window_bits;
-    if (cc <= 0) {
+    const bool automatic = cc <= 0;
+    if (automatic) {
         const char* e = getenv("PORLA_COMMIT_WINDOW");
-        cc = e ? atoi(e) : 16;
+        cc = e ? atoi(e) : 20;
     }
     if (cc < 2) cc = 2;
     if (cc > 20) cc = 20;
@@ -38,10 +41,16 @@ int FixedBase<C>::build(const Affine<typename C::Fp>* d_base, size_t n, int wind
     size_t free_b = 0, total_b = 0;
     PORLA_HIP(hipMemGetInfo(&free_b, &total_b));
     free_b += table_cap;
-    for (;; cc--) {  // shrink the window until the table (plus its construction scratch) fits in a quarter of free HBM
+    size_t budget = free_b / 4;
+    if (automatic && !getenv("PORLA_COMMIT_WINDOW")) {
+        const char* g = getenv("PORLA_COMMIT_TABLE_GB");
+        const size_t cap = (size_t)((g ? atof(g) : 20.0) * 1e9);
+        if (cap < budget) budget = cap;
+    }
+    for (;; cc--) {  // shrink the window until the table fits the budget
         int Wc = (C::SCALAR_BITS + 1 + cc - 1) / cc;
         size_t bytes = n * (size_t)Wc * ((size_t)1 << (cc - 1)) * sizeof(Affine<M>);
-        if (bytes <= free_b / 4 || cc <= 4) break;
+        if (bytes <= budget || cc <= 4) break;
     }
     c = cc;
     W = (C::SCALAR_BITS + 1 + c - 1) / c;
