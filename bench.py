@@ -9,7 +9,11 @@ scheme, single 2^20-point BN254 G1 MSM on 1 MI355X"), inputs resident in HBM in 
 big-endian scalars + 64-B X||Y points, porla/main.go:118-138) when the timed region starts.  With N > 1 every rank owns
 its own 2^20 pairs (input-range sharding, weak scaling), produces one partial Jacobian sum, the 96-byte partials are
 exchanged with one RCCL all_gather and folded with N-1 group additions: the whole job is one N*2^20-pair
-MSM per step.  The same JSON line carries `kzg_commits`: the second half of BASELINE.json's metric ("KZG commits/s"),
+MSM per step.  Steps are independent MSMs; `--in-flight 2` (default) keeps two of them in flight on two streams through the
+two-phase API (porla_bn254_msm_device_begin/_end) -- the audit issues its MSMs in pairs (Server.hpp:900-901) -- so the
+latency-bound tail of one MSM (bucket reduction, host fold) overlaps the bucket accumulation of the next; every step is
+still one complete MSM whose result is produced and checked, and K steps = K results inside the timed region
+(`--in-flight 1` = blocking calls).  The same JSON line carries `kzg_commits`: the second half of BASELINE.json's metric ("KZG commits/s"),
 2^17 rows x 128 coefficients per GPU against the resident SRS (compute_digest_from_srs hoisted over rows), timed
 separately after the MSM region.
 
@@ -76,6 +80,8 @@ def main():
     ap.add_argument("--log2rows", type=int, default=17, help="kzg_commit rows per GPU = 2^log2rows; icc rows = 2^(log2rows-2)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / bit-exact check leg")
     ap.add_argument("--no-commits", action="store_true", help="bn254_msm: skip the kzg_commits leg")
+    ap.add_argument("--in-flight", type=int, default=2, help="bn254_msm: independent MSMs in flight (1 = blocking calls; 2 = the "
+                    "audit's pair of MSMs, Server.hpp:900-901, overlapped on two streams)")
     args = ap.parse_args()
 
     import torch
@@ -108,16 +114,21 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed(step):
-        """W warmup + K timed steps, barrier + synchronize on both sides, MAX over ranks; returns (seconds, kernel ms, last result)"""
+    def timed(step, drain=None):
+        """W warmup + K timed steps, barrier + synchronize on both sides, MAX over ranks; returns (seconds, kernel ms, last
+        result).  `drain` (pipelined steps) retires whatever is still in flight: the timed region contains K complete steps."""
         res = None
         for _ in range(args.warmup):
             res = step()
+        if drain:
+            res = drain() or res
         sync()
         mx.profile_enable(True)
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            res = step()
+            res = step() or res
+        if drain:
+            res = drain() or res
         sync()
         el = time.perf_counter() - t0
         prof = mx.profile_get()
@@ -203,12 +214,39 @@ def main():
         gen_s = time.time() - t0
         d_sc, d_pt = to_dev(sc), to_dev(pt)
 
-        def step():
-            # N == 1: one MSM -> 64-byte affine.  N > 1: per-rank partial Jacobian, ONE RCCL all_gather of N x 96 bytes,
-            # N-1 group additions + one inversion on the host (porla_amd/sharded.py)
-            return sharded.sharded_msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n, stream, dev)
+        depth = max(1, min(3, args.in_flight))
+        streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+        state = {"k": 0, "inflight": []}
 
-        el, kern, result = timed(step)
+        def retire():
+            # N == 1: 64-byte affine.  N > 1: this rank's partial Jacobian, ONE RCCL all_gather of N x 96 bytes, N-1 group
+            # additions + one inversion on the host (porla_amd/sharded.py)
+            slot = state["inflight"].pop(0)
+            part = mx.msm_end(slot, partial=world > 1)
+            return part if world == 1 else sharded.fold_partials("bn254", sharded.gather_partials(part, dev))
+
+        def step():
+            # every step is one complete 2^20-pair MSM (all kernels + host fold + result); with in_flight > 1 the next
+            # MSM is enqueued on another stream before the oldest one is retired, so the latency-bound tail of one
+            # (bucket reduction, host fold) overlaps the bucket accumulation of the next
+            res = None
+            if depth == 1:
+                return sharded.sharded_msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n, stream, dev)
+            if len(state["inflight"]) == depth:
+                res = retire()
+            slot = 1 + state["k"] % depth
+            mx.msm_begin(slot, d_sc.data_ptr(), d_pt.data_ptr(), n, streams[state["k"] % depth].cuda_stream)
+            state["inflight"].append(slot)
+            state["k"] += 1
+            return res
+
+        def drain():
+            res = None
+            while state["inflight"]:
+                res = retire()
+            return res
+
+        el, kern, result = timed(step, drain)
         commits = None if args.no_commits else kzg_commit_leg(1 << args.log2rows)
         if rank == 0:
             cpu = None
@@ -230,7 +268,7 @@ def main():
                 "vs_baseline": None, "dtype": "u32x8 (256-bit modular integer)", "data": "synthetic",
                 "config": {"workload": "KZG scheme, single 2^%d-point BN254 G1 MSM per GPU, inputs resident in HBM, "
                                        "output 64-B affine point" % args.log2n,
-                           "pairs_per_gpu": n,
+                           "pairs_per_gpu": n, "msm_in_flight": depth,
                            "sharding": "input-pair range per rank + RCCL all_gather of 96-B Jacobian partials"
                            if world > 1 else "single GPU", "input_gen_s": round(gen_s, 1)},
                 "roofline": roofline(kern, MSM_BYTES_PER_PAIR * n, "bn254_msm"), "cpu_baseline": cpu,
@@ -290,7 +328,7 @@ def main():
                    "vs_baseline": None, "dtype": "u32x8 (256-bit modular integer)", "data": "synthetic",
                    "config": {"workload": "IPA scheme, 2^%d-point secp256k1 ecmult_multi per GPU (points 2^i*G, scalars "
                                           "SHA-256(\"ecmult\"||i) as bench_ecmult.c), inputs resident in HBM" % args.log2n,
-                              "pairs_per_gpu": n, "input_gen_s": round(gen_s, 1)},
+                              "pairs_per_gpu": n, "msm_in_flight": depth, "input_gen_s": round(gen_s, 1)},
                    "roofline": roofline(kern, MSM_BYTES_PER_PAIR * n, "secp256k1_msm"), "cpu_baseline": cpu,
                    "bit_exact_vs_oracle": verified, "result": result.hex() if result else None}
     else:  # icc

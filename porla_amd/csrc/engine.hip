@@ -51,13 +51,20 @@ static int prof_slot(const char* name) {
     g_prof.push_back(ProfSlot{name, 0, 0});
     return (int)g_prof.size() - 1;
 }
+static std::vector<hipEvent_t> g_event_pool;   // events are recycled: creating two per kernel launch costs more than the launch
+static hipEvent_t take_event() {
+    if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
 ProfScope::ProfScope(const char* name, hipStream_t s) : slot(-1), stream(s), e0(nullptr), e1(nullptr), on(false) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!g_prof_on) return;
     on = true;
     slot = prof_slot(name);
-    (void)hipEventCreate(&e0);
-    (void)hipEventCreate(&e1);
+    e0 = take_event();
+    e1 = take_event();
     (void)hipEventRecord(e0, stream);
 }
 ProfScope::~ProfScope() {
@@ -75,8 +82,8 @@ void prof_flush() {
             g_prof[p.slot].ms += ms;
             g_prof[p.slot].launches += 1;
         }
-        (void)hipEventDestroy(p.e0);
-        (void)hipEventDestroy(p.e1);
+        g_event_pool.push_back(p.e0);
+        g_event_pool.push_back(p.e1);
     }
     g_pending.clear();
 }
@@ -87,17 +94,20 @@ static std::vector<Workspace*> g_ws;
 int g_window_override = 0;
 int g_use_glv = getenv("PORLA_MSM_GLV") ? (getenv("PORLA_MSM_GLV")[0] == '1' ? 1 : 0) : -1;  // -1: per-curve default
 
-int get_workspace(Workspace** out) {
+int get_workspace_slot(int slot, Workspace** out) {
+    if (slot < 0 || slot >= MSM_SLOTS) { set_last_error("porla: MSM slot out of range"); return PORLA_ERR_ARG; }
     int dev = 0;
     PORLA_HIP(hipGetDevice(&dev));
-    for (auto* w : g_ws) if (w->device == dev) { *out = w; return PORLA_OK; }
+    for (auto* w : g_ws) if (w->device == dev && w->slot == slot) { *out = w; return PORLA_OK; }
     Workspace* w = new Workspace();
     w->device = dev;
+    w->slot = slot;
     PORLA_HIP(hipStreamCreateWithFlags(&w->own_stream, hipStreamNonBlocking));
     g_ws.push_back(w);
     *out = w;
     return PORLA_OK;
 }
+int get_workspace(Workspace** out) { return get_workspace_slot(0, out); }
 
 // ------------------------------------------------------------------------------------------------ C ABI helpers
 template <class C>
@@ -219,6 +229,20 @@ int porla_bn254_msm_host(const uint8_t* scalars, const uint8_t* points, size_t n
 }
 int porla_bn254_jac_sum(const uint8_t* jacs, size_t count, uint8_t out_affine[64]) {
     return abi_jac_sum<Bn254G1>(jacs, count, out_affine);
+}
+
+int porla_bn254_msm_device_begin(int slot, const void* d_scalars, const void* d_points, size_t n, void* s) {
+    if (n && (!d_scalars || !d_points)) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    return msm_device_begin<Bn254G1>(slot, (const uint8_t*)d_scalars, (const uint8_t*)d_points, n, (hipStream_t)s);
+}
+int porla_bn254_msm_device_end(int slot, uint8_t* out, int jacobian) {
+    if (!out) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    XYZZ<Bn254Fp> tot;
+    int rc = msm_device_end<Bn254G1>(slot, &tot);
+    if (rc) return rc;
+    if (jacobian) h_xyzz_to_jac_bytes<Bn254Fp>(out, tot);
+    else h_affine_to_bytes<Bn254Fp>(out, h_xyzz_to_affine<Bn254Fp>(tot));
+    return PORLA_OK;
 }
 
 int porla_secp256k1_msm_device(const void* d_scalars, const void* d_points, size_t n, uint8_t out_affine[64], void* s) {

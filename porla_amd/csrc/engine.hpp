@@ -37,6 +37,12 @@ template <class C>
 int msm_device(const uint8_t* d_scalars, const uint8_t* d_points, size_t n, hipStream_t stream,
                XYZZ<typename C::Fp>* total);
 
+// two-phase form (see msm_impl.cuh)
+template <class C>
+int msm_device_begin(int slot, const uint8_t* d_scalars, const uint8_t* d_points, size_t n, hipStream_t stream);
+template <class C>
+int msm_device_end(int slot, XYZZ<typename C::Fp>* total);
+
 // host buffers -> device -> msm
 template <class C>
 int msm_host(const uint8_t* scalars, const uint8_t* points, size_t n, XYZZ<typename C::Fp>* total);
@@ -64,7 +70,11 @@ struct Workspace {
     void* h_windows = nullptr;  // pinned
     size_t h_windows_cap = 0;
     hipStream_t own_stream = nullptr;
+    int slot = 0;
+    hipEvent_t done = nullptr;  // recorded after the last kernel + D2H copy of a launched MSM
+    int pend_W = 0, pend_c = 0; // window count / width of the launched, not yet folded MSM (0 = none)
 };
+constexpr int MSM_SLOTS = 4;
 // Batched fixed-base commitments (fixed_base.cuh): resident table of window multiples of one base.
 // Calls on one object are serialised by `mu`; the *_device form leaves its kernels in flight on the caller's stream
 // (one stream per object at a time: the slice-partial scratch is shared between calls).
@@ -99,7 +109,8 @@ struct FixedBase {
 extern std::mutex g_ws_mu;
 extern int g_window_override;
 extern int g_use_glv;  // 1: GLV split of every scalar; 0: plain signed windows over the full scalar; -1: the curve's default
-int get_workspace(Workspace** out);
+int get_workspace(Workspace** out);                 // slot 0 of the current device
+int get_workspace_slot(int slot, Workspace** out);  // g_ws_mu held by the caller
 hipStream_t engine_stream();  // this device's engine-owned non-blocking stream
 
 // icc.hip: the ICC butterfly network as an n x n matrix of 32-byte big-endian coefficients mod the group order

@@ -31,10 +31,10 @@ static inline int choose_window(size_t m, int bits) {
 }
 
 template <class C>
-static int msm_core(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_points_be, size_t n, hipStream_t stream,
-                    XYZZ<typename C::Fp>* total) {
+static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_points_be, size_t n, hipStream_t stream) {
     using M = typename C::Fp;
-    if (n == 0) { *total = xyzz_inf<M>(); return PORLA_OK; }
+    ws->pend_W = 0;
+    if (n == 0) return PORLA_OK;
     if (n >= (1ull << 30)) { set_last_error("porla: MSM length must be < 2^30"); return PORLA_ERR_ARG; }
     const bool glv = g_use_glv < 0 ? C::GLV_DEFAULT : g_use_glv != 0;
     const int bits = glv ? C::Glv::BITS : C::SCALAR_BITS;
@@ -142,9 +142,30 @@ static int msm_core(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_po
     }
     PORLA_HIP(hipGetLastError());
     PORLA_HIP(hipMemcpyAsync(ws->h_windows, ws->windows.p, (size_t)W * sizeof(XYZZ<M>), hipMemcpyDeviceToHost, stream));
-    PORLA_HIP(hipStreamSynchronize(stream));
-    *total = h_fold_windows64<M>((const XYZZ<M>*)ws->h_windows, W, c);
+    if (!ws->done) PORLA_HIP(hipEventCreateWithFlags(&ws->done, hipEventDisableTiming));
+    PORLA_HIP(hipEventRecord(ws->done, stream));
+    ws->pend_W = W;
+    ws->pend_c = c;
     return PORLA_OK;
+}
+
+// waits for the launched MSM of this workspace and folds its window sums on the host
+template <class C>
+static int msm_finish(Workspace* ws, XYZZ<typename C::Fp>* total) {
+    using M = typename C::Fp;
+    if (ws->pend_W == 0) { *total = xyzz_inf<M>(); return PORLA_OK; }
+    PORLA_HIP(hipEventSynchronize(ws->done));
+    *total = h_fold_windows64<M>((const XYZZ<M>*)ws->h_windows, ws->pend_W, ws->pend_c);
+    ws->pend_W = 0;
+    return PORLA_OK;
+}
+
+template <class C>
+static int msm_core(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_points_be, size_t n, hipStream_t stream,
+                    XYZZ<typename C::Fp>* total) {
+    int rc = msm_launch<C>(ws, d_scalars, d_points_be, n, stream);
+    if (rc) return rc;
+    return msm_finish<C>(ws, total);
 }
 
 template <class C>
@@ -157,6 +178,29 @@ int msm_device(const uint8_t* d_scalars, const uint8_t* d_points, size_t n, hipS
     if ((rc = get_workspace(&ws))) return rc;
     return msm_core<C>(ws, d_scalars, d_points, n, stream, total);
 }
+// Two-phase form: several MSMs in flight on different streams, each in its own workspace slot (1 .. MSM_SLOTS-1; slot 0
+// belongs to the blocking calls).  begin enqueues all kernels and returns; end waits for that slot and folds on the host.
+template <class C>
+int msm_device_begin(int slot, const uint8_t* d_scalars, const uint8_t* d_points, size_t n, hipStream_t stream) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    Workspace* ws;
+    if ((rc = get_workspace_slot(slot, &ws))) return rc;
+    if (ws->pend_W) { set_last_error("porla: MSM slot still has a pending result (call the matching _end first)"); return PORLA_ERR_STATE; }
+    return msm_launch<C>(ws, d_scalars, d_points, n, stream);
+}
+template <class C>
+int msm_device_end(int slot, XYZZ<typename C::Fp>* total) {
+    Workspace* ws;
+    {
+        std::lock_guard<std::mutex> lk(g_ws_mu);
+        int rc = get_workspace_slot(slot, &ws);
+        if (rc) return rc;
+    }
+    return msm_finish<C>(ws, total);
+}
+
 template <class C>
 int msm_host(const uint8_t* scalars, const uint8_t* points, size_t n, XYZZ<typename C::Fp>* total) {
     int rc = ensure_device();

@@ -149,6 +149,17 @@ def msm_device(curve, d_scalars, d_points, n, stream=0, partial=False):
     return out.raw
 
 
+def msm_begin(slot, d_scalars, d_points, n, stream=0):
+    """two-phase BN254 MSM: enqueue on `stream` into workspace slot 1..3 (include/porla_gpu.h)"""
+    _check(lib.porla_bn254_msm_device_begin(slot, ctypes.c_void_p(d_scalars), ctypes.c_void_p(d_points), n, ctypes.c_void_p(stream)))
+
+
+def msm_end(slot, partial=False):
+    out = ctypes.create_string_buffer(96 if partial else 64)
+    _check(lib.porla_bn254_msm_device_end(slot, out, 1 if partial else 0))
+    return out.raw
+
+
 def msm_host(curve, scalars, points, n):
     out = ctypes.create_string_buffer(64)
     _check(getattr(lib, "porla_%s_msm_host" % curve)(bytes(scalars), bytes(points), n, out))

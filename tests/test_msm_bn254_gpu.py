@@ -221,3 +221,30 @@ def test_scale_2_22_pairs_and_range_partition_invariance(mx):
         parts += mx.msm_device("bn254", d_sc.data_ptr() + 32 * lo, d_pt.data_ptr() + 64 * lo, n // 4, stream, partial=True)
     assert mx.jac_sum("bn254", parts, 4) == got
     assert got == common.oracle_msm(bytes(d_sc.cpu().numpy()), pt, n)
+
+
+def test_two_phase_api_keeps_independent_msms_in_flight(mx, inputs):
+    """porla_bn254_msm_device_begin/_end: three MSMs in flight on three streams, retired in order; a slot cannot be begun
+    twice; results (affine and Jacobian-partial forms) equal the blocking call"""
+    import torch
+    from porla_amd import lib
+    sc, pt = inputs
+    n = 1 << 14
+    d_sc = torch.frombuffer(bytearray(sc), dtype=torch.uint8).cuda()
+    d_pt = torch.frombuffer(bytearray(pt), dtype=torch.uint8).cuda()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    sizes = [n, 3000, 129]
+    want = [common.oracle_msm(sc, pt, m) for m in sizes]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for k, m in enumerate(sizes):
+            mx.msm_begin(1 + k, d_sc.data_ptr(), d_pt.data_ptr(), m, streams[k].cuda_stream)
+        assert lib.porla_bn254_msm_device_begin(1, ctypes.c_void_p(d_sc.data_ptr()), ctypes.c_void_p(d_pt.data_ptr()), 10, None) != 0
+        for k in range(3):
+            if rep == 1:
+                part = mx.msm_end(1 + k, partial=True)
+                assert mx.jac_sum("bn254", part, 1) == want[k]
+            else:
+                assert mx.msm_end(1 + k) == want[k]
+    assert lib.porla_bn254_msm_device_begin(7, None, None, 0, None) != 0        # slot out of range
+    assert mx.msm_end(2) == bytes(64)                                              # nothing pending: the empty sum
