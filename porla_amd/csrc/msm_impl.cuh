@@ -10,10 +10,25 @@ namespace porla {
 
 static inline int ilog2(size_t n) { int l = 0; while (n >>= 1) l++; return l; }
 
-// Window width for m sub-scalars of `bits` bits: minimise  W*m (bucket additions) + 3*W*2^(c-1) (bucket reduction: the
-// weight is fitted to the 2^20 sweeps in profiles/ -- the reduction is latency-bound, so it grows slower than its work).  Widths are skipped when the average bucket (m / 2^(c-1) entries) would
-// not fit one work item, or when the top window (holding only `top` bits) would crowd all entries into a few buckets of
-// more than 64 work items each -- both still work (heavy buckets are split and combined) but cost time.
+// segment length of k_bucket_reduce: the shortest that still gives every lane of the chip (1024 SIMDs x 64) a segment
+static inline uint32_t reduce_segment(size_t total_buckets, uint32_t B) {
+    static const uint32_t Lenv = getenv("PORLA_REDUCE_L") ? (uint32_t)atoi(getenv("PORLA_REDUCE_L")) : 0;
+    uint32_t L = 1;
+    while (L < 8 && total_buckets / L > 65536) L *= 2;
+    if (Lenv) L = Lenv;
+    return B < L ? B : L;
+}
+
+// Window width for m sub-scalars of `bits` bits, from a time model in microseconds fitted to the sweeps in profiles/
+// (2^7 .. 2^20 pairs):
+//   digit extraction     ~6 us per window (the per-tile loop over windows)
+//   bucket accumulation  throughput W*m / 10.2 G additions/s, but never faster than the longest dependent chain at ~9.5 us
+//                        per entry for a lone wave: the average bucket plus 4 sigma, or -- the usual culprit -- a top window
+//                        that holds only `top` bits and crowds all m entries into 2^(top-1) buckets (work items cap a chain
+//                        at CHUNK entries)
+//   bucket reduction     ~(2L + 1.5(c-1) + 13) dependent group operations per lane at ~9.8 us (running sums over L buckets,
+//                        a (c-1)-bit scalar multiple, shuffle tree), growing mildly with the number of lanes until the
+//                        segments exceed one per lane of the chip, proportionally beyond
 static inline int choose_window(size_t m, int bits) {
     if (g_window_override >= 2 && g_window_override <= 20) return g_window_override;
     int best = 2;
@@ -21,10 +36,31 @@ static inline int choose_window(size_t m, int bits) {
     for (int c = 2; c <= 20; c++) {
         const int W = (bits + 1 + c - 1) / c;
         const int top = bits + 1 - c * (W - 1);                       // bits left for the top window, 1 .. c
-        const double load = (double)m / (double)((size_t)1 << (c - 1));
-        const double top_load = (double)m / (double)((size_t)1 << (top > 1 ? top - 1 : 0));
-        const bool crowded = (load > 0.75 * CHUNK || (W > 1 && top_load > 64.0 * CHUNK)) && c < 20;
-        const double cost = (double)W * (double)m + 3.0 * W * (double)((size_t)1 << (c - 1)) + (crowded ? 1e18 : 0.0);
+        const double B = (double)((size_t)1 << (c - 1));
+        const double load = (double)m / B;                             // average entries per bucket
+        const double top_load = W > 1 ? (double)m / (double)((size_t)1 << (top > 1 ? top - 1 : 0)) : 0.0;
+        // ---- bucket accumulation: waves of 64 work items, 4096 resident at once (4 per SIMD); a full round of chains of
+        // `load` entries costs load * 25.7 us (10.2 G additions/s), a partial last round runs closer to the lone-wave rate
+        const double items = (double)W * B * (load > 20.0 ? 1.0 : 1.0 - __builtin_exp(-load));
+        const double waves = items / 64.0;
+        const double full = (double)(size_t)(waves / 4096.0);
+        const double rest = waves - full * 4096.0;
+        double t_sum = full * load * 25.7 + (rest > 0.5 ? load * (6.7 + 19.0 * rest / 4096.0) : 0.0);
+        double chain = load + 4.0 * __builtin_sqrt(load) + 1.0;      // the longest dependent chain (lone wave: ~9.5 us / entry)
+        const double top_chain = top_load < (double)CHUNK ? top_load : (double)CHUNK;
+        if (top_chain > chain) chain = top_chain;
+        if (chain > (double)CHUNK) chain = (double)CHUNK;
+        if (t_sum < chain * 9.5) t_sum = chain * 9.5;
+        // ---- heavy buckets: split into work items, one wave folds each bucket's item sums
+        double t_combine = 0.0;
+        if (top_load > (double)CHUNK) t_combine = 70.0 + top_load / CHUNK / 64.0 * 9.8;
+        if (load > 0.6 * CHUNK) t_combine += 1e6;                      // every bucket would need the combine pass
+        // ---- bucket reduction + per-window fold
+        const uint32_t L = reduce_segment((size_t)(W * B), (uint32_t)B);
+        const double lanes = (double)W * B / L;
+        const double t_reduce = (2.0 * L + 1.5 * (c - 1) + 13.0) * 9.8 * (lanes > 65536.0 ? 1.15 * lanes / 65536.0 : 0.85 + 0.3 * lanes / 65536.0)
+                                + (lanes / W > 64.0 ? 65.0 : 7.0);
+        const double cost = 6.0 * W + t_sum + t_combine + t_reduce;
         if (cost < best_cost) { best_cost = cost; best = c; }
     }
     return best;
@@ -43,8 +79,7 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
     const int c = choose_window(n_sub, bits);
     const int W = (bits + 1 + c - 1) / c;
     const uint32_t B = 1u << (c - 1);
-    static const uint32_t Lenv = getenv("PORLA_REDUCE_L") ? (uint32_t)atoi(getenv("PORLA_REDUCE_L")) : 8;
-    const uint32_t L = B < Lenv ? B : Lenv;
+    const uint32_t L = reduce_segment((size_t)W * B, B);
     const uint32_t T = B / L;
     const uint32_t wavesPerWindow = (T + 63) / 64;
     const size_t nb = (size_t)W * B;
