@@ -260,6 +260,11 @@ def main():
                 cpu = {"value": round(n / cpu_s / 1e6, 4), "unit": "Mmul/s", "cores": cores, "kind": "port",
                        "sample": "the same 2^%d pairs, oracle/bn254_ref.c bucket MSM range-split over %d threads "
                                  "(CPU restatement, not gnark); %.1f s wall" % (args.log2n, cores, cpu_s)}
+            if not args.no_cpu and world > 1:
+                # whole-job check at N > 1 (no cpu_baseline is reported there): the N * 2^20-pair MSM over every rank's
+                # scalars (rank g: SHA-256 stream starting at g * 2^20) against the oracle
+                all_sc = sc + b"".join(common.synth_scalars(n, start=g * n) for g in range(1, world))
+                verified = common.oracle_msm(all_sc, pt * world, world * n, threads=common.ncpu()) == result
             failed = verified is False or (commits is not None and commits.get("bit_exact_vs_oracle") is False)
             out = {
                 "metric": "BN254 G1 MSM Mscalar-mul/s at 2^20 pts", "value": round(world * n * args.steps / el / 1e6, 3),
