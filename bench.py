@@ -90,14 +90,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # PORLA_DIST_BACKEND=gloo: exercise the multi-rank path on a box with fewer GPUs than ranks (ranks share devices, the
+    # 96-byte partials travel over gloo on the host); the driver's runs use nccl = RCCL over xGMI, one rank per GPU
+    backend = os.environ.get("PORLA_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")    # where collective payloads live
 
     from porla_amd import multiexp as mx
     from porla_amd import sharded
@@ -134,7 +142,7 @@ def main():
         prof = mx.profile_get()
         mx.profile_enable(False)
         if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            t = torch.tensor([el], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         timed.totals = {name: ms / args.steps for name, ms, cnt in prof}   # per step, all launches of the kernel
@@ -223,7 +231,7 @@ def main():
             # additions + one inversion on the host (porla_amd/sharded.py)
             slot = state["inflight"].pop(0)
             part = mx.msm_end(slot, partial=world > 1)
-            return part if world == 1 else sharded.fold_partials("bn254", sharded.gather_partials(part, dev))
+            return part if world == 1 else sharded.fold_partials("bn254", sharded.gather_partials(part, coll_dev))
 
         def step():
             # every step is one complete 2^20-pair MSM (all kernels + host fold + result); with in_flight > 1 the next
@@ -231,7 +239,7 @@ def main():
             # (bucket reduction, host fold) overlaps the bucket accumulation of the next
             res = None
             if depth == 1:
-                return sharded.sharded_msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n, stream, dev)
+                return sharded.sharded_msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n, stream, coll_dev)
             if len(state["inflight"]) == depth:
                 res = retire()
             slot = 1 + state["k"] % depth
@@ -310,7 +318,7 @@ def main():
         d_sc, d_pt = to_dev(sc), to_dev(pt)
 
         def step():
-            return sharded.sharded_msm_device("secp256k1", d_sc.data_ptr(), d_pt.data_ptr(), n, stream, dev)
+            return sharded.sharded_msm_device("secp256k1", d_sc.data_ptr(), d_pt.data_ptr(), n, stream, coll_dev)
 
         el, kern, result = timed(step)
         if rank == 0:
@@ -333,7 +341,7 @@ def main():
                    "vs_baseline": None, "dtype": "u32x8 (256-bit modular integer)", "data": "synthetic",
                    "config": {"workload": "IPA scheme, 2^%d-point secp256k1 ecmult_multi per GPU (points 2^i*G, scalars "
                                           "SHA-256(\"ecmult\"||i) as bench_ecmult.c), inputs resident in HBM" % args.log2n,
-                              "pairs_per_gpu": n, "msm_in_flight": depth, "input_gen_s": round(gen_s, 1)},
+                              "pairs_per_gpu": n, "input_gen_s": round(gen_s, 1)},
                    "roofline": roofline(kern, MSM_BYTES_PER_PAIR * n, "secp256k1_msm"), "cpu_baseline": cpu,
                    "bit_exact_vs_oracle": verified, "result": result.hex() if result else None}
     else:  # icc
