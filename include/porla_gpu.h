@@ -82,6 +82,8 @@ int porla_secp256k1_msm_device(const void *d_scalars, const void *d_points, size
                                void *hip_stream);
 int porla_secp256k1_msm_device_partial(const void *d_scalars, const void *d_points, size_t n,
                                        uint8_t out_jacobian[96], void *hip_stream);
+int porla_secp256k1_msm_device_begin(int slot, const void *d_scalars, const void *d_points, size_t n, void *hip_stream);
+int porla_secp256k1_msm_device_end(int slot, uint8_t *out, int jacobian);   /* the two MSMs of the IPA audit, Server.hpp:842-848 */
 int porla_secp256k1_msm_host(const uint8_t *scalars, const uint8_t *points, size_t n, uint8_t out_affine[64]);
 int porla_secp256k1_jac_sum(const uint8_t *jacobians, size_t count, uint8_t out_affine[64]);
 

@@ -245,6 +245,20 @@ int porla_bn254_msm_device_end(int slot, uint8_t* out, int jacobian) {
     return PORLA_OK;
 }
 
+int porla_secp256k1_msm_device_begin(int slot, const void* d_scalars, const void* d_points, size_t n, void* s) {
+    if (n && (!d_scalars || !d_points)) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    return msm_device_begin<Secp256k1G>(slot, (const uint8_t*)d_scalars, (const uint8_t*)d_points, n, (hipStream_t)s);
+}
+int porla_secp256k1_msm_device_end(int slot, uint8_t* out, int jacobian) {
+    if (!out) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    XYZZ<Secp256k1Fp> tot;
+    int rc = msm_device_end<Secp256k1G>(slot, &tot);
+    if (rc) return rc;
+    if (jacobian) h_xyzz_to_jac_bytes<Secp256k1Fp>(out, tot);
+    else h_affine_to_bytes<Secp256k1Fp>(out, h_xyzz_to_affine<Secp256k1Fp>(tot));
+    return PORLA_OK;
+}
+
 int porla_secp256k1_msm_device(const void* d_scalars, const void* d_points, size_t n, uint8_t out_affine[64], void* s) {
     return abi_msm_device<Secp256k1G>(d_scalars, d_points, n, out_affine, s, false);
 }

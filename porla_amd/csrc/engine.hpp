@@ -75,6 +75,7 @@ struct Workspace {
     int pend_W = 0, pend_c = 0; // window count / width of the launched, not yet folded MSM (0 = none)
 };
 constexpr int MSM_SLOTS = 4;
+constexpr size_t MSM_SCAN_MAX = 1u << 16;  // inputs up to this size are scanned for their longest scalar first
 // Batched fixed-base commitments (fixed_base.cuh): resident table of window multiples of one base.
 // Calls on one object are serialised by `mu`; the *_device form leaves its kernels in flight on the caller's stream
 // (one stream per object at a time: the slice-partial scratch is shared between calls).

@@ -148,6 +148,26 @@ __global__ void k_points_to_mont(const uint8_t* __restrict__ in, Affine<typename
     }
 }
 
+// OR of all scalars, limb by limb (big-endian 32-byte scalars): tells the host how many windows are really needed.  The
+// audit's coefficients are abs(int32) (bn254_scalar_set_int, utils.h:271-275; Server.hpp:617-621): 2 windows instead of 16.
+static __global__ void __launch_bounds__(256)
+k_scalar_or(const uint8_t* __restrict__ scalars, uint32_t n, uint32_t* __restrict__ out8) {
+    uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        uint32_t t[8];
+        load_be256(t, scalars + (size_t)i * 32);
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc[k] |= t[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        uint32_t v = acc[k];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v |= __shfl_xor(v, m, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicOr(&out8[k], v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Two-pass LDS counting sort of the (window, bucket) keys -- no global atomics on the data path.
 //

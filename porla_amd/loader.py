@@ -60,8 +60,9 @@ def _declare(L):
     L.porla_gpu_set_msm_glv.argtypes = [ctypes.c_int]; L.porla_gpu_set_msm_glv.restype = ctypes.c_int
     L.porla_glv_split.argtypes = [ctypes.c_int, u8p, u8p, ctypes.POINTER(ctypes.c_int), u8p, ctypes.POINTER(ctypes.c_int)]
     L.porla_glv_split.restype = ctypes.c_int
-    L.porla_bn254_msm_device_begin.argtypes = [ctypes.c_int, vp, vp, sz, vp]; L.porla_bn254_msm_device_begin.restype = ctypes.c_int
-    L.porla_bn254_msm_device_end.argtypes = [ctypes.c_int, u8p, ctypes.c_int]; L.porla_bn254_msm_device_end.restype = ctypes.c_int
+    for curve in ("bn254", "secp256k1"):
+        f = getattr(L, "porla_%s_msm_device_begin" % curve); f.argtypes = [ctypes.c_int, vp, vp, sz, vp]; f.restype = ctypes.c_int
+        f = getattr(L, "porla_%s_msm_device_end" % curve); f.argtypes = [ctypes.c_int, u8p, ctypes.c_int]; f.restype = ctypes.c_int
     for curve in ("bn254", "secp256k1"):
         f = getattr(L, "porla_%s_msm_device" % curve); f.argtypes = [vp, vp, sz, u8p, vp]; f.restype = ctypes.c_int
         f = getattr(L, "porla_%s_msm_device_partial" % curve); f.argtypes = [vp, vp, sz, u8p, vp]; f.restype = ctypes.c_int

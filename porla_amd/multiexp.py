@@ -149,14 +149,15 @@ def msm_device(curve, d_scalars, d_points, n, stream=0, partial=False):
     return out.raw
 
 
-def msm_begin(slot, d_scalars, d_points, n, stream=0):
-    """two-phase BN254 MSM: enqueue on `stream` into workspace slot 1..3 (include/porla_gpu.h)"""
-    _check(lib.porla_bn254_msm_device_begin(slot, ctypes.c_void_p(d_scalars), ctypes.c_void_p(d_points), n, ctypes.c_void_p(stream)))
+def msm_begin(slot, d_scalars, d_points, n, stream=0, curve="bn254"):
+    """two-phase MSM: enqueue on `stream` into workspace slot 1..3 (include/porla_gpu.h)"""
+    fn = getattr(lib, "porla_%s_msm_device_begin" % curve)
+    _check(fn(slot, ctypes.c_void_p(d_scalars), ctypes.c_void_p(d_points), n, ctypes.c_void_p(stream)))
 
 
-def msm_end(slot, partial=False):
+def msm_end(slot, partial=False, curve="bn254"):
     out = ctypes.create_string_buffer(96 if partial else 64)
-    _check(lib.porla_bn254_msm_device_end(slot, out, 1 if partial else 0))
+    _check(getattr(lib, "porla_%s_msm_device_end" % curve)(slot, out, 1 if partial else 0))
     return out.raw
 
 
