@@ -1,0 +1,19 @@
+"""GPU: a short run of the randomised differential test (tools/fuzz_msm.py: sizes x window overrides 2..20 x GLV on/off x
+scalar distributions x repeated / infinity / cancelling points, both curves) against the oracle.  The long runs are recorded
+in profiles/ (98 641 cases, 0 mismatches at the time of writing)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_short_fuzz(seed):
+    r = subprocess.run([sys.executable, os.path.join(common.ROOT, "tools", "fuzz_msm.py"), "8", str(seed)],
+                       capture_output=True, text=True, timeout=300, cwd=common.ROOT)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
