@@ -5,11 +5,13 @@
 //   libsecp256k1 field_5x52 (porla/Utils/secp256k1_lib/field_5x52_impl.h:432 fe_mul, :449 fe_sqr).
 //
 // Design notes (MI355X):
-//  * There is no dense contraction here, so no MFMA: a field product is 64 + 64 v_mad_u64_u32
-//    (32x32+64 -> 64, quarter-rate VALU) plus carry bookkeeping; everything lives in VGPRs.
+//  * There is no dense contraction here, so no MFMA: a Montgomery product is 64 + 64 v_mad_u64_u32
+//    (32x32+64 -> 64; measured 5.7 cycles per wave instruction) plus carry bookkeeping; everything lives in VGPRs.
 //  * gfx950 needs two wait states between a VALU write of VCC/SGPR and a VALU read of it, so long
-//    v_addc chains stall a lone wave.  The product-scanning (Comba) form below keeps one 96-bit column
-//    accumulator and lets hipcc interleave the carry updates with the next multiply.
+//    v_addc chains stall a lone wave.  The product-scanning (Comba) form keeps one 96-bit column accumulator; the
+//    device form is generated assembly (fe_mul_gfx950.inc, tools/gen_fe_mul_asm.py) with rotating SGPR carries and
+//    per-modulus variants (bounded limbs, sparse p_icc, special-form secp256k1), the portable form below is what the
+//    host pass runs and what tools/fe_check.hip compares the assembly against.
 //  * All loops are fully unrolled with compile-time indices: limbs never leave registers.
 #pragma once
 #include <hip/hip_runtime.h>

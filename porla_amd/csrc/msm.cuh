@@ -22,8 +22,9 @@
 //   k_window_reduce     one wave per window folds the per-wave partials
 //   host                Horner over the W window sums (W*c doublings), affine normalisation, marshal
 //
-// HBM traffic per pair (c = 16, W = 16): 96 B input + 64 B converted point + 2*W*4 B keys + W*4 B index
-// + W * 64 B gathers (cache-resident) -- the kernel is VALU (integer multiply) bound, see DESIGN.md.
+// Traffic per pair (c = 16, W = 16): 96 B input + 64 B converted point + 2 * W * 4 B sort items + W * 4 B index + W gathers
+// of a 64-B point (the 64 MiB point set lives in the Infinity Cache; PMC: 3.2 GB of fabric requests per 2^20-pair launch).
+// The accumulation is VALU (integer multiply) bound at 91 % of the mixed-addition peak, see DESIGN.md s4.
 #pragma once
 #include "ec.cuh"
 #include "glv.cuh"
