@@ -104,6 +104,13 @@ void porla_fixed_base_destroy(porla_fixed_base *fb);
 /* KZG: rows of n_samples coefficients (4096 bytes per row for NUM_CHUNKS = 128) against the resident SRS */
 int  porla_kzg_commit_batch_device(const void *d_rows, size_t n_rows, void *d_out, void *hip_stream);
 int  porla_kzg_commit_batch_host(const uint8_t *rows, size_t n_rows, uint8_t *out);
+/* Client side, batched (Client::initialize computes both per block, porla/Client/Client.hpp:408-455):
+ *   digest     = compute_digest (main.go:70-89) per row: alpha * f(tau) * G1[0]; rows as for commit_batch
+ *   complement = compute_digest_complement (main.go:91-101) per scalar: s * h_MAC; scalars 32 bytes big-endian each
+ *                (the reference passes its 16-byte AES output: left-pad it with 16 zero bytes)
+ * Needs init_key + init_SRS in this process (tau, alpha and the hiding base are the client's secrets). */
+int  porla_kzg_digest_batch_device(const void *d_rows, size_t n_rows, void *d_out, void *hip_stream);
+int  porla_kzg_complement_batch_device(const void *d_scalars, size_t n, void *d_out, void *hip_stream);
 /* window bits used when the SRS table is (re)built; 0 = automatic */
 int  porla_kzg_set_commit_window(int window_bits);
 

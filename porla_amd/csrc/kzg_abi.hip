@@ -22,6 +22,26 @@ using Fr = Bn254Fr;
 
 namespace {
 
+// compute_digest hoisted over rows (main.go:70-89): out[r] = big-endian bytes of alpha * f_r(tau) mod r, f_r given by n
+// coefficients of 32 big-endian bytes (fr.SetBytes: reduced mod r), Horner from the top coefficient.  One lane per row.
+__global__ void __launch_bounds__(256)
+k_kzg_eval_rows(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_coeffs, Fe<Bn254Fr> tau, Fe<Bn254Fr> alpha,
+                uint8_t* __restrict__ out) {
+    using F = Bn254Fr;
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const uint8_t* row = rows + (size_t)r * n_coeffs * 32;
+    Fe<F> acc = fe_zero<F>();
+    for (uint32_t i = n_coeffs; i-- > 0;) {
+        Fe<F> c;
+        load_be256(c.v, row + (size_t)i * 32);
+        fe_reduce_plain<F>(c.v, 6);
+        acc = fe_add<F>(fe_mul<F>(acc, tau), fe_to_mont<F>(c));
+    }
+    acc = fe_from_mont<F>(fe_mul<F>(acc, alpha));
+    store_be256(out + (size_t)r * 32, acc.v);
+}
+
 struct KzgState {
     std::mutex mu;
     bool have_key = false;
@@ -35,6 +55,10 @@ struct KzgState {
     bool d_srs_dirty = true;      // host copy changed since the last upload
     FixedBase<Bn254G1> fb;        // window-multiples table of the SRS (fixed_base.cuh), rebuilt when the SRS changes
     int commit_window = 0;        // 0 = automatic
+    FixedBase<Bn254G1> fb_g, fb_h;   // one-point tables of G1[0] and of the MAC hiding base (client-side batches)
+    bool fb_g_dirty = true, fb_h_dirty = true;
+    void* d_eval = nullptr;       // scratch: evaluated scalars of a digest batch
+    size_t d_eval_cap = 0;
     bool have_g2 = false;
     G2Affine g2[2];               // SRS.G2[0], SRS.G2[1]
     Affine<Fp> h_mac;             // MAC hiding base (main.go:28,58-59)
@@ -177,6 +201,7 @@ void init_SRS(GoInt SRS_size, GoSlice* out, GoInt64* out_len) {
     g.h_mac = h_xyzz_to_affine<Fp>(h_scalar_mul<Fp>(g.srs[0], k));
 
     g.d_srs_dirty = true;  // uploaded to HBM on first use by a commit (the client side never needs the GPU)
+    g.fb_g_dirty = g.fb_h_dirty = true;
 }
 
 // main.go:62-68: SRS.ReadFrom
@@ -200,6 +225,7 @@ void init_SRS_from_data(GoInt SRS_size, GoSlice* in) {
         g.have_g2 = g2_decompress(b + 4 + 32 * cnt, &g.g2[0]) && g2_decompress(b + 4 + 32 * cnt + 64, &g.g2[1]);
     }
     g.d_srs_dirty = true;
+    g.fb_g_dirty = true;
 }
 
 // main.go:70-89: alpha * f(tau) * G1[0] -- Horner over Fr and ONE scalar multiplication (host)
@@ -350,6 +376,54 @@ void neg_point(GoSlice* point) {
 void set_inf_point(GoSlice* point) {
     uint8_t out[64] = {0};
     copy_out(point, out, 64);
+}
+
+// ---- client side, batched: compute_digest (main.go:70-89) and compute_digest_complement (main.go:91-101) over many rows ----
+static int one_point_table(FixedBase<Bn254G1>& fb, bool& dirty, const Affine<Fp>& point) {
+    if (!dirty) return PORLA_OK;
+    uint8_t be[64];
+    h_affine_to_bytes<Fp>(be, point);
+    std::lock_guard<std::mutex> lk(fb.mu);
+    int rc = fb.build_from_host_bytes(be, 1, 0, engine_stream());
+    if (rc) return rc;
+    dirty = false;
+    return PORLA_OK;
+}
+
+int porla_kzg_digest_batch_device(const void* d_rows, size_t n_rows, void* d_out, void* hip_stream) {
+    if (n_rows && (!d_rows || !d_out)) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!g.have_key || g.srs.empty()) { set_last_error("porla: init_key / init_SRS first"); return PORLA_ERR_STATE; }
+    if (n_rows == 0) return PORLA_OK;
+    if ((rc = one_point_table(g.fb_g, g.fb_g_dirty, g.srs[0]))) return rc;
+    if (g.d_eval_cap < n_rows * 32) {
+        if (g.d_eval) PORLA_HIP(hipFree(g.d_eval));
+        g.d_eval = nullptr; g.d_eval_cap = 0;
+        PORLA_HIP(hipMalloc(&g.d_eval, n_rows * 32 + 256));
+        g.d_eval_cap = n_rows * 32 + 256;
+    }
+    hipStream_t stream = (hipStream_t)hip_stream;
+    {
+        ProfScope ps("kzg_eval_rows", stream);
+        hipLaunchKernelGGL(k_kzg_eval_rows, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, (const uint8_t*)d_rows,
+                           (uint32_t)n_rows, (uint32_t)g.n_samples, g.tau, g.alpha, (uint8_t*)g.d_eval);
+    }
+    std::lock_guard<std::mutex> lk2(g.fb_g.mu);
+    return g.fb_g.commit_device((const uint8_t*)g.d_eval, n_rows, 1, 32, (uint8_t*)d_out, stream);
+}
+
+int porla_kzg_complement_batch_device(const void* d_scalars, size_t n, void* d_out, void* hip_stream) {
+    if (n && (!d_scalars || !d_out)) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (g.srs.empty()) { set_last_error("porla: init_SRS first (it draws the MAC hiding base)"); return PORLA_ERR_STATE; }
+    if (n == 0) return PORLA_OK;
+    if ((rc = one_point_table(g.fb_h, g.fb_h_dirty, g.h_mac))) return rc;
+    std::lock_guard<std::mutex> lk2(g.fb_h.mu);
+    return g.fb_h.commit_device((const uint8_t*)d_scalars, n, 1, 32, (uint8_t*)d_out, (hipStream_t)hip_stream);
 }
 
 // ---- batched form of compute_digest_from_srs (include/porla_gpu.h) ----

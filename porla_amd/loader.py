@@ -78,6 +78,8 @@ def _declare(L):
     L.porla_fixed_base_destroy.argtypes = [vp]; L.porla_fixed_base_destroy.restype = None
     L.porla_kzg_commit_batch_device.argtypes = [vp, sz, vp, vp]; L.porla_kzg_commit_batch_device.restype = ctypes.c_int
     L.porla_kzg_commit_batch_host.argtypes = [u8p, sz, u8p]; L.porla_kzg_commit_batch_host.restype = ctypes.c_int
+    L.porla_kzg_digest_batch_device.argtypes = [vp, sz, vp, vp]; L.porla_kzg_digest_batch_device.restype = ctypes.c_int
+    L.porla_kzg_complement_batch_device.argtypes = [vp, sz, vp, vp]; L.porla_kzg_complement_batch_device.restype = ctypes.c_int
     L.porla_kzg_set_commit_window.argtypes = [ctypes.c_int]; L.porla_kzg_set_commit_window.restype = ctypes.c_int
     L.porla_icc_mac_encode_device.argtypes = [vp, sz, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_int, vp, vp]
     L.porla_icc_mac_encode_device.restype = ctypes.c_int

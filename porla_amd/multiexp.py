@@ -222,6 +222,16 @@ def kzg_commit_batch_device(d_rows, n_rows, d_out, stream=0):
     _check(lib.porla_kzg_commit_batch_device(ctypes.c_void_p(d_rows), n_rows, ctypes.c_void_p(d_out), ctypes.c_void_p(stream)))
 
 
+def kzg_digest_batch_device(d_rows, n_rows, d_out, stream=0):
+    """compute_digest (Client.hpp:408-419) over n_rows rows resident in HBM"""
+    _check(lib.porla_kzg_digest_batch_device(ctypes.c_void_p(d_rows), n_rows, ctypes.c_void_p(d_out), ctypes.c_void_p(stream)))
+
+
+def kzg_complement_batch_device(d_scalars, n, d_out, stream=0):
+    """compute_digest_complement (Client.hpp:445-453) over n 32-byte big-endian scalars resident in HBM"""
+    _check(lib.porla_kzg_complement_batch_device(ctypes.c_void_p(d_scalars), n, ctypes.c_void_p(d_out), ctypes.c_void_p(stream)))
+
+
 def profile_enable(on=True):
     lib.porla_gpu_profile_enable(1 if on else 0)
 

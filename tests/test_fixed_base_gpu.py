@@ -161,3 +161,42 @@ def test_secp256k1_pedersen_commit(mx, c):
     assert got == common.oracle_commit_batch("secp256k1", bytes(rows), n_rows, 128, base)
     assert got[:64] == common.oracle_commit_batch("secp256k1", bytes(rows), 1, 128, base, naive=True)
     fb.close()
+
+
+def test_client_side_digest_and_complement_batches(mx):
+    """porla_kzg_digest_batch / porla_kzg_complement_batch == the reference symbols compute_digest /
+    compute_digest_complement called row by row (porla/Client/Client.hpp:408-455 -> main.go:70-101), and the digest equals
+    the oracle's; Client::initialize builds every block MAC as digest + complement (Client.hpp:216-226)"""
+    import ctypes
+    import torch
+    mx.init_key(TAU, ALPHA)
+    mx.init_SRS(128)
+    n_rows = 300
+    rows = bytearray(rows_bytes(n_rows, 128, b"digest"))
+    rows[0:32] = (R + 5).to_bytes(32, "big")          # a coefficient >= r (SetBytes reduces)
+    rows[4096:4096 + 4096] = bytes(4096)               # an all-zero block -> infinity
+    rows = bytes(rows)
+    d_rows = torch.frombuffer(bytearray(rows), dtype=torch.uint8).cuda()
+    d_out = torch.empty(64 * n_rows, dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    mx.kzg_digest_batch_device(d_rows.data_ptr(), n_rows, d_out.data_ptr(), s)
+    torch.cuda.synchronize()
+    got = bytes(d_out.cpu().numpy())
+    o = common.oracle()
+    o.oracle_kzg_init_key(TAU, ctypes.c_size_t(16), ALPHA, ctypes.c_size_t(16))
+    o.oracle_kzg_init_srs(ctypes.c_size_t(128), (1).to_bytes(32, "big"))
+    for r in (0, 1, 2, 150, 299):
+        want = ctypes.create_string_buffer(64)
+        o.oracle_kzg_compute_digest(rows[4096 * r:4096 * r + 4096], want)
+        assert got[64 * r:64 * r + 64] == want.raw
+        assert got[64 * r:64 * r + 64] == mx.compute_digest(rows[4096 * r:4096 * r + 4096])
+    assert got[64:128] == bytes(64)
+    # complements: 16-byte PRF outputs left-padded to 32 bytes
+    prf = [hashlib.sha256(b"prf" + i.to_bytes(4, "little")).digest()[:16] for i in range(n_rows)]
+    scal = b"".join(bytes(16) + p for p in prf)
+    d_sc = torch.frombuffer(bytearray(scal), dtype=torch.uint8).cuda()
+    mx.kzg_complement_batch_device(d_sc.data_ptr(), n_rows, d_out.data_ptr(), s)
+    torch.cuda.synchronize()
+    comp = bytes(d_out.cpu().numpy())
+    for r in (0, 7, 299):
+        assert comp[64 * r:64 * r + 64] == mx.compute_digest_complement(prf[r])
