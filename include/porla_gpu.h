@@ -111,6 +111,12 @@ int  porla_kzg_commit_batch_host(const uint8_t *rows, size_t n_rows, uint8_t *ou
  * Needs init_key + init_SRS in this process (tau, alpha and the hiding base are the client's secrets). */
 int  porla_kzg_digest_batch_device(const void *d_rows, size_t n_rows, void *d_out, void *hip_stream);
 int  porla_kzg_complement_batch_device(const void *d_scalars, size_t n, void *d_out, void *hip_stream);
+/* diagnostics of the host pairing behind verify_proof (main.go:177-193): scalar * G2 generator as 128 bytes
+ * X.A1 || X.A0 || Y.A1 || Y.A0 big-endian; e(p1, q1) * e(p2, q2) == 1 ? (returns 1 / 0; slow = 1: the literal form with
+ * affine Miller steps and the exponent (p^12 - 1)/r, kept as the reference for the fast form) */
+int  porla_bn254_g2_mul_generator(const uint8_t scalar_be[32], uint8_t out[128]);
+int  porla_bn254_pairing_product_is_one(const uint8_t p1[64], const uint8_t q1[128], const uint8_t p2[64], const uint8_t q2[128],
+                                        int slow);
 /* window bits used when the SRS table is (re)built; 0 = automatic */
 int  porla_kzg_set_commit_window(int window_bits);
 

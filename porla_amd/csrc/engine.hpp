@@ -97,10 +97,13 @@ struct FixedBase {
     size_t io_rows_cap = 0;
     uint8_t* io_out = nullptr;
     size_t io_out_cap = 0;
+    uint32_t last_S = 1;                      // slices per row of the last commit_device (layout of `partial`)
+    static constexpr size_t HOST_FINISH_MAX_ROWS = 8;
     std::mutex mu;
     void release();
     int build(const Affine<typename C::Fp>* d_base, size_t n, int window_bits, hipStream_t stream);
     int build_from_host_bytes(const uint8_t* points_be, size_t n, int window_bits, hipStream_t stream);
+    // d_out == nullptr: stop after the slice fold; the row sums stay in `partial` (row r at partial[r * last_S])
     int commit_device(const uint8_t* d_rows, size_t n_rows, size_t n_coeffs, size_t row_stride, uint8_t* d_out,
                       hipStream_t stream);
     int commit_host(const uint8_t* rows, size_t n_rows, size_t n_coeffs, size_t row_stride, uint8_t* out,

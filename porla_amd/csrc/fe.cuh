@@ -274,13 +274,54 @@ PORLA_HD Fe<M> fe_mul_pseudo_mersenne(const Fe<M>& a, const Fe<M>& b) {
     return out;
 }
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+// Host pass: the same Montgomery product (radix 2^256) with 4 x 64-bit limbs and 128-bit products (CIOS) -- about 2.5x the
+// speed of the 32-bit form above on x86-64; it carries every host-side tail (window fold, single-point operations, the
+// pairing of verify_proof).  fe_mul_generic stays the reference the device assembly is checked against (tools/fe_check.hip).
+template <class M>
+inline Fe<M> fe_mul_host64(const Fe<M>& a, const Fe<M>& b) {
+    typedef unsigned __int128 u128;
+    static const uint64_t inv = [] {
+        const uint64_t p0 = ((uint64_t)M::P[1] << 32) | M::P[0];
+        uint64_t x = 1;                                   // Newton: x <- x (2 - p0 x)
+        for (int i = 0; i < 6; i++) x *= 2 - p0 * x;
+        return 0 - x;
+    }();
+    uint64_t A[4], B[4], Pm[4], t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        A[i] = ((uint64_t)a.v[2 * i + 1] << 32) | a.v[2 * i];
+        B[i] = ((uint64_t)b.v[2 * i + 1] << 32) | b.v[2 * i];
+        Pm[i] = ((uint64_t)M::P[2 * i + 1] << 32) | M::P[2 * i];
+    }
+    for (int i = 0; i < 4; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) { c += (u128)A[j] * B[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+        c += t[4]; t[4] = (uint64_t)c; t[5] = (uint64_t)(c >> 64);
+        const uint64_t m = t[0] * inv;
+        c = (u128)m * Pm[0] + t[0];
+        c >>= 64;
+        for (int j = 1; j < 4; j++) { c += (u128)m * Pm[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+        c += t[4]; t[3] = (uint64_t)c; t[4] = t[5] + (uint64_t)(c >> 64);
+    }
+    uint64_t d[4];
+    u128 br = 0;
+    for (int i = 0; i < 4; i++) { u128 x = (u128)t[i] - Pm[i] - (uint64_t)br; d[i] = (uint64_t)x; br = (x >> 64) & 1; }
+    const bool ge = t[4] != 0 || br == 0;
+    Fe<M> r;
+    for (int i = 0; i < 4; i++) { const uint64_t w = ge ? d[i] : t[i]; r.v[2 * i] = (uint32_t)w; r.v[2 * i + 1] = (uint32_t)(w >> 32); }
+    return r;
+}
+#endif
+
 template <class M>
 PORLA_HD Fe<M> fe_mul(const Fe<M>& a, const Fe<M>& b) {
     if (M::PSEUDO_MERSENNE) return fe_mul_pseudo_mersenne<M>(a, b);
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(PORLA_NO_ASM_MUL)
     return fe_mul_gfx950<M>(a, b);
-#else
+#elif defined(__HIP_DEVICE_COMPILE__)
     return fe_mul_generic<M>(a, b);
+#else
+    return fe_mul_host64<M>(a, b);
 #endif
 }
 

@@ -113,7 +113,7 @@ int FixedBase<C>::commit_device(const uint8_t* d_rows, size_t n_rows, size_t n_c
     if (n_rows == 0) return PORLA_OK;
     if (!table || n_coeffs > n_points) { set_last_error("porla: fixed base not built / too few base points"); return PORLA_ERR_STATE; }
     if (n_rows > 0xfffffff0u || n_coeffs > 0xffffu) { set_last_error("porla: commit batch too large"); return PORLA_ERR_ARG; }
-    if (n_coeffs == 0) { PORLA_HIP(hipMemsetAsync(d_out, 0, n_rows * 64, stream)); return PORLA_OK; }
+    if (n_coeffs == 0) { if (d_out) PORLA_HIP(hipMemsetAsync(d_out, 0, n_rows * 64, stream)); return PORLA_OK; }
     // slices per row: enough lanes to fill 256 CUs x 4 SIMDs x 3 waves
     static const size_t target = getenv("PORLA_COMMIT_LANES") ? (size_t)atol(getenv("PORLA_COMMIT_LANES")) : (size_t)196608;
     uint32_t S = 1;
@@ -137,7 +137,8 @@ int FixedBase<C>::commit_device(const uint8_t* d_rows, size_t n_rows, size_t n_c
         hipLaunchKernelGGL((k_fb_fold<C>), dim3((unsigned)((n_rows + rows_per_wave - 1) / rows_per_wave)), dim3(64), 0,
                            stream, partial, (uint32_t)n_rows, S, G);
     }
-    {
+    last_S = S;
+    if (d_out) {
         ProfScope ps("fb_finish", stream);
         hipLaunchKernelGGL((k_fb_finish<C>), dim3((unsigned)((n_rows + 63) / 64)), dim3(64), 0, stream,
                            (const XYZZ<M>*)partial, (uint32_t)n_rows, S, d_out);
@@ -164,6 +165,19 @@ int FixedBase<C>::commit_host(const uint8_t* rows, size_t n_rows, size_t n_coeff
         io_out_cap = n_rows * 64 + 256;
     }
     if (in_bytes) PORLA_HIP(hipMemcpyAsync(io_rows, rows, in_bytes, hipMemcpyHostToDevice, stream));
+    if (n_rows <= HOST_FINISH_MAX_ROWS && n_coeffs > 0) {
+        // a handful of rows (the reference calls compute_digest_from_srs one row at a time): the projective sums come back
+        // and the host normalises them -- one inversion costs ~25 us there against ~250 us of dependent products on a lone wave
+        using M = typename C::Fp;
+        int rc = commit_device(io_rows, n_rows, n_coeffs, row_stride, nullptr, stream);
+        if (rc) return rc;
+        XYZZ<M> sums[HOST_FINISH_MAX_ROWS];
+        for (size_t r = 0; r < n_rows; r++)
+            PORLA_HIP(hipMemcpyAsync(&sums[r], partial + r * last_S, sizeof(XYZZ<M>), hipMemcpyDeviceToHost, stream));
+        PORLA_HIP(hipStreamSynchronize(stream));
+        for (size_t r = 0; r < n_rows; r++) h_affine_to_bytes<M>(out + 64 * r, h_xyzz_to_affine<M>(sums[r]));
+        return PORLA_OK;
+    }
     int rc = commit_device(io_rows, n_rows, n_coeffs, row_stride, io_out, stream);
     if (rc) return rc;
     PORLA_HIP(hipMemcpyAsync(out, io_out, n_rows * 64, hipMemcpyDeviceToHost, stream));

@@ -378,6 +378,33 @@ void set_inf_point(GoSlice* point) {
     copy_out(point, out, 64);
 }
 
+// ---- diagnostics of the host pairing (verify_proof's engine): lets the tests check bilinearity and compare the fast
+// final exponentiation / projective Miller loop with the literal reference form
+static void g2_to_bytes(uint8_t out[128], const G2Affine& q) {
+    if (q.inf) { memset(out, 0, 128); return; }
+    h_fe_to_be<Fp>(out, q.x.a1); h_fe_to_be<Fp>(out + 32, q.x.a0); h_fe_to_be<Fp>(out + 64, q.y.a1); h_fe_to_be<Fp>(out + 96, q.y.a0);
+}
+static G2Affine g2_from_bytes(const uint8_t in[128]) {
+    G2Affine q;
+    q.x.a1 = h_fe_from_be<Fp>(in); q.x.a0 = h_fe_from_be<Fp>(in + 32); q.y.a1 = h_fe_from_be<Fp>(in + 64); q.y.a0 = h_fe_from_be<Fp>(in + 96);
+    q.inf = f2_is_zero(q.x) && f2_is_zero(q.y);
+    return q;
+}
+int porla_bn254_g2_mul_generator(const uint8_t scalar_be[32], uint8_t out[128]) {
+    if (!scalar_be || !out) return PORLA_ERR_ARG;
+    Fe<Fr> s = h_fe_from_be<Fr>(scalar_be);
+    uint32_t k[8];
+    h_fe_to_plain<Fr>(k, s);
+    g2_to_bytes(out, g2_scalar_mul(g2_generator(), k));
+    return PORLA_OK;
+}
+int porla_bn254_pairing_product_is_one(const uint8_t p1[64], const uint8_t q1[128], const uint8_t p2[64], const uint8_t q2[128],
+                                       int slow) {
+    if (!p1 || !q1 || !p2 || !q2) return PORLA_ERR_ARG;
+    return pairing_product_is_one(h_affine_from_bytes<Fp>(p1), g2_from_bytes(q1), h_affine_from_bytes<Fp>(p2), g2_from_bytes(q2),
+                                  slow != 0) ? 1 : 0;
+}
+
 // ---- client side, batched: compute_digest (main.go:70-89) and compute_digest_complement (main.go:91-101) over many rows ----
 static int one_point_table(FixedBase<Bn254G1>& fb, bool& dirty, const Affine<Fp>& point) {
     if (!dirty) return PORLA_OK;

@@ -2,10 +2,12 @@
 //   * G1 / G2 compressed (de)serialisation of the SRS wire blob  (kzg.SRS.WriteTo / ReadFrom, main.go:48,67)
 //   * G2 scalar multiplication for SRS.G2[1] = tau * G2gen        (kzg.NewSRS, main.go:46)
 //   * a pairing-product check for kzg.Verify                       (main.go:187)
-// None of this is on the data-parallel hot path (one call per audit, Client.hpp:1635-1663), so it is written for
-// clarity, not speed: Fp12 = Fp2[w]/(w^6 - xi), xi = 9 + u, the plain ate pairing f_{t-1,Q}(P) (no Frobenius
-// constants needed) and a final exponentiation by the literal integer (p^12 - 1)/r.  kzg.Verify only tests
-// e(A,G2)*e(-H,Q) == 1, and every non-degenerate bilinear pairing on G1 x G2 agrees on that predicate.
+// None of this is on the data-parallel hot path (one call per audit, Client.hpp:1635-1663): Fp12 = Fp2[w]/(w^6 - xi),
+// xi = 9 + u, the plain ate pairing f_{t-1,Q}(P) with inversion-free (projective) line steps, and the final exponentiation
+// split as usual: easy part f^((p^6-1)(p^2+1)) by conjugation, one inversion and a Frobenius, hard part f^((p^4-p^2+1)/r)
+// by the BN addition chain over f^x, f^(x^2), f^(x^3) and Frobenius maps (exponent identity checked in
+// tests/test_constants.py).  The literal exponentiation by (p^12-1)/r is kept as the slow reference (pairing self-check).
+// kzg.Verify only tests e(A,G2)*e(-H,Q) == 1, and every non-degenerate bilinear pairing on G1 x G2 agrees on that predicate.
 #pragma once
 #include "host_curve.hpp"
 #include <vector>
@@ -80,6 +82,19 @@ inline Fp2 f2_inv(const Fp2& a) {
     return Fp2{fe_mul<Bn254Fp>(a.a0, i), fe_neg<Bn254Fp>(fe_mul<Bn254Fp>(a.a1, i))};
 }
 inline Fp2 f2_xi() { return Fp2{fp_small(9), fp_small(1)}; }  // 9 + u
+inline Fp2 f2_conj(const Fp2& a) { return Fp2{a.a0, fe_neg<Bn254Fp>(a.a1)}; }
+inline Fp2 f2_mul_xi(const Fp2& a) {  // (a0 + a1 u)(9 + u) = (9 a0 - a1) + (a0 + 9 a1) u
+    FpE a0_8 = fe_dbl<Bn254Fp>(fe_dbl<Bn254Fp>(fe_dbl<Bn254Fp>(a.a0))), a1_8 = fe_dbl<Bn254Fp>(fe_dbl<Bn254Fp>(fe_dbl<Bn254Fp>(a.a1)));
+    return Fp2{fe_sub<Bn254Fp>(fe_add<Bn254Fp>(a0_8, a.a0), a.a1), fe_add<Bn254Fp>(fe_add<Bn254Fp>(a1_8, a.a1), a.a0)};
+}
+inline Fp2 f2_pow(const Fp2& a, const uint32_t e[8]) {
+    Fp2 acc = Fp2{fe_one<Bn254Fp>(), fe_zero<Bn254Fp>()};
+    for (int i = 255; i >= 0; i--) {
+        acc = f2_mul(acc, acc);
+        if ((e[i >> 5] >> (i & 31)) & 1) acc = f2_mul(acc, a);
+    }
+    return acc;
+}
 inline bool f2_lex_largest(const Fp2& a) {  // E2.LexicographicallyLargest
     if (fe_is_zero<Bn254Fp>(a.a1)) return fp_lex_largest(a.a0);
     return fp_lex_largest(a.a1);
@@ -210,6 +225,76 @@ inline bool f12_is_one(const Fp12& a) {
     return true;
 }
 
+// conjugation = the p^6 Frobenius: w -> -w
+inline Fp12 f12_conj(const Fp12& a) {
+    Fp12 r = a;
+    r.c[1] = f2_neg(a.c[1]); r.c[3] = f2_neg(a.c[3]); r.c[5] = f2_neg(a.c[5]);
+    return r;
+}
+// Fp6 = Fp2[v]/(v^3 - xi), v = w^2: helpers for the Fp12 inversion
+struct Fp6 { Fp2 a0, a1, a2; };
+inline Fp6 f6_mul(const Fp6& a, const Fp6& b) {
+    Fp2 t0 = f2_mul(a.a0, b.a0), t1 = f2_mul(a.a1, b.a1), t2 = f2_mul(a.a2, b.a2);
+    Fp2 c0 = f2_add(t0, f2_mul_xi(f2_add(f2_mul(a.a1, b.a2), f2_mul(a.a2, b.a1))));
+    Fp2 c1 = f2_add(f2_add(f2_mul(a.a0, b.a1), f2_mul(a.a1, b.a0)), f2_mul_xi(t2));
+    Fp2 c2 = f2_add(f2_add(f2_mul(a.a0, b.a2), f2_mul(a.a2, b.a0)), t1);
+    return Fp6{c0, c1, c2};
+}
+inline Fp6 f6_sub(const Fp6& a, const Fp6& b) { return Fp6{f2_sub(a.a0, b.a0), f2_sub(a.a1, b.a1), f2_sub(a.a2, b.a2)}; }
+inline Fp6 f6_mul_v(const Fp6& a) { return Fp6{f2_mul_xi(a.a2), a.a0, a.a1}; }
+inline Fp6 f6_inv(const Fp6& a) {
+    Fp2 t0 = f2_sub(f2_sqr(a.a0), f2_mul_xi(f2_mul(a.a1, a.a2)));
+    Fp2 t1 = f2_sub(f2_mul_xi(f2_sqr(a.a2)), f2_mul(a.a0, a.a1));
+    Fp2 t2 = f2_sub(f2_sqr(a.a1), f2_mul(a.a0, a.a2));
+    Fp2 d = f2_add(f2_mul(a.a0, t0), f2_mul_xi(f2_add(f2_mul(a.a2, t1), f2_mul(a.a1, t2))));
+    Fp2 di = f2_inv(d);
+    return Fp6{f2_mul(t0, di), f2_mul(t1, di), f2_mul(t2, di)};
+}
+// a = A + w B with A = (c0, c2, c4), B = (c1, c3, c5) in Fp6, w^2 = v:  a^-1 = (A - w B) / (A^2 - v B^2)
+inline Fp12 f12_inv(const Fp12& a) {
+    Fp6 A{a.c[0], a.c[2], a.c[4]}, B{a.c[1], a.c[3], a.c[5]};
+    Fp6 d = f6_inv(f6_sub(f6_mul(A, A), f6_mul_v(f6_mul(B, B))));
+    Fp6 ra = f6_mul(A, d), rb = f6_mul(B, d);
+    Fp12 r;
+    r.c[0] = ra.a0; r.c[2] = ra.a1; r.c[4] = ra.a2;
+    r.c[1] = f2_neg(rb.a0); r.c[3] = f2_neg(rb.a1); r.c[5] = f2_neg(rb.a2);
+    return r;
+}
+// p-power Frobenius: (sum c_i w^i)^p = sum conj(c_i) * gamma^i * w^i with gamma = xi^((p-1)/6)
+inline const Fp2* f12_frob_gammas() {
+    static Fp2 g[6];
+    static bool ready = false;
+    if (!ready) {
+        uint32_t e[8];   // (p - 1) / 6
+        uint64_t rem = 0;
+        uint32_t pm1[8];
+        for (int i = 0; i < 8; i++) pm1[i] = Bn254Fp::P[i];
+        pm1[0] -= 1;
+        for (int i = 7; i >= 0; i--) { uint64_t cur = (rem << 32) | pm1[i]; e[i] = (uint32_t)(cur / 6); rem = cur % 6; }
+        g[0] = f2_one();
+        g[1] = f2_pow(f2_xi(), e);
+        for (int i = 2; i < 6; i++) g[i] = f2_mul(g[i - 1], g[1]);
+        ready = true;
+    }
+    return g;
+}
+inline Fp12 f12_frob(const Fp12& a) {
+    const Fp2* g = f12_frob_gammas();
+    Fp12 r;
+    for (int i = 0; i < 6; i++) r.c[i] = f2_mul(f2_conj(a.c[i]), g[i]);
+    return r;
+}
+// a^x, x = 4965661367192848881 (the BN254 parameter)
+inline Fp12 f12_pow_x(const Fp12& a) {
+    const uint64_t x = 4965661367192848881ull;
+    Fp12 acc = a;
+    for (int i = 61; i >= 0; i--) {   // bit 62 is the top bit of x
+        acc = f12_mul(acc, acc);
+        if ((x >> i) & 1) acc = f12_mul(acc, a);
+    }
+    return acc;
+}
+
 // line through T and Q (twist points, T != -Q) evaluated at P = (xP, yP) in G1, then T <- T + Q
 // l(P) = yP - lambda*xP * w + (lambda*xT - yT) * w^3     (psi(x',y') = (x' w^2, y' w^3))
 inline Fp12 line_and_add(G2Affine* T, const G2Affine& Q, const Affine<Bn254Fp>& P, bool dbl) {
@@ -234,8 +319,67 @@ inline Fp12 line_and_add(G2Affine* T, const G2Affine& Q, const Affine<Bn254Fp>& 
     return l;
 }
 
-// Miller function f_{t-1,Q}(P), t - 1 = 6 x^2, x = 4965661367192848881 (plain ate pairing)
+// Inversion-free line steps: T = (X : Y : Z) projective on the twist (x = X/Z, y = Y/Z).  The line is scaled by a non-zero
+// Fp2 factor (the cleared denominators), which the final exponentiation kills (Fp2 lies in a proper subfield).
+struct G2Proj { Fp2 X, Y, Z; };
+// tangent at T evaluated at P, then T <- 2T.   lambda = A/B, A = 3X^2, B = 2YZ;  line * (B Z)
+inline Fp12 line_double_proj(G2Proj* T, const Affine<Bn254Fp>& P) {
+    Fp2 XX = f2_sqr(T->X);
+    Fp2 A = f2_add(f2_add(XX, XX), XX);
+    Fp2 YZ = f2_mul(T->Y, T->Z);
+    Fp2 B = f2_add(YZ, YZ);
+    Fp2 BB = f2_sqr(B);
+    Fp12 l;
+    for (int i = 0; i < 6; i++) l.c[i] = f2_zero();
+    l.c[0] = f2_mul_fp(f2_mul(B, T->Z), P.y);                               // B Z yP
+    l.c[1] = f2_neg(f2_mul_fp(f2_mul(A, T->Z), P.x));                       // -A Z xP
+    l.c[3] = f2_sub(f2_mul(A, T->X), f2_mul(B, T->Y));                      // A X - B Y
+    Fp2 D = f2_mul(BB, T->Z);                                               // B^2 Z
+    Fp2 XBB = f2_mul(T->X, BB);
+    Fp2 N3 = f2_sub(f2_mul(f2_sqr(A), T->Z), f2_add(XBB, XBB));             // A^2 Z - 2 X B^2
+    G2Proj R;
+    R.X = f2_mul(N3, B);
+    R.Y = f2_sub(f2_mul(A, f2_sub(XBB, N3)), f2_mul(T->Y, f2_mul(BB, B)));  // A (X B^2 - N3) - Y B^3
+    R.Z = f2_mul(B, D);
+    *T = R;
+    return l;
+}
+// chord through T and the affine Q evaluated at P, then T <- T + Q.   lambda = A/B, A = y2 Z - Y, B = x2 Z - X;  line * B
+inline Fp12 line_add_proj(G2Proj* T, const G2Affine& Q, const Affine<Bn254Fp>& P) {
+    Fp2 A = f2_sub(f2_mul(Q.y, T->Z), T->Y);
+    Fp2 B = f2_sub(f2_mul(Q.x, T->Z), T->X);
+    Fp12 l;
+    for (int i = 0; i < 6; i++) l.c[i] = f2_zero();
+    l.c[0] = f2_mul_fp(B, P.y);
+    l.c[1] = f2_neg(f2_mul_fp(A, P.x));
+    l.c[3] = f2_sub(f2_mul(A, Q.x), f2_mul(B, Q.y));
+    Fp2 BB = f2_sqr(B);
+    Fp2 D = f2_mul(BB, T->Z);
+    Fp2 N3 = f2_sub(f2_mul(f2_sqr(A), T->Z), f2_mul(BB, f2_add(T->X, f2_mul(Q.x, T->Z))));
+    G2Proj R;
+    R.X = f2_mul(N3, B);
+    R.Y = f2_sub(f2_mul(A, f2_sub(f2_mul(Q.x, D), N3)), f2_mul(Q.y, f2_mul(B, D)));
+    R.Z = f2_mul(B, D);
+    *T = R;
+    return l;
+}
 inline Fp12 miller_ate(const Affine<Bn254Fp>& P, const G2Affine& Q) {
+    static const uint32_t S[4] = {0xe87cfd46u, 0xf83e9682u, 0xeeb859fbu, 0x6f4d8248u};   // 6 x^2
+    Fp12 f = f12_one();
+    if (aff_is_inf<Bn254Fp>(P) || Q.inf) return f;
+    G2Proj T{Q.x, Q.y, f2_one()};
+    int top = 127;
+    while (!((S[top >> 5] >> (top & 31)) & 1)) top--;
+    for (int i = top - 1; i >= 0; i--) {
+        f = f12_mul(f, f);
+        f = f12_mul(f, line_double_proj(&T, P));
+        if ((S[i >> 5] >> (i & 31)) & 1) f = f12_mul(f, line_add_proj(&T, Q, P));
+    }
+    return f;
+}
+
+// the same Miller function with affine steps (one Fp2 inversion each): the slow reference for the self-check
+inline Fp12 miller_ate_affine(const Affine<Bn254Fp>& P, const G2Affine& Q) {
     // 6*x^2 = 147946756881789318990833708069417712966 = 0x6f4d8248eeb859fbf83e9682e87cfd46
     static const uint32_t S[4] = {0xe87cfd46u, 0xf83e9682u, 0xeeb859fbu, 0x6f4d8248u};
     Fp12 f = f12_one();
@@ -268,11 +412,36 @@ inline Fp12 f12_pow_final(const Fp12& a) {
     return acc;
 }
 
-// e(P1,Q1) * e(P2,Q2) == 1 ?
+// f^((p^12 - 1)/r): easy part by conjugation / inversion / Frobenius, hard part by the BN addition chain
+// y0 * y1^2 * y2^6 * y3^12 * y4^18 * y5^30 * y6^36 (its exponent equals (p^4 - p^2 + 1)/r exactly)
+inline Fp12 f12_final_exp(const Fp12& a) {
+    Fp12 f = f12_mul(f12_conj(a), f12_inv(a));          // a^(p^6 - 1)
+    f = f12_mul(f12_frob(f12_frob(f)), f);              // ^(p^2 + 1): now in the cyclotomic subgroup, f^-1 = conj(f)
+    Fp12 fx = f12_pow_x(f), fx2 = f12_pow_x(fx), fx3 = f12_pow_x(fx2);
+    Fp12 fp = f12_frob(f), fp2 = f12_frob(fp), fp3 = f12_frob(fp2);
+    Fp12 y0 = f12_mul(f12_mul(fp, fp2), fp3);
+    Fp12 y1 = f12_conj(f);
+    Fp12 y2 = f12_frob(f12_frob(fx2));
+    Fp12 y3 = f12_conj(f12_frob(fx));
+    Fp12 y4 = f12_conj(f12_mul(fx, f12_frob(fx2)));
+    Fp12 y5 = f12_conj(fx2);
+    Fp12 y6 = f12_conj(f12_mul(fx3, f12_frob(fx3)));
+    Fp12 t0 = f12_mul(f12_mul(f12_mul(y6, y6), y4), y5);
+    Fp12 t1 = f12_mul(f12_mul(y3, y5), t0);
+    t0 = f12_mul(t0, y2);
+    t1 = f12_mul(f12_mul(t1, t1), t0);
+    t1 = f12_mul(t1, t1);
+    t0 = f12_mul(t1, y1);
+    t1 = f12_mul(t1, y0);
+    t0 = f12_mul(t0, t0);
+    return f12_mul(t0, t1);
+}
+
+// e(P1,Q1) * e(P2,Q2) == 1 ?   slow = true: affine Miller steps + the literal exponent (the reference form)
 inline bool pairing_product_is_one(const Affine<Bn254Fp>& P1, const G2Affine& Q1, const Affine<Bn254Fp>& P2,
-                                   const G2Affine& Q2) {
-    Fp12 f = f12_mul(miller_ate(P1, Q1), miller_ate(P2, Q2));
-    return f12_is_one(f12_pow_final(f));
+                                   const G2Affine& Q2, bool slow = false) {
+    if (slow) return f12_is_one(f12_pow_final(f12_mul(miller_ate_affine(P1, Q1), miller_ate_affine(P2, Q2))));
+    return f12_is_one(f12_final_exp(f12_mul(miller_ate(P1, Q1), miller_ate(P2, Q2))));
 }
 
 }  // namespace porla

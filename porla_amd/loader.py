@@ -80,6 +80,8 @@ def _declare(L):
     L.porla_kzg_commit_batch_host.argtypes = [u8p, sz, u8p]; L.porla_kzg_commit_batch_host.restype = ctypes.c_int
     L.porla_kzg_digest_batch_device.argtypes = [vp, sz, vp, vp]; L.porla_kzg_digest_batch_device.restype = ctypes.c_int
     L.porla_kzg_complement_batch_device.argtypes = [vp, sz, vp, vp]; L.porla_kzg_complement_batch_device.restype = ctypes.c_int
+    L.porla_bn254_g2_mul_generator.argtypes = [u8p, u8p]; L.porla_bn254_g2_mul_generator.restype = ctypes.c_int
+    L.porla_bn254_pairing_product_is_one.argtypes = [u8p, u8p, u8p, u8p, ctypes.c_int]; L.porla_bn254_pairing_product_is_one.restype = ctypes.c_int
     L.porla_kzg_set_commit_window.argtypes = [ctypes.c_int]; L.porla_kzg_set_commit_window.restype = ctypes.c_int
     L.porla_icc_mac_encode_device.argtypes = [vp, sz, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_int, vp, vp]
     L.porla_icc_mac_encode_device.restype = ctypes.c_int
