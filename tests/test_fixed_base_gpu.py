@@ -200,3 +200,39 @@ def test_client_side_digest_and_complement_batches(mx):
     comp = bytes(d_out.cpu().numpy())
     for r in (0, 7, 299):
         assert comp[64 * r:64 * r + 64] == mx.compute_digest_complement(prf[r])
+
+
+def test_eight_threads_call_the_plugin_concurrently(mx, srs128):
+    """the server calls compute_digest_from_srs / add_point / mult_point / neg_point from 8 pool threads at once
+    (porla/Server/Server.hpp:1054-1078, 1530-1535, 1600-1608); ctypes releases the GIL, so these really overlap"""
+    import threading
+    mx.init_key(TAU, ALPHA)
+    blob = mx.init_SRS(128)
+    mx.init_SRS_from_data(128, blob)
+    rows = rows_bytes(8, 128, b"thr")
+    want = common.oracle_commit_batch("bn254", rows, 8, 128, srs128)
+    errors = []
+
+    def worker(t):
+        try:
+            row = rows[4096 * t:4096 * t + 4096]
+            for _ in range(25):
+                c = mx.compute_digest_from_srs(row)
+                if c != want[64 * t:64 * t + 64]:
+                    errors.append("commit %d" % t)
+                k = (t + 2).to_bytes(32, "big")
+                p = mx.bn254_mult(c, k)
+                acc = mx.bn254_set_infinity()
+                for _ in range(t + 2):
+                    acc = mx.bn254_add(acc, c)
+                if acc != p or mx.bn254_add(p, mx.bn254_neg(p)) != bytes(64):
+                    errors.append("point ops %d" % t)
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:5]
