@@ -14,7 +14,7 @@
 // the 64 lanes of a wave walk (i, w) in lock-step and their gathers fall into the same 2 MiB sub-table.
 //
 //   k_fb_base_powers   thread per base point: 2^(c*w) * G_i for all w (c*W dependent doublings)
-//   k_fb_multiples     thread per (pair, chunk): (j*K+1)*B by double-and-add, then K-1 additions of B -> XYZZ scratch
+//   k_fb_multiples     wave per run of entries, lanes interleaved: (m+1)*B by double-and-add, then additions of 64*B -> XYZZ scratch
 //   k_fb_normalize     XYZZ -> affine with one inversion per 32 entries (Montgomery's trick) -> table
 //   k_fb_commit        lane = row (x slice): scalar -> reduce mod order -> signed digits -> gather + 8M+2S mixed add
 //   k_fb_fold          G lanes per row: fold the slice partials (sequential + wave-shuffle tree)
@@ -76,64 +76,74 @@ k_fb_base_powers(const Affine<typename C::Fp>* __restrict__ base, uint32_t n_poi
     }
 }
 
-// scratch[(pair - pair0) * H + k] = (k+1) * pow[pair], k < H; thread = (pair, chunk of K consecutive k)
+// scratch[(pair - pair0) * H + k] = (k+1) * pow[pair], k < H.  A group of `lanes` lanes owns a run of `lanes * K`
+// consecutive entries of one pair, INTERLEAVED (lane l: entries l, l + lanes, l + 2 lanes, ...): a store of the group covers
+// consecutive entries (8 KiB when lanes = 64), and a lane still pays one addition per entry (of lanes * B) after its
+// double-and-add start.  Small tables (H < 1024) put 64 / lanes pairs in a wave so that K stays 16.
 template <class C>
 __global__ void __launch_bounds__(64)
-k_fb_multiples(const XYZZ<typename C::Fp>* __restrict__ pow, uint32_t pair0, uint32_t n_pairs, uint32_t H, uint32_t K,
-               XYZZ<typename C::Fp>* __restrict__ scratch) {
+k_fb_multiples(const XYZZ<typename C::Fp>* __restrict__ pow, uint32_t pair0, uint32_t n_pairs, uint32_t H, uint32_t lanes,
+               uint32_t K, XYZZ<typename C::Fp>* __restrict__ scratch) {
     using M = typename C::Fp;
-    const uint32_t chunks = H / K;
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_pairs * chunks) return;
-    uint32_t pair = t / chunks, j = t % chunks;
+    const uint32_t run = lanes * K;                 // entries per lane group
+    const uint32_t runs = H / run;                  // groups per pair
+    const uint32_t groups_per_wave = 64 / lanes;
+    const uint32_t group = blockIdx.x * groups_per_wave + threadIdx.x / lanes;
+    if (group >= n_pairs * runs) return;
+    const uint32_t pair = group / runs, j = group % runs, lane = threadIdx.x % lanes;
     XYZZ<M> Bp = load_xyzz<M>(pow + pair0 + pair);
-    // first = (j*K + 1) * B by left-to-right double-and-add
-    uint32_t m = j * K + 1;
+    // first = (j*run + lane + 1) * B by left-to-right double-and-add
+    const uint32_t m = j * run + lane + 1;
     XYZZ<M> acc = xyzz_inf<M>();
     for (int bit = 31 - __clz(m); bit >= 0; bit--) {
         xyzz_double_cold<M>(&acc);
         if ((m >> bit) & 1) xyzz_add_cold<M>(&acc, &Bp);
     }
-    XYZZ<M>* dst = scratch + (size_t)pair * H + (size_t)j * K;
+    XYZZ<M> step = Bp;                               // lanes * B (lanes is a power of two)
+    for (uint32_t l = lanes; l > 1; l >>= 1) xyzz_double_cold<M>(&step);
+    XYZZ<M>* dst = scratch + (size_t)pair * H + (size_t)j * run + lane;
     for (uint32_t k = 0; k < K; k++) {
-        store_xyzz<M>(dst + k, acc);
-        if (k + 1 < K) xyzz_add_cold<M>(&acc, &Bp);
+        store_xyzz<M>(dst + (size_t)k * lanes, acc);
+        if (k + 1 < K) xyzz_add_cold<M>(&acc, &step);
     }
 }
 
-// table[k] = affine(scratch[k]); one inversion per NB entries (Montgomery's trick; the running prefix products are staged in
-// the x half of the thread's own output slots, which are overwritten by the result in the second pass)
+// table[k] = affine(scratch[k]); one inversion per NB entries of a lane (Montgomery's trick; the running prefix products are
+// staged in the x half of the lane's own output slots, which are overwritten by the result in the second pass).  A wave owns
+// 64 * NB consecutive entries, lanes interleaved, so loads and stores are coalesced.
 template <class C>
 __global__ void __launch_bounds__(64)
 k_fb_normalize(const XYZZ<typename C::Fp>* __restrict__ scratch, size_t n, Affine<typename C::Fp>* __restrict__ table) {
     using M = typename C::Fp;
     constexpr int NB = 32;
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t k0 = t * NB;
-    if (k0 >= n) return;
-    const int cnt = (n - k0 < (size_t)NB) ? (int)(n - k0) : NB;
+    const size_t base = (size_t)blockIdx.x * 64 * NB + threadIdx.x;
+    if (base >= n) return;
+    int cnt = 0;
+    while (cnt < NB && base + (size_t)cnt * 64 < n) cnt++;
     Fe<M> run = fe_one<M>();
 #pragma unroll 1
     for (int k = 0; k < cnt; k++) {
-        Fe<M> z = load_fe<M>(reinterpret_cast<const uint32_t*>(scratch + k0 + k) + 24);  // zzz
+        const size_t e = base + (size_t)k * 64;
+        Fe<M> z = load_fe<M>(reinterpret_cast<const uint32_t*>(scratch + e) + 24);  // zzz
         if (fe_is_zero<M>(z)) z = fe_one<M>();
-        store_fe<M>(reinterpret_cast<uint32_t*>(table + k0 + k), run);
+        store_fe<M>(reinterpret_cast<uint32_t*>(table + e), run);
         run = fe_mul_call<M>(run, z);
     }
     Fe<M> inv = fe_inv_dev<M>(run);
 #pragma unroll 1
     for (int k = cnt - 1; k >= 0; k--) {
-        XYZZ<M> p = load_xyzz<M>(scratch + k0 + k);
+        const size_t e = base + (size_t)k * 64;
+        XYZZ<M> p = load_xyzz<M>(scratch + e);
         Affine<M> a;
         if (xyzz_is_inf<M>(p)) {
             a.x = fe_zero<M>(); a.y = fe_zero<M>();
         } else {
-            Fe<M> prefix = load_fe<M>(reinterpret_cast<const uint32_t*>(table + k0 + k));
+            Fe<M> prefix = load_fe<M>(reinterpret_cast<const uint32_t*>(table + e));
             Fe<M> iz = fe_mul_call<M>(inv, prefix);
             inv = fe_mul_call<M>(inv, p.zzz);
             a = xyzz_to_affine_with_inv<M>(p, iz);
         }
-        store_affine<M>(table + k0 + k, a);
+        store_affine<M>(table + e, a);
     }
 }
 

@@ -79,19 +79,23 @@ int FixedBase<C>::build(const Affine<typename C::Fp>* d_base, size_t n, int wind
         ProfScope ps("fb_base_powers", stream);
         hipLaunchKernelGGL((k_fb_base_powers<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_base, (uint32_t)n, c, W, pow);
     }
-    const uint32_t K = H < 64 ? H : 64;
+    // lane groups of k_fb_multiples: 16 entries per lane for small tables, 64 lanes x up to 64 entries for large ones
+    const uint32_t lanes = H >= 1024 ? 64 : (H >= 16 ? H / 16 : 1);
+    uint32_t K = H / lanes;
+    if (K > 64) K = 64;
+    const uint32_t runs = H / (lanes * K);
+    const uint32_t groups_per_wave = 64 / lanes;
     for (size_t p0 = 0; p0 < pairs; p0 += batch_pairs) {
         size_t np = pairs - p0 < batch_pairs ? pairs - p0 : batch_pairs;
-        size_t threads = np * (H / K);
         {
             ProfScope ps("fb_multiples", stream);
-            hipLaunchKernelGGL((k_fb_multiples<C>), dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, stream,
-                               (const XYZZ<M>*)pow, (uint32_t)p0, (uint32_t)np, H, K, scratch);
+            hipLaunchKernelGGL((k_fb_multiples<C>), dim3((unsigned)((np * runs + groups_per_wave - 1) / groups_per_wave)), dim3(64), 0,
+                               stream, (const XYZZ<M>*)pow, (uint32_t)p0, (uint32_t)np, H, lanes, K, scratch);
         }
         size_t cnt = np * H;
         {
             ProfScope ps("fb_normalize", stream);
-            hipLaunchKernelGGL((k_fb_normalize<C>), dim3((unsigned)((cnt / 32 + 1 + 63) / 64)), dim3(64), 0, stream,
+            hipLaunchKernelGGL((k_fb_normalize<C>), dim3((unsigned)((cnt + 64 * 32 - 1) / (64 * 32))), dim3(64), 0, stream,
                                (const XYZZ<M>*)scratch, cnt, table + p0 * H);
         }
     }
