@@ -42,6 +42,7 @@ HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E peak, /opt/skills/guides/MI355X_MIC
 MSM_BYTES_PER_PAIR = 96       # 32-B scalar + 64-B affine point
 COMMIT_BYTES_PER_ROW = 4096 + 64  # 128 x 32-B coefficients in, 64-B point out (SRS table resident)
 ICC_BYTES_PER_ELEMENT = 64    # 32 B in + 32 B out
+FE_MUL_PEAK_G = 133.0         # measured back-to-back 256-bit Montgomery products, G/s per GPU (profiles/r01_b_ubench_asm_mul.txt)
 
 KERNEL_SYMBOL = {  # profile slot -> substring of the kernel symbol in the rocprofv3 output
     "bucket_sum": "k_bucket_sum", "bucket_reduce": "k_bucket_reduce", "partition_sort": "k_partition_sort",
@@ -148,14 +149,28 @@ def main():
         timed.totals = {name: ms / args.steps for name, ms, cnt in prof}   # per step, all launches of the kernel
         return el, {name: ms / max(cnt, 1) for name, ms, cnt in prof}, res
 
-    def roofline(kern, algo_bytes_per_launch, workload):
+    def roofline(kern, algo_bytes_per_launch, workload, fe_mults_per_launch=None):
         if not kern:
             return None
         dom = max(kern, key=kern.get)
         ach = algo_bytes_per_launch / (kern[dom] * 1e-3) / 1e9
-        return {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBPS, 6), "traffic": pmc_traffic(dom, workload),
-                "kernel_ms": round(kern[dom], 4), "all_kernels_ms": {k: round(v, 4) for k, v in kern.items()}}
+        r = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+             "frac": round(ach / HBM_PEAK_GBPS, 6), "traffic": pmc_traffic(dom, workload),
+             "kernel_ms": round(kern[dom], 4), "all_kernels_ms": {k: round(v, 4) for k, v in kern.items()}}
+        if fe_mults_per_launch:
+            # the elliptic-curve kernels are bound by the 32x32->64 multiplier issue rate, which neither "hbm" nor "mfma"
+            # names: the supplement prices the dominant kernel's 256-bit modular multiplications against the rate the
+            # multiply microbenchmark sustains on this chip (tools/fe_check.hip --bench, profiles/r01_b_ubench_asm_mul.txt)
+            g = fe_mults_per_launch / (kern[dom] * 1e-3) / 1e9
+            r["int_multiplier"] = {"achieved": round(g, 2), "peak": FE_MUL_PEAK_G, "unit": "G fe_mul/s (256-bit modular)",
+                                   "frac": round(g / FE_MUL_PEAK_G, 4),
+                                   "note": "mixed addition = 8M + 2S = 10 fe_mul; peak = measured back-to-back fe_mul rate"}
+        return r
+
+    def msm_fe_mults(n):
+        # one mixed addition (10 fe_mul) per (sub-scalar, window) digit; zero digits (2^-c of them) are not subtracted
+        c, windows, glv = mx.last_msm_shape()
+        return 10.0 * n * (2 if glv else 1) * windows
 
     # ---------------------------------------------------------------- KZG batched commitments (shared by two workloads)
     def kzg_setup():
@@ -189,7 +204,8 @@ def main():
         out = {"value": round(world * rows_n * args.steps / el, 1), "unit": "commits/s", "rows_per_gpu": rows_n,
                "coefficients_per_row": 128, "equiv_Mmul_per_s": round(world * rows_n * 128 * args.steps / el / 1e6, 1),
                "ms_per_step": round(el / args.steps * 1e3, 4), "table_build_s": round(build_s, 3),
-               "roofline": roofline(kern, COMMIT_BYTES_PER_ROW * rows_n, "kzg_commit")}
+               "roofline": roofline(kern, COMMIT_BYTES_PER_ROW * rows_n, "kzg_commit",
+                                    10.0 * rows_n * 128 * mx.kzg_commit_shape()[1])}
         cpu = None
         ok = None
         if not args.no_cpu and rank == 0:
@@ -284,7 +300,7 @@ def main():
                            "pairs_per_gpu": n, "msm_in_flight": depth,
                            "sharding": "input-pair range per rank + RCCL all_gather of 96-B Jacobian partials"
                            if world > 1 else "single GPU", "input_gen_s": round(gen_s, 1)},
-                "roofline": roofline(kern, MSM_BYTES_PER_PAIR * n, "bn254_msm"), "cpu_baseline": cpu,
+                "roofline": roofline(kern, MSM_BYTES_PER_PAIR * n, "bn254_msm", msm_fe_mults(n)), "cpu_baseline": cpu,
                 "bit_exact_vs_oracle": verified, "result": result.hex() if result else None, "kzg_commits": commits,
             }
     elif args.workload == "kzg_commit":
@@ -342,7 +358,7 @@ def main():
                    "config": {"workload": "IPA scheme, 2^%d-point secp256k1 ecmult_multi per GPU (points 2^i*G, scalars "
                                           "SHA-256(\"ecmult\"||i) as bench_ecmult.c), inputs resident in HBM" % args.log2n,
                               "pairs_per_gpu": n, "input_gen_s": round(gen_s, 1)},
-                   "roofline": roofline(kern, MSM_BYTES_PER_PAIR * n, "secp256k1_msm"), "cpu_baseline": cpu,
+                   "roofline": roofline(kern, MSM_BYTES_PER_PAIR * n, "secp256k1_msm", msm_fe_mults(n)), "cpu_baseline": cpu,
                    "bit_exact_vs_oracle": verified, "result": result.hex() if result else None}
     else:  # icc
         from porla_amd import icc

@@ -58,6 +58,8 @@ int         porla_gpu_set_msm_window(int c);
 /* 1: split every scalar with the curve endomorphism (half the windows); 0: plain windows over the full scalar;
  * -1 (default): per curve -- secp256k1 on (as the reference does, ecmult_impl.h:621-634), BN254 off (measured slower) */
 int         porla_gpu_set_msm_glv(int on);
+/* diagnostic: window bits, window count and GLV flag of the most recently launched MSM (what the automatic choice was) */
+int         porla_gpu_last_msm_shape(int *c, int *windows, int *glv);
 /* diagnostic: the scalar split the digit kernel applies (host execution of the same code): scalar mod n = k1 + lambda*k2,
  * magnitudes as 16-byte big-endian, signs as 0/1.  curve: 0 = BN254, 1 = secp256k1. */
 int         porla_glv_split(int curve, const uint8_t scalar_be[32], uint8_t k1_mag_be[16], int *k1_neg,
@@ -119,6 +121,8 @@ int  porla_bn254_pairing_product_is_one(const uint8_t p1[64], const uint8_t q1[1
                                         int slow);
 /* window bits used when the SRS table is (re)built; 0 = automatic */
 int  porla_kzg_set_commit_window(int window_bits);
+/* diagnostic: window bits / windows per coefficient of the SRS table currently resident (0, 0 before the first batch) */
+int  porla_kzg_commit_shape(int *window_bits, int *windows);
 
 /* ---- ICC encode (CRebuild_Cached data part + align_MAC scalar part) ----
  * rows_in : n_rows * n_cols elements, 32 bytes little-endian each (8 x uint32 LE words, utils.h:353-364; the layout

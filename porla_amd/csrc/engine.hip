@@ -92,6 +92,7 @@ void prof_flush() {
 std::mutex g_ws_mu;  // serialises MSM calls (compute_digest_from_srs may be called from 8 threads)
 static std::vector<Workspace*> g_ws;
 int g_window_override = 0;
+int g_last_shape[3] = {0, 0, 0};
 int g_use_glv = getenv("PORLA_MSM_GLV") ? (getenv("PORLA_MSM_GLV")[0] == '1' ? 1 : 0) : -1;  // -1: per-curve default
 
 int get_workspace_slot(int slot, Workspace** out) {
@@ -197,6 +198,12 @@ int porla_gpu_profile_get(int slot, char* name, size_t name_cap, double* total_m
     return PORLA_OK;
 }
 int porla_gpu_set_msm_window(int c) { g_window_override = c; return PORLA_OK; }
+int porla_gpu_last_msm_shape(int* c, int* windows, int* glv) {
+    if (c) *c = g_last_shape[0];
+    if (windows) *windows = g_last_shape[1];
+    if (glv) *glv = g_last_shape[2];
+    return PORLA_OK;
+}
 int porla_gpu_set_msm_glv(int on) { g_use_glv = on < 0 ? -1 : (on != 0); return PORLA_OK; }
 
 // host execution of the very code the digit kernel runs (glv.cuh is __host__ __device__): lets the CPU tests pin the

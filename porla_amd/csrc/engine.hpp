@@ -112,6 +112,7 @@ struct FixedBase {
 
 extern std::mutex g_ws_mu;
 extern int g_window_override;
+extern int g_last_shape[3];   // window bits, window count, GLV flag of the most recently launched MSM (diagnostic)
 extern int g_use_glv;  // 1: GLV split of every scalar; 0: plain signed windows over the full scalar; -1: the curve's default
 int get_workspace(Workspace** out);                 // slot 0 of the current device
 int get_workspace_slot(int slot, Workspace** out);  // g_ws_mu held by the caller

@@ -471,5 +471,11 @@ int porla_kzg_set_commit_window(int window_bits) {
     if (window_bits != g.commit_window) { g.commit_window = window_bits; g.d_srs_dirty = true; }
     return PORLA_OK;
 }
+int porla_kzg_commit_shape(int* window_bits, int* windows) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (window_bits) *window_bits = g.fb.c;
+    if (windows) *windows = g.fb.W;
+    return PORLA_OK;
+}
 
 }  // extern "C"

@@ -205,6 +205,7 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
     PORLA_HIP(hipEventRecord(ws->done, stream));
     ws->pend_W = W;
     ws->pend_c = c;
+    g_last_shape[0] = c; g_last_shape[1] = W; g_last_shape[2] = glv ? 1 : 0;
     return PORLA_OK;
 }
 

@@ -58,6 +58,7 @@ def _declare(L):
     L.porla_gpu_profile_get.restype = ctypes.c_int
     L.porla_gpu_set_msm_window.argtypes = [ctypes.c_int]; L.porla_gpu_set_msm_window.restype = ctypes.c_int
     L.porla_gpu_set_msm_glv.argtypes = [ctypes.c_int]; L.porla_gpu_set_msm_glv.restype = ctypes.c_int
+    L.porla_gpu_last_msm_shape.argtypes = [ctypes.POINTER(ctypes.c_int)] * 3; L.porla_gpu_last_msm_shape.restype = ctypes.c_int
     L.porla_glv_split.argtypes = [ctypes.c_int, u8p, u8p, ctypes.POINTER(ctypes.c_int), u8p, ctypes.POINTER(ctypes.c_int)]
     L.porla_glv_split.restype = ctypes.c_int
     for curve in ("bn254", "secp256k1"):
@@ -83,6 +84,7 @@ def _declare(L):
     L.porla_bn254_g2_mul_generator.argtypes = [u8p, u8p]; L.porla_bn254_g2_mul_generator.restype = ctypes.c_int
     L.porla_bn254_pairing_product_is_one.argtypes = [u8p, u8p, u8p, u8p, ctypes.c_int]; L.porla_bn254_pairing_product_is_one.restype = ctypes.c_int
     L.porla_kzg_set_commit_window.argtypes = [ctypes.c_int]; L.porla_kzg_set_commit_window.restype = ctypes.c_int
+    L.porla_kzg_commit_shape.argtypes = [ctypes.POINTER(ctypes.c_int)] * 2; L.porla_kzg_commit_shape.restype = ctypes.c_int
     L.porla_icc_mac_encode_device.argtypes = [vp, sz, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_int, vp, vp]
     L.porla_icc_mac_encode_device.restype = ctypes.c_int
     L.porla_icc_mac_encode_host.argtypes = [u8p, sz, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_int, u8p]

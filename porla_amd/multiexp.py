@@ -236,6 +236,20 @@ def profile_enable(on=True):
     lib.porla_gpu_profile_enable(1 if on else 0)
 
 
+def kzg_commit_shape():
+    """(window bits, windows per coefficient) of the resident SRS table"""
+    c, w = ctypes.c_int(0), ctypes.c_int(0)
+    lib.porla_kzg_commit_shape(ctypes.byref(c), ctypes.byref(w))
+    return c.value, w.value
+
+
+def last_msm_shape():
+    """(window bits, window count, GLV flag) of the most recently launched MSM"""
+    c, w, g = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    lib.porla_gpu_last_msm_shape(ctypes.byref(c), ctypes.byref(w), ctypes.byref(g))
+    return c.value, w.value, bool(g.value)
+
+
 def profile_get():
     """[(kernel name, total ms, launches)]"""
     res = []
