@@ -49,7 +49,8 @@ int         porla_gpu_device_count(void);
 int         porla_gpu_set_device(int device);
 const char *porla_gpu_last_error(void);
 /* Per-kernel timing with HIP events recorded on the launch stream.  enable=1 starts (and clears) the
- * accumulation; porla_gpu_profile_get(i, ...) returns kernel name, summed milliseconds and launch count
+ * accumulation for every kernel, enable=2 for each workload's dominant kernel only (two event packets per recorded
+ * kernel leave the GPU idle for ~10 us around it -- bench.py times with 2 and takes the full breakdown separately); porla_gpu_profile_get(i, ...) returns kernel name, summed milliseconds and launch count
  * for slot i, or a negative value past the last slot. */
 int         porla_gpu_profile_enable(int enable);
 int         porla_gpu_profile_get(int slot, char *name, size_t name_cap, double *total_ms, long long *launches);

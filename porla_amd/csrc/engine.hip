@@ -42,7 +42,7 @@ int ensure_device() {
 struct ProfSlot { std::string name; double ms = 0; long long launches = 0; };
 struct PendingEv { int slot; hipEvent_t e0, e1; };
 static std::mutex g_prof_mu;
-static bool g_prof_on = false;
+static int g_prof_level = 0;   // 0 off, 1 every scope, 2 dominant kernels only
 static std::vector<ProfSlot> g_prof;
 static std::vector<PendingEv> g_pending;
 
@@ -58,9 +58,9 @@ static hipEvent_t take_event() {
     (void)hipEventCreate(&e);
     return e;
 }
-ProfScope::ProfScope(const char* name, hipStream_t s) : slot(-1), stream(s), e0(nullptr), e1(nullptr), on(false) {
+ProfScope::ProfScope(const char* name, hipStream_t s, bool dominant) : slot(-1), stream(s), e0(nullptr), e1(nullptr), on(false) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (!g_prof_on) return;
+    if (g_prof_level == 0 || (g_prof_level == 2 && !dominant)) return;
     on = true;
     slot = prof_slot(name);
     e0 = take_event();
@@ -184,7 +184,7 @@ const char* porla_gpu_last_error(void) { return g_last_error.c_str(); }
 int porla_gpu_profile_enable(int enable) {
     prof_flush();
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof_on = enable != 0;
+    g_prof_level = enable < 0 ? 0 : (enable > 2 ? 1 : enable);
     if (enable) g_prof.clear();
     return PORLA_OK;
 }

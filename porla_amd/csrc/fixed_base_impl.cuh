@@ -131,7 +131,7 @@ int FixedBase<C>::commit_device(const uint8_t* d_rows, size_t n_rows, size_t n_c
         partial_cap = need + need / 8;
     }
     {
-        ProfScope ps("fb_commit", stream);
+        ProfScope ps("fb_commit", stream, true);
         hipLaunchKernelGGL((k_fb_commit<C>), dim3((unsigned)((n_rows + 255) / 256), S), dim3(256), 0, stream, d_rows,
                            (uint32_t)n_rows, (uint32_t)n_coeffs, row_stride, (const Affine<M>*)table, c, W, S, partial);
     }

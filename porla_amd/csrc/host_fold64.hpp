@@ -155,4 +155,23 @@ inline XYZZ<M> h_fold_windows64(const XYZZ<M>* win, int W, int c) {
     return F.to(acc);
 }
 
+// Tree form of the bucket reduction (msm.cuh, k_tree_level): window w arrives as fin[w][0] = S (sum of its buckets) and
+// fin[w][1 + k] = M_k (sum of the buckets whose index has bit k set), k < c - 1, and is worth S + sum_k 2^k M_k.
+// total = sum_w 2^(c*w) * that: one Horner pass over single bits -- the same W*c doublings, W*c additions.
+template <class M>
+inline XYZZ<M> h_fold_tree64(const XYZZ<M>* fin, int W, int c) {
+    static const Fp64<M> F;
+    typename Fp64<M>::Pt acc = F.inf();
+    for (int w = W - 1; w >= 0; w--) {
+        const XYZZ<M>* f = fin + (size_t)w * c;
+        if (!Fp64<M>::is_zero(acc.zz)) acc = F.dbl(acc);          // bit c-1 of the bucket index does not exist
+        for (int k = c - 2; k >= 0; k--) {
+            if (!Fp64<M>::is_zero(acc.zz)) acc = F.dbl(acc);
+            acc = F.padd(acc, F.from(f[1 + k]));
+        }
+        acc = F.padd(acc, F.from(f[0]));
+    }
+    return F.to(acc);
+}
+
 }  // namespace porla

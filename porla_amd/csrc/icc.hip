@@ -109,7 +109,7 @@ static int icc_encode_core(IccWs* ws, int curve, const uint8_t* d_rows, size_t n
             const size_t col_tiles = (ncols + ((size_t)1 << cc_log) - 1) >> cc_log;
             const dim3 grid((unsigned)(col_tiles * (n >> ns)));
             const bool first = pz == 0, last = pz == passes - 1;
-            ProfScope ps("icc_fused", stream);
+            ProfScope ps("icc_fused", stream, true);
 #define PORLA_ICC_LAUNCH(F, L)                                                                                              \
     hipLaunchKernelGGL((k_icc_fused<Q, F, L>), grid, dim3(256), 0, stream, (IccElem<Q>*)ws->work.p,                         \
                        (const IccElem<Q>*)ws->tw.p, (uint32_t)n, (uint32_t)ncols, s, ns, cc_log, d_rows, wt, use_wt, out)

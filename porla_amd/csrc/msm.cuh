@@ -639,6 +639,113 @@ k_window_reduce(const XYZZ<typename C::Fp>* __restrict__ partial, uint32_t perWi
     if (threadIdx.x == 0) store_xyzz<M>(out + w, acc);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Bucket reduction as a BIT-SLICED TREE: no scalar multiples, log2(B) dependent additions instead of the ~45 dependent
+// group operations of the segment form above, and 2 additions per bucket in total.
+//   sum_b (b+1) B_b = S + sum_k 2^k M_k,   S = sum of the window's buckets,  M_k = sum of the buckets whose index has bit k set.
+// Level l = 0 .. c-2 halves the node count; node i of level l covers buckets [i 2^(l+1), (i+1) 2^(l+1)) and holds
+//   S^l[i]   = S^(l-1)[2i] + S^(l-1)[2i+1]                       (S^(-1) = the buckets themselves)
+//   M_k^l[i] = M_k^(l-1)[2i] + M_k^(l-1)[2i+1]     for k < l-1
+//   M_(l-1)^l[i] = S^(l-2)[4i+1] + S^(l-2)[4i+3]                 (M_(l-1)^(l-1)[j] is S^(l-2)[2j+1]: an alias, never copied)
+// so a level is (l+1) * nodes INDEPENDENT additions: one lane each.  The S levels are kept (their odd entries are read two
+// levels later), the M slots ping-pong.  The last level writes fin[w][0] = S, fin[w][1+k] = M_k (k < c-1) and the host runs
+// the Horner fold over single bits (h_fold_tree64): the W*c doublings it already did, W*c additions instead of W.
+template <class M>
+struct TreeLevelArgs {
+    const XYZZ<M>* s_prev;   // S^(l-1): 2 n entries (the buckets at l = 0)
+    const XYZZ<M>* s_prev2;  // S^(l-2): 4 n entries (the buckets at l = 1; unused at l = 0)
+    const XYZZ<M>* m_prev;   // M^(l-1): slot k at m_prev + k * m_prev_stride, k < l-1
+    XYZZ<M>* s_out;          // S^l: n entries
+    XYZZ<M>* m_out;          // M^l: slot k at m_out + k * m_out_stride, k < l
+    XYZZ<M>* fin;            // last level only: [W][nlev + 1]
+    uint32_t n;              // nodes of this level, all windows together
+    uint32_t m_prev_stride, m_out_stride;
+    uint32_t l;
+    uint32_t nlev;           // c - 1
+    uint32_t last;           // 1: write fin instead of s_out / m_out (+ one copy task per node for the aliased M_l)
+};
+
+// one addition (or, at the last level, one copy) of level a.l; s = slot, i = node (global index: the S levels and fin),
+// jp / jo = the node's index inside the m_prev / m_out slot arrays
+template <class M>
+__device__ __forceinline__ void tree_task(const TreeLevelArgs<M>& a, uint32_t s, uint32_t i, uint32_t jp, uint32_t jo) {
+    const XYZZ<M>*pa, *pb;
+    if (s == a.l + 1) {                           // last level: the aliased top slot is copied into fin
+        XYZZ<M> v = load_xyzz<M>(a.s_prev + 2 * (size_t)i + 1);
+        store_xyzz<M>(a.fin + (size_t)i * (a.nlev + 1) + 1 + a.l, v);
+        return;
+    }
+    if (s == a.l) { pa = a.s_prev + 2 * (size_t)i; pb = pa + 1; }
+    else if (s + 1 == a.l) { pa = a.s_prev2 + 4 * (size_t)i + 1; pb = pa + 2; }
+    else { pa = a.m_prev + (size_t)s * a.m_prev_stride + 2 * (size_t)jp; pb = pa + 1; }
+    XYZZ<M> x = load_xyzz<M>(pa), y = load_xyzz<M>(pb);
+    xyzz_add_cold<M>(&x, &y);
+    XYZZ<M>* out;
+    if (a.last) out = a.fin + (size_t)i * (a.nlev + 1) + (s == a.l ? 0 : 1 + s);
+    else out = (s == a.l) ? a.s_out + i : a.m_out + (size_t)s * a.m_out_stride + jo;
+    store_xyzz<M>(out, x);
+}
+
+// one level over all windows: grid covers (l + 1 + last) * n tasks, node index fastest (coalesced 256-B reads per lane pair)
+template <class C>
+__global__ void __launch_bounds__(256)
+k_tree_level(TreeLevelArgs<typename C::Fp> a) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t slots = a.l + 1 + a.last;
+    if (t >= slots * a.n) return;
+    const uint32_t i = t % a.n;
+    tree_task<typename C::Fp>(a, t / a.n, i, i, i);
+}
+
+// the last levels l0 .. nlev-1 of ONE window per block (few nodes are left: launch gaps would dominate).  The levels
+// exchange their nodes through global memory, a block-wide barrier between them.  Blocks run at their own pace, so the M
+// slots of the tail are PRIVATE to the window (m_tail halves, per_window entries each per window) -- the all-window slot
+// arrays of the level kernels interleave windows and change layout from level to level; only level l0 reads them.
+// s_lev[l] = S^l (all windows: a node's address does not depend on the level another window is at).
+template <class M>
+struct TreeTailArgs {
+    const XYZZ<M>* buckets;
+    XYZZ<M>* s_lev[24];
+    const XYZZ<M>* m_global;  // M^(l0-1) as written by k_tree_level (stride 2 * (nb >> (l0+1)))
+    XYZZ<M>* m_tail[2];
+    XYZZ<M>* fin;
+    uint32_t nb;      // W * B
+    uint32_t B;
+    uint32_t per_window;
+    uint32_t l0;
+    uint32_t nlev;
+};
+template <class C>
+__global__ void __launch_bounds__(1024)
+k_tree_tail(TreeTailArgs<typename C::Fp> a) {
+    using M = typename C::Fp;
+    const uint32_t w = blockIdx.x;
+    for (uint32_t l = a.l0; l < a.nlev; l++) {
+        const uint32_t nw = a.B >> (l + 1);            // nodes of this window at level l
+        TreeLevelArgs<M> lv;
+        lv.s_prev = l ? a.s_lev[l - 1] : a.buckets;
+        lv.s_prev2 = l >= 2 ? a.s_lev[l - 2] : a.buckets;
+        lv.n = a.nb >> (l + 1);
+        const bool first = (l == a.l0);
+        lv.m_prev = first ? a.m_global : a.m_tail[(l + 1) & 1] + (size_t)w * a.per_window;
+        lv.m_prev_stride = first ? 2 * lv.n : 2 * nw;
+        lv.s_out = a.s_lev[l];
+        lv.m_out = a.m_tail[l & 1] + (size_t)w * a.per_window;
+        lv.m_out_stride = nw;
+        lv.fin = a.fin;
+        lv.l = l;
+        lv.nlev = a.nlev;
+        lv.last = (l + 1 == a.nlev) ? 1u : 0u;
+        const uint32_t tasks = (l + 1 + lv.last) * nw;
+        for (uint32_t t = threadIdx.x; t < tasks; t += blockDim.x) {
+            const uint32_t j = t % nw, i = w * nw + j;
+            tree_task<M>(lv, t / nw, i, first ? i : j, j);
+        }
+        __threadfence();
+        __syncthreads();
+    }
+}
+
 // wave per multi-item bucket: buckets[b] = sum of its item sums (ctrl[2] buckets listed in heavy_list)
 template <class C>
 __global__ void __launch_bounds__(64)

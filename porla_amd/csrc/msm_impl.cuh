@@ -4,6 +4,8 @@
 #include "engine.hpp"
 #include "host_fold64.hpp"
 #include <cstdlib>
+#include <chrono>
+#include <cstdio>
 #include "../../include/porla_gpu.h"
 
 namespace porla {
@@ -17,6 +19,24 @@ static inline uint32_t reduce_segment(size_t total_buckets, uint32_t B) {
     while (L < 8 && total_buckets / L > 65536) L *= 2;
     if (Lenv) L = Lenv;
     return B < L ? B : L;
+}
+
+// Bucket reduction: the bit-sliced tree of msm.cuh (default) or the older segment form (PORLA_REDUCE=segment, kept for A/B runs).
+static inline bool reduce_is_tree() {
+    static const bool tree = !(getenv("PORLA_REDUCE") && getenv("PORLA_REDUCE")[0] == 's');
+    return tree;
+}
+// threads of the per-window tail block: the tail takes over at the first level whose additions per window fit one pass
+static inline uint32_t tree_tail_threads() {
+    static const uint32_t t = getenv("PORLA_TREE_TAIL") ? (uint32_t)atoi(getenv("PORLA_TREE_TAIL")) : 256u;
+    uint32_t r = (t + 63) / 64 * 64;
+    return r < 64 ? 64 : (r > 1024 ? 1024 : r);
+}
+static inline uint32_t tree_tail_start(uint32_t B, uint32_t nlev) {
+    const uint32_t cap = tree_tail_threads();
+    uint32_t l = 0;
+    while (l + 1 < nlev && (l + 1) * (B >> (l + 1)) > cap) l++;
+    return l;
 }
 
 // Window width for m sub-scalars of `bits` bits, from a time model in microseconds fitted to the sweeps in profiles/
@@ -66,9 +86,13 @@ static inline int choose_window(size_t m, int bits) {
     return best;
 }
 
+#define PORLA_TRACE(tag) do { if (trace_on) { auto now = std::chrono::steady_clock::now(); \
+    fprintf(stderr, "[trace slot %d] %-18s %8.1f us\n", ws->slot, tag, std::chrono::duration<double, std::micro>(now - t_tr).count()); t_tr = now; } } while (0)
 template <class C>
 static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_points_be, size_t n, hipStream_t stream) {
     using M = typename C::Fp;
+    static const bool trace_on = getenv("PORLA_TRACE_LAUNCH") != nullptr;
+    auto t_tr = std::chrono::steady_clock::now();
     ws->pend_W = 0;
     if (n == 0) return PORLA_OK;
     if (n >= (1ull << 30)) { set_last_error("porla: MSM length must be < 2^30"); return PORLA_ERR_ARG; }
@@ -81,7 +105,7 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
         if (ws->h_windows_cap < 64 * 1024) {
             if (ws->h_windows) PORLA_HIP(hipHostFree(ws->h_windows));
             ws->h_windows_cap = 64 * 1024;
-            PORLA_HIP(hipHostMalloc(&ws->h_windows, ws->h_windows_cap, hipHostMallocDefault));
+            PORLA_HIP(hipHostMalloc(&ws->h_windows, ws->h_windows_cap, hipHostMallocMapped));
         }
         int rc0;
         if ((rc0 = ws->cursor.ensure((CTRL_WORDS + 8) * 4))) return rc0;
@@ -131,12 +155,22 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
     if ((rc = ws->buckets.ensure(nb * sizeof(XYZZ<M>)))) return rc;
     if ((rc = ws->partial.ensure((size_t)W * wavesPerWindow * sizeof(XYZZ<M>)))) return rc;
     if ((rc = ws->windows.ensure((size_t)W * sizeof(XYZZ<M>)))) return rc;
-    if (ws->h_windows_cap < (size_t)W * sizeof(XYZZ<M>)) {
+    const bool tree = reduce_is_tree();
+    const uint32_t nlev = (uint32_t)(c - 1);
+    if (tree) {
+        if ((rc = ws->tree_s.ensure((nb + 1) * sizeof(XYZZ<M>)))) return rc;               // all S levels: nb/2 + nb/4 + ...
+        if ((rc = ws->tree_m.ensure((2 * (nb / 4) + 2) * sizeof(XYZZ<M>)))) return rc;     // two ping-pong halves
+        if ((rc = ws->tree_mt.ensure((2 * (size_t)W * (B / 4 + 1) + 2) * sizeof(XYZZ<M>)))) return rc;  // the tail's private halves
+    }
+    if (ws->h_windows_cap < (size_t)W * c * sizeof(XYZZ<M>)) {
         if (ws->h_windows) PORLA_HIP(hipHostFree(ws->h_windows));
         ws->h_windows_cap = 64 * 1024;
-        PORLA_HIP(hipHostMalloc(&ws->h_windows, ws->h_windows_cap, hipHostMallocDefault));
+        PORLA_HIP(hipHostMalloc(&ws->h_windows, ws->h_windows_cap, hipHostMallocMapped));
     }
+    void* h_windows_dev = nullptr;
+    PORLA_HIP(hipHostGetDevicePointer(&h_windows_dev, ws->h_windows, 0));
 
+    PORLA_TRACE("alloc");
     uint32_t* ctrl = (uint32_t*)ws->cursor.p;
     PORLA_HIP(hipMemsetAsync(ctrl, 0, CTRL_WORDS * 4, stream));
     const Affine<M>* pts = (const Affine<M>*)ws->pts.p;
@@ -149,6 +183,7 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
             hipLaunchKernelGGL((k_points_to_mont<C, false>), dim3((n32 + 255) / 256), dim3(256), 0, stream, d_points_be,
                                (Affine<M>*)ws->pts.p, n32);
     }
+    PORLA_TRACE("to_mont");
     const int lowbits = sort_lowbits(c);
     const int P = 1 << (c - 1 - lowbits);
     {
@@ -166,6 +201,7 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
                            (const uint16_t*)ws->tile_off.p, T_tiles, tile_cap, c, lowbits, (uint32_t*)ws->counts.p,
                            (uint32_t*)ws->starts.p, (uint32_t*)ws->entries.p, ctrl);
     }
+    PORLA_TRACE("sort");
     {
         ProfScope ps("size_order", stream);
         hipLaunchKernelGGL(k_size_hist, dim3(nblk), dim3(1024), 0, stream, (const uint32_t*)ws->counts.p, (uint32_t)nb,
@@ -176,19 +212,67 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
                            (const uint32_t*)ws->blk_off.p, nblk, (uint2*)ws->order.p, (uint32_t*)ws->fill.p,
                            (uint32_t*)ws->heavy.p, ctrl, (uint4*)ws->buckets.p);
     }
+    PORLA_TRACE("size_order");
     {
-        ProfScope ps("bucket_sum", stream);
+        ProfScope ps("bucket_sum", stream, true);
         hipLaunchKernelGGL((k_bucket_sum<C>), dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, stream, pts,
                            (const uint32_t*)ws->entries.p, (const uint32_t*)ws->starts.p,
                            (const uint32_t*)ws->counts.p, (const uint2*)ws->order.p, (const uint32_t*)ws->fill.p,
                            (const uint32_t*)ctrl, (XYZZ<M>*)ws->buckets.p, (XYZZ<M>*)ws->chunk_out.p);
     }
+    PORLA_TRACE("bucket_sum");
     {
         ProfScope ps("bucket_combine", stream);
         hipLaunchKernelGGL((k_bucket_combine<C>), dim3(2048), dim3(64), 0, stream, (const uint32_t*)ws->heavy.p,
                            (const uint32_t*)ws->fill.p, (const uint32_t*)ws->counts.p, (const uint32_t*)ctrl,
                            (const XYZZ<M>*)ws->chunk_out.p, (XYZZ<M>*)ws->buckets.p);
     }
+    PORLA_TRACE("combine");
+    if (tree) {
+        // S level l at tree_s + (nb - (nb >> l)) (nb/2 + ... + nb/2^l entries before it); M slots of level l in half l & 1
+        XYZZ<M>* s_base = (XYZZ<M>*)ws->tree_s.p;
+        XYZZ<M>* m_half[2] = {(XYZZ<M>*)ws->tree_m.p, (XYZZ<M>*)ws->tree_m.p + nb / 4 + 1};
+        auto s_level = [&](uint32_t l) { return s_base + (nb - (nb >> l)); };
+        const uint32_t l0 = tree_tail_start(B, nlev);
+        {
+            ProfScope ps("bucket_reduce", stream);
+            for (uint32_t l = 0; l < l0; l++) {
+                TreeLevelArgs<M> a;
+                a.s_prev = l ? s_level(l - 1) : (const XYZZ<M>*)ws->buckets.p;
+                a.s_prev2 = l >= 2 ? s_level(l - 2) : (const XYZZ<M>*)ws->buckets.p;
+                a.m_prev = m_half[(l + 1) & 1];
+                a.s_out = s_level(l);
+                a.m_out = m_half[l & 1];
+                a.fin = nullptr;   // only the tail holds the last level
+                a.n = (uint32_t)(nb >> (l + 1));
+                a.m_prev_stride = 2 * a.n; a.m_out_stride = a.n;
+                a.l = l; a.nlev = nlev; a.last = 0;
+                const size_t tasks = (size_t)(l + 1) * a.n;
+                hipLaunchKernelGGL((k_tree_level<C>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, stream, a);
+                PORLA_TRACE("tree_level");
+            }
+        }
+        {
+            ProfScope ps("window_reduce", stream);
+            TreeTailArgs<M> t;
+            t.buckets = (const XYZZ<M>*)ws->buckets.p;
+            for (uint32_t l = 0; l < 24; l++) t.s_lev[l] = l < nlev ? s_level(l) : nullptr;
+            t.m_global = m_half[(l0 + 1) & 1];
+            t.per_window = B / 4 + 1;
+            t.m_tail[0] = (XYZZ<M>*)ws->tree_mt.p; t.m_tail[1] = (XYZZ<M>*)ws->tree_mt.p + (size_t)W * t.per_window + 1;
+            t.fin = (XYZZ<M>*)h_windows_dev;
+            t.nb = (uint32_t)nb; t.B = B; t.l0 = l0; t.nlev = nlev;
+            uint32_t need = (l0 + 2) * (B >> (l0 + 1));
+            uint32_t threads = (need + 63) / 64 * 64;
+            if (threads > tree_tail_threads()) threads = tree_tail_threads();
+            if (threads < 64) threads = 64;
+            hipLaunchKernelGGL((k_tree_tail<C>), dim3(W), dim3(threads), 0, stream, t);
+            PORLA_TRACE("tree_tail");
+        }
+        // no copy packet: the last level stores its W * c results straight into the pinned host buffer (a D2H hipMemcpyAsync
+        // was seen to block the launching thread for milliseconds while another MSM is in flight)
+        PORLA_HIP(hipGetLastError());
+    } else {
     {
         ProfScope ps("bucket_reduce", stream);
         hipLaunchKernelGGL((k_bucket_reduce<C>), dim3(W * wavesPerWindow), dim3(64), 0, stream,
@@ -201,10 +285,14 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
     }
     PORLA_HIP(hipGetLastError());
     PORLA_HIP(hipMemcpyAsync(ws->h_windows, ws->windows.p, (size_t)W * sizeof(XYZZ<M>), hipMemcpyDeviceToHost, stream));
+    }
+    PORLA_TRACE("reduce");
     if (!ws->done) PORLA_HIP(hipEventCreateWithFlags(&ws->done, hipEventDisableTiming));
     PORLA_HIP(hipEventRecord(ws->done, stream));
+    PORLA_TRACE("event");
     ws->pend_W = W;
     ws->pend_c = c;
+    ws->pend_tree = tree;
     g_last_shape[0] = c; g_last_shape[1] = W; g_last_shape[2] = glv ? 1 : 0;
     return PORLA_OK;
 }
@@ -215,7 +303,8 @@ static int msm_finish(Workspace* ws, XYZZ<typename C::Fp>* total) {
     using M = typename C::Fp;
     if (ws->pend_W == 0) { *total = xyzz_inf<M>(); return PORLA_OK; }
     PORLA_HIP(hipEventSynchronize(ws->done));
-    *total = h_fold_windows64<M>((const XYZZ<M>*)ws->h_windows, ws->pend_W, ws->pend_c);
+    *total = ws->pend_tree ? h_fold_tree64<M>((const XYZZ<M>*)ws->h_windows, ws->pend_W, ws->pend_c)
+                           : h_fold_windows64<M>((const XYZZ<M>*)ws->h_windows, ws->pend_W, ws->pend_c);
     ws->pend_W = 0;
     return PORLA_OK;
 }

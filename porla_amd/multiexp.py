@@ -233,7 +233,8 @@ def kzg_complement_batch_device(d_scalars, n, d_out, stream=0):
 
 
 def profile_enable(on=True):
-    lib.porla_gpu_profile_enable(1 if on else 0)
+    """False/0: off; True/1: HIP events around every kernel; 2: around the workload's dominant kernel only"""
+    lib.porla_gpu_profile_enable(int(on))
 
 
 def kzg_commit_shape():
