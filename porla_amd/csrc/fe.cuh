@@ -40,6 +40,12 @@ struct Bn254Fp {
     static constexpr int SPARE_BITS = 2;            // p < 2^254
     static constexpr bool PSEUDO_MERSENNE = false;
     static constexpr uint32_t FOLD = 0;
+    // reduced-radix form (fe30.cuh, Montgomery radix 2^270): 2^270 mod p, and 2^(256+270) mod p -- the factor that takes a
+    // plain residue into the 2^270 form through fe_mul (which divides by 2^256)
+    static constexpr uint32_t R1_30[8] = {0x5accccc9u, 0xf89a7d3au, 0x9a1dcc9du, 0x50fea7bdu,
+                                          0xdf1160f4u, 0x9e7d8ca3u, 0xed6d3304u, 0x279be39au};
+    static constexpr uint32_t R2_30[8] = {0x5b61e465u, 0x0c82ea1du, 0xf298bc82u, 0x87f2ef02u,
+                                          0x4050e665u, 0x9938cdbeu, 0xdf213851u, 0x2c026cedu};
 };
 
 // secp256k1 base field p = 2^256 - 2^32 - 977 (field_5x52.h:13-15 of the vendored tree).  Like the reference's own field

@@ -27,6 +27,7 @@
 // The accumulation is VALU (integer multiply) bound at 91 % of the mixed-addition peak, see DESIGN.md s4.
 #pragma once
 #include "ec.cuh"
+#include "ec30.cuh"
 #include "glv.cuh"
 
 namespace porla {
@@ -42,6 +43,8 @@ struct Bn254G1 {
     // 254-bit scalars fill 16 windows of 16 bits exactly; the GLV split would halve the windows but double the entries per
     // bucket and the gathered point set (measured: 3.31 ms vs 2.85 ms at 2^20) -- off by default, on with porla_gpu_set_msm_glv(1)
     static constexpr bool GLV_DEFAULT = false;
+    // bucket accumulation in the reduced-radix field form (fe30.cuh / ec30.cuh): 1.2-1.5x the field-product rate
+    static constexpr bool F30_BUCKETS = true;
 };
 struct Secp256k1G {
     using Fp = Secp256k1Fp;
@@ -53,6 +56,7 @@ struct Secp256k1G {
     // 256-bit scalars need a carry-only 17th window at c = 16 (one bucket with half of all entries); the GLV split (which
     // the reference's secp256k1 path also applies, ecmult_impl.h:621-634) gives 8 windows of 17 bits instead
     static constexpr bool GLV_DEFAULT = true;
+    static constexpr bool F30_BUCKETS = false;   // the special-form product of secp256k1's field is already cheaper
 };
 
 constexpr uint32_t KEY_NONE = 0xffffffffu;
@@ -119,7 +123,9 @@ __device__ __forceinline__ XYZZ<M> load_xyzz(const XYZZ<M>* src) {
 // ------------------------------------------------------------------------------------------------
 // G1Affine.Unmarshal semantics for the uncompressed form (main.go:130): X, Y <- SetBytes (reduced
 // mod p); (0,0) stays (0,0) = infinity.  Output: Montgomery limbs, 64 B per point.
-template <class C, bool GLV>
+// F30: the residues are stored in the 2^270 Montgomery form of fe30.cuh (still canonical 256-bit values) -- the MSM's
+// bucket accumulation with C::F30_BUCKETS; every other consumer takes the 2^256 form.
+template <class C, bool GLV, bool F30 = false>
 __global__ void k_points_to_mont(const uint8_t* __restrict__ in, Affine<typename C::Fp>* __restrict__ out, uint32_t n) {
     using M = typename C::Fp;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -129,8 +135,16 @@ __global__ void k_points_to_mont(const uint8_t* __restrict__ in, Affine<typename
     load_be256(y.v, in + (size_t)i * 64 + 32);
     fe_reduce_plain<M>(x.v, 6);
     fe_reduce_plain<M>(y.v, 6);
-    x = fe_to_mont<M>(x);
-    y = fe_to_mont<M>(y);
+    if constexpr (F30) {
+        Fe<M> r2;
+#pragma unroll
+        for (int k = 0; k < 8; k++) r2.v[k] = M::R2_30[k];
+        x = fe_mul<M>(x, r2);
+        y = fe_mul<M>(y, r2);
+    } else {
+        x = fe_to_mont<M>(x);
+        y = fe_to_mont<M>(y);
+    }
     if (GLV) {
         // P at 2i, phi(P) = (beta * x, y) at 2i + 1; infinity (0, 0) stays (0, 0)
         Fe<M> beta;
@@ -564,6 +578,41 @@ k_bucket_sum(const Affine<typename C::Fp>* __restrict__ pts, const uint32_t* __r
     const uint32_t cb = chunk_base[b];
     if (cb == NO_CHUNK) store_xyzz<M>(buckets + b, acc);
     else store_xyzz<M>(chunk_out + cb + item.y, acc);
+}
+
+// The same accumulation in the reduced-radix field form (ec30.cuh): the points arrive in the 2^270 Montgomery form
+// (k_points_to_mont with C::F30_BUCKETS), the item's sum leaves in the 2^256 form every later kernel works in.
+template <class C, int V>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V == 0 ? 3 : (V == 1 ? 4 : 2), V == 0 ? 3 : (V == 1 ? 4 : 2))))
+k_bucket_sum30(const Affine<typename C::Fp>* __restrict__ pts, const uint32_t* __restrict__ entries,
+               const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
+               const uint2* __restrict__ order, const uint32_t* __restrict__ chunk_base,
+               const uint32_t* __restrict__ ctrl, XYZZ<typename C::Fp>* __restrict__ buckets,
+               XYZZ<typename C::Fp>* __restrict__ chunk_out) {
+    using M = typename C::Fp;
+    uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= ctrl[3]) return;
+    uint2 item = order[tid];
+    const uint32_t b = item.x;
+    const uint32_t first = item.y * CHUNK;
+    uint32_t cnt = counts[b] - first;
+    if (cnt > CHUNK) cnt = CHUNK;
+    const uint32_t* e = entries + starts[b] + first;
+    XYZZ30<M> acc;
+    acc.inf = true;
+    uint32_t ent = e[0];
+    for (uint32_t k = 0; k < cnt; k++) {
+        uint32_t cur = ent;
+        if (k + 1 < cnt) ent = e[k + 1];
+        Affine<M> a = load_affine<M>(pts, cur & 0x7fffffffu);
+        if (aff_is_inf<M>(a)) continue;
+        a = aff_neg_if<M>(a, (cur >> 31) != 0);
+        xyzz30_madd<M>(acc, f30_from_fe<M>(a.x), f30_from_fe<M>(a.y));
+    }
+    const XYZZ<M> out = xyzz30_to_xyzz<M>(acc);
+    const uint32_t cb = chunk_base[b];
+    if (cb == NO_CHUNK) store_xyzz<M>(buckets + b, out);
+    else store_xyzz<M>(chunk_out + cb + item.y, out);
 }
 
 

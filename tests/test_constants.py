@@ -17,7 +17,7 @@ def struct_tables(path, struct):
     assert m, struct
     body = m.group(1)
     out = {}
-    for name in ("P", "R1", "R2", "ORDER"):
+    for name in ("P", "R1", "R2", "ORDER", "R1_30", "R2_30"):
         mm = re.search(r"\b%s\[8\]\s*=\s*\{([^}]*)\}" % name, body)
         if mm:
             out[name] = [int(x.strip().rstrip("u"), 0) for x in mm.group(1).split(",") if x.strip()]
@@ -40,6 +40,8 @@ def test_field_parameter_packs():
             assert p == 2**256 - 2**32 - 977
         else:
             assert t["R1"] == m["R1"] and t["R2"] == m["R2"], struct
+        if struct == "Bn254Fp":   # reduced-radix form of fe30.cuh: Montgomery radix 2^270
+            assert t["R1_30"] == gc.limbs(pow(2, 270, p)) and t["R2_30"] == gc.limbs(pow(2, 256 + 270, p))
 
 
 def test_group_orders():
@@ -52,3 +54,12 @@ def test_final_exponent_and_ate_loop():
     text = open(os.path.join(CSRC, "pairing_host.hpp")).read()
     m = re.search(r"S\[4\]\s*=\s*\{([^}]*)\}", text)
     assert [int(x.strip().rstrip("u"), 0) for x in m.group(1).split(",")] == gc.limbs(6 * gc.BN_X ** 2, 4)
+
+
+def test_reduced_radix_column_sums_fit_64_bits():
+    """fe30.cuh accumulates the 16..18 products of a column in one 64-bit register without carries: the worst case must fit"""
+    import check_fe30_bounds as cb
+    assert all(cb.check(name, p) for name, p in cb.MODULI.items())
+    # and the generated assembly is what the generator produces
+    import gen_fe30_asm as g30
+    assert open(os.path.join(CSRC, "fe30_mul_gfx950.inc")).read() == g30.HDR + "\n" + g30.gen(False) + "\n" + g30.gen(True)

@@ -17,3 +17,14 @@ def test_assembly_product_matches_portable_product():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.strip().endswith("OK")
+
+
+def test_reduced_radix_product_matches_portable_product():
+    """fe30.cuh (9 x 30-bit limbs, radix 2^270; the bucket accumulation's field form): the generated assembly blocks equal
+    the portable form limb for limb and the 8 x 32-bit Montgomery product after the radix change, for reduced, unreduced
+    (< 2^258), all-ones, p and 1 operands, products and squares, over every modulus (tools/fe30_check.hip)"""
+    exe = os.path.join(common.ROOT, "porla_amd", "fe30_check")
+    assert os.path.exists(exe), "build it with make -C porla_amd/csrc"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("0 mismatches") == 3, r.stdout

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Worst-case column sums of fe30.cuh:f30_mul / f30_sqr for every modulus the engine uses: all must stay below 2^64.
+Operand limbs 0..7 <= 2^30 - 1, limb 8 <= TOP - 1 (value < 2^258 -> TOP = 2^18); m_i <= 2^30 - 1; the modulus limbs are exact."""
+MODULI = {
+    "bn254_p": 21888242871839275222246405745257275088696311157297823662689037894645226208583,
+    "bn254_r": 21888242871839275222246405745257275088548364400416034343698204186575808495617,
+    "p_icc": 207 * 2**248 + 1,
+}
+MASK = 2**30 - 1
+def check(name, p, top_bits=18):
+    P = [(p >> (30 * i)) & MASK for i in range(9)]
+    amax = [MASK] * 8 + [2**top_bits - 1]
+    carry = 0
+    worst = 0
+    for k in range(17):
+        t = carry
+        for i in range(9):
+            j = k - i
+            if 0 <= j <= 8:
+                t += amax[i] * amax[j]
+                if not (k < 9 and i == k):
+                    pass
+        # reduction products m_i * P_{k-i}, i <= min(k, 8); for k < 9 this includes m_k * P_0
+        for i in range(9):
+            j = k - i
+            if 0 <= j <= 8:
+                t += MASK * P[j]
+        worst = max(worst, t)
+        carry = t >> 30
+    ok = worst < 2**64
+    print("%-8s worst column %.4f x 2^64  %s" % (name, worst / 2**64, "ok" if ok else "OVERFLOW"))
+    return ok
+if __name__ == "__main__":
+    import sys
+    sys.exit(0 if all([check(n, p) for n, p in MODULI.items()]) else 1)
