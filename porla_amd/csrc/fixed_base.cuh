@@ -21,6 +21,7 @@
 //   k_fb_finish        lane = row: one inversion, Montgomery -> big-endian X||Y (64 zero bytes = infinity)
 #pragma once
 #include "msm.cuh"
+#include <type_traits>
 
 namespace porla {
 
@@ -142,6 +143,14 @@ k_fb_normalize(const XYZZ<typename C::Fp>* __restrict__ scratch, size_t n, Affin
             Fe<M> iz = fe_mul_call<M>(inv, prefix);
             inv = fe_mul_call<M>(inv, p.zzz);
             a = xyzz_to_affine_with_inv<M>(p, iz);
+            if constexpr (C::F30_BUCKETS) {
+                // the table feeds k_fb_commit's reduced-radix accumulation: residues in the 2^270 Montgomery form
+                Fe<M> r1;
+#pragma unroll
+                for (int q = 0; q < 8; q++) r1.v[q] = M::R1_30[q];
+                a.x = fe_mul_call<M>(a.x, r1);
+                a.y = fe_mul_call<M>(a.y, r1);
+            }
         }
         store_affine<M>(table + e, a);
     }
@@ -166,7 +175,11 @@ k_fb_commit(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_coeffs
     const uint32_t Bh = 1u << (c - 1);
     const uint32_t mask = (1u << c) - 1;
     const uint8_t* row = rows + (size_t)r * row_stride;
-    XYZZ<M> acc = xyzz_inf<M>();
+    // accumulator: the reduced-radix form of ec30.cuh where the curve has it (the table is then in the 2^270 form too)
+    using Acc = typename std::conditional<C::F30_BUCKETS, XYZZ30<M>, XYZZ<M>>::type;
+    Acc acc;
+    if constexpr (C::F30_BUCKETS) acc.inf = true;
+    else acc = xyzz_inf<M>();
     for (uint32_t i = i0; i < i1; i++) {
         uint32_t t[8];
         load_be256(t, row + (size_t)i * 32);
@@ -216,14 +229,19 @@ k_fb_commit(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_coeffs
             }
             if (cur_valid) {
                 Affine<M> a = aff_neg_if<M>(cur, cur_neg);
-                xyzz_madd<M>(acc, a);
+                if constexpr (C::F30_BUCKETS) {
+                    if (!aff_is_inf<M>(a)) xyzz30_madd<M>(acc, f30_from_fe<M>(a.x), f30_from_fe<M>(a.y));
+                } else {
+                    xyzz_madd<M>(acc, a);
+                }
             }
             if (nxt_valid) cur = nxt;
             cur_valid = nxt_valid;
             cur_neg = nxt_neg;
         }
     }
-    store_xyzz<M>(partial + (size_t)r * S + s, acc);
+    if constexpr (C::F30_BUCKETS) store_xyzz<M>(partial + (size_t)r * S + s, xyzz30_to_xyzz<M>(acc));
+    else store_xyzz<M>(partial + (size_t)r * S + s, acc);
 }
 
 // G lanes per row (G a power of two, 2 <= G <= 64, G <= S): fold the S slice partials of a row into partial[row * S]
