@@ -86,6 +86,103 @@ __device__ __forceinline__ void xyzz30_madd(XYZZ30<M>& p, const F30<M>& ax, cons
     p.zzz = f30_mul<M>(p.zzz, PPP);
 }
 
+// 2 * p (dbl-2008-s-1, a = 0); p not infinity.  Out of line, operands by value (see xyzz30_double_affine).
+//   U = 2 Y1 (<= 6), V = U^2, W = U V, S = X1 V, M = 3 X1^2 (<= 3), X3 = M^2 - 2S + 3p (<= 4), Y3 = M (S - X3 + 5p) - W Y1 + 2p (<= 3)
+template <class M>
+__device__ __noinline__ XYZZ30<M> xyzz30_double(F30<M> x, F30<M> y, F30<M> zz, F30<M> zzz) {
+    XYZZ30<M> r;
+    F30<M> U = f30_small_mul<M, 2>(y);
+    F30<M> V = f30_sqr<M>(U);
+    F30<M> W = f30_mul<M>(U, V);
+    F30<M> S = f30_mul<M>(x, V);
+    F30<M> XX = f30_sqr<M>(x);
+    F30<M> Mm = f30_small_mul<M, 3>(XX);
+    F30<M> MM = f30_sqr<M>(Mm);
+    F30<M> S2 = f30_small_mul<M, 2>(S);
+    F30<M> X3 = f30_sub<M, 3>(MM, S2);
+    F30<M> D = f30_sub<M, 5>(S, X3);
+    F30<M> T1 = f30_mul<M>(Mm, D);
+    F30<M> T2 = f30_mul<M>(W, y);
+    r.x = X3;
+    r.y = f30_sub<M, 2>(T1, T2);
+    r.zz = f30_mul<M>(V, zz);
+    r.zzz = f30_mul<M>(W, zzz);
+    r.inf = f30_product_is_zero<M>(V);
+    return r;
+}
+
+// p += q (add-2008-s), all exceptional cases.  Bounds as for the mixed form: X <= 5, Y <= 3, ZZ, ZZZ <= 1 on both sides;
+//   U1 = X1 ZZ2, U2 = X2 ZZ1, S1 = Y1 ZZZ2, S2 = Y2 ZZZ1 (<= 1);  P = U2 - U1 + 2p (<= 3);  R = S2 - S1 + 2p (<= 3);
+//   Q = U1 PP;  X3 = RR - (PPP + 2Q) + 4p (<= 5);  Y3 = R (Q - X3 + 6p) - S1 PPP + 2p (<= 3)
+template <class M>
+__device__ __forceinline__ void xyzz30_add(XYZZ30<M>& p, const XYZZ30<M>& q) {
+    if (q.inf) return;
+    if (p.inf) { p = q; return; }
+    F30<M> U1 = f30_mul<M>(p.x, q.zz);
+    F30<M> U2 = f30_mul<M>(q.x, p.zz);
+    F30<M> S1 = f30_mul<M>(p.y, q.zzz);
+    F30<M> S2 = f30_mul<M>(q.y, p.zzz);
+    F30<M> Pp = f30_sub<M, 2>(U2, U1);
+    F30<M> Rr = f30_sub<M, 2>(S2, S1);
+    F30<M> PP = f30_sqr<M>(Pp);
+    F30<M> RR = f30_sqr<M>(Rr);
+    if (f30_product_is_zero<M>(PP)) {
+        if (f30_product_is_zero<M>(RR)) p = xyzz30_double<M>(p.x, p.y, p.zz, p.zzz);
+        else p.inf = true;
+        return;
+    }
+    F30<M> PPP = f30_mul<M>(Pp, PP);
+    F30<M> Q = f30_mul<M>(U1, PP);
+    F30<M> E = f30_add2<M>(PPP, Q);
+    F30<M> X3 = f30_sub<M, 4>(RR, E);
+    F30<M> D = f30_sub<M, 6>(Q, X3);
+    F30<M> T1 = f30_mul<M>(Rr, D);
+    F30<M> T2 = f30_mul<M>(S1, PPP);
+    p.x = X3;
+    p.y = f30_sub<M, 2>(T1, T2);
+    p.zz = f30_mul<M>(f30_mul<M>(p.zz, q.zz), PP);
+    p.zzz = f30_mul<M>(f30_mul<M>(p.zzz, q.zzz), PPP);
+}
+
+// Memory form between the kernels of the reduced-radix path ("lazy"): the four residues in the 2^270 Montgomery form, NOT
+// reduced (X <= 5p + 2^246 < 2^256 and the others below that), each packed into 8 words; infinity = all words zero (a
+// finite point's ZZ is never 0 mod p, and a stored ZZ is a product's result, so it is never the word pattern 0).
+template <class M>
+__device__ __forceinline__ void xyzz30_store_lazy(XYZZ<M>* dst, const XYZZ30<M>& p) {
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+    if (p.inf) {
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        uint4* q = reinterpret_cast<uint4*>(d);
+#pragma unroll
+        for (int i = 0; i < 8; i++) q[i] = z;
+        return;
+    }
+    Fe<M> t;
+    f30_pack<M>(t.v, p.x);   { uint4* q = reinterpret_cast<uint4*>(d);      q[0] = make_uint4(t.v[0], t.v[1], t.v[2], t.v[3]); q[1] = make_uint4(t.v[4], t.v[5], t.v[6], t.v[7]); }
+    f30_pack<M>(t.v, p.y);   { uint4* q = reinterpret_cast<uint4*>(d + 8);  q[0] = make_uint4(t.v[0], t.v[1], t.v[2], t.v[3]); q[1] = make_uint4(t.v[4], t.v[5], t.v[6], t.v[7]); }
+    f30_pack<M>(t.v, p.zz);  { uint4* q = reinterpret_cast<uint4*>(d + 16); q[0] = make_uint4(t.v[0], t.v[1], t.v[2], t.v[3]); q[1] = make_uint4(t.v[4], t.v[5], t.v[6], t.v[7]); }
+    f30_pack<M>(t.v, p.zzz); { uint4* q = reinterpret_cast<uint4*>(d + 24); q[0] = make_uint4(t.v[0], t.v[1], t.v[2], t.v[3]); q[1] = make_uint4(t.v[4], t.v[5], t.v[6], t.v[7]); }
+}
+template <class M>
+__device__ __forceinline__ XYZZ30<M> xyzz30_load_lazy(const XYZZ<M>* src) {
+    const uint4* q = reinterpret_cast<const uint4*>(src);
+    uint4 w[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = q[i];
+    XYZZ30<M> p;
+    uint32_t t[8];
+    t[0] = w[0].x; t[1] = w[0].y; t[2] = w[0].z; t[3] = w[0].w; t[4] = w[1].x; t[5] = w[1].y; t[6] = w[1].z; t[7] = w[1].w;
+    p.x = f30_unpack<M>(t);
+    t[0] = w[2].x; t[1] = w[2].y; t[2] = w[2].z; t[3] = w[2].w; t[4] = w[3].x; t[5] = w[3].y; t[6] = w[3].z; t[7] = w[3].w;
+    p.y = f30_unpack<M>(t);
+    t[0] = w[4].x; t[1] = w[4].y; t[2] = w[4].z; t[3] = w[4].w; t[4] = w[5].x; t[5] = w[5].y; t[6] = w[5].z; t[7] = w[5].w;
+    p.zz = f30_unpack<M>(t);
+    p.inf = (t[0] | t[1] | t[2] | t[3] | t[4] | t[5] | t[6] | t[7]) == 0;
+    t[0] = w[6].x; t[1] = w[6].y; t[2] = w[6].z; t[3] = w[6].w; t[4] = w[7].x; t[5] = w[7].y; t[6] = w[7].z; t[7] = w[7].w;
+    p.zzz = f30_unpack<M>(t);
+    return p;
+}
+
 // the accumulator as an ec.cuh XYZZ in the 2^256 Montgomery form (canonical residues); infinity = all zero
 template <class M>
 __device__ __forceinline__ XYZZ<M> xyzz30_to_xyzz(const XYZZ30<M>& p) {

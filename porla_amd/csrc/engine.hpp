@@ -67,16 +67,15 @@ struct Buf {
 };
 struct Workspace {
     int device = -1;
-    Buf pts, keys, entries, counts, starts, fill, cursor, buckets, partial, windows, in_scalars, in_points;
+    Buf pts, keys, entries, counts, starts, fill, cursor, buckets, in_scalars, in_points;
     Buf order, blk_hist, blk_off, tile_off, heavy, chunk_out;
     Buf tree_s, tree_m, tree_mt;  // bucket reduction tree: S levels, M ping-pong halves (all windows / tail-private)
-    void* h_windows = nullptr;  // pinned
+    void* h_windows = nullptr;  // pinned, device-mapped: the tree's last level writes [W][c] (S, M_0 .. M_(c-2)) per window
     size_t h_windows_cap = 0;
     hipStream_t own_stream = nullptr;
     int slot = 0;
     hipEvent_t done = nullptr;  // recorded after the last kernel + D2H copy of a launched MSM
     int pend_W = 0, pend_c = 0; // window count / width of the launched, not yet folded MSM (0 = none)
-    bool pend_tree = false;     // h_windows holds the tree form [W][c] (S, M_0 .. M_(c-2)) instead of W window sums
 };
 constexpr int MSM_SLOTS = 4;
 constexpr size_t MSM_SCAN_MAX = 1u << 16;  // inputs up to this size are scanned for their longest scalar first

@@ -142,19 +142,6 @@ struct Fp64 {
     }
 };
 
-// total = sum_w 2^(c*w) * win[w]
-template <class M>
-inline XYZZ<M> h_fold_windows64(const XYZZ<M>* win, int W, int c) {
-    static const Fp64<M> F;
-    typename Fp64<M>::Pt acc = F.inf();
-    for (int w = W - 1; w >= 0; w--) {
-        if (!Fp64<M>::is_zero(acc.zz))
-            for (int d = 0; d < c; d++) acc = F.dbl(acc);
-        acc = F.padd(acc, F.from(win[w]));
-    }
-    return F.to(acc);
-}
-
 // Tree form of the bucket reduction (msm.cuh, k_tree_level): window w arrives as fin[w][0] = S (sum of its buckets) and
 // fin[w][1 + k] = M_k (sum of the buckets whose index has bit k set), k < c - 1, and is worth S + sum_k 2^k M_k.
 // total = sum_w 2^(c*w) * that: one Horner pass over single bits -- the same W*c doublings, W*c additions.

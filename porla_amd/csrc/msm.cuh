@@ -29,6 +29,7 @@
 #include "ec.cuh"
 #include "ec30.cuh"
 #include "glv.cuh"
+#include <type_traits>
 
 namespace porla {
 
@@ -581,7 +582,8 @@ k_bucket_sum(const Affine<typename C::Fp>* __restrict__ pts, const uint32_t* __r
 }
 
 // The same accumulation in the reduced-radix field form (ec30.cuh): the points arrive in the 2^270 Montgomery form
-// (k_points_to_mont with C::F30_BUCKETS), the item's sum leaves in the 2^256 form every later kernel works in.
+// (k_points_to_mont<.., F30>), the item's sum leaves in the lazy memory form of ec30.cuh, which the combine and tree kernels
+// of this curve read; the last tree level converts to the 2^256 form for the host.
 template <class C, int V>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V == 0 ? 3 : (V == 1 ? 4 : 2), V == 0 ? 3 : (V == 1 ? 4 : 2))))
 k_bucket_sum30(const Affine<typename C::Fp>* __restrict__ pts, const uint32_t* __restrict__ entries,
@@ -609,10 +611,8 @@ k_bucket_sum30(const Affine<typename C::Fp>* __restrict__ pts, const uint32_t* _
         a = aff_neg_if<M>(a, (cur >> 31) != 0);
         xyzz30_madd<M>(acc, f30_from_fe<M>(a.x), f30_from_fe<M>(a.y));
     }
-    const XYZZ<M> out = xyzz30_to_xyzz<M>(acc);
     const uint32_t cb = chunk_base[b];
-    if (cb == NO_CHUNK) store_xyzz<M>(buckets + b, out);
-    else store_xyzz<M>(chunk_out + cb + item.y, out);
+    xyzz30_store_lazy<M>(cb == NO_CHUNK ? buckets + b : chunk_out + cb + item.y, acc);
 }
 
 
@@ -636,56 +636,6 @@ __device__ __forceinline__ XYZZ<M> wave_sum(XYZZ<M> p) {
         xyzz_add_cold<M>(&p, &o);
     }
     return p;
-}
-
-// window w: sum_b (b+1) * bucket[w*B + b].  Thread t of the window owns buckets [t*L, t*L + L).
-// Grid: W * wavesPerWindow blocks of 64 threads; partial[w*wavesPerWindow + j] per wave.
-template <class C>
-__global__ void __launch_bounds__(64)
-k_bucket_reduce(const XYZZ<typename C::Fp>* __restrict__ buckets, uint32_t B, uint32_t L,
-                uint32_t wavesPerWindow, XYZZ<typename C::Fp>* __restrict__ partial) {
-    using M = typename C::Fp;
-    uint32_t w = blockIdx.x / wavesPerWindow;
-    uint32_t j = blockIdx.x % wavesPerWindow;
-    uint32_t t = j * 64 + threadIdx.x;  // segment index inside the window
-    uint32_t T = B / L;
-    XYZZ<M> res = xyzz_inf<M>();
-    if (t < T) {
-        const XYZZ<M>* seg = buckets + (size_t)w * B + (size_t)t * L;
-        XYZZ<M> run = xyzz_inf<M>(), sum = xyzz_inf<M>();
-        for (uint32_t k = L; k-- > 0;) {
-            XYZZ<M> bk = load_xyzz<M>(seg + k);
-            xyzz_add_cold<M>(&run, &bk);
-            xyzz_add_cold<M>(&sum, &run);
-        }
-        // res = sum + (t*L) * run
-        uint32_t off = t * L;
-        XYZZ<M> acc = xyzz_inf<M>();
-        for (int bit = 31 - __clz(off | 1); bit >= 0; bit--) {
-            xyzz_double_cold<M>(&acc);
-            if ((off >> bit) & 1) xyzz_add_cold<M>(&acc, &run);
-        }
-        xyzz_add_cold<M>(&sum, &acc);
-        res = sum;
-    }
-    res = wave_sum<M>(res);
-    if (threadIdx.x == 0) store_xyzz<M>(partial + blockIdx.x, res);
-}
-
-// one wave per window folds its partials
-template <class C>
-__global__ void __launch_bounds__(64)
-k_window_reduce(const XYZZ<typename C::Fp>* __restrict__ partial, uint32_t perWindow,
-                XYZZ<typename C::Fp>* __restrict__ out) {
-    using M = typename C::Fp;
-    uint32_t w = blockIdx.x;
-    XYZZ<M> acc = xyzz_inf<M>();
-    for (uint32_t k = threadIdx.x; k < perWindow; k += 64) {
-        XYZZ<M> p = load_xyzz<M>(partial + (size_t)w * perWindow + k);
-        xyzz_add_cold<M>(&acc, &p);
-    }
-    acc = wave_sum<M>(acc);
-    if (threadIdx.x == 0) store_xyzz<M>(out + w, acc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -714,25 +664,53 @@ struct TreeLevelArgs {
     uint32_t last;           // 1: write fin instead of s_out / m_out (+ one copy task per node for the aliased M_l)
 };
 
+// How the reduction kernels read, add and write bucket sums: the lazy reduced-radix form of ec30.cuh where the curve's
+// accumulation uses it, ec.cuh's XYZZ otherwise; `fin` (read by the host) is always XYZZ in the 2^256 form.
+template <class C>
+struct Node {
+    using M = typename C::Fp;
+    using T = typename std::conditional<C::F30_BUCKETS, XYZZ30<M>, XYZZ<M>>::type;
+    static __device__ __forceinline__ T load(const XYZZ<M>* p) {
+        if constexpr (C::F30_BUCKETS) return xyzz30_load_lazy<M>(p);
+        else return load_xyzz<M>(p);
+    }
+    static __device__ __forceinline__ void add(T& a, const T& b) {
+        if constexpr (C::F30_BUCKETS) xyzz30_add<M>(a, b);
+        else xyzz_add_cold<M>(&a, &b);
+    }
+    static __device__ __forceinline__ void store(XYZZ<M>* p, const T& a) {
+        if constexpr (C::F30_BUCKETS) xyzz30_store_lazy<M>(p, a);
+        else store_xyzz<M>(p, a);
+    }
+    static __device__ __forceinline__ void store_final(XYZZ<M>* p, const T& a) {
+        if constexpr (C::F30_BUCKETS) store_xyzz<M>(p, xyzz30_to_xyzz<M>(a));
+        else store_xyzz<M>(p, a);
+    }
+    static __device__ __forceinline__ T inf() {
+        if constexpr (C::F30_BUCKETS) { T r; r.x = r.y = r.zz = r.zzz = F30<M>{}; r.inf = true; return r; }
+        else return xyzz_inf<M>();
+    }
+};
+
 // one addition (or, at the last level, one copy) of level a.l; s = slot, i = node (global index: the S levels and fin),
 // jp / jo = the node's index inside the m_prev / m_out slot arrays
-template <class M>
-__device__ __forceinline__ void tree_task(const TreeLevelArgs<M>& a, uint32_t s, uint32_t i, uint32_t jp, uint32_t jo) {
+template <class C>
+__device__ __forceinline__ void tree_task(const TreeLevelArgs<typename C::Fp>& a, uint32_t s, uint32_t i, uint32_t jp, uint32_t jo) {
+    using M = typename C::Fp;
+    using N = Node<C>;
     const XYZZ<M>*pa, *pb;
     if (s == a.l + 1) {                           // last level: the aliased top slot is copied into fin
-        XYZZ<M> v = load_xyzz<M>(a.s_prev + 2 * (size_t)i + 1);
-        store_xyzz<M>(a.fin + (size_t)i * (a.nlev + 1) + 1 + a.l, v);
+        typename N::T v = N::load(a.s_prev + 2 * (size_t)i + 1);
+        N::store_final(a.fin + (size_t)i * (a.nlev + 1) + 1 + a.l, v);
         return;
     }
     if (s == a.l) { pa = a.s_prev + 2 * (size_t)i; pb = pa + 1; }
     else if (s + 1 == a.l) { pa = a.s_prev2 + 4 * (size_t)i + 1; pb = pa + 2; }
     else { pa = a.m_prev + (size_t)s * a.m_prev_stride + 2 * (size_t)jp; pb = pa + 1; }
-    XYZZ<M> x = load_xyzz<M>(pa), y = load_xyzz<M>(pb);
-    xyzz_add_cold<M>(&x, &y);
-    XYZZ<M>* out;
-    if (a.last) out = a.fin + (size_t)i * (a.nlev + 1) + (s == a.l ? 0 : 1 + s);
-    else out = (s == a.l) ? a.s_out + i : a.m_out + (size_t)s * a.m_out_stride + jo;
-    store_xyzz<M>(out, x);
+    typename N::T x = N::load(pa), y = N::load(pb);
+    N::add(x, y);
+    if (a.last) N::store_final(a.fin + (size_t)i * (a.nlev + 1) + (s == a.l ? 0 : 1 + s), x);
+    else N::store((s == a.l) ? a.s_out + i : a.m_out + (size_t)s * a.m_out_stride + jo, x);
 }
 
 // one level over all windows: grid covers (l + 1 + last) * n tasks, node index fastest (coalesced 256-B reads per lane pair)
@@ -743,7 +721,7 @@ k_tree_level(TreeLevelArgs<typename C::Fp> a) {
     uint32_t slots = a.l + 1 + a.last;
     if (t >= slots * a.n) return;
     const uint32_t i = t % a.n;
-    tree_task<typename C::Fp>(a, t / a.n, i, i, i);
+    tree_task<C>(a, t / a.n, i, i, i);
 }
 
 // the last levels l0 .. nlev-1 of ONE window per block (few nodes are left: launch gaps would dominate).  The levels
@@ -788,7 +766,7 @@ k_tree_tail(TreeTailArgs<typename C::Fp> a) {
         const uint32_t tasks = (l + 1 + lv.last) * nw;
         for (uint32_t t = threadIdx.x; t < tasks; t += blockDim.x) {
             const uint32_t j = t % nw, i = w * nw + j;
-            tree_task<M>(lv, t / nw, i, first ? i : j, j);
+            tree_task<C>(lv, t / nw, i, first ? i : j, j);
         }
         __threadfence();
         __syncthreads();
@@ -802,18 +780,29 @@ k_bucket_combine(const uint32_t* __restrict__ heavy_list, const uint32_t* __rest
                  const uint32_t* __restrict__ counts, const uint32_t* __restrict__ ctrl,
                  const XYZZ<typename C::Fp>* __restrict__ chunk_out, XYZZ<typename C::Fp>* __restrict__ buckets) {
     using M = typename C::Fp;
+    using N = Node<C>;
+    __shared__ XYZZ<M> stage[64];
     const uint32_t n_heavy = ctrl[2];
     for (uint32_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {
         const uint32_t b = heavy_list[h];
         const uint32_t items = (counts[b] + CHUNK - 1) / CHUNK;
         const XYZZ<M>* src = chunk_out + chunk_base[b];
-        XYZZ<M> acc = xyzz_inf<M>();
+        typename N::T acc = N::inf();
         for (uint32_t k = threadIdx.x; k < items; k += 64) {
-            XYZZ<M> p = load_xyzz<M>(src + k);
-            xyzz_add_cold<M>(&acc, &p);
+            typename N::T p = N::load(src + k);
+            N::add(acc, p);
         }
-        acc = wave_sum<M>(acc);
-        if (threadIdx.x == 0) store_xyzz<M>(buckets + b, acc);
+        // fold the 64 lane sums through LDS in the memory form (one wave: no barrier needed beyond the LDS fence)
+        for (uint32_t m = 32; m >= 1; m >>= 1) {
+            N::store(&stage[threadIdx.x], acc);
+            __syncthreads();
+            if (threadIdx.x < m) {
+                typename N::T o = N::load(&stage[threadIdx.x + m]);
+                N::add(acc, o);
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) N::store(buckets + b, acc);
     }
 }
 

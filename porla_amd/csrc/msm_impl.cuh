@@ -12,20 +12,6 @@ namespace porla {
 
 static inline int ilog2(size_t n) { int l = 0; while (n >>= 1) l++; return l; }
 
-// segment length of k_bucket_reduce: the shortest that still gives every lane of the chip (1024 SIMDs x 64) a segment
-static inline uint32_t reduce_segment(size_t total_buckets, uint32_t B) {
-    static const uint32_t Lenv = getenv("PORLA_REDUCE_L") ? (uint32_t)atoi(getenv("PORLA_REDUCE_L")) : 0;
-    uint32_t L = 1;
-    while (L < 8 && total_buckets / L > 65536) L *= 2;
-    if (Lenv) L = Lenv;
-    return B < L ? B : L;
-}
-
-// Bucket reduction: the bit-sliced tree of msm.cuh (default) or the older segment form (PORLA_REDUCE=segment, kept for A/B runs).
-static inline bool reduce_is_tree() {
-    static const bool tree = !(getenv("PORLA_REDUCE") && getenv("PORLA_REDUCE")[0] == 's');
-    return tree;
-}
 // threads of the per-window tail block: the tail takes over at the first level whose additions per window fit one pass
 static inline uint32_t tree_tail_threads() {
     static const uint32_t t = getenv("PORLA_TREE_TAIL") ? (uint32_t)atoi(getenv("PORLA_TREE_TAIL")) : 256u;
@@ -46,9 +32,11 @@ static inline uint32_t tree_tail_start(uint32_t B, uint32_t nlev) {
 //                        per entry for a lone wave: the average bucket plus 4 sigma, or -- the usual culprit -- a top window
 //                        that holds only `top` bits and crowds all m entries into 2^(top-1) buckets (work items cap a chain
 //                        at CHUNK entries)
-//   bucket reduction     ~(2L + 1.5(c-1) + 13) dependent group operations per lane at ~9.8 us (running sums over L buckets,
-//                        a (c-1)-bit scalar multiple, shuffle tree), growing mildly with the number of lanes until the
-//                        segments exceed one per lane of the chip, proportionally beyond
+//   bucket reduction     the tree's levels: throughput TREE_US_PER_ADD per addition, never below one launch + one
+//                        dependent addition (TREE_LEVEL_US); TREE_TAIL_LEVEL_US per level of the per-window tail kernel
+constexpr double TREE_US_PER_ADD = 1.5e-4;     // 262 144 additions of level 0 at c = 16 in 39 us (reduced-radix form)
+constexpr double TREE_LEVEL_US = 12.5;
+constexpr double TREE_TAIL_LEVEL_US = 12.5;
 static inline int choose_window(size_t m, int bits) {
     if (g_window_override >= 2 && g_window_override <= 20) return g_window_override;
     int best = 2;
@@ -75,11 +63,19 @@ static inline int choose_window(size_t m, int bits) {
         double t_combine = 0.0;
         if (top_load > (double)CHUNK) t_combine = 70.0 + top_load / CHUNK / 64.0 * 9.8;
         if (load > 0.6 * CHUNK) t_combine += 1e6;                      // every bucket would need the combine pass
-        // ---- bucket reduction + per-window fold
-        const uint32_t L = reduce_segment((size_t)(W * B), (uint32_t)B);
-        const double lanes = (double)W * B / L;
-        const double t_reduce = (2.0 * L + 1.5 * (c - 1) + 13.0) * 9.8 * (lanes > 65536.0 ? 1.15 * lanes / 65536.0 : 0.85 + 0.3 * lanes / 65536.0)
-                                + (lanes / W > 64.0 ? 65.0 : 7.0);
+        // ---- bucket reduction (bit-sliced tree, msm.cuh): level l holds W (l+1) B / 2^(l+1) independent additions; a level
+        // launch costs at least one addition's latency, the per-window tail levels run back to back in one kernel; the host
+        // then folds W c single-bit terms
+        double t_reduce = 0.3 * W * c;
+        {
+            const uint32_t Bu = 1u << (c - 1), nlev = (uint32_t)(c - 1);
+            const uint32_t l0 = tree_tail_start(Bu, nlev);
+            for (uint32_t l = 0; l < nlev; l++) {
+                const double tasks = (double)W * (l + 1) * (double)(Bu >> (l + 1));
+                if (l < l0) { const double t = tasks * TREE_US_PER_ADD; t_reduce += t > TREE_LEVEL_US ? t : TREE_LEVEL_US; }
+                else t_reduce += TREE_TAIL_LEVEL_US;
+            }
+        }
         const double cost = 6.0 * W + t_sum + t_combine + t_reduce;
         if (cost < best_cost) { best_cost = cost; best = c; }
     }
@@ -127,9 +123,6 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
     const int c = choose_window(n_sub, bits);
     const int W = (bits + 1 + c - 1) / c;
     const uint32_t B = 1u << (c - 1);
-    const uint32_t L = reduce_segment((size_t)W * B, B);
-    const uint32_t T = B / L;
-    const uint32_t wavesPerWindow = (T + 63) / 64;
     const size_t nb = (size_t)W * B;
     const uint32_t n32 = (uint32_t)n;
 
@@ -153,11 +146,8 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
     if ((rc = ws->blk_hist.ensure((size_t)CHUNK * nblk * 4))) return rc;
     if ((rc = ws->blk_off.ensure((size_t)CHUNK * nblk * 4))) return rc;
     if ((rc = ws->buckets.ensure(nb * sizeof(XYZZ<M>)))) return rc;
-    if ((rc = ws->partial.ensure((size_t)W * wavesPerWindow * sizeof(XYZZ<M>)))) return rc;
-    if ((rc = ws->windows.ensure((size_t)W * sizeof(XYZZ<M>)))) return rc;
-    const bool tree = reduce_is_tree();
     const uint32_t nlev = (uint32_t)(c - 1);
-    if (tree) {
+    {
         if ((rc = ws->tree_s.ensure((nb + 1) * sizeof(XYZZ<M>)))) return rc;               // all S levels: nb/2 + nb/4 + ...
         if ((rc = ws->tree_m.ensure((2 * (nb / 4) + 2) * sizeof(XYZZ<M>)))) return rc;     // two ping-pong halves
         if ((rc = ws->tree_mt.ensure((2 * (size_t)W * (B / 4 + 1) + 2) * sizeof(XYZZ<M>)))) return rc;  // the tail's private halves
@@ -237,7 +227,7 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
                            (const XYZZ<M>*)ws->chunk_out.p, (XYZZ<M>*)ws->buckets.p);
     }
     PORLA_TRACE("combine");
-    if (tree) {
+    {
         // S level l at tree_s + (nb - (nb >> l)) (nb/2 + ... + nb/2^l entries before it); M slots of level l in half l & 1
         XYZZ<M>* s_base = (XYZZ<M>*)ws->tree_s.p;
         XYZZ<M>* m_half[2] = {(XYZZ<M>*)ws->tree_m.p, (XYZZ<M>*)ws->tree_m.p + nb / 4 + 1};
@@ -281,27 +271,12 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
         // no copy packet: the last level stores its W * c results straight into the pinned host buffer (a D2H hipMemcpyAsync
         // was seen to block the launching thread for milliseconds while another MSM is in flight)
         PORLA_HIP(hipGetLastError());
-    } else {
-    {
-        ProfScope ps("bucket_reduce", stream);
-        hipLaunchKernelGGL((k_bucket_reduce<C>), dim3(W * wavesPerWindow), dim3(64), 0, stream,
-                           (const XYZZ<M>*)ws->buckets.p, B, L, wavesPerWindow, (XYZZ<M>*)ws->partial.p);
     }
-    {
-        ProfScope ps("window_reduce", stream);
-        hipLaunchKernelGGL((k_window_reduce<C>), dim3(W), dim3(64), 0, stream, (const XYZZ<M>*)ws->partial.p,
-                           wavesPerWindow, (XYZZ<M>*)ws->windows.p);
-    }
-    PORLA_HIP(hipGetLastError());
-    PORLA_HIP(hipMemcpyAsync(ws->h_windows, ws->windows.p, (size_t)W * sizeof(XYZZ<M>), hipMemcpyDeviceToHost, stream));
-    }
-    PORLA_TRACE("reduce");
     if (!ws->done) PORLA_HIP(hipEventCreateWithFlags(&ws->done, hipEventDisableTiming));
     PORLA_HIP(hipEventRecord(ws->done, stream));
     PORLA_TRACE("event");
     ws->pend_W = W;
     ws->pend_c = c;
-    ws->pend_tree = tree;
     g_last_shape[0] = c; g_last_shape[1] = W; g_last_shape[2] = glv ? 1 : 0;
     return PORLA_OK;
 }
@@ -312,8 +287,7 @@ static int msm_finish(Workspace* ws, XYZZ<typename C::Fp>* total) {
     using M = typename C::Fp;
     if (ws->pend_W == 0) { *total = xyzz_inf<M>(); return PORLA_OK; }
     PORLA_HIP(hipEventSynchronize(ws->done));
-    *total = ws->pend_tree ? h_fold_tree64<M>((const XYZZ<M>*)ws->h_windows, ws->pend_W, ws->pend_c)
-                           : h_fold_windows64<M>((const XYZZ<M>*)ws->h_windows, ws->pend_W, ws->pend_c);
+    *total = h_fold_tree64<M>((const XYZZ<M>*)ws->h_windows, ws->pend_W, ws->pend_c);
     ws->pend_W = 0;
     return PORLA_OK;
 }
