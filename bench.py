@@ -42,10 +42,13 @@ HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E peak, /opt/skills/guides/MI355X_MIC
 MSM_BYTES_PER_PAIR = 96       # 32-B scalar + 64-B affine point
 COMMIT_BYTES_PER_ROW = 4096 + 64  # 128 x 32-B coefficients in, 64-B point out (SRS table resident)
 ICC_BYTES_PER_ELEMENT = 64    # 32 B in + 32 B out
-FE_MUL_PEAK_G = 133.0         # measured back-to-back 256-bit Montgomery products, G/s per GPU (profiles/r01_b_ubench_asm_mul.txt)
+# measured back-to-back 256-bit modular products, G/s per GPU.  BN254 kernels accumulate in the reduced-radix form of
+# fe30.cuh: 180.7 G products/s and 213.6 G squares/s (profiles/r01_k_ubench_fe30.txt) -> 186.5 for the 8M + 2S mix of a mixed
+# addition; secp256k1 keeps the 8 x 32-bit special-form product (profiles/r01_b_ubench_asm_mul.txt)
+FE_MUL_PEAK_G = {"bn254_msm": 186.5, "kzg_commit": 186.5, "secp256k1_msm": 133.0}
 
 KERNEL_SYMBOL = {  # profile slot -> substring of the kernel symbol in the rocprofv3 output
-    "bucket_sum": "k_bucket_sum", "bucket_reduce": "k_bucket_reduce", "partition_sort": "k_partition_sort",
+    "bucket_sum": "k_bucket_sum", "tree_levels": "k_tree_level", "tree_tail": "k_tree_tail", "partition_sort": "k_partition_sort",
     "fb_commit": "k_fb_commit", "digits_partition": "k_digits_partition", "points_to_mont": "k_points_to_mont",
     "icc_fused": "k_icc_fused", "icc_stages_r4": "k_icc_stages", "icc_stages_r2": "k_icc_stages", "icc_load": "k_icc_load", "icc_finish": "k_icc_finish",
 }
@@ -172,11 +175,13 @@ def main():
         if fe_mults_per_launch:
             # the elliptic-curve kernels are bound by the 32x32->64 multiplier issue rate, which neither "hbm" nor "mfma"
             # names: the supplement prices the dominant kernel's 256-bit modular multiplications against the rate the
-            # multiply microbenchmark sustains on this chip (tools/fe_check.hip --bench, profiles/r01_b_ubench_asm_mul.txt)
+            # multiply microbenchmark sustains on this chip (tools/fe30_check.hip --bench, tools/ubench.hip; profiles/r01_k_ubench_fe30.txt, r01_b_ubench_asm_mul.txt)
             g = fe_mults_per_launch / (kern[dom] * 1e-3) / 1e9
-            r["int_multiplier"] = {"achieved": round(g, 2), "peak": FE_MUL_PEAK_G, "unit": "G fe_mul/s (256-bit modular)",
-                                   "frac": round(g / FE_MUL_PEAK_G, 4),
-                                   "note": "mixed addition = 8M + 2S = 10 fe_mul; peak = measured back-to-back fe_mul rate"}
+            peak = FE_MUL_PEAK_G[workload]
+            r["int_multiplier"] = {"achieved": round(g, 2), "peak": peak, "unit": "G fe_mul/s (256-bit modular)",
+                                   "frac": round(g / peak, 4),
+                                   "note": "mixed addition = 8M + 2S = 10 fe_mul; peak = measured back-to-back product rate "
+                                           "of the field form the kernel uses (8M + 2S mix)"}
         return r
 
     def msm_fe_mults(n):
