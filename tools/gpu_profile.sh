@@ -8,11 +8,12 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 WORKLOAD=${WORKLOAD:-bn254_msm}
-BENCH="python3 $PWD/bench.py --steps 10 --warmup 2 --workload $WORKLOAD"
+BENCH="python3 $PWD/bench.py --workload $WORKLOAD"
+SHORT="--steps 10 --warmup 2"
 if [ "${SKIP_TESTS:-0}" != 1 ]; then (timeout 900 python3 -m pytest tests -m gpu -x -q 2>&1 | tail -5) > "$OUT/pytest.txt"; fi
 (timeout 600 $BENCH 2>/dev/null | grep '^{') > "$OUT/bench_n1.json"
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o run -- $BENCH --no-cpu > "$OUT/bench_under_rocprof.txt" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o run -- $BENCH $SHORT --no-cpu > "$OUT/bench_under_rocprof.txt" 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o run -- $BENCH --no-cpu --steps 3 --warmup 1 > "$OUT/pmc_fetch.txt" 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o run -- $BENCH --no-cpu --steps 3 --warmup 1 > "$OUT/pmc_write.txt" 2>&1
 cd "$OUT"
