@@ -592,8 +592,8 @@ k_bucket_sum(const Affine<typename C::Fp>* __restrict__ pts, const uint32_t* __r
 // The same accumulation in the reduced-radix field form (ec30.cuh): the points arrive in the 2^270 Montgomery form
 // (k_points_to_mont<.., F30>), the item's sum leaves in the lazy memory form of ec30.cuh, which the combine and tree kernels
 // of this curve read; the last tree level converts to the 2^256 form for the host.
-template <class C, int V>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(V == 0 ? 3 : (V == 1 ? 4 : 2), V == 0 ? 3 : (V == 1 ? 4 : 2))))
+template <class C>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_bucket_sum30(const Affine<typename C::Fp>* __restrict__ pts, const uint32_t* __restrict__ entries,
                const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
                const uint2* __restrict__ order, const uint32_t* __restrict__ chunk_base,

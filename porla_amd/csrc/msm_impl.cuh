@@ -211,15 +211,12 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
     PORLA_TRACE("size_order");
     {
         ProfScope ps("bucket_sum", stream, true);
-        if constexpr (C::F30_BUCKETS) {
-            static const int variant = getenv("PORLA_F30_VARIANT") ? atoi(getenv("PORLA_F30_VARIANT")) : 0;
-#define PORLA_LAUNCH_F30(V) hipLaunchKernelGGL((k_bucket_sum30<C, V>), dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, stream, pts, \
-                               (const uint32_t*)ws->entries.p, (const uint32_t*)ws->starts.p, \
-                               (const uint32_t*)ws->counts.p, (const uint2*)ws->order.p, (const uint32_t*)ws->fill.p, \
-                               (const uint32_t*)ctrl, (XYZZ<M>*)ws->buckets.p, (XYZZ<M>*)ws->chunk_out.p)
-            if (variant == 1) PORLA_LAUNCH_F30(1); else if (variant == 2) PORLA_LAUNCH_F30(2); else PORLA_LAUNCH_F30(0);
-#undef PORLA_LAUNCH_F30
-        } else
+        if constexpr (C::F30_BUCKETS)
+            hipLaunchKernelGGL((k_bucket_sum30<C>), dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, stream, pts,
+                               (const uint32_t*)ws->entries.p, (const uint32_t*)ws->starts.p,
+                               (const uint32_t*)ws->counts.p, (const uint2*)ws->order.p, (const uint32_t*)ws->fill.p,
+                               (const uint32_t*)ctrl, (XYZZ<M>*)ws->buckets.p, (XYZZ<M>*)ws->chunk_out.p);
+        else
             hipLaunchKernelGGL((k_bucket_sum<C>), dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, stream, pts,
                                (const uint32_t*)ws->entries.p, (const uint32_t*)ws->starts.p,
                                (const uint32_t*)ws->counts.p, (const uint2*)ws->order.p, (const uint32_t*)ws->fill.p,
