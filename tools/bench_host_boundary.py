@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive latency of the reference's own boundary: compute_multi_exp(scalars, points, n) with HOST buffers (pageable
+memory, as the unmodified Server passes them), next to the device-resident call.  Not bench.py's `value`."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import ctypes
+from porla_amd import multiexp as mx, lib
+from porla_amd.multiexp import _slice
+from tests import common
+sc, pt = common.cached_inputs(1 << 20)
+d_sc = torch.frombuffer(bytearray(sc), dtype=torch.uint8).cuda()
+d_pt = torch.frombuffer(bytearray(pt), dtype=torch.uint8).cuda()
+s = torch.cuda.current_stream().cuda_stream
+for n in (3200, 1 << 14, 1 << 17, 1 << 20):
+    # the caller's buffers exist before the call, as in the reference (no Python-side copies inside the timed region)
+    bs, bp, out = ctypes.create_string_buffer(sc[:32 * n], 32 * n), ctypes.create_string_buffer(pt[:64 * n], 64 * n), ctypes.create_string_buffer(64)
+    ss, sp, so = _slice(bs), _slice(bp), _slice(out)
+    reps = 10
+    for _ in range(3):
+        lib.compute_multi_exp(ctypes.byref(ss), ctypes.byref(sp), n, ctypes.byref(so))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        lib.compute_multi_exp(ctypes.byref(ss), ctypes.byref(sp), n, ctypes.byref(so))
+    t_host = (time.perf_counter() - t0) / reps * 1e3
+    r_host = out.raw
+    for _ in range(3):
+        r_dev = mx.msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n, s)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r_dev = mx.msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n, s)
+    t_dev = (time.perf_counter() - t0) / reps * 1e3
+    print(json.dumps({"n": n, "host_buffers_ms": round(t_host, 3), "device_resident_ms": round(t_dev, 3), "same_result": r_host == r_dev,
+                      "input_MiB": round(96 * n / 2**20, 2), "host_path_GBps": round(96 * n / (max(t_host - t_dev, 1e-6) * 1e-3) / 1e9, 1)}), flush=True)
