@@ -61,6 +61,9 @@ struct Secp256k1Fp {
     static constexpr int SPARE_BITS = 0;
     static constexpr bool PSEUDO_MERSENNE = true;   // p = 2^256 - (2^32 + FOLD)
     static constexpr uint32_t FOLD = 977;
+    // reduced-radix form (fe30.cuh): plain residues there too, so both conversion factors are 1
+    static constexpr uint32_t R1_30[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+    static constexpr uint32_t R2_30[8] = {1, 0, 0, 0, 0, 0, 0, 0};
 };
 
 // ---------------------------------------------------------------- element type

@@ -107,15 +107,86 @@ __device__ __forceinline__ F30<M> f30_sqr_portable(const F30<M>& a) {
     return r;
 }
 
+// ---------------------------------------------------------------- special-form modulus p = 2^256 - 2^32 - FOLD (secp256k1)
+// Plain residues (no Montgomery factor), as in fe.cuh and in the reference's field_5x52.  The 18-limb schoolbook product is
+// folded with 2^270 = 2^14 (2^32 + FOLD) = C1 2^30 + C0 (mod p), then everything above 2^256 once more with
+// 2^256 = 2^32 + FOLD.  Operands: limbs 0..7 < 2^30, limb 8 < 2^19 (value < 2^259).  Result: limbs < 2^30, value < 2^256 + 2^49.
+template <class M>
+struct PM30 {
+    static constexpr uint32_t C0 = (M::FOLD << 14) & F30_MASK;              // low limb of 2^14 (2^32 + FOLD); FOLD < 2^16
+    static constexpr uint32_t C1 = (1u << 16) + ((M::FOLD << 14) >> 30);    // 2^46 / 2^30 (+ the carry of FOLD 2^14)
+};
+template <class M>
+__device__ __forceinline__ void f30_pm_fold(F30<M>& r, const uint32_t (&L)[18]) {
+    // phase 2: columns 0..9 of  lo + hi * (C1 2^30 + C0),  hi = L[9..17]
+    uint64_t t = 0;
+    uint32_t R[10];
+#pragma unroll
+    for (int j = 0; j < 10; j++) {
+        if (j < 9) { t += L[j]; t += (uint64_t)L[9 + j] * PM30<M>::C0; }
+        if (j >= 1) t += (uint64_t)L[9 + j - 1] * PM30<M>::C1;
+        R[j] = (uint32_t)t & F30_MASK;
+        t >>= 30;
+    }
+    // hi < 2^248, so hi * (C1 2^30 + C0) < 2^295: R[9] < 2^25 and nothing is left in t.
+    // phase 3: g1 = bits 256.. of limb 8, g2 = R[9] (weight 2^270):  + g1 (2^32 + FOLD) + g2 (C1 2^30 + C0)
+    const uint32_t g1 = R[8] >> 16, g2 = R[9];
+    uint64_t u = (uint64_t)R[0] + (uint64_t)g1 * M::FOLD + (uint64_t)g2 * PM30<M>::C0;
+    r.v[0] = (uint32_t)u & F30_MASK;
+    u >>= 30;
+    u += (uint64_t)R[1] + ((uint64_t)g1 << 2) + (uint64_t)g2 * PM30<M>::C1;
+    r.v[1] = (uint32_t)u & F30_MASK;
+    uint32_t carry = (uint32_t)(u >> 30);
+#pragma unroll
+    for (int j = 2; j < 8; j++) {
+        uint32_t x = R[j] + carry;
+        r.v[j] = x & F30_MASK;
+        carry = x >> 30;
+    }
+    r.v[8] = (R[8] & 0xffffu) + carry;
+}
+template <class M>
+__device__ __forceinline__ F30<M> f30_mul_pm_portable(const F30<M>& a, const F30<M>& b) {
+    uint64_t t = 0;
+    uint32_t L[18];
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+#pragma unroll
+        for (int i = (k > 8 ? k - 8 : 0); i <= (k < 8 ? k : 8); i++) t += (uint64_t)a.v[i] * b.v[k - i];
+        L[k] = (uint32_t)t & F30_MASK;
+        t >>= 30;
+    }
+    L[17] = (uint32_t)t;
+    F30<M> r;
+    f30_pm_fold<M>(r, L);
+    return r;
+}
+template <class M>
+__device__ __forceinline__ F30<M> f30_sqr_pm_portable(const F30<M>& a) { return f30_mul_pm_portable<M>(a, a); }
+
 // The device forms: generated assembly blocks (tools/gen_fe30_asm.py), 205 / 169 instructions per product / square.
 #if defined(__HIP_DEVICE_COMPILE__)
 #include "fe30_mul_gfx950.inc"
 #else
 template <class M>
-__device__ __forceinline__ F30<M> f30_mul(const F30<M>& a, const F30<M>& b) { return f30_mul_portable<M>(a, b); }
+__device__ __forceinline__ F30<M> f30_mul_mont(const F30<M>& a, const F30<M>& b) { return f30_mul_portable<M>(a, b); }
 template <class M>
-__device__ __forceinline__ F30<M> f30_sqr(const F30<M>& a) { return f30_sqr_portable<M>(a); }
+__device__ __forceinline__ F30<M> f30_sqr_mont(const F30<M>& a) { return f30_sqr_portable<M>(a); }
+template <class M>
+__device__ __forceinline__ F30<M> f30_mul_pm(const F30<M>& a, const F30<M>& b) { return f30_mul_pm_portable<M>(a, b); }
+template <class M>
+__device__ __forceinline__ F30<M> f30_sqr_pm(const F30<M>& a) { return f30_sqr_pm_portable<M>(a); }
 #endif
+template <class M>
+__device__ __forceinline__ F30<M> f30_mul(const F30<M>& a, const F30<M>& b) {
+    if constexpr (M::PSEUDO_MERSENNE) return f30_mul_pm<M>(a, b);
+    else return f30_mul_mont<M>(a, b);
+}
+template <class M>
+__device__ __forceinline__ F30<M> f30_sqr(const F30<M>& a) {
+    if constexpr (M::PSEUDO_MERSENNE) return f30_sqr_pm<M>(a);
+    else return f30_sqr_mont<M>(a);
+}
 
 // 8 x 32-bit words (a value < 2^256) -> 9 x 30-bit limbs
 template <class M>
@@ -221,11 +292,22 @@ __device__ __forceinline__ bool f30_product_is_zero(const F30<M>& a) {
 template <class M>
 __device__ __forceinline__ F30<M> f30_from_fe(const Fe<M>& a) { return f30_unpack<M>(a.v); }
 
-// canonical residue of a normal value below 2^256 (in practice a product's result, <= p + 2^246): at most one subtraction
+// canonical residue of a product's result (normal limbs; < p + 2^246 in the Montgomery form, < 2^256 + 2^49 in the special
+// form, where bit 256 may be set): at most two subtractions of p
 template <class M>
 __device__ __forceinline__ Fe<M> f30_to_fe_canonical(const F30<M>& a) {
     uint32_t t[8], s[8];
-    f30_pack<M>(t, a);
+    f30_pack<M>(t, a);                                   // the low 256 bits
+    if constexpr (M::PSEUDO_MERSENNE) {
+        if (a.v[8] >> 16) {                              // value = 2^256 + t: subtract p = 2^256 - (2^32 + FOLD)
+            uint64_t c = (uint64_t)t[0] + M::FOLD;
+            t[0] = (uint32_t)c; c >>= 32;
+            c += (uint64_t)t[1] + 1u;
+            t[1] = (uint32_t)c; c >>= 32;
+#pragma unroll
+            for (int i = 2; i < 8; i++) { c += t[i]; t[i] = (uint32_t)c; c >>= 32; }
+        }
+    }
     uint32_t br = sub_p<M>(s, t);
     Fe<M> r;
 #pragma unroll

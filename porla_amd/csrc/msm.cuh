@@ -44,8 +44,11 @@ struct Bn254G1 {
     // 254-bit scalars fill 16 windows of 16 bits exactly; the GLV split would halve the windows but double the entries per
     // bucket and the gathered point set (measured: 3.31 ms vs 2.85 ms at 2^20) -- off by default, on with porla_gpu_set_msm_glv(1)
     static constexpr bool GLV_DEFAULT = false;
-    // bucket accumulation in the reduced-radix field form (fe30.cuh / ec30.cuh): 1.2-1.5x the field-product rate
+    // bucket accumulation in the reduced-radix field form (fe30.cuh / ec30.cuh): 1.35-1.6x the field-product rate
     static constexpr bool F30_BUCKETS = true;
+    // ... and the sums stay in that form ("lazy" memory form of ec30.cuh: unreduced residues, X <= 5p < 2^256) through the
+    // combine and tree kernels
+    static constexpr bool F30_LAZY = true;
 };
 struct Secp256k1G {
     using Fp = Secp256k1Fp;
@@ -57,7 +60,8 @@ struct Secp256k1G {
     // 256-bit scalars need a carry-only 17th window at c = 16 (one bucket with half of all entries); the GLV split (which
     // the reference's secp256k1 path also applies, ecmult_impl.h:621-634) gives 8 windows of 17 bits instead
     static constexpr bool GLV_DEFAULT = true;
-    static constexpr bool F30_BUCKETS = false;   // the special-form product of secp256k1's field is already cheaper
+    static constexpr bool F30_BUCKETS = true;    // special-form product on 30-bit limbs: 194 against 133 G products/s
+    static constexpr bool F30_LAZY = false;      // 5p > 2^256: an unreduced X does not fit the 32-byte memory form
 };
 
 constexpr uint32_t KEY_NONE = 0xffffffffu;
@@ -620,7 +624,9 @@ k_bucket_sum30(const Affine<typename C::Fp>* __restrict__ pts, const uint32_t* _
         xyzz30_madd<M>(acc, f30_from_fe<M>(a.x), f30_from_fe<M>(a.y));
     }
     const uint32_t cb = chunk_base[b];
-    xyzz30_store_lazy<M>(cb == NO_CHUNK ? buckets + b : chunk_out + cb + item.y, acc);
+    XYZZ<M>* dst = cb == NO_CHUNK ? buckets + b : chunk_out + cb + item.y;
+    if constexpr (C::F30_LAZY) xyzz30_store_lazy<M>(dst, acc);
+    else store_xyzz<M>(dst, xyzz30_to_xyzz<M>(acc));
 }
 
 
@@ -672,30 +678,30 @@ struct TreeLevelArgs {
     uint32_t last;           // 1: write fin instead of s_out / m_out (+ one copy task per node for the aliased M_l)
 };
 
-// How the reduction kernels read, add and write bucket sums: the lazy reduced-radix form of ec30.cuh where the curve's
-// accumulation uses it, ec.cuh's XYZZ otherwise; `fin` (read by the host) is always XYZZ in the 2^256 form.
+// How the reduction kernels read, add and write bucket sums: the lazy reduced-radix form of ec30.cuh where the curve has
+// it (C::F30_LAZY), ec.cuh's XYZZ otherwise; `fin` (read by the host) is always XYZZ in the 2^256 form.
 template <class C>
 struct Node {
     using M = typename C::Fp;
-    using T = typename std::conditional<C::F30_BUCKETS, XYZZ30<M>, XYZZ<M>>::type;
+    using T = typename std::conditional<C::F30_LAZY, XYZZ30<M>, XYZZ<M>>::type;
     static __device__ __forceinline__ T load(const XYZZ<M>* p) {
-        if constexpr (C::F30_BUCKETS) return xyzz30_load_lazy<M>(p);
+        if constexpr (C::F30_LAZY) return xyzz30_load_lazy<M>(p);
         else return load_xyzz<M>(p);
     }
     static __device__ __forceinline__ void add(T& a, const T& b) {
-        if constexpr (C::F30_BUCKETS) xyzz30_add<M>(a, b);
+        if constexpr (C::F30_LAZY) xyzz30_add<M>(a, b);
         else xyzz_add_cold<M>(&a, &b);
     }
     static __device__ __forceinline__ void store(XYZZ<M>* p, const T& a) {
-        if constexpr (C::F30_BUCKETS) xyzz30_store_lazy<M>(p, a);
+        if constexpr (C::F30_LAZY) xyzz30_store_lazy<M>(p, a);
         else store_xyzz<M>(p, a);
     }
     static __device__ __forceinline__ void store_final(XYZZ<M>* p, const T& a) {
-        if constexpr (C::F30_BUCKETS) store_xyzz<M>(p, xyzz30_to_xyzz<M>(a));
+        if constexpr (C::F30_LAZY) store_xyzz<M>(p, xyzz30_to_xyzz<M>(a));
         else store_xyzz<M>(p, a);
     }
     static __device__ __forceinline__ T inf() {
-        if constexpr (C::F30_BUCKETS) { T r; r.x = r.y = r.zz = r.zzz = F30<M>{}; r.inf = true; return r; }
+        if constexpr (C::F30_LAZY) { T r; r.x = r.y = r.zz = r.zzz = F30<M>{}; r.inf = true; return r; }
         else return xyzz_inf<M>();
     }
 };

@@ -27,4 +27,4 @@ def test_reduced_radix_product_matches_portable_product():
     assert os.path.exists(exe), "build it with make -C porla_amd/csrc"
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("0 mismatches") == 3, r.stdout
+    assert r.stdout.count(" 0 mismatches") == 4, r.stdout

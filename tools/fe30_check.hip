@@ -21,7 +21,9 @@ __global__ void k_mul30(const uint32_t* a, const uint32_t* b, uint32_t* out, int
     F30<M> x, y;
     for (int k = 0; k < 9; k++) { x.v[k] = a[i * 9 + k]; y.v[k] = b[i * 9 + k]; }
     F30<M> z = square ? f30_sqr<M>(x) : f30_mul<M>(x, y);
-    F30<M> zp = square ? f30_sqr_portable<M>(x) : f30_mul_portable<M>(x, y);   // the assembly must equal the portable form limb for limb
+    F30<M> zp;                                  // the assembly must equal the portable form limb for limb
+    if constexpr (M::PSEUDO_MERSENNE) zp = square ? f30_sqr_pm_portable<M>(x) : f30_mul_pm_portable<M>(x, y);
+    else zp = square ? f30_sqr_portable<M>(x) : f30_mul_portable<M>(x, y);
     for (int k = 0; k < 9; k++) out[i * 9 + k] = z.v[k] | (z.v[k] != zp.v[k] ? 0x80000000u : 0u);
 }
 template <class M>
@@ -183,6 +185,58 @@ static int check(const char* name) {
     return bad;
 }
 
+// special-form modulus: plain residues, f30_mul(x, y) = x*y mod p (value < 2^256 + 2^73, limbs normal)
+template <class M>
+static int check_pm(const char* name) {
+    const int n = 1 << 16;
+    std::vector<uint32_t> a(n * 9), b(n * 9), got(n * 9);
+    std::mt19937_64 rng(13);
+    for (int i = 0; i < n; i++) {
+        int mode = i & 7;
+        for (int k = 0; k < 9; k++) { a[i * 9 + k] = (uint32_t)rng() & F30_MASK; b[i * 9 + k] = (uint32_t)rng() & F30_MASK; }
+        a[i * 9 + 8] &= 0xffff; b[i * 9 + 8] &= 0xffff;                                     // < 2^256
+        if (mode == 1) { a[i * 9 + 8] = (uint32_t)rng() & 0x7ffff; b[i * 9 + 8] = (uint32_t)rng() & 0x7ffff; }   // unreduced, < 2^259
+        if (mode == 2) for (int k = 0; k < 9; k++) { a[i * 9 + k] = k < 8 ? F30_MASK : 0x7ffff; b[i * 9 + k] = a[i * 9 + k]; }
+        if (mode == 3) for (int k = 0; k < 9; k++) a[i * 9 + k] = k < 8 ? F30_MASK : 0x7ffff;
+        if (mode == 4) for (int k = 0; k < 9; k++) b[i * 9 + k] = a[i * 9 + k];
+        if (mode == 5) for (int k = 0; k < 9; k++) a[i * 9 + k] = P30<M>::limb(k);         // p itself
+        if (mode == 6) for (int k = 0; k < 9; k++) a[i * 9 + k] = (k == 0);                // one
+        if (i == 7) for (int k = 0; k < 9; k++) a[i * 9 + k] = 0;
+    }
+    uint32_t *da, *db, *dout;
+    CK(hipMalloc(&da, n * 36)); CK(hipMalloc(&db, n * 36)); CK(hipMalloc(&dout, n * 36));
+    CK(hipMemcpy(da, a.data(), n * 36, hipMemcpyHostToDevice));
+    CK(hipMemcpy(db, b.data(), n * 36, hipMemcpyHostToDevice));
+    int bad = 0;
+    for (int square = 0; square < 2; square++) {
+        hipLaunchKernelGGL(k_mul30<M>, dim3(n / 256), dim3(256), 0, 0, da, db, dout, n, square);
+        CK(hipMemcpy(got.data(), dout, n * 36, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; i++) {
+            Fe<M> x = limbs_mod_p<M>(&a[i * 9]);
+            Fe<M> y = square ? x : limbs_mod_p<M>(&b[i * 9]);
+            uint32_t t[16] = {0};                                      // schoolbook product, then long division
+            for (int p = 0; p < 8; p++) {
+                uint64_t c = 0;
+                for (int q = 0; q < 8; q++) { c += (uint64_t)x.v[p] * y.v[q] + t[p + q]; t[p + q] = (uint32_t)c; c >>= 32; }
+                t[p + 8] = (uint32_t)c;
+            }
+            Fe<M> want = mod_p<M>(t, 16);
+            const uint32_t* z = &got[i * 9];
+            bool limbs_ok = true;
+            for (int k = 0; k < 8; k++) if (z[k] > F30_MASK) limbs_ok = false;
+            if (z[8] > (1u << 16)) limbs_ok = false;                   // value < 2^256 + 2^73
+            Fe<M> have = limbs_mod_p<M>(z);
+            if (!limbs_ok || !fe_eq<M>(want, have)) {
+                if (bad < 5) printf("%s: mismatch at %d (square=%d mode=%d) limbs_ok=%d value_ok=%d\n", name, i, square, i & 7, limbs_ok, (int)fe_eq<M>(want, have));
+                bad++;
+            }
+        }
+    }
+    CK(hipFree(da)); CK(hipFree(db)); CK(hipFree(dout));
+    printf("%s: %d products + %d squares checked, %d mismatches\n", name, n, n, bad);
+    return bad;
+}
+
 template <class F>
 static double time_ms(F f, int reps = 3) {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -200,6 +254,7 @@ int main(int argc, char** argv) {
     bad += check<Bn254Fp>("bn254_p");
     bad += check<IccBn254Fr>("bn254_r");
     bad += check<IccFp>("p_icc");
+    bad += check_pm<Secp256k1Fp>("secp256k1_p");
     if (argc > 1 && !strcmp(argv[1], "--bench")) {
         hipDeviceProp_t prop; (void)hipGetDeviceProperties(&prop, 0);
         const int CUS = prop.multiProcessorCount;
@@ -215,6 +270,10 @@ int main(int argc, char** argv) {
                    (double)blocks * 256 * it * 2 / ms / 1e6, ms * 1e-3 * 2.4e9 / (it * 2) / w);
             ms = time_ms([&] { hipLaunchKernelGGL((k_bench<Bn254Fp, 1>), dim3(blocks), dim3(256), 0, 0, buf, it); });
             printf("f30_sqr<Bn254Fp>  waves/SIMD=%d  %.3f ms  %.2f Gsqr/s\n", w, ms, (double)blocks * 256 * it * 2 / ms / 1e6);
+            ms = time_ms([&] { hipLaunchKernelGGL((k_bench<Secp256k1Fp, 0>), dim3(blocks), dim3(256), 0, 0, buf, it); });
+            printf("f30_mul<Secp256k1> waves/SIMD=%d  %.3f ms  %.2f Gmul/s\n", w, ms, (double)blocks * 256 * it * 2 / ms / 1e6);
+            ms = time_ms([&] { hipLaunchKernelGGL((k_bench<Secp256k1Fp, 1>), dim3(blocks), dim3(256), 0, 0, buf, it); });
+            printf("f30_sqr<Secp256k1> waves/SIMD=%d  %.3f ms  %.2f Gsqr/s\n", w, ms, (double)blocks * 256 * it * 2 / ms / 1e6);
             if (w <= 4) {
                 ms = time_ms([&] { hipLaunchKernelGGL((k_madd30<Bn254Fp>), dim3(blocks), dim3(256), 0, 0, buf, 128); });
                 printf("xyzz30_madd       waves/SIMD=%d  %.3f ms  %.2f Gadd/s\n", w, ms, (double)blocks * 256 * 128 / ms / 1e6);
