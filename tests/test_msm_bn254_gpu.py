@@ -88,6 +88,28 @@ def test_edge_points(mx, inputs):
     assert got == bytes(64)
 
 
+def test_eip196_precompile_vectors_through_the_plugin(mx):
+    """external known answers (tests/golden/eip196_kat.json, go-ethereum's alt_bn128 precompile test data) through the
+    reference's own symbols: add_point, mult_point and compute_multi_exp"""
+    import json
+    import os
+    kat = json.load(open(os.path.join(common.ROOT, "tests", "golden", "eip196_kat.json")))
+    one = (1).to_bytes(32, "big")
+    for e in kat["add"]:
+        a, b, want = bytes.fromhex(e["a"]), bytes.fromhex(e["b"]), bytes.fromhex(e["sum"])
+        assert mx.bn254_add(a, b) == want
+        assert mx.bn254_multi_exp(a + b, one + one, 2) == want
+    for e in kat["mul"]:
+        p, k, want = bytes.fromhex(e["p"]), bytes.fromhex(e["k"]), bytes.fromhex(e["r"])
+        assert mx.bn254_mult(p, k) == want
+        assert mx.bn254_multi_exp(p, k, 1) == want
+        # the same scalar spread over many pairs: k P = sum_i k_i P with sum k_i = k
+        parts = [int.from_bytes(k, "big") // 1000] * 999
+        parts.append(int.from_bytes(k, "big") - sum(parts))
+        sc = b"".join(x.to_bytes(32, "big") for x in parts)
+        assert mx.bn254_multi_exp(p * 1000, sc, 1000) == want
+
+
 def test_audit_like_distribution(mx, inputs):
     """abs(int32) coefficients (utils.h:271-275) over 64-way repeated points: the real audit's shape"""
     import random
