@@ -89,7 +89,7 @@ __device__ __forceinline__ void xyzz30_madd(XYZZ30<M>& p, const F30<M>& ax, cons
 // 2 * p (dbl-2008-s-1, a = 0); p not infinity.  Out of line, operands by value (see xyzz30_double_affine).
 //   U = 2 Y1 (<= 6), V = U^2, W = U V, S = X1 V, M = 3 X1^2 (<= 3), X3 = M^2 - 2S + 3p (<= 4), Y3 = M (S - X3 + 5p) - W Y1 + 2p (<= 3)
 template <class M>
-__device__ __noinline__ XYZZ30<M> xyzz30_double(F30<M> x, F30<M> y, F30<M> zz, F30<M> zzz) {
+__device__ __forceinline__ XYZZ30<M> xyzz30_double_body(const F30<M>& x, const F30<M>& y, const F30<M>& zz, const F30<M>& zzz) {
     XYZZ30<M> r;
     F30<M> U = f30_small_mul<M, 2>(y);
     F30<M> V = f30_sqr<M>(U);
@@ -109,6 +109,10 @@ __device__ __noinline__ XYZZ30<M> xyzz30_double(F30<M> x, F30<M> y, F30<M> zz, F
     r.zzz = f30_mul<M>(W, zzz);
     r.inf = f30_product_is_zero<M>(V);
     return r;
+}
+template <class M>
+__device__ __noinline__ XYZZ30<M> xyzz30_double(F30<M> x, F30<M> y, F30<M> zz, F30<M> zzz) {
+    return xyzz30_double_body<M>(x, y, zz, zzz);
 }
 
 // p += q (add-2008-s), all exceptional cases.  Bounds as for the mixed form: X <= 5, Y <= 3, ZZ, ZZZ <= 1 on both sides;
@@ -181,6 +185,28 @@ __device__ __forceinline__ XYZZ30<M> xyzz30_load_lazy(const XYZZ<M>* src) {
     t[0] = w[6].x; t[1] = w[6].y; t[2] = w[6].z; t[3] = w[6].w; t[4] = w[7].x; t[5] = w[7].y; t[6] = w[7].z; t[7] = w[7].w;
     p.zzz = f30_unpack<M>(t);
     return p;
+}
+
+// Out-of-line group operations on the lazy memory form (for the scalar-multiplication ladders of mac_fft.cuh, whose
+// working set -- a table of multiples -- lives in private memory anyway): one body of each in the instruction cache.
+//   *p += (neg ? -1 : 1) * (phi ? (beta X, Y, ZZ, ZZZ) : (X, Y, ZZ, ZZZ)) of *q;   beta30 = beta in the 2^270 form
+template <class M>
+__device__ __noinline__ void xyzz30_add_mem(XYZZ<M>* p, const XYZZ<M>* q, uint32_t neg, uint32_t phi, const F30<M>* beta30) {
+    XYZZ30<M> a = xyzz30_load_lazy<M>(p), b = xyzz30_load_lazy<M>(q);
+    if (!b.inf) {
+        if (phi) b.x = f30_mul<M>(b.x, *beta30);
+        if (neg) b.y = f30_sub<M, 4>(F30<M>{}, b.y);       // 4p - Y <= 4p: fine as an operand, never stored
+    }
+    xyzz30_add<M>(a, b);
+    xyzz30_store_lazy<M>(p, a);
+}
+template <class M>
+__device__ __noinline__ void xyzz30_double_mem(XYZZ<M>* p, int times) {
+    XYZZ30<M> a = xyzz30_load_lazy<M>(p);
+    if (a.inf) return;
+#pragma unroll 1
+    for (int t = 0; t < times && !a.inf; t++) a = xyzz30_double_body<M>(a.x, a.y, a.zz, a.zzz);
+    xyzz30_store_lazy<M>(p, a);
 }
 
 // the accumulator as an ec.cuh XYZZ in the 2^256 Montgomery form (canonical residues); infinity = all zero

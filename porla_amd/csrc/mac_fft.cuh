@@ -89,6 +89,136 @@ __device__ __noinline__ XYZZ<M> xyzz_scalar_mul(XYZZ<M> P, const uint32_t k[8]) 
     return acc;
 }
 
+// ---------------------------------------------------------------- the same ladder in the reduced-radix form (C::F30_LAZY)
+// k * P with the curve's endomorphism: k = k1 + lambda k2 (glv.cuh; |k1|, |k2| < 2^128), then ONE joint ladder over both
+// halves -- 33 signed 4-bit windows, 4 doublings each, and per window at most one addition from the table of P's multiples
+// and one from the same table with X scaled by beta (= the table of phi(P)): 132 doublings + <= 66 additions instead of
+// 260 + 65, every field product in the 9 x 30-bit form of fe30.cuh.  Points are in the lazy memory form of ec30.cuh.
+template <class C>
+__device__ __noinline__ void mac30_scalar_mul(XYZZ<typename C::Fp>* out, const XYZZ<typename C::Fp>* P, const uint32_t k[8]) {
+    using M = typename C::Fp;
+    using G = typename C::Glv;
+    uint32_t nz = 0;
+#pragma unroll
+    for (int i = 1; i < 8; i++) nz |= k[i];
+    uint4* o4 = reinterpret_cast<uint4*>(out);
+    const uint4* p4 = reinterpret_cast<const uint4*>(P);
+    if (nz == 0 && k[0] <= 1) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) o4[i] = k[0] ? p4[i] : make_uint4(0, 0, 0, 0);
+        return;
+    }
+    uint32_t m[2][4];
+    bool ng[2];
+    glv_split<G>(k, m[0], ng[0], m[1], ng[1]);
+    // beta in the 2^270 form
+    Fe<M> bplain, r2;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { bplain.v[i] = G::BETA[i]; r2.v[i] = M::R2_30[i]; }
+    const F30<M> beta30 = f30_from_fe<M>(fe_mul_call<M>(bplain, r2));
+    XYZZ<M> tbl[8];
+    {
+        uint4* t4 = reinterpret_cast<uint4*>(&tbl[0]);
+#pragma unroll
+        for (int i = 0; i < 8; i++) t4[i] = p4[i];
+    }
+#pragma unroll 1
+    for (int i = 1; i < 8; i++) {
+        const uint4* s4 = reinterpret_cast<const uint4*>(&tbl[i - 1]);
+        uint4* d4 = reinterpret_cast<uint4*>(&tbl[i]);
+#pragma unroll
+        for (int j = 0; j < 8; j++) d4[j] = s4[j];
+        xyzz30_add_mem<M>(&tbl[i], P, 0, 0, &beta30);
+    }
+    // signed digits, least significant first: d in [-8, 8]; 32 windows cover 128 bits, the 33rd takes the carry
+    int8_t dig[2][33];
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {
+        uint32_t carry = 0;
+#pragma unroll 1
+        for (int i = 0; i < 32; i++) {
+            uint32_t limb = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) limb = (j == (i >> 3)) ? m[h][j] : limb;
+            uint32_t d = ((limb >> ((i & 7) * 4)) & 15u) + carry;
+            if (d > 8) { dig[h][i] = (int8_t)((int)d - 16); carry = 1; }
+            else { dig[h][i] = (int8_t)d; carry = 0; }
+        }
+        dig[h][32] = (int8_t)carry;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) o4[i] = make_uint4(0, 0, 0, 0);      // infinity
+#pragma unroll 1
+    for (int i = 32; i >= 0; i--) {
+        xyzz30_double_mem<M>(out, 4);
+#pragma unroll 1
+        for (int h = 0; h < 2; h++) {
+            const int d = dig[h][i];
+            if (d != 0) xyzz30_add_mem<M>(out, &tbl[(d < 0 ? -d : d) - 1], (uint32_t)((d < 0) != ng[h]), (uint32_t)h, &beta30);
+        }
+    }
+}
+
+// 64-byte big-endian affine MACs -> work array in the lazy memory form; part 1 (Y): times wt
+template <class C>
+__global__ void __launch_bounds__(64)
+k_mac_load30(const uint8_t* __restrict__ in, uint32_t n, XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restrict__ wt,
+             int use_wt) {
+    using M = typename C::Fp;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<M> a;
+    load_be256(a.x.v, in + (size_t)i * 64);
+    load_be256(a.y.v, in + (size_t)i * 64 + 32);
+    fe_reduce_plain<M>(a.x.v, 6);
+    fe_reduce_plain<M>(a.y.v, 6);
+    XYZZ<M> p;                                  // lazy form: residues in the 2^270 form; infinity = all zero
+    if (aff_is_inf<M>(a)) {
+        p.x = fe_zero<M>(); p.y = p.x; p.zz = p.x; p.zzz = p.x;
+    } else {
+        Fe<M> r2;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { r2.v[j] = M::R2_30[j]; p.zz.v[j] = M::R1_30[j]; }
+        p.x = fe_mul_call<M>(a.x, r2);
+        p.y = fe_mul_call<M>(a.y, r2);
+        p.zzz = p.zz;
+    }
+    if (use_wt) {
+        uint32_t k[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) k[j] = wt[j];
+        XYZZ<M> r;
+        mac30_scalar_mul<C>(&r, &p, k);
+        p = r;
+    }
+    store_xyzz<M>(work + i, p);
+}
+
+template <class C>
+__global__ void __launch_bounds__(64)
+k_mac_stage30(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restrict__ tws, uint32_t n, int s) {
+    using M = typename C::Fp;
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n / 2) return;
+    const uint32_t m2 = 1u << (s - 1);
+    const uint32_t j = t & (m2 - 1);
+    const uint32_t k = ((t >> (s - 1)) << s) + j;
+    const uint32_t e = j * (n >> (s - 1));
+    uint32_t sc[8];
+    const uint4* q = reinterpret_cast<const uint4*>(tws + (size_t)e * 8);
+    uint4 a = q[0], b = q[1];
+    sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
+    XYZZ<M> hi = load_xyzz<M>(work + k + m2);
+    XYZZ<M> tm;
+    mac30_scalar_mul<C>(&tm, &hi, sc);
+    XYZZ<M> sum = load_xyzz<M>(work + k);
+    XYZZ<M> dif = sum;
+    xyzz30_add_mem<M>(&sum, &tm, 0, 0, nullptr);
+    xyzz30_add_mem<M>(&dif, &tm, 1, 0, nullptr);
+    store_xyzz<M>(work + k, sum);
+    store_xyzz<M>(work + k + m2, dif);
+}
+
 // 64-byte big-endian affine MACs -> XYZZ work array; part 1 (Y): times wt (Server.hpp:1528-1536)
 template <class C>
 __global__ void __launch_bounds__(64)
@@ -200,6 +330,7 @@ k_mac_finish(const XYZZ<typename C::Fp>* __restrict__ work, uint32_t n, uint8_t*
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     XYZZ<M> p = load_xyzz<M>(work + i);
+    if constexpr (C::F30_LAZY) p = xyzz30_to_xyzz<M>(xyzz30_load_lazy<M>(&p));   // the reduced-radix ladder's work array
     uint8_t* dst = out + (size_t)i * 64;
     if (xyzz_is_inf<M>(p)) {
         uint4 z = make_uint4(0, 0, 0, 0);

@@ -35,7 +35,7 @@ template <class C> struct FbOf;
 template <> struct FbOf<Bn254G1> { static FixedBase<Bn254G1>& get(MacWs* w) { return w->fb_bn; } };
 template <> struct FbOf<Secp256k1G> { static FixedBase<Secp256k1G>& get(MacWs* w) { return w->fb_secp; } };
 static std::mutex g_mac_mu;
-static size_t g_matrix_max = getenv("PORLA_MAC_MATRIX_MAX") ? (size_t)atol(getenv("PORLA_MAC_MATRIX_MAX")) : 2048;
+static size_t g_matrix_max = getenv("PORLA_MAC_MATRIX_MAX") ? (size_t)atol(getenv("PORLA_MAC_MATRIX_MAX")) : 1024;
 static std::vector<MacWs*> g_mac_ws;
 
 static int get_mac_ws(MacWs** out) {
@@ -126,13 +126,21 @@ static int mac_encode_core(MacWs* ws, int curve, const uint8_t* d_in, size_t n, 
     }
     {
         ProfScope ps("mac_load", stream);
-        hipLaunchKernelGGL((k_mac_load<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_in, (uint32_t)n,
-                           (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->wt.p, use_wt);
+        if constexpr (C::F30_LAZY)
+            hipLaunchKernelGGL((k_mac_load30<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_in, (uint32_t)n,
+                               (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->wt.p, use_wt);
+        else
+            hipLaunchKernelGGL((k_mac_load<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_in, (uint32_t)n,
+                               (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->wt.p, use_wt);
     }
     for (int s = 1; s <= logn; s++) {
         ProfScope ps("mac_stage", stream);
-        hipLaunchKernelGGL((k_mac_stage<C>), dim3((unsigned)((n / 2 + 63) / 64)), dim3(64), 0, stream, (XYZZ<M>*)ws->work.p,
-                           (const uint32_t*)ws->tws.p, (uint32_t)n, s);
+        if constexpr (C::F30_LAZY)
+            hipLaunchKernelGGL((k_mac_stage30<C>), dim3((unsigned)((n / 2 + 63) / 64)), dim3(64), 0, stream, (XYZZ<M>*)ws->work.p,
+                               (const uint32_t*)ws->tws.p, (uint32_t)n, s);
+        else
+            hipLaunchKernelGGL((k_mac_stage<C>), dim3((unsigned)((n / 2 + 63) / 64)), dim3(64), 0, stream, (XYZZ<M>*)ws->work.p,
+                               (const uint32_t*)ws->tws.p, (uint32_t)n, s);
     }
     {
         ProfScope ps("mac_finish", stream);
