@@ -159,20 +159,15 @@ __device__ __noinline__ void mac30_scalar_mul(XYZZ<typename C::Fp>* out, const X
     }
 }
 
-// 64-byte big-endian affine MACs -> work array in the lazy memory form; part 1 (Y): times wt
-template <class C>
-__global__ void __launch_bounds__(64)
-k_mac_load30(const uint8_t* __restrict__ in, uint32_t n, XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restrict__ wt,
-             int use_wt) {
-    using M = typename C::Fp;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// 64-byte big-endian affine point -> lazy memory form (residues in the 2^270 form; infinity = all zero)
+template <class M>
+__device__ __forceinline__ XYZZ<M> load_affine_be_lazy(const uint8_t* src) {
     Affine<M> a;
-    load_be256(a.x.v, in + (size_t)i * 64);
-    load_be256(a.y.v, in + (size_t)i * 64 + 32);
+    load_be256(a.x.v, src);
+    load_be256(a.y.v, src + 32);
     fe_reduce_plain<M>(a.x.v, 6);
     fe_reduce_plain<M>(a.y.v, 6);
-    XYZZ<M> p;                                  // lazy form: residues in the 2^270 form; infinity = all zero
+    XYZZ<M> p;
     if (aff_is_inf<M>(a)) {
         p.x = fe_zero<M>(); p.y = p.x; p.zz = p.x; p.zzz = p.x;
     } else {
@@ -183,6 +178,18 @@ k_mac_load30(const uint8_t* __restrict__ in, uint32_t n, XYZZ<typename C::Fp>* _
         p.y = fe_mul_call<M>(a.y, r2);
         p.zzz = p.zz;
     }
+    return p;
+}
+
+// 64-byte big-endian affine MACs -> work array in the lazy memory form; part 1 (Y): times wt
+template <class C>
+__global__ void __launch_bounds__(64)
+k_mac_load30(const uint8_t* __restrict__ in, uint32_t n, XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restrict__ wt,
+             int use_wt) {
+    using M = typename C::Fp;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    XYZZ<M> p = load_affine_be_lazy<M>(in + (size_t)i * 64);
     if (use_wt) {
         uint32_t k[8];
 #pragma unroll
@@ -312,14 +319,26 @@ k_mac_mix(const uint8_t* __restrict__ a0, const uint8_t* __restrict__ a1, uint32
     const uint4* q = reinterpret_cast<const uint4*>(tws + (size_t)i * tw_step * 8);
     uint4 a = q[0], b = q[1];
     sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
-    XYZZ<M> tm = xyzz_scalar_mul<M>(load_affine_be<M>(a1 + (size_t)i * 64), sc);
-    XYZZ<M> um = load_affine_be<M>(a0 + (size_t)i * 64);
-    XYZZ<M> sum = um;
-    xyzz_add_cold<M>(&sum, &tm);
-    XYZZ<M> ntm = xyzz_neg<M>(tm);
-    xyzz_add_cold<M>(&um, &ntm);
-    store_affine_be<M>(out + (size_t)i * 64, sum);
-    store_affine_be<M>(out + ((size_t)i + len) * 64, um);
+    if constexpr (C::F30_LAZY) {      // the reduced-radix ladder (mac30_scalar_mul)
+        XYZZ<M> hi = load_affine_be_lazy<M>(a1 + (size_t)i * 64);
+        XYZZ<M> tm;
+        mac30_scalar_mul<C>(&tm, &hi, sc);
+        XYZZ<M> sum = load_affine_be_lazy<M>(a0 + (size_t)i * 64);
+        XYZZ<M> dif = sum;
+        xyzz30_add_mem<M>(&sum, &tm, 0, 0, nullptr);
+        xyzz30_add_mem<M>(&dif, &tm, 1, 0, nullptr);
+        store_affine_be<M>(out + (size_t)i * 64, xyzz30_to_xyzz<M>(xyzz30_load_lazy<M>(&sum)));
+        store_affine_be<M>(out + ((size_t)i + len) * 64, xyzz30_to_xyzz<M>(xyzz30_load_lazy<M>(&dif)));
+    } else {
+        XYZZ<M> tm = xyzz_scalar_mul<M>(load_affine_be<M>(a1 + (size_t)i * 64), sc);
+        XYZZ<M> um = load_affine_be<M>(a0 + (size_t)i * 64);
+        XYZZ<M> sum = um;
+        xyzz_add_cold<M>(&sum, &tm);
+        XYZZ<M> ntm = xyzz_neg<M>(tm);
+        xyzz_add_cold<M>(&um, &ntm);
+        store_affine_be<M>(out + (size_t)i * 64, sum);
+        store_affine_be<M>(out + ((size_t)i + len) * 64, um);
+    }
 }
 
 // XYZZ work array -> 64-byte big-endian affine MACs (infinity = 64 zero bytes, main.go:224-230)
