@@ -148,9 +148,15 @@ __device__ __forceinline__ void xyzz30_add(XYZZ30<M>& p, const XYZZ30<M>& q) {
     p.zzz = f30_mul<M>(f30_mul<M>(p.zzz, q.zzz), PPP);
 }
 
-// Memory form between the kernels of the reduced-radix path ("lazy"): the four residues in the 2^270 Montgomery form, NOT
-// reduced (X <= 5p + 2^246 < 2^256 and the others below that), each packed into 8 words; infinity = all words zero (a
-// finite point's ZZ is never 0 mod p, and a stored ZZ is a product's result, so it is never the word pattern 0).
+// Memory form between the kernels of the reduced-radix path ("lazy"): BN254 -- the four residues in the 2^270 Montgomery
+// form, NOT reduced (X <= 5p + 2^246 < 2^256 and the others below that), each packed into 8 words; secp256k1 (p ~ 2^256) --
+// the four residues reduced to canonical form on the way out.  Infinity = all words zero (a finite point's ZZ is never
+// 0 mod p; BN254: a stored ZZ is a product's result below p + 2^246 that is not p, so never the word pattern 0).
+__device__ __forceinline__ void store_words8(uint32_t* d, const uint32_t (&w)[8]) {
+    uint4* q = reinterpret_cast<uint4*>(d);
+    q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
 template <class M>
 __device__ __forceinline__ void xyzz30_store_lazy(XYZZ<M>* dst, const XYZZ30<M>& p) {
     uint32_t* d = reinterpret_cast<uint32_t*>(dst);
@@ -162,10 +168,19 @@ __device__ __forceinline__ void xyzz30_store_lazy(XYZZ<M>* dst, const XYZZ30<M>&
         return;
     }
     Fe<M> t;
-    f30_pack<M>(t.v, p.x);   { uint4* q = reinterpret_cast<uint4*>(d);      q[0] = make_uint4(t.v[0], t.v[1], t.v[2], t.v[3]); q[1] = make_uint4(t.v[4], t.v[5], t.v[6], t.v[7]); }
-    f30_pack<M>(t.v, p.y);   { uint4* q = reinterpret_cast<uint4*>(d + 8);  q[0] = make_uint4(t.v[0], t.v[1], t.v[2], t.v[3]); q[1] = make_uint4(t.v[4], t.v[5], t.v[6], t.v[7]); }
-    f30_pack<M>(t.v, p.zz);  { uint4* q = reinterpret_cast<uint4*>(d + 16); q[0] = make_uint4(t.v[0], t.v[1], t.v[2], t.v[3]); q[1] = make_uint4(t.v[4], t.v[5], t.v[6], t.v[7]); }
-    f30_pack<M>(t.v, p.zzz); { uint4* q = reinterpret_cast<uint4*>(d + 24); q[0] = make_uint4(t.v[0], t.v[1], t.v[2], t.v[3]); q[1] = make_uint4(t.v[4], t.v[5], t.v[6], t.v[7]); }
+    if constexpr (M::PSEUDO_MERSENNE) {
+        // special-form modulus (p ~ 2^256): an unreduced X <= 5p does not fit 256 bits and a product's result may have bit 256
+        // set, so the four residues are stored canonically here (one fold + at most two subtractions each)
+        t = f30_to_fe_canonical<M>(f30_pm_reduce<M>(p.x));   store_words8(d, t.v);
+        t = f30_to_fe_canonical<M>(f30_pm_reduce<M>(p.y));   store_words8(d + 8, t.v);
+        t = f30_to_fe_canonical<M>(p.zz);                    store_words8(d + 16, t.v);
+        t = f30_to_fe_canonical<M>(p.zzz);                   store_words8(d + 24, t.v);
+    } else {
+        f30_pack<M>(t.v, p.x);   store_words8(d, t.v);
+        f30_pack<M>(t.v, p.y);   store_words8(d + 8, t.v);
+        f30_pack<M>(t.v, p.zz);  store_words8(d + 16, t.v);
+        f30_pack<M>(t.v, p.zzz); store_words8(d + 24, t.v);
+    }
 }
 template <class M>
 __device__ __forceinline__ XYZZ30<M> xyzz30_load_lazy(const XYZZ<M>* src) {

@@ -145,6 +145,26 @@ __device__ __forceinline__ void f30_pm_fold(F30<M>& r, const uint32_t (&L)[18]) 
     }
     r.v[8] = (R[8] & 0xffffu) + carry;
 }
+// value < 2^259 (normal limbs) -> the same residue below 2^256 + 2^49: only the bits above 2^256 are folded
+template <class M>
+__device__ __forceinline__ F30<M> f30_pm_reduce(const F30<M>& a) {
+    F30<M> r;
+    const uint32_t g1 = a.v[8] >> 16;
+    uint64_t u = (uint64_t)a.v[0] + (uint64_t)g1 * M::FOLD;
+    r.v[0] = (uint32_t)u & F30_MASK;
+    u >>= 30;
+    u += (uint64_t)a.v[1] + ((uint64_t)g1 << 2);
+    r.v[1] = (uint32_t)u & F30_MASK;
+    uint32_t carry = (uint32_t)(u >> 30);
+#pragma unroll
+    for (int j = 2; j < 8; j++) {
+        uint32_t x = a.v[j] + carry;
+        r.v[j] = x & F30_MASK;
+        carry = x >> 30;
+    }
+    r.v[8] = (a.v[8] & 0xffffu) + carry;
+    return r;
+}
 template <class M>
 __device__ __forceinline__ F30<M> f30_mul_pm_portable(const F30<M>& a, const F30<M>& b) {
     uint64_t t = 0;

@@ -61,7 +61,7 @@ struct Secp256k1G {
     // the reference's secp256k1 path also applies, ecmult_impl.h:621-634) gives 8 windows of 17 bits instead
     static constexpr bool GLV_DEFAULT = true;
     static constexpr bool F30_BUCKETS = true;    // special-form product on 30-bit limbs: 194 against 133 G products/s
-    static constexpr bool F30_LAZY = false;      // 5p > 2^256: an unreduced X does not fit the 32-byte memory form
+    static constexpr bool F30_LAZY = true;       // memory form: canonical residues (5p > 2^256: an unreduced X does not fit 32 bytes)
 };
 
 constexpr uint32_t KEY_NONE = 0xffffffffu;
