@@ -28,7 +28,7 @@ static inline uint32_t tree_tail_start(uint32_t B, uint32_t nlev) {
 // Window width for m sub-scalars of `bits` bits, from a time model in microseconds fitted to the sweeps in profiles/
 // (2^7 .. 2^20 pairs):
 //   digit extraction     ~6 us per window (the per-tile loop over windows)
-//   bucket accumulation  throughput W*m / 10.2 G additions/s, but never faster than the longest dependent chain at ~9.5 us
+//   bucket accumulation  throughput W*m / 13.5 G additions/s (reduced-radix form), but never faster than the longest dependent chain at ~5.6 us
 //                        per entry for a lone wave: the average bucket plus 4 sigma, or -- the usual culprit -- a top window
 //                        that holds only `top` bits and crowds all m entries into 2^(top-1) buckets (work items cap a chain
 //                        at CHUNK entries)
@@ -47,21 +47,24 @@ static inline int choose_window(size_t m, int bits) {
         const double B = (double)((size_t)1 << (c - 1));
         const double load = (double)m / B;                             // average entries per bucket
         const double top_load = W > 1 ? (double)m / (double)((size_t)1 << (top > 1 ? top - 1 : 0)) : 0.0;
-        // ---- bucket accumulation: waves of 64 work items, 4096 resident at once (4 per SIMD); a full round of chains of
-        // `load` entries costs load * 25.7 us (10.2 G additions/s), a partial last round runs closer to the lone-wave rate
+        // ---- bucket accumulation: work items in waves of 64, 4096 waves resident at once (4 per SIMD).  With at least one
+        // resident round the kernel is throughput bound: (entries - items) additions (an item's first entry is a copy) at 14 G/s,
+        // stretched by the drain of the last round -- the fewer rounds, the larger its share (fitted at 2^20 pairs: c = 15 .. 18,
+        // 1.06 .. 7.5 rounds, 1.53 / 1.30 / 1.08 / 0.95 ms).  Below one round the chains run closer to the lone-wave rate.
         const double items = (double)W * B * (load > 20.0 ? 1.0 : 1.0 - __builtin_exp(-load));
         const double waves = items / 64.0;
-        const double full = (double)(size_t)(waves / 4096.0);
-        const double rest = waves - full * 4096.0;
-        double t_sum = full * load * 25.7 + (rest > 0.5 ? load * (6.7 + 19.0 * rest / 4096.0) : 0.0);
-        double chain = load + 4.0 * __builtin_sqrt(load) + 1.0;      // the longest dependent chain (lone wave: ~9.5 us / entry)
+        const double rounds = waves / 4096.0;
+        const double adds = (double)W * (double)m > items ? (double)W * (double)m - items : 0.0;
+        double t_sum = rounds >= 1.0 ? adds / 14.0e3 * (1.0 + 0.22 / rounds)
+                                     : (waves > 0.5 ? load * (4.0 + 15.4 * rounds) : 0.0);
+        double chain = load + 4.0 * __builtin_sqrt(load) + 1.0;      // the longest dependent chain (lone wave: ~5.6 us / entry)
         const double top_chain = top_load < (double)CHUNK ? top_load : (double)CHUNK;
         if (top_chain > chain) chain = top_chain;
         if (chain > (double)CHUNK) chain = (double)CHUNK;
-        if (t_sum < chain * 9.5) t_sum = chain * 9.5;
+        if (t_sum < chain * 5.6) t_sum = chain * 5.6;
         // ---- heavy buckets: split into work items, one wave folds each bucket's item sums
         double t_combine = 0.0;
-        if (top_load > (double)CHUNK) t_combine = 70.0 + top_load / CHUNK / 64.0 * 9.8;
+        if (top_load > (double)CHUNK) t_combine = 50.0 + top_load / CHUNK / 64.0 * 7.0;
         if (load > 0.6 * CHUNK) t_combine += 1e6;                      // every bucket would need the combine pass
         // ---- bucket reduction (bit-sliced tree, msm.cuh): level l holds W (l+1) B / 2^(l+1) independent additions; a level
         // launch costs at least one addition's latency, the per-window tail levels run back to back in one kernel; the host
@@ -76,7 +79,9 @@ static inline int choose_window(size_t m, int bits) {
                 else t_reduce += TREE_TAIL_LEVEL_US;
             }
         }
-        const double cost = 6.0 * W + t_sum + t_combine + t_reduce;
+        // ---- LDS counting sort: ~6.6 ps per entry while a partition's buckets fit the staging area (c <= 16), slower beyond
+        const double t_sort = (double)W * (double)m * 6.6e-6 * (c <= 16 ? 1.0 : (c == 17 ? 1.4 : 4.5));
+        const double cost = 6.0 * W + t_sum + t_sort + t_combine + t_reduce;
         if (cost < best_cost) { best_cost = cost; best = c; }
     }
     return best;
