@@ -175,7 +175,7 @@ def main():
         if fe_mults_per_launch:
             # the elliptic-curve kernels are bound by the 32x32->64 multiplier issue rate, which neither "hbm" nor "mfma"
             # names: the supplement prices the dominant kernel's 256-bit modular multiplications against the rate the
-            # multiply microbenchmark sustains on this chip (tools/fe30_check.hip --bench, tools/ubench.hip; profiles/r01_k_ubench_fe30.txt, r01_b_ubench_asm_mul.txt)
+            # multiply microbenchmark sustains on this chip (tools/fe30_check.hip --bench, tools/ubench.hip; profiles/r01_l_ubench_fe30.txt)
             g = fe_mults_per_launch / (kern[dom] * 1e-3) / 1e9
             peak = FE_MUL_PEAK_G[workload]
             r["int_multiplier"] = {"achieved": round(g, 2), "peak": peak, "unit": "G fe_mul/s (256-bit modular)",
