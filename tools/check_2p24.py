@@ -15,5 +15,6 @@ parts = b""
 for k in range(8):
     lo = k * (n // 8)
     parts += mx.msm_device("bn254", d_sc.data_ptr() + 32 * lo, d_pt.data_ptr() + 64 * lo, n // 8, s, partial=True)
-print("2^24 pairs: %.2f ms, %.1f Mmul/s; 8-way range fold equal: %s; repeat equal: %s" % (el * 1e3, n / el / 1e6, mx.jac_sum("bn254", parts, 8) == got, got == got2))
+shape = mx.last_msm_shape()
+print("2^24 pairs: %.2f ms, %.1f Mmul/s (window bits, windows, GLV of the last range MSM: %s); 8-way range fold equal: %s; repeat equal: %s" % (el * 1e3, n / el / 1e6, shape, mx.jac_sum("bn254", parts, 8) == got, got == got2))
 t0 = time.perf_counter(); want = common.oracle_msm(bytes(d_sc.cpu().numpy()), pt, n); print("oracle %.1f s, equal: %s" % (time.perf_counter() - t0, want == got))
