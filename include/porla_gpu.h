@@ -79,6 +79,10 @@ int porla_bn254_msm_device_begin(int slot, const void *d_scalars, const void *d_
 int porla_bn254_msm_device_end(int slot, uint8_t *out, int jacobian);
 int porla_bn254_msm_host(const uint8_t *scalars, const uint8_t *points, size_t n, uint8_t out_affine[64]);
 int porla_bn254_jac_sum(const uint8_t *jacobians, size_t count, uint8_t out_affine[64]);
+/* the MSM's host tail on its own (no device needed): the bucket-reduction tree leaves, per window w < windows, S_w and
+ * M_{w,k} (k < window_bits - 1) -- here as 64-byte affine points, sums[w * window_bits + 0] = S_w, [.. + 1 + k] = M_{w,k} --
+ * and the result is sum_w 2^(window_bits * w) * (S_w + sum_k 2^k M_{w,k}).  Exists for the CPU test of that fold. */
+int porla_bn254_tree_fold(const uint8_t *sums_affine, int windows, int window_bits, uint8_t out_affine[64]);
 
 /* ---- secp256k1 MSM (canonical encodings: 32-byte BE scalar, 64-byte x||y BE affine, zeros = infinity) ---- */
 int porla_secp256k1_msm_device(const void *d_scalars, const void *d_points, size_t n, uint8_t out_affine[64],
@@ -89,6 +93,7 @@ int porla_secp256k1_msm_device_begin(int slot, const void *d_scalars, const void
 int porla_secp256k1_msm_device_end(int slot, uint8_t *out, int jacobian);   /* the two MSMs of the IPA audit, Server.hpp:842-848 */
 int porla_secp256k1_msm_host(const uint8_t *scalars, const uint8_t *points, size_t n, uint8_t out_affine[64]);
 int porla_secp256k1_jac_sum(const uint8_t *jacobians, size_t count, uint8_t out_affine[64]);
+int porla_secp256k1_tree_fold(const uint8_t *sums_affine, int windows, int window_bits, uint8_t out_affine[64]);
 
 /* ---- batched fixed-base commitments ----
  * out[r] = sum_{i < n_coeffs} (row_r[i] mod order) * base[i] for every row r, as 64-byte X||Y big-endian affine points.

@@ -2,6 +2,7 @@
 // Host language is C++ (the reference's plug-in is Go over cgo; no Go toolchain exists in this image,
 // and the reference's callers are C++: porla/Utils/utils.h:277-292).
 #include "engine.hpp"
+#include "host_fold64.hpp"
 #include "../../include/porla_gpu.h"
 
 #include <cstdio>
@@ -133,6 +134,15 @@ static int abi_msm_host(const uint8_t* scalars, const uint8_t* points, size_t n,
     return PORLA_OK;
 }
 template <class C>
+static int abi_tree_fold(const uint8_t* sums, int W, int c, uint8_t* out) {
+    using M = typename C::Fp;
+    if (W < 1 || c < 2 || c > 20 || !sums || !out) { set_last_error("porla: bad argument"); return PORLA_ERR_ARG; }
+    std::vector<XYZZ<M>> fin((size_t)W * c);
+    for (size_t i = 0; i < fin.size(); i++) fin[i] = xyzz_from_affine<M>(h_affine_from_bytes<M>(sums + 64 * i));
+    h_affine_to_bytes<M>(out, h_xyzz_to_affine<M>(h_fold_tree64<M>(fin.data(), W, c)));
+    return PORLA_OK;
+}
+template <class C>
 static int abi_jac_sum(const uint8_t* jacs, size_t count, uint8_t* out) {
     using M = typename C::Fp;
     if (count && !jacs) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
@@ -236,6 +246,12 @@ int porla_bn254_msm_host(const uint8_t* scalars, const uint8_t* points, size_t n
 }
 int porla_bn254_jac_sum(const uint8_t* jacs, size_t count, uint8_t out_affine[64]) {
     return abi_jac_sum<Bn254G1>(jacs, count, out_affine);
+}
+int porla_bn254_tree_fold(const uint8_t* sums, int windows, int window_bits, uint8_t out_affine[64]) {
+    return abi_tree_fold<Bn254G1>(sums, windows, window_bits, out_affine);
+}
+int porla_secp256k1_tree_fold(const uint8_t* sums, int windows, int window_bits, uint8_t out_affine[64]) {
+    return abi_tree_fold<Secp256k1G>(sums, windows, window_bits, out_affine);
 }
 
 int porla_bn254_msm_device_begin(int slot, const void* d_scalars, const void* d_points, size_t n, void* s) {

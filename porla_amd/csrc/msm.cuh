@@ -49,6 +49,7 @@ struct Bn254G1 {
     // ... and the sums stay in that form ("lazy" memory form of ec30.cuh: unreduced residues, X <= 5p < 2^256) through the
     // combine and tree kernels
     static constexpr bool F30_LAZY = true;
+    static constexpr int BUCKET_SUM_WAVES = 4;   // waves per SIMD k_bucket_sum30 is compiled for
 };
 struct Secp256k1G {
     using Fp = Secp256k1Fp;
@@ -62,6 +63,7 @@ struct Secp256k1G {
     static constexpr bool GLV_DEFAULT = true;
     static constexpr bool F30_BUCKETS = true;    // special-form product on 30-bit limbs: 194 against 133 G products/s
     static constexpr bool F30_LAZY = true;       // memory form: canonical residues (5p > 2^256: an unreduced X does not fit 32 bytes)
+    static constexpr int BUCKET_SUM_WAVES = 3;   // the fold's temporaries do not fit 128 registers
 };
 
 constexpr uint32_t KEY_NONE = 0xffffffffu;
@@ -597,7 +599,7 @@ k_bucket_sum(const Affine<typename C::Fp>* __restrict__ pts, const uint32_t* __r
 // (k_points_to_mont<.., F30>), the item's sum leaves in the lazy memory form of ec30.cuh, which the combine and tree kernels
 // of this curve read; the last tree level converts to the 2^256 form for the host.
 template <class C>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C::BUCKET_SUM_WAVES, 4)))
 k_bucket_sum30(const Affine<typename C::Fp>* __restrict__ pts, const uint32_t* __restrict__ entries,
                const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
                const uint2* __restrict__ order, const uint32_t* __restrict__ chunk_base,

@@ -69,6 +69,7 @@ def _declare(L):
         f = getattr(L, "porla_%s_msm_device_partial" % curve); f.argtypes = [vp, vp, sz, u8p, vp]; f.restype = ctypes.c_int
         f = getattr(L, "porla_%s_msm_host" % curve); f.argtypes = [u8p, u8p, sz, u8p]; f.restype = ctypes.c_int
         f = getattr(L, "porla_%s_jac_sum" % curve); f.argtypes = [u8p, sz, u8p]; f.restype = ctypes.c_int
+        f = getattr(L, "porla_%s_tree_fold" % curve); f.argtypes = [u8p, ctypes.c_int, ctypes.c_int, u8p]; f.restype = ctypes.c_int
     L.porla_fixed_base_create.argtypes = [ctypes.c_int, u8p, sz, ctypes.c_int, ctypes.POINTER(vp)]
     L.porla_fixed_base_create.restype = ctypes.c_int
     L.porla_fixed_base_info.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),

@@ -98,3 +98,27 @@ def test_jac_sum_folds_partials():
     parts += (1).to_bytes(32, "big") + (1).to_bytes(32, "big") + bytes(32)      # infinity
     assert mx.jac_sum("bn254", parts, 4) == o.g1_marshal(o.g1_mul(o.G1, 23))
     assert mx.jac_sum("bn254", b"", 0) == bytes(64)
+
+
+def test_tree_fold_is_the_weighted_sum_of_its_bit_slices():
+    """the MSM's host tail (host_fold64.hpp:h_fold_tree64): windows of S / M_k sums -> sum_w 2^(c w) (S_w + sum_k 2^k M_wk),
+    checked against Python integers on G multiples, with empty (infinity) slots"""
+    import ctypes
+    import random
+    import bn254_py as o
+    from porla_amd import lib
+    rnd = random.Random(5)
+    for W, c in ((1, 2), (3, 5), (2, 16), (16, 16), (15, 17)):
+        ks, blob = [], b""
+        for w in range(W):
+            for j in range(c):
+                k = 0 if rnd.random() < 0.2 else rnd.randrange(1, 1 << 64)
+                ks.append(k)
+                blob += o.g1_marshal(o.g1_mul(o.G1, k)) if k else bytes(64)
+        want = 0
+        for w in range(W):
+            v = ks[w * c] + sum(ks[w * c + 1 + k] << k for k in range(c - 1))
+            want += v << (c * w)
+        out = ctypes.create_string_buffer(64)
+        assert lib.porla_bn254_tree_fold(blob, W, c, out) == 0
+        assert out.raw == o.g1_marshal(o.g1_mul(o.G1, want % o.R))
