@@ -148,10 +148,15 @@ __global__ void k_icc_twiddles(IccElem<Q>* __restrict__ tw, uint32_t n, const Fe
     st_elem<Q>(tw + e, t);
 }
 
+// unit_tw: the twiddle is w^0 = 1 (j = 0: every butterfly of stage 1, half of stage 2, ...): no product
 template <class Q>
-__device__ __forceinline__ void butterfly(IccElem<Q>& a, IccElem<Q>& b, const IccElem<Q>& tw, bool neg_tw) {
-    Fe<IccFp> tp = fe_mul<IccFp>(tw.p, b.p);
-    Fe<Q> tq = fe_mul<Q>(tw.q, b.q);
+__device__ __forceinline__ void butterfly(IccElem<Q>& a, IccElem<Q>& b, const IccElem<Q>& tw, bool neg_tw, bool unit_tw = false) {
+    Fe<IccFp> tp = b.p;
+    Fe<Q> tq = b.q;
+    if (!unit_tw) {
+        tp = fe_mul<IccFp>(tw.p, b.p);
+        tq = fe_mul<Q>(tw.q, b.q);
+    }
     Fe<IccFp> sp = fe_add<IccFp>(a.p, tp), dp = fe_sub<IccFp>(a.p, tp);
     Fe<Q> sq = fe_add<Q>(a.q, tq), dq = fe_sub<Q>(a.q, tq);
     // multiplying by -tw swaps the two outputs
@@ -361,7 +366,7 @@ k_icc_fused(IccElem<Q>* __restrict__ work, const IccElem<Q>* __restrict__ tw, ui
                 IccElem<Q> a, b;
                 a.p = ld_fe<IccFp>(pa); a.q = ld_fe<Q>(pa + 8);
                 b.p = ld_fe<IccFp>(pb); b.q = ld_fe<Q>(pb + 8);
-                butterfly<Q>(a, b, t1, false);
+                butterfly<Q>(a, b, t1, false, j == 0);
                 st_fe<IccFp>(pa, a.p); st_fe<Q>(pa + 8, a.q);
                 st_fe<IccFp>(pb, b.p); st_fe<Q>(pb + 8, b.q);
             }
