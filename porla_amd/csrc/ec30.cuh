@@ -224,6 +224,111 @@ __device__ __noinline__ void xyzz30_double_mem(XYZZ<M>* p, int times) {
     xyzz30_store_lazy<M>(p, a);
 }
 
+// ---------------------------------------------------------------- one addition on the four lanes of a quad
+// The small levels of the reduction tree are chains of dependent additions with nothing else to run: a lone wave pays
+// ~0.5 us per field product, 14 of them in sequence.  Here the 14 products of p + q are spread over 4 lanes in 4 rounds
+// (values travel between the lanes by DPP quad permutes), so the chain is 4 products long:
+//   lane          0              1               2                3
+//   loads     X1, ZZ2        X2, ZZ1         Y1, ZZZ2         Y2, ZZZ1
+//   round 1   U1 = X1 ZZ2    U2 = X2 ZZ1     S1 = Y1 ZZZ2     S2 = Y2 ZZZ1
+//   round 2   PP = (U2-U1)^2 ZZ1 ZZ2         ZZZ1 ZZZ2        RR = (S2-S1)^2
+//   round 3   PPP = P PP     ZZ3 = . PP      -                Q = U1 PP
+//   round 4   T2 = S1 PPP    -               ZZZ3 = . PPP     T1 = R (Q - X3),  X3 = RR - PPP - 2Q
+//   result                   ZZ3             ZZZ3             X3,  Y3 = T1 - T2
+// Exceptional operands (infinity, p = +-q) are detected in rounds 1-2 and handed to one lane's ordinary addition.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_quad(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+template <class M, int CTRL>
+__device__ __forceinline__ F30<M> f30_quad(const F30<M>& a) {
+    F30<M> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = dpp_quad<CTRL>(a.v[i]);
+    return r;
+}
+template <class M>
+__device__ __forceinline__ F30<M> f30_sel(bool c, const F30<M>& a, const F30<M>& b) {
+    F30<M> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = c ? a.v[i] : b.v[i];
+    return r;
+}
+// one coordinate (0 = X, 1 = Y, 2 = ZZ, 3 = ZZZ) of a memory-form point
+template <class M>
+__device__ __forceinline__ F30<M> xyzz30_load_coord(const XYZZ<M>* p, int c, bool* all_zero) {
+    const uint4* q = reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(p) + 8 * c);
+    const uint4 a = q[0], b = q[1];
+    uint32_t t[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    *all_zero = (a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) == 0;
+    return f30_unpack<M>(t);
+}
+// final: the 2^256 Montgomery form the host reads; otherwise the lazy memory form
+template <class M>
+__device__ __forceinline__ void xyzz30_store_coord(XYZZ<M>* p, int c, const F30<M>& v, bool final) {
+    uint32_t* d = reinterpret_cast<uint32_t*>(p) + 8 * c;
+    Fe<M> t;
+    if (final) {
+        t = f30_to_fe_canonical<M>(f30_mul<M>(v, f30_const<M>(M::R1)));
+    } else if constexpr (M::PSEUDO_MERSENNE) {
+        t = f30_to_fe_canonical<M>(f30_pm_reduce<M>(v));
+    } else {
+        f30_pack<M>(t.v, v);
+    }
+    store_words8(d, t.v);
+}
+template <class M>
+__device__ __noinline__ void xyzz30_add_one_lane(const XYZZ<M>* pa, const XYZZ<M>* pb, XYZZ<M>* out, bool final) {
+    XYZZ30<M> a = xyzz30_load_lazy<M>(pa), b = xyzz30_load_lazy<M>(pb);
+    xyzz30_add<M>(a, b);
+    if (final) {
+        const XYZZ<M> r = xyzz30_to_xyzz<M>(a);
+        uint32_t* d = reinterpret_cast<uint32_t*>(out);
+        store_words8(d, r.x.v); store_words8(d + 8, r.y.v); store_words8(d + 16, r.zz.v); store_words8(d + 24, r.zzz.v);
+    } else {
+        xyzz30_store_lazy<M>(out, a);
+    }
+}
+// *out = *pa + *pb.  Called by ALL FOUR lanes of a quad with the same arguments; lane = position in the wave;
+// live = false: compute but do not store (padding quads keep the permutes well defined).
+template <class M>
+__device__ __forceinline__ void xyzz30_add_quad(const XYZZ<M>* pa, const XYZZ<M>* pb, XYZZ<M>* out, bool final, bool live,
+                                                uint32_t lane) {
+    const uint32_t r = lane & 3u;
+    const XYZZ<M>* sa = (r & 1u) ? pb : pa;
+    const XYZZ<M>* sb = (r & 1u) ? pa : pb;
+    bool za, zb;
+    const F30<M> A = xyzz30_load_coord<M>(sa, (int)(r >> 1), &za);
+    const F30<M> B = xyzz30_load_coord<M>(sb, 2 + (int)(r >> 1), &zb);
+    bool special = zb;                                   // a ZZ / ZZZ of zero: that operand is infinity
+    const F30<M> M1 = f30_mul<M>(A, B);                  // U1, U2, S1, S2
+    const bool edge = (r == 0u) || (r == 3u);
+    const F30<M> rcv = f30_quad<M, 0xB1>(f30_sel<M>(edge, B, M1));   // lanes 0<->1, 2<->3
+    const F30<M> D = f30_sub<M, 2>(f30_sel<M>(r == 0u, rcv, M1), f30_sel<M>(r == 0u, M1, rcv));   // lane 0: P, lane 3: R
+    const F30<M> M2 = f30_mul<M>(f30_sel<M>(edge, D, B), f30_sel<M>(edge, D, rcv));           // PP, ZZ1 ZZ2, ZZZ1 ZZZ2, RR
+    if (r == 0u && f30_product_is_zero<M>(M2)) special = true;                                    // same x
+    const unsigned long long bal = __ballot(special);
+    if ((bal >> (lane & 60u)) & 0xfull) {
+        if (r == 0u && live) xyzz30_add_one_lane<M>(pa, pb, out, final);
+        return;
+    }
+    const F30<M> bPP = f30_quad<M, 0x00>(M2);
+    const F30<M> bU1 = f30_quad<M, 0x00>(M1);
+    const F30<M> M3 = f30_mul<M>(r == 0u ? D : (r == 3u ? bU1 : M2), r == 0u ? M2 : bPP);       // PPP, ZZ3, -, Q
+    const F30<M> bPPP = f30_quad<M, 0x00>(M3);
+    const F30<M> bS1 = f30_quad<M, 0xAA>(M1);
+    const F30<M> E = f30_add2<M>(bPPP, M3);              // lane 3: PPP + 2Q
+    const F30<M> X3 = f30_sub<M, 4>(M2, E);              // lane 3: RR - E
+    const F30<M> Dq = f30_sub<M, 6>(M3, X3);             // lane 3: Q - X3
+    const F30<M> M4 = f30_mul<M>(r == 0u ? bS1 : (r == 3u ? D : M2), r == 3u ? Dq : bPPP);       // T2, -, ZZZ3, T1
+    const F30<M> bT2 = f30_quad<M, 0x00>(M4);
+    const F30<M> Y3 = f30_sub<M, 2>(M4, bT2);            // lane 3
+    if (!live) return;
+    if (r == 3u) { xyzz30_store_coord<M>(out, 0, X3, final); xyzz30_store_coord<M>(out, 1, Y3, final); }
+    else if (r == 1u) xyzz30_store_coord<M>(out, 2, M3, final);
+    else if (r == 2u) xyzz30_store_coord<M>(out, 3, M4, final);
+}
+
 // the accumulator as an ec.cuh XYZZ in the 2^256 Montgomery form (canonical residues); infinity = all zero
 template <class M>
 __device__ __forceinline__ XYZZ<M> xyzz30_to_xyzz(const XYZZ30<M>& p) {

@@ -710,23 +710,54 @@ struct Node {
 
 // one addition (or, at the last level, one copy) of level a.l; s = slot, i = node (global index: the S levels and fin),
 // jp / jo = the node's index inside the m_prev / m_out slot arrays
+template <class M>
+struct TreeOp {
+    const XYZZ<M>*pa, *pb;   // operands (copy: pa only)
+    XYZZ<M>* out;
+    bool final;              // out is fin (2^256 form for the host)
+    bool copy;               // last level: the aliased top slot is copied into fin
+};
+template <class M>
+__device__ __forceinline__ TreeOp<M> tree_op(const TreeLevelArgs<M>& a, uint32_t s, uint32_t i, uint32_t jp, uint32_t jo) {
+    TreeOp<M> o;
+    o.final = a.last != 0;
+    o.copy = (s == a.l + 1);
+    if (o.copy) {
+        o.pa = a.s_prev + 2 * (size_t)i + 1; o.pb = o.pa;
+        o.out = a.fin + (size_t)i * (a.nlev + 1) + 1 + a.l;
+        return o;
+    }
+    if (s == a.l) { o.pa = a.s_prev + 2 * (size_t)i; o.pb = o.pa + 1; }
+    else if (s + 1 == a.l) { o.pa = a.s_prev2 + 4 * (size_t)i + 1; o.pb = o.pa + 2; }
+    else { o.pa = a.m_prev + (size_t)s * a.m_prev_stride + 2 * (size_t)jp; o.pb = o.pa + 1; }
+    if (a.last) o.out = a.fin + (size_t)i * (a.nlev + 1) + (s == a.l ? 0 : 1 + s);
+    else o.out = (s == a.l) ? a.s_out + i : a.m_out + (size_t)s * a.m_out_stride + jo;
+    return o;
+}
 template <class C>
 __device__ __forceinline__ void tree_task(const TreeLevelArgs<typename C::Fp>& a, uint32_t s, uint32_t i, uint32_t jp, uint32_t jo) {
     using M = typename C::Fp;
     using N = Node<C>;
-    const XYZZ<M>*pa, *pb;
-    if (s == a.l + 1) {                           // last level: the aliased top slot is copied into fin
-        typename N::T v = N::load(a.s_prev + 2 * (size_t)i + 1);
-        N::store_final(a.fin + (size_t)i * (a.nlev + 1) + 1 + a.l, v);
+    const TreeOp<M> o = tree_op<M>(a, s, i, jp, jo);
+    typename N::T x = N::load(o.pa);
+    if (!o.copy) {
+        typename N::T y = N::load(o.pb);
+        N::add(x, y);
+    }
+    if (o.final) N::store_final(o.out, x);
+    else N::store(o.out, x);
+}
+// the same on the four lanes of a quad (ec30.cuh:xyzz30_add_quad): ALL lanes of the quad call it with the same arguments
+template <class C>
+__device__ __forceinline__ void tree_task_quad(const TreeLevelArgs<typename C::Fp>& a, uint32_t s, uint32_t i, uint32_t jp, uint32_t jo,
+                                               bool live, uint32_t lane) {
+    using M = typename C::Fp;
+    const TreeOp<M> o = tree_op<M>(a, s, i, jp, jo);
+    if (o.copy) {                                     // uniform over the quad
+        if (live && (lane & 3u) == 0u) Node<C>::store_final(o.out, Node<C>::load(o.pa));
         return;
     }
-    if (s == a.l) { pa = a.s_prev + 2 * (size_t)i; pb = pa + 1; }
-    else if (s + 1 == a.l) { pa = a.s_prev2 + 4 * (size_t)i + 1; pb = pa + 2; }
-    else { pa = a.m_prev + (size_t)s * a.m_prev_stride + 2 * (size_t)jp; pb = pa + 1; }
-    typename N::T x = N::load(pa), y = N::load(pb);
-    N::add(x, y);
-    if (a.last) N::store_final(a.fin + (size_t)i * (a.nlev + 1) + (s == a.l ? 0 : 1 + s), x);
-    else N::store((s == a.l) ? a.s_out + i : a.m_out + (size_t)s * a.m_out_stride + jo, x);
+    xyzz30_add_quad<M>(o.pa, o.pb, o.out, o.final, live, lane);
 }
 
 // one level over all windows: grid covers (l + 1 + last) * n tasks, node index fastest (coalesced 256-B reads per lane pair)
@@ -738,6 +769,19 @@ k_tree_level(TreeLevelArgs<typename C::Fp> a) {
     if (t >= slots * a.n) return;
     const uint32_t i = t % a.n;
     tree_task<C>(a, t / a.n, i, i, i);
+}
+
+// a level with few additions (latency bound): four lanes per addition
+template <class C>
+__global__ void __launch_bounds__(256)
+k_tree_level_quad(TreeLevelArgs<typename C::Fp> a) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total = (a.l + 1 + a.last) * a.n;
+    uint32_t t = tid >> 2;
+    const bool live = t < total;
+    if (!live) t = total - 1;                         // padding quads compute a valid task and store nothing
+    const uint32_t i = t % a.n;
+    tree_task_quad<C>(a, t / a.n, i, i, i, live, threadIdx.x & 63u);
 }
 
 // the last levels l0 .. nlev-1 of ONE window per block (few nodes are left: launch gaps would dominate).  The levels
@@ -758,7 +802,7 @@ struct TreeTailArgs {
     uint32_t l0;
     uint32_t nlev;
 };
-template <class C>
+template <class C, bool QUAD>
 __global__ void __launch_bounds__(1024)
 k_tree_tail(TreeTailArgs<typename C::Fp> a) {
     using M = typename C::Fp;
@@ -780,9 +824,21 @@ k_tree_tail(TreeTailArgs<typename C::Fp> a) {
         lv.nlev = a.nlev;
         lv.last = (l + 1 == a.nlev) ? 1u : 0u;
         const uint32_t tasks = (l + 1 + lv.last) * nw;
-        for (uint32_t t = threadIdx.x; t < tasks; t += blockDim.x) {
-            const uint32_t j = t % nw, i = w * nw + j;
-            tree_task<C>(lv, t / nw, i, first ? i : j, j);
+        if constexpr (QUAD) {
+            // four lanes per addition; every pass runs whole quads (padding quads redo the last task without storing)
+            const uint32_t per_pass = blockDim.x >> 2;
+            for (uint32_t t0 = 0; t0 < tasks; t0 += per_pass) {
+                uint32_t t = t0 + (threadIdx.x >> 2);
+                const bool live = t < tasks;
+                if (!live) t = tasks - 1;
+                const uint32_t j = t % nw, i = w * nw + j;
+                tree_task_quad<C>(lv, t / nw, i, first ? i : j, j, live, threadIdx.x & 63u);
+            }
+        } else {
+            for (uint32_t t = threadIdx.x; t < tasks; t += blockDim.x) {
+                const uint32_t j = t % nw, i = w * nw + j;
+                tree_task<C>(lv, t / nw, i, first ? i : j, j);
+            }
         }
         __threadfence();
         __syncthreads();

@@ -18,8 +18,14 @@ static inline uint32_t tree_tail_threads() {
     uint32_t r = (t + 63) / 64 * 64;
     return r < 64 ? 64 : (r > 1024 ? 1024 : r);
 }
-static inline uint32_t tree_tail_start(uint32_t B, uint32_t nlev) {
-    const uint32_t cap = tree_tail_threads();
+// quad = four lanes per addition (curves with the reduced-radix memory form): a pass of the tail holds threads / 4 additions
+static inline bool tree_quad() {
+    static const bool q = !(getenv("PORLA_TREE_QUAD") && getenv("PORLA_TREE_QUAD")[0] == '0');
+    return q;
+}
+constexpr uint32_t TREE_QUAD_MAX_TASKS = 16384;    // levels up to this many additions run four lanes per addition
+static inline uint32_t tree_tail_start(uint32_t B, uint32_t nlev, bool quad) {
+    const uint32_t cap = quad ? tree_tail_threads() / 4 : tree_tail_threads();
     uint32_t l = 0;
     while (l + 1 < nlev && (l + 1) * (B >> (l + 1)) > cap) l++;
     return l;
@@ -33,10 +39,12 @@ static inline uint32_t tree_tail_start(uint32_t B, uint32_t nlev) {
 //                        that holds only `top` bits and crowds all m entries into 2^(top-1) buckets (work items cap a chain
 //                        at CHUNK entries)
 //   bucket reduction     the tree's levels: throughput TREE_US_PER_ADD per addition, never below one launch + one
-//                        dependent addition (TREE_LEVEL_US); TREE_TAIL_LEVEL_US per level of the per-window tail kernel
+//                        dependent addition (TREE_LEVEL_US; TREE_QUAD_LEVEL_US with four lanes per addition);
+//                        TREE_TAIL_LEVEL_US per level of the per-window tail kernel
 constexpr double TREE_US_PER_ADD = 1.5e-4;     // 262 144 additions of level 0 at c = 16 in 39 us (reduced-radix form)
 constexpr double TREE_LEVEL_US = 12.5;
-constexpr double TREE_TAIL_LEVEL_US = 12.5;
+constexpr double TREE_QUAD_LEVEL_US = 7.0;     // a level of <= TREE_QUAD_MAX_TASKS additions, four lanes per addition
+constexpr double TREE_TAIL_LEVEL_US = 6.5;
 static inline int choose_window(size_t m, int bits) {
     if (g_window_override >= 2 && g_window_override <= 20) return g_window_override;
     int best = 2;
@@ -72,11 +80,12 @@ static inline int choose_window(size_t m, int bits) {
         double t_reduce = 0.3 * W * c;
         {
             const uint32_t Bu = 1u << (c - 1), nlev = (uint32_t)(c - 1);
-            const uint32_t l0 = tree_tail_start(Bu, nlev);
+            const uint32_t l0 = tree_tail_start(Bu, nlev, true);
             for (uint32_t l = 0; l < nlev; l++) {
                 const double tasks = (double)W * (l + 1) * (double)(Bu >> (l + 1));
-                if (l < l0) { const double t = tasks * TREE_US_PER_ADD; t_reduce += t > TREE_LEVEL_US ? t : TREE_LEVEL_US; }
-                else t_reduce += TREE_TAIL_LEVEL_US;
+                if (l >= l0) t_reduce += TREE_TAIL_LEVEL_US;
+                else if (tasks <= (double)TREE_QUAD_MAX_TASKS) t_reduce += TREE_QUAD_LEVEL_US;
+                else { const double t = tasks * TREE_US_PER_ADD; t_reduce += t > TREE_LEVEL_US ? t : TREE_LEVEL_US; }
             }
         }
         // ---- LDS counting sort: ~6.6 ps per entry while a partition's buckets fit the staging area (c <= 16), slower beyond
@@ -240,7 +249,8 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
         XYZZ<M>* s_base = (XYZZ<M>*)ws->tree_s.p;
         XYZZ<M>* m_half[2] = {(XYZZ<M>*)ws->tree_m.p, (XYZZ<M>*)ws->tree_m.p + nb / 4 + 1};
         auto s_level = [&](uint32_t l) { return s_base + (nb - (nb >> l)); };
-        const uint32_t l0 = tree_tail_start(B, nlev);
+        const bool quad = C::F30_LAZY && tree_quad();
+        const uint32_t l0 = tree_tail_start(B, nlev, quad);
         {
             ProfScope ps("tree_levels", stream);
             for (uint32_t l = 0; l < l0; l++) {
@@ -255,6 +265,13 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
                 a.m_prev_stride = 2 * a.n; a.m_out_stride = a.n;
                 a.l = l; a.nlev = nlev; a.last = 0;
                 const size_t tasks = (size_t)(l + 1) * a.n;
+                if constexpr (C::F30_LAZY) {
+                    if (quad && tasks <= TREE_QUAD_MAX_TASKS) {
+                        hipLaunchKernelGGL((k_tree_level_quad<C>), dim3((unsigned)((4 * tasks + 255) / 256)), dim3(256), 0, stream, a);
+                        PORLA_TRACE("tree_level");
+                        continue;
+                    }
+                }
                 hipLaunchKernelGGL((k_tree_level<C>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, stream, a);
                 PORLA_TRACE("tree_level");
             }
@@ -269,11 +286,16 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
             t.m_tail[0] = (XYZZ<M>*)ws->tree_mt.p; t.m_tail[1] = (XYZZ<M>*)ws->tree_mt.p + (size_t)W * t.per_window + 1;
             t.fin = (XYZZ<M>*)h_windows_dev;
             t.nb = (uint32_t)nb; t.B = B; t.l0 = l0; t.nlev = nlev;
-            uint32_t need = (l0 + 2) * (B >> (l0 + 1));
+            uint32_t need = (l0 + 2) * (B >> (l0 + 1)) * (quad ? 4u : 1u);
             uint32_t threads = (need + 63) / 64 * 64;
             if (threads > tree_tail_threads()) threads = tree_tail_threads();
             if (threads < 64) threads = 64;
-            hipLaunchKernelGGL((k_tree_tail<C>), dim3(W), dim3(threads), 0, stream, t);
+            if constexpr (C::F30_LAZY) {
+                if (quad) hipLaunchKernelGGL((k_tree_tail<C, true>), dim3(W), dim3(threads), 0, stream, t);
+                else hipLaunchKernelGGL((k_tree_tail<C, false>), dim3(W), dim3(threads), 0, stream, t);
+            } else {
+                hipLaunchKernelGGL((k_tree_tail<C, false>), dim3(W), dim3(threads), 0, stream, t);
+            }
             PORLA_TRACE("tree_tail");
         }
         // no copy packet: the last level stores its W * c results straight into the pinned host buffer (a D2H hipMemcpyAsync
