@@ -110,6 +110,48 @@ def test_eip196_precompile_vectors_through_the_plugin(mx):
         assert mx.bn254_multi_exp(p * 1000, sc, 1000) == want
 
 
+@pytest.mark.parametrize("curve", ["bn254", "secp256k1"])
+def test_reduction_tree_exceptional_operands(mx, inputs, curve):
+    """the same point (or a point and its negative) in NEIGHBOURING buckets: the reduction tree then adds equal sums
+    (doubling), opposite sums (infinity) and empty nodes at several levels -- the exceptional path of the quad-lane addition"""
+    if curve == "bn254":
+        import bn254_py as o
+        P0 = inputs[1][:64]
+        negP0 = o.neg_point(P0)
+        oracle = lambda sc, pt, n: common.oracle_msm(sc, pt, n, naive=True)
+    else:
+        pts = common.secp_bench_points(4)
+        P0 = pts[:64]
+        pm = 2**256 - 2**32 - 977
+        negP0 = P0[:32] + ((pm - int.from_bytes(P0[32:], "big")) % pm).to_bytes(32, "big")
+        oracle = lambda sc, pt, n: common.oracle_secp_msm(sc, pt, n)
+    be = lambda v: v.to_bytes(32, "big")
+    cases = [
+        ([1, 2], [P0, P0]),                                 # buckets 0 and 1 hold P: level 0 doubles
+        ([1, 2], [P0, negP0]),                              # P and -P: S = infinity, M_0 = -P
+        ([1, 2, 3, 4], [P0] * 4),                           # equal sums at levels 0 and 1
+        ([1, 2, 3, 4], [P0, negP0, P0, negP0]),
+        (list(range(1, 33)), [P0] * 32),                    # every bucket of a 32-bucket block holds P
+        (list(range(1, 33)), [P0, negP0] * 16),
+        ([5, 5 + (1 << 16), 5 + (1 << 32)], [P0, P0, negP0]),   # the same pattern in three windows
+    ]
+    for ks, ps in cases:
+        sc, pt, n = b"".join(be(k) for k in ks), b"".join(ps), len(ks)
+        want = oracle(sc, pt, n)
+        assert mx.msm_host(curve, sc, pt, n) == want
+        for c in (2, 5, 8):                                  # small windows: more tree levels per bucket index bit
+            lib_set(mx, c)
+            try:
+                assert mx.msm_host(curve, sc, pt, n) == want
+            finally:
+                lib_set(mx, 0)
+
+
+def lib_set(mx, c):
+    from porla_amd import lib
+    lib.porla_gpu_set_msm_window(c)
+
+
 def test_audit_like_distribution(mx, inputs):
     """abs(int32) coefficients (utils.h:271-275) over 64-way repeated points: the real audit's shape"""
     import random
