@@ -72,7 +72,7 @@ int porla_bn254_msm_device(const void *d_scalars, const void *d_points, size_t n
 int porla_bn254_msm_device_partial(const void *d_scalars, const void *d_points, size_t n, uint8_t out_jacobian[96],
                                    void *hip_stream);
 /* Two-phase form for independent MSMs in flight at once (e.g. the audit's two MSMs, Server.hpp:900-901): begin enqueues
- * every kernel of one MSM on hip_stream and returns; end waits for that slot, folds the window sums on the host and writes
+ * every kernel of one MSM on hip_stream and returns; end waits for that slot, folds the reduction tree's sums on the host and writes
  * 64 bytes affine (jacobian = 0) or 96 bytes Jacobian (jacobian = 1).  slot in 1..3 (0 is used by the blocking calls);
  * one begin per slot until its end.  Overlap comes from using a different stream per slot. */
 int porla_bn254_msm_device_begin(int slot, const void *d_scalars, const void *d_points, size_t n, void *hip_stream);

@@ -1,4 +1,4 @@
-// Host tail of the MSM in 4 x 64-bit limbs: the Horner fold of the W window sums (W*c dependent doublings + W additions)
+// Host tail of the MSM in 4 x 64-bit limbs: the Horner fold of the tree's single-bit sums (W*c dependent doublings and additions)
 // is a purely sequential chain, so it runs on one host core -- with 64x64->128 products it costs ~60 us instead of the
 // ~270 us of the portable 8 x 32-bit code shared with the device.  Same Montgomery radix (R = 2^256) as fe.cuh, so
 // elements convert by repacking limbs.  The reference does this fold inside gnark's MultiExp / at the end of

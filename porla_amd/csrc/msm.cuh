@@ -14,17 +14,19 @@
 //                       grouped by bucket (coalesced reads of the tile runs)
 //   k_size_hist/scan/order  work items (<= CHUNK entries of one bucket) counting-sorted BY SIZE, largest first, so the 64
 //                       lanes of a wave run the same trip count; a heavy bucket becomes many items (skew-proof)
-//   k_bucket_sum        ONE THREAD PER WORK ITEM: walks its index list, gathers 64-B points (L2 / Infinity-Cache
-//                       resident: 2^20 points = 64 MiB) and accumulates with the 8M+2S mixed add
+//   k_bucket_sum30      ONE THREAD PER WORK ITEM: walks its index list, gathers 64-B points (L2 / Infinity-Cache
+//                       resident: 2^20 points = 64 MiB) and accumulates with the 8M+2S mixed add in the reduced-radix
+//                       field form of fe30.cuh / ec30.cuh (k_bucket_sum: the same on 8 x 32-bit limbs, kept for curves
+//                       without that form)
 //   k_bucket_combine    wave per multi-item bucket: folds that bucket's item sums (no-op for uniform scalars)
-//   k_bucket_reduce     per window sum_b (b+1)*B_b: per-thread running sums over L buckets, small scalar
-//                       multiple for the segment offset, wave-shuffle tree
-//   k_window_reduce     one wave per window folds the per-wave partials
-//   host                Horner over the W window sums (W*c doublings), affine normalisation, marshal
+//   k_tree_level(_quad), k_tree_tail   per window sum_b (b+1)*B_b as a bit-sliced tree: S (plain sum) and M_k (sum of the
+//                       buckets with index bit k set) per node, log2(B) levels of independent additions; small levels run
+//                       each addition on the four lanes of a quad, the last levels in one block per window
+//   host                one Horner pass over the W*c single-bit terms (host_fold64.hpp), affine normalisation, marshal
 //
-// Traffic per pair (c = 16, W = 16): 96 B input + 64 B converted point + 2 * W * 4 B sort items + W * 4 B index + W gathers
-// of a 64-B point (the 64 MiB point set lives in the Infinity Cache; PMC: 3.2 GB of fabric requests per 2^20-pair launch).
-// The accumulation is VALU (integer multiply) bound at 91 % of the mixed-addition peak, see DESIGN.md s4.
+// Traffic per pair (c = 17, W = 15): 96 B input + 64 B converted point + 2 * W * 4 B sort items + W * 4 B index + W gathers
+// of a 64-B point (the 64 MiB point set lives in the Infinity Cache; PMC: 3.1 GB of fabric requests per 2^20-pair launch).
+// The accumulation is VALU (integer multiply) bound, see DESIGN.md s4.
 #pragma once
 #include "ec.cuh"
 #include "ec30.cuh"
@@ -656,7 +658,7 @@ __device__ __forceinline__ XYZZ<M> wave_sum(XYZZ<M> p) {
 
 // ------------------------------------------------------------------------------------------------
 // Bucket reduction as a BIT-SLICED TREE: no scalar multiples, log2(B) dependent additions instead of the ~45 dependent
-// group operations of the segment form above, and 2 additions per bucket in total.
+// group operations of the earlier running-sum form, and 2 additions per bucket in total.
 //   sum_b (b+1) B_b = S + sum_k 2^k M_k,   S = sum of the window's buckets,  M_k = sum of the buckets whose index has bit k set.
 // Level l = 0 .. c-2 halves the node count; node i of level l covers buckets [i 2^(l+1), (i+1) 2^(l+1)) and holds
 //   S^l[i]   = S^(l-1)[2i] + S^(l-1)[2i+1]                       (S^(-1) = the buckets themselves)

@@ -311,7 +311,7 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
     return PORLA_OK;
 }
 
-// waits for the launched MSM of this workspace and folds its window sums on the host
+// waits for the launched MSM of this workspace and folds the tree's per-window S / M_k sums on the host
 template <class C>
 static int msm_finish(Workspace* ws, XYZZ<typename C::Fp>* total) {
     using M = typename C::Fp;
