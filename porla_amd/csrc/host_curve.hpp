@@ -1,5 +1,5 @@
 // Host-side (CPU) tail of the engine: the few latency-bound group operations that stay on the host --
-// Horner fold of the W window sums, projective -> affine normalisation, (un)marshalling, and the
+// projective -> affine normalisation, (un)marshalling, and the
 // single-point operations of the plug-in (add_point / mult_point / neg_point, porla/main.go:195-230),
 // which SURVEY.md s8(e) classifies as "replicas only" (one 64-byte operand: a PCIe round trip would cost
 // more than the arithmetic).  It reuses the SAME limb code as the device (fe.cuh / ec.cuh are
@@ -127,17 +127,6 @@ inline XYZZ<M> h_scalar_mul(const Affine<M>& a, const uint32_t k[8]) {
     for (int i = top; i >= 0; i--) {
         acc = xyzz_double<M>(acc);
         if ((k[i >> 5] >> (i & 31)) & 1) xyzz_madd<M>(acc, a);
-    }
-    return acc;
-}
-
-// Horner fold of window sums: total = sum_w 2^(c*w) * win[w]
-template <class M>
-inline XYZZ<M> h_fold_windows(const XYZZ<M>* win, int W, int c) {
-    XYZZ<M> acc = xyzz_inf<M>();
-    for (int w = W - 1; w >= 0; w--) {
-        for (int d = 0; d < c; d++) acc = xyzz_double<M>(acc);
-        xyzz_add<M>(acc, win[w]);
     }
     return acc;
 }

@@ -646,16 +646,6 @@ __device__ __forceinline__ XYZZ<M> xyzz_shfl_xor(const XYZZ<M>& p, int mask) {
     }
     return r;
 }
-template <class M>
-__device__ __forceinline__ XYZZ<M> wave_sum(XYZZ<M> p) {
-#pragma unroll 1
-    for (int m = 32; m >= 1; m >>= 1) {
-        XYZZ<M> o = xyzz_shfl_xor<M>(p, m);
-        xyzz_add_cold<M>(&p, &o);
-    }
-    return p;
-}
-
 // ------------------------------------------------------------------------------------------------
 // Bucket reduction as a BIT-SLICED TREE: no scalar multiples, log2(B) dependent additions instead of the ~45 dependent
 // group operations of the earlier running-sum form, and 2 additions per bucket in total.
