@@ -212,8 +212,12 @@ constexpr int SORT_LOWBITS = 10;               // buckets per partition = 2^10 u
 constexpr int SORT_MAX_LOW = 4096;             // LDS counters of k_partition_sort (lowbits <= 12)
 constexpr int SORT_STAGE_CAP = 34816;          // indices a block can stage in LDS before writing them out coalesced (136 KiB)
 
-static inline int sort_lowbits(int c) {
+// m = entries per window at most.  Wider partitions (up to 2^12 buckets) while a partition's expected entries still fit the
+// LDS staging area: fewer, longer tile runs (c = 17 at 2^20 pairs: 32 partitions with 512-B runs instead of 64 with 256 B)
+static inline int sort_lowbits(int c, size_t m, int W) {
     int lb = (c - 1) < SORT_LOWBITS ? (c - 1) : SORT_LOWBITS;
+    // (only while the grid keeps at least 256 blocks: small inputs want the parallelism, not the longer runs)
+    while (lb < c - 1 && lb < 12 && (m >> (c - 1 - lb - 1)) <= 32768 && ((size_t)W << (c - 1 - lb - 1)) >= 256) lb++;
     if (c - 1 - lb > 7) lb = c - 1 - 7;  // at most MAX_PARTS = 2^7 partitions
     return lb;
 }

@@ -188,7 +188,7 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
                                (Affine<M>*)ws->pts.p, n32);
     }
     PORLA_TRACE("to_mont");
-    const int lowbits = sort_lowbits(c);
+    const int lowbits = sort_lowbits(c, n_sub, W);
     const int P = 1 << (c - 1 - lowbits);
     {
         ProfScope ps("digits_partition", stream);
