@@ -89,7 +89,7 @@ static inline int choose_window(size_t m, int bits) {
             }
         }
         // ---- LDS counting sort: ~6.6 ps per entry while a partition's buckets fit the staging area (c <= 16), slower beyond
-        const double t_sort = (double)W * (double)m * 6.6e-6 * (c <= 16 ? 1.0 : (c == 17 ? 1.4 : 4.5));
+        const double t_sort = (double)W * (double)m * 6.6e-6 * (c <= 16 ? 1.0 : (c == 17 ? 1.1 : 4.5));
         const double cost = 6.0 * W + t_sum + t_sort + t_combine + t_reduce;
         if (cost < best_cost) { best_cost = cost; best = c; }
     }
