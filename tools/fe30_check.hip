@@ -277,6 +277,10 @@ int main(int argc, char** argv) {
             if (w <= 4) {
                 ms = time_ms([&] { hipLaunchKernelGGL((k_madd30<Bn254Fp>), dim3(blocks), dim3(256), 0, 0, buf, 128); });
                 printf("xyzz30_madd       waves/SIMD=%d  %.3f ms  %.2f Gadd/s\n", w, ms, (double)blocks * 256 * 128 / ms / 1e6);
+                if (w == 4) {   // the same loop 8x longer: does the rate hold for the duration of a real accumulation kernel?
+                    ms = time_ms([&] { hipLaunchKernelGGL((k_madd30<Bn254Fp>), dim3(blocks), dim3(256), 0, 0, buf, 1024); });
+                    printf("xyzz30_madd (long) waves/SIMD=%d  %.3f ms  %.2f Gadd/s\n", w, ms, (double)blocks * 256 * 1024 / ms / 1e6);
+                }
                 ms = time_ms([&] { hipLaunchKernelGGL((k_madd32<Bn254Fp>), dim3(blocks), dim3(256), 0, 0, buf, 128); });
                 printf("xyzz_madd (8x32)  waves/SIMD=%d  %.3f ms  %.2f Gadd/s\n", w, ms, (double)blocks * 256 * 128 / ms / 1e6);
             }
