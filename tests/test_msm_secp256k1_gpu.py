@@ -110,3 +110,14 @@ def test_full_size_2_20(mx):
     d_pt = torch.frombuffer(bytearray(pt), dtype=torch.uint8).cuda()
     got = mx.msm_device("secp256k1", d_sc.data_ptr(), d_pt.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
     assert got == common.secp_bench_expected(sc, n)
+
+
+def test_committed_bench_style_vectors(mx):
+    """tests/golden/secp256k1_golden.json through the engine (host-buffer entry point)"""
+    import json
+    import os
+    gold = json.load(open(os.path.join(common.ROOT, "tests", "golden", "secp256k1_golden.json")))
+    for case in gold["cases"]:
+        n = case["n"]
+        sc, pt = common.secp_bench_scalars(n), common.secp_bench_points(n)
+        assert mx.msm_host("secp256k1", sc, pt, n) == bytes.fromhex(case["result_xy"])
