@@ -26,6 +26,9 @@ struct XYZZ30 {
     bool inf;
 };
 
+template <class M>
+__device__ __forceinline__ XYZZ<M> xyzz30_to_xyzz(const XYZZ30<M>& p);   // defined at the end of this file
+
 // 2 * (affine a) in the 2^270 form; a != infinity.  Rare (a bucket receives the point it already holds): kept out of line.
 // Arguments by value (registers): a pointer to the caller's copies would make the compiler spill them on every iteration.
 template <class M>
