@@ -99,8 +99,8 @@ int porla_secp256k1_tree_fold(const uint8_t *sums_affine, int windows, int windo
  * out[r] = sum_{i < n_coeffs} (row_r[i] mod order) * base[i] for every row r, as 64-byte X||Y big-endian affine points.
  * rows: coefficient i of row r at rows + r*row_stride + 32*i, 32 bytes big-endian (bn254_scalar, utils.h:307-318).
  * The base is expanded once into a table of window multiples resident in HBM (window_bits c, 0 = automatic: the
- * widest c <= 20 whose table fits min(a quarter of the free HBM, PORLA_COMMIT_TABLE_GB = 20 GB): 18 bits = 16 GB for
- * 128 BN254 points); a commitment is then n_coeffs * ceil((bits+1)/c) mixed additions.  curve: 0 = BN254 G1, 1 = secp256k1. */
+ * widest c <= 20 whose table fits min(a quarter of the free HBM, PORLA_COMMIT_TABLE_GB = 64 GB): 20 bits = 56 GB for
+ * 128 BN254 points on a 288 GB MI355X); a commitment is then n_coeffs * ceil((bits+1)/c) mixed additions.  curve: 0 = BN254 G1, 1 = secp256k1. */
 typedef struct porla_fixed_base porla_fixed_base;
 int  porla_fixed_base_create(int curve, const uint8_t *points, size_t n_points, int window_bits, porla_fixed_base **out);
 int  porla_fixed_base_info(const porla_fixed_base *fb, int *window_bits, int *windows, unsigned long long *table_bytes);
@@ -112,6 +112,8 @@ void porla_fixed_base_destroy(porla_fixed_base *fb);
 /* KZG: rows of n_samples coefficients (4096 bytes per row for NUM_CHUNKS = 128) against the resident SRS */
 int  porla_kzg_commit_batch_device(const void *d_rows, size_t n_rows, void *d_out, void *hip_stream);
 int  porla_kzg_commit_batch_host(const uint8_t *rows, size_t n_rows, uint8_t *out);
+/* frees the HBM copies of the KZG state (SRS + window table, one-point tables, scratch); rebuilt on the next use */
+int  porla_kzg_release_device_memory(void);
 /* Client side, batched (Client::initialize computes both per block, porla/Client/Client.hpp:408-455):
  *   digest     = compute_digest (main.go:70-89) per row: alpha * f(tau) * G1[0]; rows as for commit_batch
  *   complement = compute_digest_complement (main.go:91-101) per scalar: s * h_MAC; scalars 32 bytes big-endian each

@@ -471,6 +471,22 @@ int porla_kzg_set_commit_window(int window_bits) {
     if (window_bits != g.commit_window) { g.commit_window = window_bits; g.d_srs_dirty = true; }
     return PORLA_OK;
 }
+// frees the HBM copies that belong to the KZG state (SRS, its window-multiples table -- 56 GB by default --, the one-point
+// tables of the client-side batches and scratch); they are rebuilt by the next call that needs them
+int porla_kzg_release_device_memory(void) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    g.fb.release();
+    g.fb_g.release();
+    g.fb_h.release();
+    g.fb_g_dirty = g.fb_h_dirty = true;
+    if (g.d_srs) (void)hipFree(g.d_srs);
+    g.d_srs = nullptr; g.d_srs_cap = 0; g.d_srs_device = -1;
+    g.d_srs_dirty = true;
+    if (g.d_eval) (void)hipFree(g.d_eval);
+    g.d_eval = nullptr; g.d_eval_cap = 0;
+    return PORLA_OK;
+}
+
 int porla_kzg_commit_shape(int* window_bits, int* windows) {
     std::lock_guard<std::mutex> lk(g.mu);
     if (window_bits) *window_bits = g.fb.c;

@@ -236,3 +236,15 @@ def test_eight_threads_call_the_plugin_concurrently(mx, srs128):
     for th in threads:
         th.join()
     assert not errors, errors[:5]
+
+
+def test_release_device_memory_and_rebuild(mx, srs128):
+    """porla_kzg_release_device_memory frees the SRS table; the next commitment rebuilds it and gives the same bytes"""
+    import torch
+    from porla_amd import lib
+    rows = common.synth_scalars(128 * 3, 555)
+    a = mx.kzg_commit_batch_host(rows, 3)
+    free0 = torch.cuda.mem_get_info()[0]
+    assert lib.porla_kzg_release_device_memory() == 0
+    assert torch.cuda.mem_get_info()[0] > free0 + (1 << 30)          # the table alone is tens of GB
+    assert mx.kzg_commit_batch_host(rows, 3) == a
