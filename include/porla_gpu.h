@@ -54,6 +54,9 @@ const char *porla_gpu_last_error(void);
  * for slot i, or a negative value past the last slot. */
 int         porla_gpu_profile_enable(int enable);
 int         porla_gpu_profile_get(int slot, char *name, size_t name_cap, double *total_ms, long long *launches);
+/* frees the MSM scratch of every workspace slot of every device (reallocated by the next MSM); PORLA_ERR_STATE while a
+ * two-phase MSM is pending */
+int         porla_gpu_release_msm_workspaces(void);
 /* MSM tuning override (0 = automatic): window bits c */
 int         porla_gpu_set_msm_window(int c);
 /* 1: split every scalar with the curve endomorphism (half the windows); 0: plain windows over the full scalar;

@@ -207,6 +207,19 @@ int porla_gpu_profile_get(int slot, char* name, size_t name_cap, double* total_m
     if (launches) *launches = g_prof[slot].launches;
     return PORLA_OK;
 }
+// frees the MSM scratch of every workspace slot (it grows with the largest call seen: ~0.5 GiB per slot at 2^20 pairs);
+// refused while a two-phase MSM is still pending
+int porla_gpu_release_msm_workspaces(void) {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    for (auto* w : g_ws) if (w->pend_W) { set_last_error("porla: an MSM is still pending (call the matching _end first)"); return PORLA_ERR_STATE; }
+    for (auto* w : g_ws) {
+        Buf* bufs[] = {&w->pts, &w->keys, &w->entries, &w->counts, &w->starts, &w->fill, &w->cursor, &w->buckets, &w->in_scalars,
+                       &w->in_points, &w->order, &w->blk_hist, &w->blk_off, &w->tile_off, &w->heavy, &w->chunk_out, &w->tree_s,
+                       &w->tree_m, &w->tree_mt};
+        for (Buf* b : bufs) b->release();
+    }
+    return PORLA_OK;
+}
 int porla_gpu_set_msm_window(int c) { g_window_override = c; return PORLA_OK; }
 int porla_gpu_last_msm_shape(int* c, int* windows, int* glv) {
     if (c) *c = g_last_shape[0];

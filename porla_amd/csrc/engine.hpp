@@ -64,6 +64,10 @@ struct Buf {
         cap = want;
         return PORLA_OK;
     }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+    }
 };
 struct Workspace {
     int device = -1;

@@ -87,6 +87,7 @@ def _declare(L):
     L.porla_kzg_set_commit_window.argtypes = [ctypes.c_int]; L.porla_kzg_set_commit_window.restype = ctypes.c_int
     L.porla_kzg_commit_shape.argtypes = [ctypes.POINTER(ctypes.c_int)] * 2; L.porla_kzg_commit_shape.restype = ctypes.c_int
     L.porla_kzg_release_device_memory.argtypes = []; L.porla_kzg_release_device_memory.restype = ctypes.c_int
+    L.porla_gpu_release_msm_workspaces.argtypes = []; L.porla_gpu_release_msm_workspaces.restype = ctypes.c_int
     L.porla_icc_mac_encode_device.argtypes = [vp, sz, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_int, vp, vp]
     L.porla_icc_mac_encode_device.restype = ctypes.c_int
     L.porla_icc_mac_encode_host.argtypes = [u8p, sz, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_int, u8p]

@@ -312,3 +312,21 @@ def test_two_phase_api_keeps_independent_msms_in_flight(mx, inputs):
                 assert mx.msm_end(1 + k) == want[k]
     assert lib.porla_bn254_msm_device_begin(7, None, None, 0, None) != 0        # slot out of range
     assert mx.msm_end(2) == bytes(64)                                              # nothing pending: the empty sum
+
+
+def test_release_workspaces_and_reuse(mx, inputs):
+    """porla_gpu_release_msm_workspaces frees the scratch; the next MSM reallocates it and gives the same result; refused while
+    a two-phase MSM is pending"""
+    import torch
+    from porla_amd import lib
+    sc, pt = inputs
+    n = 3000
+    a = mx.msm_host("bn254", sc[:32 * n], pt[:64 * n], n)
+    assert lib.porla_gpu_release_msm_workspaces() == 0
+    assert mx.msm_host("bn254", sc[:32 * n], pt[:64 * n], n) == a
+    d_sc = torch.frombuffer(bytearray(sc[:32 * n]), dtype=torch.uint8).cuda()
+    d_pt = torch.frombuffer(bytearray(pt[:64 * n]), dtype=torch.uint8).cuda()
+    mx.msm_begin(1, d_sc.data_ptr(), d_pt.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    assert lib.porla_gpu_release_msm_workspaces() != 0
+    assert mx.msm_end(1) == a
+    assert lib.porla_gpu_release_msm_workspaces() == 0
