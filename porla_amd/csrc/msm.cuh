@@ -507,8 +507,7 @@ k_size_hist(const uint32_t* __restrict__ counts, uint32_t nb, uint32_t* __restri
     __syncthreads();
     if (threadIdx.x < CHUNK) {
         uint32_t v = hist[threadIdx.x];
-        blk_hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = v;
-        if (v) atomicAdd(&ctrl[4 + threadIdx.x], v);
+        blk_hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = v;   // (row totals: k_size_scan sums its row, no global atomics)
     }
 }
 
@@ -518,21 +517,17 @@ k_size_scan(const uint32_t* __restrict__ blk_hist, uint32_t* __restrict__ blk_of
             uint32_t* __restrict__ ctrl) {
     __shared__ uint32_t wsum[16];
     const uint32_t row = blockIdx.x, tid = threadIdx.x;
-    uint32_t total;
-    uint32_t v = (tid < CHUNK) ? ctrl[4 + tid] : 0;
-    uint32_t excl = block_scan_1024(v, wsum, &total);
-    __shared__ uint32_t row_base;
-    if (tid == row) row_base = excl;
-    if (row == 0 && tid == 0) ctrl[3] = total;
-    __syncthreads();
-    uint32_t run = row_base;
+    // offsets inside the row; the row's total goes to ctrl[4 + row] and k_size_order adds the rows before it
+    uint32_t run = 0;
     for (uint32_t b0 = 0; b0 < nblocks; b0 += 1024) {
         uint32_t x = (b0 + tid < nblocks) ? blk_hist[(size_t)row * nblocks + b0 + tid] : 0;
         uint32_t tot;
         uint32_t e = block_scan_1024(x, wsum, &tot);
         if (b0 + tid < nblocks) blk_off[(size_t)row * nblocks + b0 + tid] = run + e;
         run += tot;
+        __syncthreads();
     }
+    if (tid == 0) ctrl[4 + row] = run;
 }
 
 // order[pos] = (bucket, item index inside the bucket); empty buckets are written as infinity (zz = 0) here.
@@ -541,7 +536,15 @@ k_size_order(const uint32_t* __restrict__ counts, uint32_t nb, const uint32_t* _
              uint2* __restrict__ order, uint32_t* __restrict__ chunk_base, uint32_t* __restrict__ heavy_list,
              uint32_t* __restrict__ ctrl, uint4* __restrict__ buckets_raw) {
     __shared__ uint32_t next[CHUNK];
-    if (threadIdx.x < CHUNK) next[threadIdx.x] = blk_off[(size_t)threadIdx.x * nblocks + blockIdx.x];
+    __shared__ uint32_t wsum[16];
+    {
+        // rows before this one (larger items): exclusive scan of the CHUNK row totals
+        uint32_t total;
+        const uint32_t v = (threadIdx.x < CHUNK) ? ctrl[4 + threadIdx.x] : 0;
+        const uint32_t excl = block_scan_1024(v, wsum, &total);
+        if (threadIdx.x < CHUNK) next[threadIdx.x] = excl + blk_off[(size_t)threadIdx.x * nblocks + blockIdx.x];
+        if (blockIdx.x == 0 && threadIdx.x == 0) ctrl[3] = total;
+    }
     __syncthreads();
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nb) return;
