@@ -48,7 +48,7 @@ ICC_BYTES_PER_ELEMENT = 64    # 32 B in + 32 B out
 FE_MUL_PEAK_G = {"bn254_msm": 186.5, "kzg_commit": 186.5, "secp256k1_msm": 199.9}
 
 KERNEL_SYMBOL = {  # profile slot -> substring of the kernel symbol in the rocprofv3 output
-    "bucket_sum": "k_bucket_sum", "tree_levels": "k_tree_level", "tree_tail": "k_tree_tail", "partition_sort": "k_partition_sort",
+    "bucket_sum": "k_bucket_sum30", "tree_levels": "k_tree_level", "tree_tail": "k_tree_tail", "partition_sort": "k_partition_sort",
     "fb_commit": "k_fb_commit", "digits_partition": "k_digits_partition", "points_to_mont": "k_points_to_mont",
     "icc_fused": "k_icc_fused", "icc_stages_r4": "k_icc_stages", "icc_stages_r2": "k_icc_stages", "icc_load": "k_icc_load", "icc_finish": "k_icc_finish",
 }
@@ -169,7 +169,7 @@ def main():
             return None
         dom = max(kern, key=kern.get)
         ach = algo_bytes_per_launch / (kern[dom] * 1e-3) / 1e9
-        r = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        r = {"bound": "hbm", "kernel": KERNEL_SYMBOL.get(dom, dom), "achieved": round(ach, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
              "frac": round(ach / HBM_PEAK_GBPS, 6), "traffic": pmc_traffic(dom, workload),
              "kernel_ms": round(kern[dom], 4), "all_kernels_ms": {k: round(v, 4) for k, v in kern.items()}}
         if fe_mults_per_launch:
