@@ -44,6 +44,9 @@ extern "C" {
 #define PORLA_ERR_ARG       (-3)   /* bad argument */
 #define PORLA_ERR_STATE     (-4)   /* e.g. SRS not initialised */
 
+#define PORLA_JACOBIAN_BYTES 96    /* X||Y||Z big-endian, the partial sum of one pair range */
+#define PORLA_DIST_ID_BYTES  128   /* an ncclUniqueId */
+
 /* ---- runtime ---- */
 int         porla_gpu_device_count(void);
 int         porla_gpu_set_device(int device);
@@ -77,10 +80,23 @@ int porla_bn254_msm_device_partial(const void *d_scalars, const void *d_points, 
 /* Two-phase form for independent MSMs in flight at once (e.g. the audit's two MSMs, Server.hpp:900-901): begin enqueues
  * every kernel of one MSM on hip_stream and returns; end waits for that slot, folds the reduction tree's sums on the host and writes
  * 64 bytes affine (jacobian = 0) or 96 bytes Jacobian (jacobian = 1).  slot in 1..3 (0 is used by the blocking calls);
- * one begin per slot until its end.  Overlap comes from using a different stream per slot. */
+ * one begin per slot until its end.  Overlap comes from using a different stream per slot.  A slot belongs to the device that
+ * was current at begin: end must run with the same current device (PORLA_ERR_STATE otherwise, or without a begin). */
 int porla_bn254_msm_device_begin(int slot, const void *d_scalars, const void *d_points, size_t n, void *hip_stream);
 int porla_bn254_msm_device_end(int slot, uint8_t *out, int jacobian);
 int porla_bn254_msm_host(const uint8_t *scalars, const uint8_t *points, size_t n, uint8_t out_affine[64]);
+/* The same over several pair ranges and devices of this process -- the multi-GPU form that stays behind the C ABI (the
+ * reference folds the partial sums of its 8 pool threads the same way, porla/Client/Client.hpp:761-787): the pairs are cut
+ * into `shards` contiguous ranges, device g of `devices` (counted from the current device, modulo the visible ones) owns a
+ * contiguous block of ranges and runs them from its own host thread, stream and workspace slots, uploading range k+1 under
+ * the kernels of range k; the range totals are added on the host.  shards <= 0 / devices <= 0: automatic (devices: as many
+ * visible ones as get >= 2^17 pairs each, or PORLA_MSM_DEVICES; shards: up to 4 ranges of >= 2^17 pairs per device).
+ * porla_bn254_msm_host -- and therefore compute_multi_exp -- takes this path from 2^18 pairs on (PORLA_MSM_SPLIT_MIN).
+ * Any (shards, devices) gives the same 64 bytes. */
+int porla_bn254_msm_host_multi(const uint8_t *scalars, const uint8_t *points, size_t n, int shards, int devices,
+                               uint8_t out_affine[64]);
+/* diagnostic: ranges and devices the most recent *_msm_host_multi used */
+int porla_gpu_last_msm_multi(int *shards, int *devices);
 int porla_bn254_jac_sum(const uint8_t *jacobians, size_t count, uint8_t out_affine[64]);
 /* the MSM's host tail on its own (no device needed): the bucket-reduction tree leaves, per window w < windows, S_w and
  * M_{w,k} (k < window_bits - 1) -- here as 64-byte affine points, sums[w * window_bits + 0] = S_w, [.. + 1 + k] = M_{w,k} --
@@ -95,8 +111,32 @@ int porla_secp256k1_msm_device_partial(const void *d_scalars, const void *d_poin
 int porla_secp256k1_msm_device_begin(int slot, const void *d_scalars, const void *d_points, size_t n, void *hip_stream);
 int porla_secp256k1_msm_device_end(int slot, uint8_t *out, int jacobian);   /* the two MSMs of the IPA audit, Server.hpp:842-848 */
 int porla_secp256k1_msm_host(const uint8_t *scalars, const uint8_t *points, size_t n, uint8_t out_affine[64]);
+int porla_secp256k1_msm_host_multi(const uint8_t *scalars, const uint8_t *points, size_t n, int shards, int devices,
+                                   uint8_t out_affine[64]);
 int porla_secp256k1_jac_sum(const uint8_t *jacobians, size_t count, uint8_t out_affine[64]);
 int porla_secp256k1_tree_fold(const uint8_t *sums_affine, int windows, int window_bits, uint8_t out_affine[64]);
+
+/* ---- one process per GPU: the range-sharded MSM across processes (BASELINE config 3) ----
+ * Every rank owns a pair range resident in its GPU's HBM, runs a full MSM over it and contributes ONE 96-byte partial
+ * Jacobian sum; the only exchange step is one ncclAllGather of world x 96 bytes (RCCL over xGMI, issued from C++ on the
+ * engine's own stream), followed by world - 1 group additions and one inversion on every rank's host.  RCCL is bound with
+ * dlopen at the first porla_dist_* call (PORLA_RCCL_LIB overrides the library name).
+ *   rank 0: porla_dist_unique_id(id), hand the 128 bytes to the other ranks by any means (the launcher's store, MPI, a file)
+ *   all   : porla_gpu_set_device(local_rank); porla_dist_init(id, rank, world)      [collective]
+ *   all   : porla_bn254_msm_device_dist(my range ...) -> the whole job's 64-byte result on every rank   [collective]
+ *           or a partial from porla_*_msm_device_partial / _device_end(slot, out, 1) handed to porla_*_dist_fold
+ *   all   : porla_dist_finalize() */
+int porla_dist_unique_id(uint8_t id_out[PORLA_DIST_ID_BYTES]);
+int porla_dist_init(const uint8_t id[PORLA_DIST_ID_BYTES], int rank, int world);
+int porla_dist_info(int *rank, int *world);     /* world = 0 before porla_dist_init */
+int porla_dist_finalize(void);
+int porla_dist_allgather_partials(const uint8_t partial[PORLA_JACOBIAN_BYTES], uint8_t *all_out /* world * 96 bytes */);
+int porla_bn254_dist_fold(const uint8_t partial[PORLA_JACOBIAN_BYTES], uint8_t out_affine[64]);
+int porla_secp256k1_dist_fold(const uint8_t partial[PORLA_JACOBIAN_BYTES], uint8_t out_affine[64]);
+int porla_bn254_msm_device_dist(const void *d_scalars, const void *d_points, size_t n_local, uint8_t out_affine[64],
+                                void *hip_stream);
+int porla_secp256k1_msm_device_dist(const void *d_scalars, const void *d_points, size_t n_local, uint8_t out_affine[64],
+                                    void *hip_stream);
 
 /* ---- batched fixed-base commitments ----
  * out[r] = sum_{i < n_coeffs} (row_r[i] mod order) * base[i] for every row r, as 64-byte X||Y big-endian affine points.

@@ -41,7 +41,7 @@ int ensure_device() {
 
 // ------------------------------------------------------------------------------------------------ profiling
 struct ProfSlot { std::string name; double ms = 0; long long launches = 0; };
-struct PendingEv { int slot; hipEvent_t e0, e1; };
+struct PendingEv { int slot; int dev; hipEvent_t e0, e1; };
 static std::mutex g_prof_mu;
 static int g_prof_level = 0;   // 0 off, 1 every scope, 2 dominant kernels only
 static std::vector<ProfSlot> g_prof;
@@ -52,9 +52,18 @@ static int prof_slot(const char* name) {
     g_prof.push_back(ProfSlot{name, 0, 0});
     return (int)g_prof.size() - 1;
 }
-static std::vector<hipEvent_t> g_event_pool;   // events are recycled: creating two per kernel launch costs more than the launch
-static hipEvent_t take_event() {
-    if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+// events are recycled (creating two per kernel launch costs more than the launch); an event belongs to the device that was
+// current when it was created, so the pool is per device
+constexpr int MAX_DEVICES = 16;
+static std::vector<hipEvent_t> g_event_pool[MAX_DEVICES];
+static int current_device_index() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEVICES) d = 0;
+    return d;
+}
+static hipEvent_t take_event(int dev) {
+    auto& pool = g_event_pool[dev];
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
     (void)hipEventCreate(&e);
     return e;
@@ -64,15 +73,16 @@ ProfScope::ProfScope(const char* name, hipStream_t s, bool dominant) : slot(-1),
     if (g_prof_level == 0 || (g_prof_level == 2 && !dominant)) return;
     on = true;
     slot = prof_slot(name);
-    e0 = take_event();
-    e1 = take_event();
+    const int dev = current_device_index();
+    e0 = take_event(dev);
+    e1 = take_event(dev);
     (void)hipEventRecord(e0, stream);
 }
 ProfScope::~ProfScope() {
     if (!on) return;
     (void)hipEventRecord(e1, stream);
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_pending.push_back(PendingEv{slot, e0, e1});
+    g_pending.push_back(PendingEv{slot, current_device_index(), e0, e1});
 }
 void prof_flush() {
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -83,23 +93,26 @@ void prof_flush() {
             g_prof[p.slot].ms += ms;
             g_prof[p.slot].launches += 1;
         }
-        g_event_pool.push_back(p.e0);
-        g_event_pool.push_back(p.e1);
+        g_event_pool[p.dev].push_back(p.e0);
+        g_event_pool[p.dev].push_back(p.e1);
     }
     g_pending.clear();
 }
 
 // ------------------------------------------------------------------------------------------------ workspace
-std::mutex g_ws_mu;  // serialises MSM calls (compute_digest_from_srs may be called from 8 threads)
+std::mutex g_ws_mu;  // the workspace registry; the use of a slot is serialised by its own Workspace::mu
 static std::vector<Workspace*> g_ws;
 int g_window_override = 0;
 int g_last_shape[3] = {0, 0, 0};
+int g_last_multi[2] = {0, 0};
+std::mutex g_multi_mu;   // one range-sharded host MSM at a time (it occupies the pipeline slots of every device it uses)
 int g_use_glv = getenv("PORLA_MSM_GLV") ? (getenv("PORLA_MSM_GLV")[0] == '1' ? 1 : 0) : -1;  // -1: per-curve default
 
 int get_workspace_slot(int slot, Workspace** out) {
     if (slot < 0 || slot >= MSM_SLOTS) { set_last_error("porla: MSM slot out of range"); return PORLA_ERR_ARG; }
     int dev = 0;
     PORLA_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_ws_mu);
     for (auto* w : g_ws) if (w->device == dev && w->slot == slot) { *out = w; return PORLA_OK; }
     Workspace* w = new Workspace();
     w->device = dev;
@@ -110,6 +123,20 @@ int get_workspace_slot(int slot, Workspace** out) {
     return PORLA_OK;
 }
 int get_workspace(Workspace** out) { return get_workspace_slot(0, out); }
+int lease_blocking_slot(Workspace** out) {
+    Workspace* w0 = nullptr;
+    int rc = get_workspace_slot(0, &w0);
+    if (rc) return rc;
+    if (w0->mu.try_lock()) { *out = w0; return PORLA_OK; }
+    for (int k = MSM_POOL_SLOT0; k < MSM_SLOTS; k++) {
+        Workspace* w = nullptr;
+        if ((rc = get_workspace_slot(k, &w))) return rc;
+        if (w->mu.try_lock()) { *out = w; return PORLA_OK; }
+    }
+    w0->mu.lock();
+    *out = w0;
+    return PORLA_OK;
+}
 
 // ------------------------------------------------------------------------------------------------ C ABI helpers
 template <class C>
@@ -129,6 +156,16 @@ static int abi_msm_host(const uint8_t* scalars, const uint8_t* points, size_t n,
     if (n && (!scalars || !points || !out)) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
     XYZZ<M> tot;
     int rc = msm_host<C>(scalars, points, n, &tot);
+    if (rc) return rc;
+    h_affine_to_bytes<M>(out, h_xyzz_to_affine<M>(tot));
+    return PORLA_OK;
+}
+template <class C>
+static int abi_msm_host_multi(const uint8_t* scalars, const uint8_t* points, size_t n, int shards, int devices, uint8_t* out) {
+    using M = typename C::Fp;
+    if (n && (!scalars || !points || !out)) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    XYZZ<M> tot;
+    int rc = msm_host_multi<C>(scalars, points, n, shards, devices, &tot);
     if (rc) return rc;
     h_affine_to_bytes<M>(out, h_xyzz_to_affine<M>(tot));
     return PORLA_OK;
@@ -156,7 +193,6 @@ static int abi_jac_sum(const uint8_t* jacs, size_t count, uint8_t* out) {
 }
 
 hipStream_t engine_stream() {
-    std::lock_guard<std::mutex> lk(g_ws_mu);
     Workspace* ws;
     if (get_workspace(&ws)) return nullptr;
     return ws->own_stream;
@@ -211,13 +247,18 @@ int porla_gpu_profile_get(int slot, char* name, size_t name_cap, double* total_m
 // refused while a two-phase MSM is still pending
 int porla_gpu_release_msm_workspaces(void) {
     std::lock_guard<std::mutex> lk(g_ws_mu);
-    for (auto* w : g_ws) if (w->pend_W) { set_last_error("porla: an MSM is still pending (call the matching _end first)"); return PORLA_ERR_STATE; }
+    for (auto* w : g_ws) if (w->pend_W || w->begun) { set_last_error("porla: an MSM is still pending (call the matching _end first)"); return PORLA_ERR_STATE; }
+    int cur = 0;
+    (void)hipGetDevice(&cur);
     for (auto* w : g_ws) {
+        std::lock_guard<std::mutex> lw(w->mu);
+        (void)hipSetDevice(w->device);
         Buf* bufs[] = {&w->pts, &w->keys, &w->entries, &w->counts, &w->starts, &w->fill, &w->cursor, &w->buckets, &w->in_scalars,
                        &w->in_points, &w->order, &w->blk_hist, &w->blk_off, &w->tile_off, &w->heavy, &w->chunk_out, &w->tree_s,
                        &w->tree_m, &w->tree_mt};
         for (Buf* b : bufs) b->release();
     }
+    (void)hipSetDevice(cur);
     return PORLA_OK;
 }
 int porla_gpu_set_msm_window(int c) { g_window_override = c; return PORLA_OK; }
@@ -257,6 +298,17 @@ int porla_bn254_msm_device_partial(const void* d_scalars, const void* d_points, 
 int porla_bn254_msm_host(const uint8_t* scalars, const uint8_t* points, size_t n, uint8_t out_affine[64]) {
     return abi_msm_host<Bn254G1>(scalars, points, n, out_affine);
 }
+int porla_bn254_msm_host_multi(const uint8_t* scalars, const uint8_t* points, size_t n, int shards, int devices, uint8_t out_affine[64]) {
+    return abi_msm_host_multi<Bn254G1>(scalars, points, n, shards, devices, out_affine);
+}
+int porla_secp256k1_msm_host_multi(const uint8_t* scalars, const uint8_t* points, size_t n, int shards, int devices, uint8_t out_affine[64]) {
+    return abi_msm_host_multi<Secp256k1G>(scalars, points, n, shards, devices, out_affine);
+}
+int porla_gpu_last_msm_multi(int* shards, int* devices) {
+    if (shards) *shards = g_last_multi[0];
+    if (devices) *devices = g_last_multi[1];
+    return PORLA_OK;
+}
 int porla_bn254_jac_sum(const uint8_t* jacs, size_t count, uint8_t out_affine[64]) {
     return abi_jac_sum<Bn254G1>(jacs, count, out_affine);
 }
@@ -267,11 +319,18 @@ int porla_secp256k1_tree_fold(const uint8_t* sums, int windows, int window_bits,
     return abi_tree_fold<Secp256k1G>(sums, windows, window_bits, out_affine);
 }
 
+static int user_slot_ok(int slot) {
+    if (slot >= 0 && slot < MSM_USER_SLOTS) return PORLA_OK;
+    set_last_error("porla: MSM slot out of range (0..3)");
+    return PORLA_ERR_ARG;
+}
 int porla_bn254_msm_device_begin(int slot, const void* d_scalars, const void* d_points, size_t n, void* s) {
+    if (user_slot_ok(slot)) return PORLA_ERR_ARG;
     if (n && (!d_scalars || !d_points)) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
     return msm_device_begin<Bn254G1>(slot, (const uint8_t*)d_scalars, (const uint8_t*)d_points, n, (hipStream_t)s);
 }
 int porla_bn254_msm_device_end(int slot, uint8_t* out, int jacobian) {
+    if (user_slot_ok(slot)) return PORLA_ERR_ARG;
     if (!out) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
     XYZZ<Bn254Fp> tot;
     int rc = msm_device_end<Bn254G1>(slot, &tot);
@@ -282,10 +341,12 @@ int porla_bn254_msm_device_end(int slot, uint8_t* out, int jacobian) {
 }
 
 int porla_secp256k1_msm_device_begin(int slot, const void* d_scalars, const void* d_points, size_t n, void* s) {
+    if (user_slot_ok(slot)) return PORLA_ERR_ARG;
     if (n && (!d_scalars || !d_points)) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
     return msm_device_begin<Secp256k1G>(slot, (const uint8_t*)d_scalars, (const uint8_t*)d_points, n, (hipStream_t)s);
 }
 int porla_secp256k1_msm_device_end(int slot, uint8_t* out, int jacobian) {
+    if (user_slot_ok(slot)) return PORLA_ERR_ARG;
     if (!out) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
     XYZZ<Secp256k1Fp> tot;
     int rc = msm_device_end<Secp256k1G>(slot, &tot);

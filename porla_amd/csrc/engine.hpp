@@ -48,6 +48,13 @@ int msm_device_end(int slot, XYZZ<typename C::Fp>* total);
 // host buffers -> device -> msm
 template <class C>
 int msm_host(const uint8_t* scalars, const uint8_t* points, size_t n, XYZZ<typename C::Fp>* total);
+// host buffers, range-sharded: `shards` contiguous pair ranges spread over `devices` visible devices (one host thread,
+// stream and workspace slot per device; the shards of one device are pipelined: the upload of a range overlaps the kernels
+// of the previous one); the range totals are folded on the host as the reference folds its 8 pool threads' partial sums
+// (porla/Client/Client.hpp:761-787).  shards / devices <= 0: automatic.
+template <class C>
+int msm_host_multi(const uint8_t* scalars, const uint8_t* points, size_t n, int shards, int devices,
+                   XYZZ<typename C::Fp>* total);
 
 int ensure_device();  // selects/validates the current device, fails loudly without one
 
@@ -70,6 +77,7 @@ struct Buf {
     }
 };
 struct Workspace {
+    std::mutex mu;   // held while kernels are enqueued on / results folded from this slot (the registry has its own lock)
     int device = -1;
     Buf pts, keys, entries, counts, starts, fill, cursor, buckets, in_scalars, in_points;
     Buf order, blk_hist, blk_off, tile_off, heavy, chunk_out;
@@ -80,8 +88,16 @@ struct Workspace {
     int slot = 0;
     hipEvent_t done = nullptr;  // recorded after the last kernel + D2H copy of a launched MSM
     int pend_W = 0, pend_c = 0; // window count / width of the launched, not yet folded MSM (0 = none)
+    bool begun = false;         // two-phase API: a begin without its end (also set for n == 0, where pend_W stays 0)
 };
-constexpr int MSM_SLOTS = 4;
+// workspace slots per device -- 0: blocking calls, 1..3: the two-phase C ABI, 4..7: msm_host_multi's pipeline,
+// 8..15: taken by blocking calls that find slot 0 busy (the reference issues its IPA MSMs from 8 pool threads at once,
+// Client.hpp:395,778: they run side by side, each on its own slot and stream, instead of queueing on one mutex)
+constexpr int MSM_SLOTS = 16;
+constexpr int MSM_USER_SLOTS = 4;
+constexpr int MSM_MULTI_SLOT0 = 4;
+constexpr int MSM_MULTI_SLOTS = 4;
+constexpr int MSM_POOL_SLOT0 = 8;
 constexpr size_t MSM_SCAN_MAX = 1u << 16;  // inputs up to this size are scanned for their longest scalar first
 // Batched fixed-base commitments (fixed_base.cuh): resident table of window multiples of one base.
 // Calls on one object are serialised by `mu`; the *_device form leaves its kernels in flight on the caller's stream
@@ -117,12 +133,14 @@ struct FixedBase {
                     hipStream_t stream);
 };
 
-extern std::mutex g_ws_mu;
+extern std::mutex g_ws_mu;   // the workspace registry (lookup / creation / release); a slot's use is under Workspace::mu
 extern int g_window_override;
+extern int g_last_multi[2];   // ranges, devices of the most recent msm_host_multi (diagnostic)
 extern int g_last_shape[3];   // window bits, window count, GLV flag of the most recently launched MSM (diagnostic)
 extern int g_use_glv;  // 1: GLV split of every scalar; 0: plain signed windows over the full scalar; -1: the curve's default
 int get_workspace(Workspace** out);                 // slot 0 of the current device
-int get_workspace_slot(int slot, Workspace** out);  // g_ws_mu held by the caller
+int get_workspace_slot(int slot, Workspace** out);  // takes g_ws_mu itself
+int lease_blocking_slot(Workspace** out);           // slot 0, or a free pool slot when it is busy; returned LOCKED (ws->mu)
 hipStream_t engine_stream();  // this device's engine-owned non-blocking stream
 
 // icc.hip: the ICC butterfly network as an n x n matrix of 32-byte big-endian coefficients mod the group order

@@ -5,6 +5,8 @@
 #include "host_fold64.hpp"
 #include <cstdlib>
 #include <chrono>
+#include <thread>
+#include <vector>
 #include <cstdio>
 #include "../../include/porla_gpu.h"
 
@@ -105,7 +107,7 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
     auto t_tr = std::chrono::steady_clock::now();
     ws->pend_W = 0;
     if (n == 0) return PORLA_OK;
-    if (n >= (1ull << 30)) { set_last_error("porla: MSM length must be < 2^30"); return PORLA_ERR_ARG; }
+    if (n >= (1ull << 30)) { set_last_error("porla: MSM length must be < 2^30 per call (range-split larger inputs)"); return PORLA_ERR_ARG; }
     const bool glv = g_use_glv < 0 ? C::GLV_DEFAULT : g_use_glv != 0;
     int bits = glv ? C::Glv::BITS : C::SCALAR_BITS;
     // Small and medium inputs: look at the scalars first.  If none of them exceeds b bits (and b is below the group order's
@@ -145,6 +147,8 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
     const uint32_t T_tiles = (uint32_t)((n + TILE - 1) / TILE);
     const uint32_t nblk = (uint32_t)((nb + 1023) / 1024);
     const size_t max_entries = (size_t)W * n_sub;
+    // the sort's cursor, starts[] and the entry offsets are 32-bit
+    if (max_entries >= (1ull << 32)) { set_last_error("porla: MSM too large for one launch (windows x sub-scalars >= 2^32): range-split it (porla_*_msm_host_multi)"); return PORLA_ERR_ARG; }
     const size_t max_items = nb + max_entries / CHUNK;          // every bucket: <= cnt/CHUNK full items + 1 remainder
     const size_t max_chunk_out = 2 * (max_entries / CHUNK) + 2; // multi-item buckets only: ceil(cnt/CHUNK) <= 2 cnt/CHUNK
     if ((rc = ws->keys.ensure((size_t)W * T_tiles * tile_cap * 4))) return rc;   // tile_items
@@ -335,48 +339,168 @@ int msm_device(const uint8_t* d_scalars, const uint8_t* d_points, size_t n, hipS
                XYZZ<typename C::Fp>* total) {
     int rc = ensure_device();
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(g_ws_mu);
     Workspace* ws;
-    if ((rc = get_workspace(&ws))) return rc;
+    if ((rc = lease_blocking_slot(&ws))) return rc;
+    std::lock_guard<std::mutex> lk(ws->mu, std::adopt_lock);
     return msm_core<C>(ws, d_scalars, d_points, n, stream, total);
 }
-// Two-phase form: several MSMs in flight on different streams, each in its own workspace slot (1 .. MSM_SLOTS-1; slot 0
+// Two-phase form: several MSMs in flight on different streams, each in its own workspace slot (1 .. MSM_USER_SLOTS-1; slot 0
 // belongs to the blocking calls).  begin enqueues all kernels and returns; end waits for that slot and folds on the host.
+// A slot belongs to the device that was current at begin: end must be called with the same current device.
 template <class C>
 int msm_device_begin(int slot, const uint8_t* d_scalars, const uint8_t* d_points, size_t n, hipStream_t stream) {
     int rc = ensure_device();
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(g_ws_mu);
     Workspace* ws;
     if ((rc = get_workspace_slot(slot, &ws))) return rc;
-    if (ws->pend_W) { set_last_error("porla: MSM slot still has a pending result (call the matching _end first)"); return PORLA_ERR_STATE; }
-    return msm_launch<C>(ws, d_scalars, d_points, n, stream);
+    std::lock_guard<std::mutex> lk(ws->mu);
+    if (ws->begun) { set_last_error("porla: MSM slot still has a pending result (call the matching _end first)"); return PORLA_ERR_STATE; }
+    rc = msm_launch<C>(ws, d_scalars, d_points, n, stream);
+    if (rc == PORLA_OK) ws->begun = true;
+    return rc;
 }
 template <class C>
 int msm_device_end(int slot, XYZZ<typename C::Fp>* total) {
     Workspace* ws;
-    {
-        std::lock_guard<std::mutex> lk(g_ws_mu);
-        int rc = get_workspace_slot(slot, &ws);
-        if (rc) return rc;
+    int rc = get_workspace_slot(slot, &ws);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(ws->mu);
+    if (!ws->begun) {
+        set_last_error("porla: no MSM was begun on this slot of the current device (end must run with the device of its begin)");
+        return PORLA_ERR_STATE;
     }
+    ws->begun = false;
     return msm_finish<C>(ws, total);
 }
 
+// one range of host pairs -> this slot's staging buffers -> kernels enqueued on the slot's own stream (ws->mu held)
 template <class C>
-int msm_host(const uint8_t* scalars, const uint8_t* points, size_t n, XYZZ<typename C::Fp>* total) {
-    int rc = ensure_device();
-    if (rc) return rc;
-    std::lock_guard<std::mutex> lk(g_ws_mu);
-    Workspace* ws;
-    if ((rc = get_workspace(&ws))) return rc;
-    if (n == 0) { *total = xyzz_inf<typename C::Fp>(); return PORLA_OK; }
+static int msm_host_launch(Workspace* ws, const uint8_t* scalars, const uint8_t* points, size_t n) {
+    int rc;
+    ws->pend_W = 0;
+    if (n == 0) return PORLA_OK;
     if ((rc = ws->in_scalars.ensure(n * 32))) return rc;
     if ((rc = ws->in_points.ensure(n * 64))) return rc;
     hipStream_t s = ws->own_stream;
     PORLA_HIP(hipMemcpyAsync(ws->in_scalars.p, scalars, n * 32, hipMemcpyHostToDevice, s));
     PORLA_HIP(hipMemcpyAsync(ws->in_points.p, points, n * 64, hipMemcpyHostToDevice, s));
-    return msm_core<C>(ws, (const uint8_t*)ws->in_scalars.p, (const uint8_t*)ws->in_points.p, n, s, total);
+    return msm_launch<C>(ws, (const uint8_t*)ws->in_scalars.p, (const uint8_t*)ws->in_points.p, n, s);
+}
+
+// pairs per range below which splitting further (or taking another device) costs more than it hides
+static inline size_t msm_multi_min_range() {
+    static const size_t v = getenv("PORLA_MSM_MIN_RANGE") ? (size_t)atoll(getenv("PORLA_MSM_MIN_RANGE")) : ((size_t)1 << 17);
+    return v < 1 ? 1 : v;
+}
+static inline int msm_multi_pipeline() {   // ranges per device when the caller leaves the shard count to the engine
+    static const int v = getenv("PORLA_MSM_PIPELINE") ? atoi(getenv("PORLA_MSM_PIPELINE")) : 4;
+    return v < 1 ? 1 : (v > 64 ? 64 : v);
+}
+extern std::mutex g_multi_mu;
+
+template <class C>
+int msm_host_multi(const uint8_t* scalars, const uint8_t* points, size_t n, int shards, int devices,
+                   XYZZ<typename C::Fp>* total) {
+    using M = typename C::Fp;
+    int rc = ensure_device();
+    if (rc) return rc;
+    *total = xyzz_inf<M>();
+    if (n == 0) return PORLA_OK;
+    int visible = 0, first = 0;
+    PORLA_HIP(hipGetDeviceCount(&visible));
+    PORLA_HIP(hipGetDevice(&first));
+    // devices: the caller's count, else PORLA_MSM_DEVICES, else every visible device that still gets a worthwhile range
+    int G = devices;
+    if (G <= 0 && getenv("PORLA_MSM_DEVICES")) G = atoi(getenv("PORLA_MSM_DEVICES"));
+    if (G <= 0) {
+        size_t by_size = n / msm_multi_min_range();
+        G = by_size < 1 ? 1 : (by_size > (size_t)visible ? visible : (int)by_size);
+    }
+    if (G > visible) G = visible;
+    if (G < 1) G = 1;
+    int S = shards;
+    if (S <= 0) {
+        size_t per_dev = n / G / msm_multi_min_range();
+        size_t pipe = (size_t)msm_multi_pipeline();
+        S = G * (int)(per_dev < 1 ? 1 : (per_dev > pipe ? pipe : per_dev));
+    }
+    if ((size_t)S > n) S = (int)n;
+    if (S < G) G = S;
+    // range s = pairs [s n / S, (s+1) n / S); device g owns the contiguous ranges [g S / G, (g+1) S / G)
+    std::vector<XYZZ<M>> part((size_t)S, xyzz_inf<M>());
+    std::vector<int> dev_rc((size_t)G, PORLA_OK);
+    std::vector<std::string> dev_err((size_t)G);
+    std::lock_guard<std::mutex> lk_multi(g_multi_mu);
+    auto worker = [&](int g) {
+        int r = PORLA_OK;
+        auto fail = [&](int code) { r = code; dev_err[g] = porla_gpu_last_error(); };
+        if (hipSetDevice((first + g) % visible) != hipSuccess) { set_last_error("porla: hipSetDevice failed"); fail(PORLA_ERR_HIP); dev_rc[g] = r; return; }
+        const int s0 = (int)((long long)g * S / G), s1 = (int)((long long)(g + 1) * S / G);
+        constexpr int PIPE = MSM_MULTI_SLOTS;
+        Workspace* slot_ws[PIPE] = {nullptr, nullptr, nullptr, nullptr};
+        int slot_shard[PIPE] = {-1, -1, -1, -1};
+        auto retire = [&](int k) {
+            if (slot_shard[k] < 0) return;
+            int rr = msm_finish<C>(slot_ws[k], &part[(size_t)slot_shard[k]]);
+            if (rr && !r) fail(rr);
+            slot_shard[k] = -1;
+        };
+        for (int s = s0; s < s1 && !r; s++) {
+            const int k = (s - s0) % PIPE;
+            if (!slot_ws[k]) {
+                int rr = get_workspace_slot(MSM_MULTI_SLOT0 + k, &slot_ws[k]);
+                if (rr) { fail(rr); break; }
+                slot_ws[k]->mu.lock();
+            }
+            retire(k);
+            const size_t lo = (size_t)((unsigned __int128)s * n / (unsigned)S), hi = (size_t)((unsigned __int128)(s + 1) * n / (unsigned)S);
+            int rr = msm_host_launch<C>(slot_ws[k], scalars + 32 * lo, points + 64 * lo, hi - lo);
+            if (rr) { fail(rr); break; }
+            slot_shard[k] = s;
+        }
+        for (int k = 0; k < PIPE; k++) {
+            if (!slot_ws[k]) continue;
+            if (slot_shard[k] >= 0) {
+                if (!r) retire(k);
+                else { (void)hipEventSynchronize(slot_ws[k]->done); slot_ws[k]->pend_W = 0; }   // drain what was enqueued
+            }
+            slot_ws[k]->mu.unlock();
+        }
+        dev_rc[g] = r;
+    };
+    if (G == 1) {
+        worker(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int g = 1; g < G; g++) th.emplace_back(worker, g);
+        worker(0);
+        for (auto& t : th) t.join();
+        (void)hipSetDevice(first);
+    }
+    for (int g = 0; g < G; g++) if (dev_rc[g]) { set_last_error(dev_err[g]); return dev_rc[g]; }
+    XYZZ<M> acc = xyzz_inf<M>();
+    for (int s = 0; s < S; s++) xyzz_add<M>(acc, part[(size_t)s]);
+    *total = acc;
+    g_last_multi[0] = S; g_last_multi[1] = G;
+    return PORLA_OK;
+}
+
+// threshold above which the blocking host-buffer form range-splits its input (upload of one range under the kernels of another)
+static inline size_t msm_host_split_min() {
+    static const size_t v = getenv("PORLA_MSM_SPLIT_MIN") ? (size_t)atoll(getenv("PORLA_MSM_SPLIT_MIN")) : ((size_t)1 << 18);
+    return v;
+}
+template <class C>
+int msm_host(const uint8_t* scalars, const uint8_t* points, size_t n, XYZZ<typename C::Fp>* total) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n >= msm_host_split_min()) return msm_host_multi<C>(scalars, points, n, 0, 0, total);
+    Workspace* ws;
+    if ((rc = lease_blocking_slot(&ws))) return rc;
+    std::lock_guard<std::mutex> lk(ws->mu, std::adopt_lock);
+    if (n == 0) { *total = xyzz_inf<typename C::Fp>(); return PORLA_OK; }
+    if ((rc = msm_host_launch<C>(ws, scalars, points, n))) return rc;
+    return msm_finish<C>(ws, total);
 }
 
 

@@ -68,8 +68,17 @@ def _declare(L):
         f = getattr(L, "porla_%s_msm_device" % curve); f.argtypes = [vp, vp, sz, u8p, vp]; f.restype = ctypes.c_int
         f = getattr(L, "porla_%s_msm_device_partial" % curve); f.argtypes = [vp, vp, sz, u8p, vp]; f.restype = ctypes.c_int
         f = getattr(L, "porla_%s_msm_host" % curve); f.argtypes = [u8p, u8p, sz, u8p]; f.restype = ctypes.c_int
+        f = getattr(L, "porla_%s_msm_host_multi" % curve); f.argtypes = [u8p, u8p, sz, ctypes.c_int, ctypes.c_int, u8p]; f.restype = ctypes.c_int
+        f = getattr(L, "porla_%s_dist_fold" % curve); f.argtypes = [u8p, u8p]; f.restype = ctypes.c_int
+        f = getattr(L, "porla_%s_msm_device_dist" % curve); f.argtypes = [vp, vp, sz, u8p, vp]; f.restype = ctypes.c_int
         f = getattr(L, "porla_%s_jac_sum" % curve); f.argtypes = [u8p, sz, u8p]; f.restype = ctypes.c_int
         f = getattr(L, "porla_%s_tree_fold" % curve); f.argtypes = [u8p, ctypes.c_int, ctypes.c_int, u8p]; f.restype = ctypes.c_int
+    L.porla_gpu_last_msm_multi.argtypes = [ctypes.POINTER(ctypes.c_int)] * 2; L.porla_gpu_last_msm_multi.restype = ctypes.c_int
+    L.porla_dist_unique_id.argtypes = [u8p]; L.porla_dist_unique_id.restype = ctypes.c_int
+    L.porla_dist_init.argtypes = [u8p, ctypes.c_int, ctypes.c_int]; L.porla_dist_init.restype = ctypes.c_int
+    L.porla_dist_info.argtypes = [ctypes.POINTER(ctypes.c_int)] * 2; L.porla_dist_info.restype = ctypes.c_int
+    L.porla_dist_finalize.argtypes = []; L.porla_dist_finalize.restype = ctypes.c_int
+    L.porla_dist_allgather_partials.argtypes = [u8p, u8p]; L.porla_dist_allgather_partials.restype = ctypes.c_int
     L.porla_fixed_base_create.argtypes = [ctypes.c_int, u8p, sz, ctypes.c_int, ctypes.POINTER(vp)]
     L.porla_fixed_base_create.restype = ctypes.c_int
     L.porla_fixed_base_info.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),

@@ -167,6 +167,61 @@ def msm_host(curve, scalars, points, n):
     return out.raw
 
 
+def msm_host_multi(curve, scalars, points, n, shards=0, devices=0):
+    """range-sharded over `shards` pair ranges and `devices` GPUs of this process (0 = automatic), behind the C ABI"""
+    out = ctypes.create_string_buffer(64)
+    _check(getattr(lib, "porla_%s_msm_host_multi" % curve)(bytes(scalars), bytes(points), n, shards, devices, out))
+    return out.raw
+
+
+def last_msm_multi():
+    """(ranges, devices) the most recent msm_host_multi used"""
+    s, d = ctypes.c_int(0), ctypes.c_int(0)
+    lib.porla_gpu_last_msm_multi(ctypes.byref(s), ctypes.byref(d))
+    return s.value, d.value
+
+
+# ---- one process per GPU: RCCL all-gather of the 96-byte partials, issued from C++ (include/porla_gpu.h) ----
+def dist_unique_id():
+    out = ctypes.create_string_buffer(128)
+    _check(lib.porla_dist_unique_id(out))
+    return out.raw
+
+
+def dist_init(unique_id, rank, world):
+    _check(lib.porla_dist_init(bytes(unique_id), rank, world))
+
+
+def dist_info():
+    r, w = ctypes.c_int(0), ctypes.c_int(0)
+    lib.porla_dist_info(ctypes.byref(r), ctypes.byref(w))
+    return r.value, w.value
+
+
+def dist_finalize():
+    _check(lib.porla_dist_finalize())
+
+
+def dist_allgather_partials(partial, world):
+    out = ctypes.create_string_buffer(96 * world)
+    _check(lib.porla_dist_allgather_partials(bytes(partial), out))
+    return out.raw
+
+
+def dist_fold(curve, partial):
+    """all ranks' 96-byte partials through one ncclAllGather, folded: the whole job's 64-byte result"""
+    out = ctypes.create_string_buffer(64)
+    _check(getattr(lib, "porla_%s_dist_fold" % curve)(bytes(partial), out))
+    return out.raw
+
+
+def msm_device_dist(curve, d_scalars, d_points, n_local, stream=0):
+    out = ctypes.create_string_buffer(64)
+    _check(getattr(lib, "porla_%s_msm_device_dist" % curve)(ctypes.c_void_p(d_scalars), ctypes.c_void_p(d_points), n_local, out,
+                                                            ctypes.c_void_p(stream)))
+    return out.raw
+
+
 def jac_sum(curve, jacobians, count):
     out = ctypes.create_string_buffer(64)
     _check(getattr(lib, "porla_%s_jac_sum" % curve)(bytes(jacobians), count, out))

@@ -311,7 +311,12 @@ def test_two_phase_api_keeps_independent_msms_in_flight(mx, inputs):
             else:
                 assert mx.msm_end(1 + k) == want[k]
     assert lib.porla_bn254_msm_device_begin(7, None, None, 0, None) != 0        # slot out of range
-    assert mx.msm_end(2) == bytes(64)                                              # nothing pending: the empty sum
+    # an end without its begin is an error (it would also be what a thread on ANOTHER device gets for this slot) ...
+    out = ctypes.create_string_buffer(64)
+    assert lib.porla_bn254_msm_device_end(2, out, 0) == -4
+    # ... while the legitimate empty MSM gives the empty sum
+    mx.msm_begin(2, d_sc.data_ptr(), d_pt.data_ptr(), 0, streams[0].cuda_stream)
+    assert mx.msm_end(2) == bytes(64)
 
 
 def test_release_workspaces_and_reuse(mx, inputs):

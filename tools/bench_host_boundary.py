@@ -33,3 +33,20 @@ for n in (3200, 1 << 14, 1 << 17, 1 << 20):
     t_dev = (time.perf_counter() - t0) / reps * 1e3
     print(json.dumps({"n": n, "host_buffers_ms": round(t_host, 3), "device_resident_ms": round(t_dev, 3), "same_result": r_host == r_dev,
                       "input_MiB": round(96 * n / 2**20, 2), "host_path_GBps": round(96 * n / (max(t_host - t_dev, 1e-6) * 1e-3) / 1e9, 1)}), flush=True)
+
+# range-sharded host path (porla_bn254_msm_host_multi): ranges per device at 2^20 pairs, one device
+n = 1 << 20
+bs, bp = ctypes.create_string_buffer(sc[:32 * n], 32 * n), ctypes.create_string_buffer(pt[:64 * n], 64 * n)
+out = ctypes.create_string_buffer(64)
+want = None
+for shards in (1, 2, 3, 4, 6, 8, 12, 16):
+    for _ in range(3):
+        lib.porla_bn254_msm_host_multi(bs, bp, n, shards, 1, out)
+    t0 = time.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        lib.porla_bn254_msm_host_multi(bs, bp, n, shards, 1, out)
+    el = (time.perf_counter() - t0) / reps * 1e3
+    want = want or out.raw
+    print(json.dumps({"n": n, "host_multi_shards": shards, "devices": 1, "ms": round(el, 3), "Mmul_s": round(n / el / 1e3, 1),
+                      "same_result": out.raw == want}), flush=True)
