@@ -304,6 +304,21 @@ __device__ __forceinline__ void xyzz30_add_quad(const XYZZ<M>* pa, const XYZZ<M>
     const F30<M> A = xyzz30_load_coord<M>(sa, (int)(r >> 1), &za);
     const F30<M> B = xyzz30_load_coord<M>(sb, 2 + (int)(r >> 1), &zb);
     bool special = zb;                                   // a ZZ / ZZZ of zero: that operand is infinity
+    if (!final) {
+        // an infinite operand (common while the sums are sparse: small inputs, the first tree levels): the result is the other
+        // operand, copied coordinate by coordinate in the memory form -- no arithmetic, and not the one-lane path below
+        const uint32_t qz = (uint32_t)(__ballot(zb) >> (lane & 60u)) & 0xfu;   // even lanes looked at *pb, odd lanes at *pa
+        if (qz) {
+            const XYZZ<M>* src = (qz & 0x5u) ? pa : pb;
+            if (live && src != out) {
+                const uint4* q = reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(src) + 8 * r);
+                uint4* d = reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(out) + 8 * r);
+                const uint4 v0 = q[0], v1 = q[1];
+                d[0] = v0; d[1] = v1;
+            }
+            return;
+        }
+    }
     const F30<M> M1 = f30_mul<M>(A, B);                  // U1, U2, S1, S2
     const bool edge = (r == 0u) || (r == 3u);
     const F30<M> rcv = f30_quad<M, 0xB1>(f30_sel<M>(edge, B, M1));   // lanes 0<->1, 2<->3

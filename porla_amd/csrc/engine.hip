@@ -103,6 +103,8 @@ void prof_flush() {
 std::mutex g_ws_mu;  // the workspace registry; the use of a slot is serialised by its own Workspace::mu
 static std::vector<Workspace*> g_ws;
 int g_window_override = 0;
+int g_small_mode = getenv("PORLA_MSM_SMALL") ? atoi(getenv("PORLA_MSM_SMALL")) : 1;
+int g_small_c = getenv("PORLA_MSM_SMALL_C") ? atoi(getenv("PORLA_MSM_SMALL_C")) : 0;
 int g_last_shape[3] = {0, 0, 0};
 int g_last_multi[2] = {0, 0};
 std::mutex g_multi_mu;   // one range-sharded host MSM at a time (it occupies the pipeline slots of every device it uses)
@@ -255,7 +257,7 @@ int porla_gpu_release_msm_workspaces(void) {
         (void)hipSetDevice(w->device);
         Buf* bufs[] = {&w->pts, &w->keys, &w->entries, &w->counts, &w->starts, &w->fill, &w->cursor, &w->buckets, &w->in_scalars,
                        &w->in_points, &w->order, &w->blk_hist, &w->blk_off, &w->tile_off, &w->heavy, &w->chunk_out, &w->tree_s,
-                       &w->tree_m, &w->tree_mt};
+                       &w->tree_m, &w->tree_mt, &w->small_part};
         for (Buf* b : bufs) b->release();
     }
     (void)hipSetDevice(cur);
@@ -266,6 +268,11 @@ int porla_gpu_last_msm_shape(int* c, int* windows, int* glv) {
     if (c) *c = g_last_shape[0];
     if (windows) *windows = g_last_shape[1];
     if (glv) *glv = g_last_shape[2];
+    return PORLA_OK;
+}
+int porla_gpu_set_msm_small(int on, int window_bits) {
+    g_small_mode = on != 0;
+    g_small_c = window_bits >= 1 && window_bits <= SMALL_MAX_C ? window_bits : 0;
     return PORLA_OK;
 }
 int porla_gpu_set_msm_glv(int on) { g_use_glv = on < 0 ? -1 : (on != 0); return PORLA_OK; }

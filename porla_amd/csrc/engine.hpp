@@ -8,6 +8,7 @@
 #include "../../include/porla_gpu.h"
 #include "host_curve.hpp"
 #include "msm.cuh"
+#include "msm_small.cuh"
 
 namespace porla {
 
@@ -81,6 +82,8 @@ struct Workspace {
     int device = -1;
     Buf pts, keys, entries, counts, starts, fill, cursor, buckets, in_scalars, in_points;
     Buf order, blk_hist, blk_off, tile_off, heavy, chunk_out;
+    Buf small_part;               // single-launch path: the blocks' sums + the per-window arrival counters
+    uint32_t small_seq = 0;
     Buf tree_s, tree_m, tree_mt;  // bucket reduction tree: S levels, M ping-pong halves (all windows / tail-private)
     void* h_windows = nullptr;  // pinned, device-mapped: the tree's last level writes [W][c] (S, M_0 .. M_(c-2)) per window
     size_t h_windows_cap = 0;
@@ -135,6 +138,8 @@ struct FixedBase {
 
 extern std::mutex g_ws_mu;   // the workspace registry (lookup / creation / release); a slot's use is under Workspace::mu
 extern int g_window_override;
+extern int g_small_mode;      // single-launch path for n <= 4096: 1 on (default), 0 off
+extern int g_small_c;         // its window bits, 0 = automatic
 extern int g_last_multi[2];   // ranges, devices of the most recent msm_host_multi (diagnostic)
 extern int g_last_shape[3];   // window bits, window count, GLV flag of the most recently launched MSM (diagnostic)
 extern int g_use_glv;  // 1: GLV split of every scalar; 0: plain signed windows over the full scalar; -1: the curve's default

@@ -3,6 +3,7 @@
 #pragma once
 #include "engine.hpp"
 #include "host_fold64.hpp"
+#include "msm_small.cuh"
 #include <cstdlib>
 #include <chrono>
 #include <thread>
@@ -98,6 +99,41 @@ static inline int choose_window(size_t m, int bits) {
     return best;
 }
 
+// the single-launch path of msm_small.cuh (n <= SMALL_MAX_N): one kernel, results + shape written to pinned memory
+template <class C>
+static int msm_small_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_points_be, size_t n, hipStream_t stream) {
+    using M = typename C::Fp;
+    int rc;
+    if (ws->h_windows_cap < 64 * 1024) {
+        if (ws->h_windows) PORLA_HIP(hipHostFree(ws->h_windows));
+        ws->h_windows_cap = 64 * 1024;
+        PORLA_HIP(hipHostMalloc(&ws->h_windows, ws->h_windows_cap, hipHostMallocMapped | hipHostMallocCoherent));
+    }
+    const size_t part_bytes = (size_t)SMALL_BLOCKS * SMALL_MAX_C * sizeof(XYZZ<M>);
+    if (ws->small_part.cap < part_bytes + 1024) {
+        if ((rc = ws->small_part.ensure(part_bytes + 1024))) return rc;
+        PORLA_HIP(hipMemsetAsync(ws->small_part.p, 0, part_bytes + 1024, stream));    // the per-window arrival counters start at zero
+    }
+    void* h_dev = nullptr;
+    PORLA_HIP(hipHostGetDevicePointer(&h_dev, ws->h_windows, 0));
+    uint32_t* counters = (uint32_t*)((uint8_t*)ws->small_part.p + part_bytes);
+    ws->small_seq++;
+    if (ws->small_seq == 0) ws->small_seq = 1;
+    ((volatile uint32_t*)ws->h_windows)[0] = 0;
+    {
+        ProfScope ps("small_msm", stream, true);
+        hipLaunchKernelGGL((k_small_msm<C>), dim3(SMALL_BLOCKS), dim3(SMALL_THREADS), 0, stream, d_scalars, d_points_be, (uint32_t)n,
+                           g_small_c | (g_use_glv == 0 ? 0x100 : 0), (XYZZ<M>*)ws->small_part.p, counters, (uint32_t*)h_dev,
+                           (XYZZ<M>*)((uint8_t*)h_dev + SMALL_HDR_WORDS * 4), ws->small_seq);
+    }
+    PORLA_HIP(hipGetLastError());
+    if (!ws->done) PORLA_HIP(hipEventCreateWithFlags(&ws->done, hipEventDisableTiming));
+    PORLA_HIP(hipEventRecord(ws->done, stream));
+    ws->pend_W = -1;            // shape known to the device only: read from the pinned header by msm_finish
+    ws->pend_c = 0;
+    return PORLA_OK;
+}
+
 #define PORLA_TRACE(tag) do { if (trace_on) { auto now = std::chrono::steady_clock::now(); \
     fprintf(stderr, "[trace slot %d] %-18s %8.1f us\n", ws->slot, tag, std::chrono::duration<double, std::micro>(now - t_tr).count()); t_tr = now; } } while (0)
 template <class C>
@@ -108,6 +144,7 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
     ws->pend_W = 0;
     if (n == 0) return PORLA_OK;
     if (n >= (1ull << 30)) { set_last_error("porla: MSM length must be < 2^30 per call (range-split larger inputs)"); return PORLA_ERR_ARG; }
+    if (n <= SMALL_MAX_N && g_small_mode != 0 && g_window_override == 0) return msm_small_launch<C>(ws, d_scalars, d_points_be, n, stream);
     const bool glv = g_use_glv < 0 ? C::GLV_DEFAULT : g_use_glv != 0;
     int bits = glv ? C::Glv::BITS : C::SCALAR_BITS;
     // Small and medium inputs: look at the scalars first.  If none of them exceeds b bits (and b is below the group order's
@@ -117,7 +154,7 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
         if (ws->h_windows_cap < 64 * 1024) {
             if (ws->h_windows) PORLA_HIP(hipHostFree(ws->h_windows));
             ws->h_windows_cap = 64 * 1024;
-            PORLA_HIP(hipHostMalloc(&ws->h_windows, ws->h_windows_cap, hipHostMallocMapped));
+            PORLA_HIP(hipHostMalloc(&ws->h_windows, ws->h_windows_cap, hipHostMallocMapped | hipHostMallocCoherent));
         }
         int rc0;
         if ((rc0 = ws->cursor.ensure((CTRL_WORDS + 8) * 4))) return rc0;
@@ -173,7 +210,7 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
     if (ws->h_windows_cap < (size_t)W * c * sizeof(XYZZ<M>)) {
         if (ws->h_windows) PORLA_HIP(hipHostFree(ws->h_windows));
         ws->h_windows_cap = 64 * 1024;
-        PORLA_HIP(hipHostMalloc(&ws->h_windows, ws->h_windows_cap, hipHostMallocMapped));
+        PORLA_HIP(hipHostMalloc(&ws->h_windows, ws->h_windows_cap, hipHostMallocMapped | hipHostMallocCoherent));
     }
     void* h_windows_dev = nullptr;
     PORLA_HIP(hipHostGetDevicePointer(&h_windows_dev, ws->h_windows, 0));
@@ -320,6 +357,28 @@ template <class C>
 static int msm_finish(Workspace* ws, XYZZ<typename C::Fp>* total) {
     using M = typename C::Fp;
     if (ws->pend_W == 0) { *total = xyzz_inf<M>(); return PORLA_OK; }
+    if (ws->pend_W < 0) {       // single-launch path: the kernel left its shape in front of the sums
+        // its last action is the release store of the sequence number into the (coherent) pinned header: poll for it instead
+        // of sleeping on the event -- the wake-up costs more than the fold -- and fall back to the event after 2 ms
+        const volatile uint32_t* hdr = (const volatile uint32_t*)ws->h_windows;
+        const auto t_spin = std::chrono::steady_clock::now();
+        bool seen = false;
+        for (uint32_t it = 0;; it++) {
+            if (__atomic_load_n((const uint32_t*)&hdr[0], __ATOMIC_ACQUIRE) == ws->small_seq) { seen = true; break; }
+            __builtin_ia32_pause();
+            if ((it & 1023u) == 1023u && std::chrono::steady_clock::now() - t_spin > std::chrono::milliseconds(2)) break;
+        }
+        if (!seen) PORLA_HIP(hipEventSynchronize(ws->done));
+        const int W = (int)hdr[1], c = (int)hdr[2];
+        ws->pend_W = 0;
+        if (hdr[0] != ws->small_seq || W < 1 || c < 1 || c > SMALL_MAX_C || (size_t)W * c * sizeof(XYZZ<M>) + SMALL_HDR_WORDS * 4 > ws->h_windows_cap) {
+            set_last_error("porla: the single-launch MSM left no valid result header");
+            return PORLA_ERR_HIP;
+        }
+        g_last_shape[0] = c; g_last_shape[1] = W; g_last_shape[2] = (int)hdr[3];
+        *total = h_fold_tree64<M>((const XYZZ<M>*)((const uint8_t*)ws->h_windows + SMALL_HDR_WORDS * 4), W, c);
+        return PORLA_OK;
+    }
     PORLA_HIP(hipEventSynchronize(ws->done));
     *total = h_fold_tree64<M>((const XYZZ<M>*)ws->h_windows, ws->pend_W, ws->pend_c);
     ws->pend_W = 0;

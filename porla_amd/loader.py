@@ -58,6 +58,7 @@ def _declare(L):
     L.porla_gpu_profile_get.restype = ctypes.c_int
     L.porla_gpu_set_msm_window.argtypes = [ctypes.c_int]; L.porla_gpu_set_msm_window.restype = ctypes.c_int
     L.porla_gpu_set_msm_glv.argtypes = [ctypes.c_int]; L.porla_gpu_set_msm_glv.restype = ctypes.c_int
+    L.porla_gpu_set_msm_small.argtypes = [ctypes.c_int, ctypes.c_int]; L.porla_gpu_set_msm_small.restype = ctypes.c_int
     L.porla_gpu_last_msm_shape.argtypes = [ctypes.POINTER(ctypes.c_int)] * 3; L.porla_gpu_last_msm_shape.restype = ctypes.c_int
     L.porla_glv_split.argtypes = [ctypes.c_int, u8p, u8p, ctypes.POINTER(ctypes.c_int), u8p, ctypes.POINTER(ctypes.c_int)]
     L.porla_glv_split.restype = ctypes.c_int

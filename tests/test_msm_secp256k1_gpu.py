@@ -12,13 +12,15 @@ pytestmark = pytest.mark.gpu
 LAMBDA = 0x5363ad4cc05c30e0a5261c028812645a122e22ea20816678df02967c1b23bd72  # the curve endomorphism's eigenvalue (tools/gen_glv.py); scalars around it stress the GLV split
 
 
-@pytest.fixture(autouse=True, params=["glv", "plain"])
+@pytest.fixture(autouse=True, params=["glv", "plain", "general"])
 def scalar_split(request):
     """every test runs with the GLV scalar split (default) and with plain full-width windows"""
     from porla_amd import lib
-    lib.porla_gpu_set_msm_glv(1 if request.param == "glv" else 0)
+    lib.porla_gpu_set_msm_glv(0 if request.param == "plain" else 1)
+    lib.porla_gpu_set_msm_small(0 if request.param == "general" else 1, 0)   # "general": the single-launch path off
     yield request.param
     lib.porla_gpu_set_msm_glv(-1)
+    lib.porla_gpu_set_msm_small(1, 0)
 P = 2**256 - 2**32 - 977
 
 

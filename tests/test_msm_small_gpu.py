@@ -1,0 +1,162 @@
+"""GPU box: the single-launch MSM of msm_small.cuh (n <= 4096 pairs -- every size the reference issues: the audit's n_points
+<= 3200 with abs(int32) coefficients, Server.hpp:585-587, 617-621, 838-848, 900-901; the client's 16 / 176 / 1408-point calls,
+Client.hpp:374-406, 756-787) against the oracle, through compute_multi_exp and the device-pointer entries, on both curves:
+every window width, every scalar length class (the kernel derives its shape from the scalars' bit length), edge operands."""
+import ctypes
+import random
+
+import pytest
+
+from tests import common
+
+pytestmark = pytest.mark.gpu
+R = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+
+
+@pytest.fixture(scope="module")
+def mx():
+    from porla_amd import multiexp
+    return multiexp
+
+
+@pytest.fixture(scope="module")
+def inputs():
+    return common.synth_inputs(4096)
+
+
+@pytest.fixture(autouse=True)
+def small_on():
+    from porla_amd import lib
+    lib.porla_gpu_set_msm_small(1, 0)
+    lib.porla_gpu_set_msm_glv(-1)
+    yield
+    lib.porla_gpu_set_msm_small(1, 0)
+
+
+def scalars_of_bits(n, bits, seed):
+    rnd = random.Random(seed)
+    return b"".join(rnd.getrandbits(bits).to_bytes(32, "big") for _ in range(n))
+
+
+@pytest.mark.parametrize("c", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("n", [1, 7, 128, 1408, 3200, 4096])
+def test_every_window_width_full_scalars(mx, inputs, c, n):
+    from porla_amd import lib
+    sc, pt = inputs
+    lib.porla_gpu_set_msm_small(1, c)
+    got = mx.bn254_multi_exp(pt[:64 * n], sc[:32 * n], n)
+    assert got == common.oracle_msm(sc, pt, n)
+    cc, W, glv = mx.last_msm_shape()
+    assert glv and (c == 0 or cc == c) and W == (126 + 1 + cc - 1) // cc     # 256-bit SHA scalars: split into 126-bit halves
+
+
+@pytest.mark.parametrize("bits", [1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 200, 249, 250, 253, 254, 255, 256])
+def test_every_scalar_length_class(mx, inputs, bits):
+    """the kernel ORs the scalars and sizes its windows from the result: short scalars -> few windows, no split;
+    > 128 bits -> endomorphism split; >= 250 bits -> reduction mod r first (fr.SetBytes, main.go:127)"""
+    _, pt = inputs
+    for n in (3, 500, 3200):
+        sc = scalars_of_bits(n, bits, bits * 1000 + n)
+        # make sure the longest scalar really has `bits` bits
+        sc = ((1 << (bits - 1)) | 1).to_bytes(32, "big") + sc[32:]
+        assert mx.bn254_multi_exp(pt[:64 * n], sc, n) == common.oracle_msm(sc, pt, n)
+        cc, W, glv = mx.last_msm_shape()
+        assert glv == (bits > 128)
+        if bits <= 128:
+            assert W == (bits + 1 + cc - 1) // cc
+
+
+def test_audit_shape_abs_int32(mx, inputs):
+    """abs(int32) coefficients (bn254_scalar_set_int, utils.h:271-275) over repeated points: 31 bits of windows, whatever their width"""
+    _, pt = inputs
+    rnd = random.Random(11)
+    for n in (128, 1408, 3200):
+        sc = b"".join(mx.bn254_scalar_set_int(rnd.getrandbits(31)) for _ in range(n))
+        pts = b"".join(pt[64 * (i % 50):64 * (i % 50) + 64] for i in range(n))
+        assert mx.bn254_multi_exp(pts, sc, n) == common.oracle_msm(sc, pts, n)
+        cc, W, glv = mx.last_msm_shape()
+        assert not glv and W * cc <= 32 + cc          # windows cover the 31 bits (+ carry), not 254
+
+
+def test_edge_operands(mx, inputs):
+    import bn254_py as o
+    sc, pt = inputs
+    P0 = pt[:64]
+    neg = o.neg_point(P0)
+    be = lambda v: v.to_bytes(32, "big")
+    cases = [
+        ([0], [P0]), ([0, 0, 0], [P0, pt[64:128], neg]),                      # all-zero scalars -> infinity
+        ([5, 5], [P0, neg]),                                                  # cancels inside one bucket
+        ([5, 5], [P0, P0]),                                                   # the bucket doubles
+        ([7, 7, 7, 7, 7], [P0] * 5),
+        ([1, 2, 3, 4, 5, 6, 7, 8], [P0] * 8), ([1, 2, 3, 4, 5, 6, 7, 8], [P0, neg] * 4),   # equal / opposite sums in neighbouring buckets
+        ([R - 1, R, R + 1, (1 << 256) - 1, 5 * R + 3], [P0, pt[64:128], pt[128:192], pt[192:256], pt[256:320]]),
+        ([3, 9, 27], [bytes(64), P0, bytes(64)]),                             # infinity points
+        ([1 << 128, (1 << 128) - 1, 1 << 127], [P0, P0, neg]),
+    ]
+    for ks, ps in cases:
+        s, p, n = b"".join(be(k) for k in ks), b"".join(ps), len(ks)
+        want = common.oracle_msm(s, p, n, naive=True)
+        for c in (0, 1, 2, 8):
+            from porla_amd import lib
+            lib.porla_gpu_set_msm_small(1, c)
+            assert mx.bn254_multi_exp(p, s, n) == want, (ks, c)
+    n = 512                                                                   # one bucket takes everything
+    assert mx.bn254_multi_exp(pt[:64] * n, sc[:32] * n, n) == common.oracle_msm(sc[:32] * n, pt[:64] * n, n)
+
+
+def test_general_and_single_launch_paths_agree(mx, inputs):
+    from porla_amd import lib
+    sc, pt = inputs
+    for n in (2, 999, 4096):
+        lib.porla_gpu_set_msm_small(1, 0)
+        a = mx.msm_host("bn254", sc[:32 * n], pt[:64 * n], n)
+        lib.porla_gpu_set_msm_small(0, 0)
+        b = mx.msm_host("bn254", sc[:32 * n], pt[:64 * n], n)
+        assert a == b == common.oracle_msm(sc, pt, n)
+
+
+@pytest.mark.parametrize("c", [0, 1, 2, 5, 8])
+def test_secp256k1(mx, c):
+    from porla_amd import lib
+    lib.porla_gpu_set_msm_small(1, c)
+    for n in (1, 16, 176, 1408, 4096):
+        sc, pt = common.secp_bench_scalars(n), common.secp_bench_points(n)
+        want = common.oracle_secp_msm(sc, pt, n)
+        assert mx.msm_host("secp256k1", sc, pt, n) == want
+        assert want == common.secp_bench_expected(sc, n)
+    n = 1408                                                                  # the IPA audit: abs(int32) coefficients
+    rnd = random.Random(3)
+    sc = b"".join(rnd.getrandbits(31).to_bytes(32, "big") for _ in range(n))
+    pt = common.secp_bench_points(n)
+    assert mx.msm_host("secp256k1", sc, pt, n) == common.oracle_secp_msm(sc, pt, n)
+    # scalars around the group order and 2^256 - 1 (no reduction happens on this curve below n; above it one subtraction)
+    N = common.SECP_N
+    vals = [N - 1, N, N + 1, (1 << 256) - 1, 1 << 255, (1 << 128) + 1]
+    sc = b"".join(v.to_bytes(32, "big") for v in vals)
+    pt = common.secp_bench_points(len(vals))
+    assert mx.msm_host("secp256k1", sc, pt, len(vals)) == common.oracle_secp_msm(sc, pt, len(vals), naive=True)
+
+
+def test_two_msms_in_flight_do_not_block_each_other(mx, inputs):
+    """the audit issues its MSMs in pairs (Server.hpp:900-901): begin() of the single-launch path returns without a host
+    round trip (no blocking pre-scan), so both are enqueued before either is waited for"""
+    import time
+    import torch
+    sc, pt = inputs
+    n = 3200
+    rnd = random.Random(5)
+    a_sc = b"".join(mx.bn254_scalar_set_int(rnd.getrandbits(31)) for _ in range(n))
+    d_a = torch.frombuffer(bytearray(a_sc), dtype=torch.uint8).cuda()
+    d_sc = torch.frombuffer(bytearray(sc[:32 * n]), dtype=torch.uint8).cuda()
+    d_pt = torch.frombuffer(bytearray(pt[:64 * n]), dtype=torch.uint8).cuda()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    want = [common.oracle_msm(a_sc, pt, n), common.oracle_msm(sc, pt, n)]
+    for _ in range(3):
+        t0 = time.perf_counter()
+        mx.msm_begin(1, d_a.data_ptr(), d_pt.data_ptr(), n, s1.cuda_stream)
+        mx.msm_begin(2, d_sc.data_ptr(), d_pt.data_ptr(), n, s2.cuda_stream)
+        t_enqueue = time.perf_counter() - t0
+        assert mx.msm_end(1) == want[0]
+        assert mx.msm_end(2) == want[1]
+    assert t_enqueue < 2e-3
