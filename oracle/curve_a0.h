@@ -136,26 +136,44 @@ static inline int msm_window_bits(size_t n) {
     return c;
 }
 
-/* bucket MSM over one contiguous range, unsigned c-bit windows over `nbits` scalar bits */
+/* bucket MSM over one contiguous range: SIGNED c-bit windows over `nbits` scalar bits (digits in (-2^(c-1), 2^(c-1)]: a digit
+ * above 2^(c-1) becomes digit - 2^c with a carry into the next window, a negative digit subtracts the point), 2^(c-1) buckets
+ * per window -- the window is one bit wider than an unsigned one at the same bucket count, as in gnark's and libsecp256k1's
+ * own bucket methods (signed digits / wNAF, ecmult_impl.h:492-567).  The group element computed is the same. */
 static inline void msm_pippenger_range(const curve_t *C, jac_t *r, const u256 *k, const aff_t *pts,
                                        size_t n, int nbits) {
-    int c = msm_window_bits(n);
-    size_t nb = ((size_t)1 << c) - 1;
+    int c = msm_window_bits(n) + 1;
+    size_t nb = (size_t)1 << (c - 1);
+    int nwin = (nbits + 1 + c - 1) / c;
     jac_t *bucket = (jac_t *)malloc(sizeof(jac_t) * nb);
+    int32_t *dig = (int32_t *)malloc(sizeof(int32_t) * (size_t)nwin * (n ? n : 1));
+    for (size_t i = 0; i < n; i++) {
+        uint32_t carry = 0;
+        for (int w = 0; w < nwin; w++) {
+            uint32_t raw = u256_bits(&k[i], w * c, c) + carry;            /* bits above 255 read as zero */
+            if (raw > nb) { dig[(size_t)w * n + i] = (int32_t)raw - (int32_t)((uint32_t)1 << c); carry = 1; }
+            else { dig[(size_t)w * n + i] = (int32_t)raw; carry = 0; }
+        }
+    }
     jac_t total; jac_set_inf(C, &total);
-    int nwin = (nbits + c - 1) / c;
     for (int w = nwin - 1; w >= 0; w--) {
         for (int d = 0; d < c; d++) jac_double(C, &total, &total);
         for (size_t b = 0; b < nb; b++) jac_set_inf(C, &bucket[b]);
         for (size_t i = 0; i < n; i++) {
-            uint32_t d = u256_bits(&k[i], w * c, c);
-            if (d) jac_add_aff(C, &bucket[d - 1], &bucket[d - 1], &pts[i]);
+            int32_t d = dig[(size_t)w * n + i];
+            if (d > 0) jac_add_aff(C, &bucket[d - 1], &bucket[d - 1], &pts[i]);
+            else if (d < 0 && !pts[i].inf) {
+                aff_t np = pts[i];
+                mod_neg(&C->F, &np.y, &pts[i].y);
+                jac_add_aff(C, &bucket[-d - 1], &bucket[-d - 1], &np);
+            }
         }
         jac_t run, sum; jac_set_inf(C, &run); jac_set_inf(C, &sum);
         for (size_t b = nb; b-- > 0;) { jac_add(C, &run, &run, &bucket[b]); jac_add(C, &sum, &sum, &run); }
         jac_add(C, &total, &total, &sum);
     }
     free(bucket);
+    free(dig);
     *r = total;
 }
 

@@ -26,7 +26,8 @@ def oracle():
 
 
 def ncpu():
-    return max(1, min(32, os.cpu_count() or 1))
+    """threads of the CPU restatement: every hardware thread of the box (hardware_concurrency())"""
+    return max(1, os.cpu_count() or 1)
 
 
 def synth_scalars(n, start=0):

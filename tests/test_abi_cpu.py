@@ -122,3 +122,16 @@ def test_tree_fold_is_the_weighted_sum_of_its_bit_slices():
         out = ctypes.create_string_buffer(64)
         assert lib.porla_bn254_tree_fold(blob, W, c, out) == 0
         assert out.raw == o.g1_marshal(o.g1_mul(o.G1, want % o.R))
+
+
+def test_eip196_vectors_through_the_host_side_symbols():
+    """add_point / mult_point (main.go:195-214) run on the host in the product too: every go-ethereum bn256Add / bn256ScalarMul
+    vector of tests/golden/eip196_kat.json through the reference's own symbols, no GPU involved"""
+    from porla_amd import multiexp as mx
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "eip196_kat.json")))
+    assert len(kat["add"]) >= 8 and len(kat["mul"]) >= 16
+    for e in kat["add"]:
+        assert mx.bn254_add(bytes.fromhex(e["a"]), bytes.fromhex(e["b"])).hex() == e["sum"], e["name"]
+        assert mx.bn254_add(bytes.fromhex(e["b"]), bytes.fromhex(e["a"])).hex() == e["sum"], e["name"]
+    for e in kat["mul"]:
+        assert mx.bn254_mult(bytes.fromhex(e["p"]), bytes.fromhex(e["k"])).hex() == e["r"], e["name"]
