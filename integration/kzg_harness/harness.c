@@ -7,10 +7,14 @@
  *   gcc -O2 -I../../include harness.c -L../../porla_amd -lmultiexp -Wl,-rpath,$PWD/../../porla_amd -o harness
  *   ./harness cpu    host-side calls only (client side: needs no GPU)
  *   ./harness gpu    everything, including compute_digest_from_srs / create_proof / compute_multi_exp on the MI355X
+ *   ./harness bench [threads] [calls]   the server's call pattern timed: `threads` pool threads (default 8, Server.hpp:1054-1078)
+ *                    each calling compute_digest_from_srs one row at a time; prints one JSON line (commits/s, latency per call)
  */
 #include "libmultiexp.h"
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <time.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -28,8 +32,25 @@ static int failures = 0;
 static void scalar_set_int(uint8_t out[32], uint32_t v) { memset(out, 0, 32); out[28] = v >> 24; out[29] = v >> 16; out[30] = v >> 8; out[31] = v; }
 static uint32_t lcg(uint32_t* s) { *s = *s * 1664525u + 1013904223u; return *s; }
 
+typedef struct { int calls; uint32_t seed; int bad; } bench_job;
+static void* bench_worker(void* arg) {
+    bench_job* j = (bench_job*)arg;
+    uint8_t row[BLOCK_SIZE], out[64], first[64];
+    uint32_t s = j->seed;
+    for (int i = 0; i < BLOCK_SIZE; i++) row[i] = (uint8_t)(lcg(&s) >> 24);
+    GoSlice s_row = slice(row, BLOCK_SIZE), s_out = slice(out, 64);
+    for (int k = 0; k < j->calls; k++) {
+        compute_digest_from_srs(&s_row, &s_out);
+        if (k == 0) memcpy(first, out, 64);
+        else if (memcmp(first, out, 64) != 0) j->bad++;
+    }
+    return NULL;
+}
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+
 int main(int argc, char** argv) {
-    const int gpu = argc > 1 && strcmp(argv[1], "gpu") == 0;
+    const int bench = argc > 1 && strcmp(argv[1], "bench") == 0;
+    const int gpu = bench || (argc > 1 && strcmp(argv[1], "gpu") == 0);
     uint8_t tau[16], alpha[16];
     memcpy(tau, TAU_KEY, 16); memcpy(alpha, SECRET_KEY, 16);
     GoSlice s_tau = slice(tau, 16), s_alpha = slice(alpha, 16);
@@ -41,6 +62,27 @@ int main(int argc, char** argv) {
     init_SRS(NUM_CHUNKS, &s_blob, &blob_len);                           /* Client.hpp:348-354 */
     CHECK(blob_len == 32 * NUM_CHUNKS + 132, "init_SRS wire blob is 32n+132 bytes (Client.hpp:350-357)");
     CHECK(srs_blob[0] == 0 && srs_blob[1] == 0 && srs_blob[2] == 0 && srs_blob[3] == NUM_CHUNKS, "blob starts with the big-endian count");
+
+    if (bench) {
+        int T = argc > 2 ? atoi(argv[2]) : 8, calls = argc > 3 ? atoi(argv[3]) : 2000;
+        if (T < 1) T = 1;
+        if (T > 64) T = 64;
+        GoSlice s_in = slice(srs_blob, (long long)blob_len);
+        init_SRS_from_data(NUM_CHUNKS, &s_in);
+        pthread_t th[64];
+        bench_job jobs[64];
+        bench_job warm = {20, 99u, 0};
+        bench_worker(&warm);                                            /* builds the SRS table */
+        double t0 = now_s();
+        for (int t = 0; t < T; t++) { jobs[t].calls = calls; jobs[t].seed = 1000u + t; jobs[t].bad = 0; pthread_create(&th[t], NULL, bench_worker, &jobs[t]); }
+        int bad = 0;
+        for (int t = 0; t < T; t++) { pthread_join(th[t], NULL); bad += jobs[t].bad; }
+        double el = now_s() - t0;
+        printf("{\"call\": \"compute_digest_from_srs\", \"caller\": \"C, pthreads\", \"threads\": %d, \"calls_per_thread\": %d, "
+               "\"commits_per_s\": %.1f, \"latency_ms_per_call\": %.4f, \"consistent\": %s}\n",
+               T, calls, T * (double)calls / el, el / calls * 1e3, bad ? "false" : "true");
+        return bad ? 1 : 0;
+    }
 
     /* a data block: chunk 0 = block id, the others pseudo-random 256-bit values (Client.hpp:367-372), as big-endian scalars */
     static uint8_t block[BLOCK_SIZE];

@@ -115,7 +115,7 @@ k_audit_finish(const uint32_t* __restrict__ partial, uint32_t n_blocks, uint32_t
     }
 }
 
-struct AuditWs { int device = -1; Buf partial; };
+struct AuditWs { int device = -1; Buf partial; UseFence fence; };
 static std::mutex g_audit_mu;
 static std::vector<AuditWs*> g_audit_ws;
 
@@ -146,6 +146,7 @@ extern "C" int porla_audit_combine_device(const void* d_rows64, const uint64_t* 
     if (per_block < 4) per_block = 4;
     const uint32_t n_blocks = total ? (total + per_block - 1) / per_block : 1;
     if ((rc = ws->partial.ensure((size_t)n_blocks * ACC_LIMBS * n_cols * 4))) return rc;
+    if ((rc = ws->fence.enter(stream))) return rc;      // `partial` is shared with an earlier combine on another stream
     {
         ProfScope ps("audit_accumulate", stream);
         hipLaunchKernelGGL(k_audit_accumulate, dim3(n_blocks, (unsigned)((n_cols + 127) / 128)), dim3(128), 0, stream,
@@ -164,5 +165,5 @@ extern "C" int porla_audit_combine_device(const void* d_rows64, const uint64_t* 
                                (uint8_t*)d_aligned_out, (uint8_t*)d_aligned_be_out, (uint8_t*)d_scalars_out);
     }
     PORLA_HIP(hipGetLastError());
-    return PORLA_OK;
+    return ws->fence.leave(stream);
 }

@@ -77,6 +77,29 @@ struct Buf {
         p = nullptr; cap = 0;
     }
 };
+// Stream ordering of scratch that is shared between calls: the *_device entry points leave their kernels in flight on the
+// caller's stream, and the next call may come on ANOTHER stream (or on the engine's own) and reuse the same scratch.  Every such
+// scratch set carries a fence: enter() makes the new stream wait for the event the previous use recorded (no-op on the same
+// stream, which orders itself); leave() records the event after the last kernel of this use.  Both are called under the
+// mutex that serialises the enqueue.
+struct UseFence {
+    hipEvent_t ev = nullptr;
+    hipStream_t last = nullptr;
+    bool used = false;
+    int enter(hipStream_t s) {
+        if (used && last != s) PORLA_HIP(hipStreamWaitEvent(s, ev, 0));
+        return PORLA_OK;
+    }
+    int leave(hipStream_t s) {
+        if (!ev) PORLA_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        PORLA_HIP(hipEventRecord(ev, s));
+        last = s;
+        used = true;
+        return PORLA_OK;
+    }
+    void reset() { if (ev) (void)hipEventDestroy(ev); ev = nullptr; used = false; last = nullptr; }
+};
+
 struct Workspace {
     std::mutex mu;   // held while kernels are enqueued on / results folded from this slot (the registry has its own lock)
     int device = -1;
@@ -103,8 +126,8 @@ constexpr int MSM_MULTI_SLOTS = 4;
 constexpr int MSM_POOL_SLOT0 = 8;
 constexpr size_t MSM_SCAN_MAX = 1u << 16;  // inputs up to this size are scanned for their longest scalar first
 // Batched fixed-base commitments (fixed_base.cuh): resident table of window multiples of one base.
-// Calls on one object are serialised by `mu`; the *_device form leaves its kernels in flight on the caller's stream
-// (one stream per object at a time: the slice-partial scratch is shared between calls).
+// Calls on one object are serialised by `mu`; the *_device form leaves its kernels in flight on the caller's stream, and a
+// later call on another stream waits (on the device, through `fence`) for them before it reuses the slice-partial scratch.
 template <class C>
 struct FixedBase {
     int device = -1;
@@ -124,7 +147,14 @@ struct FixedBase {
     uint8_t* io_out = nullptr;
     size_t io_out_cap = 0;
     uint32_t last_S = 1;                      // slices per row of the last commit_device (layout of `partial`)
+    UseFence fence;                           // orders `partial` (and the table after a rebuild) between calls on different streams
     static constexpr size_t HOST_FINISH_MAX_ROWS = 8;
+    // single-launch path for a handful of host rows (fixed_base.cuh:k_fb_commit_small): pinned staging (header, row sums,
+    // rows) + the blocks' partial sums and arrival counters in HBM
+    void* h_small = nullptr;
+    void* d_small = nullptr;
+    uint32_t small_seq = 0;
+    hipEvent_t small_done = nullptr;
     std::mutex mu;
     void release();
     int build(const Affine<typename C::Fp>* d_base, size_t n, int window_bits, hipStream_t stream);
@@ -134,6 +164,10 @@ struct FixedBase {
                       hipStream_t stream);
     int commit_host(const uint8_t* rows, size_t n_rows, size_t n_coeffs, size_t row_stride, uint8_t* out,
                     hipStream_t stream);
+    // <= FB_SMALL_MAX_ROWS rows given by pointer (they need not be contiguous: the coalescing front of compute_digest_from_srs
+    // hands over the callers' own buffers), one launch, results polled from pinned memory and normalised on the host
+    int commit_small(const uint8_t* const* row_ptrs, size_t n_rows, size_t n_coeffs, uint8_t* const* outs, hipStream_t stream);
+    static bool small_ok(size_t n_rows, size_t n_coeffs);
 };
 
 extern std::mutex g_ws_mu;   // the workspace registry (lookup / creation / release); a slot's use is under Workspace::mu

@@ -21,6 +21,7 @@
 //   k_fb_finish        lane = row: one inversion, Montgomery -> big-endian X||Y (64 zero bytes = infinity)
 #pragma once
 #include "msm.cuh"
+#include "msm_small.cuh"
 #include <type_traits>
 
 namespace porla {
@@ -242,6 +243,136 @@ k_fb_commit(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_coeffs
     }
     if constexpr (C::F30_BUCKETS) store_xyzz<M>(partial + (size_t)r * S + s, xyzz30_to_xyzz<M>(acc));
     else store_xyzz<M>(partial + (size_t)r * S + s, acc);
+}
+
+// ---------------------------------------------------------------- a handful of rows, latency-bound (the reference's real pattern)
+// compute_digest_from_srs is called ONE row at a time, from up to 8 pool threads (porla/Server/Server.hpp:550-560,
+// 1077-1078, 2061-2062), and create_proof commits two rows (main.go:164,170).  Through the batch kernels above a single row
+// costs three launches, two copies and 15 dependent additions per lane (0.28 ms).  Here ONE launch does it:
+//   block (row, slice) owns a slice of the row's (coefficient, window) pairs: a lane recodes the digit of each of its <= ~2
+//   pairs (the carry into a window from one masked compare, as in msm_small.cuh), gathers the table entry and accumulates;
+//   the 256 lane sums are folded in LDS with four lanes per addition (8 levels); the LAST block of a row to arrive folds the
+//   slices' sums and writes the row's projective sum into pinned host memory; the last row to finish publishes the sequence
+//   number the host polls for.  The rows are read where they lie: `rows` may be device memory or mapped pinned host memory
+//   (4 KB per row over PCIe costs less than a copy packet).  The host normalises (one inversion per row, ~25 us).
+constexpr int FB_SMALL_DONE_SLOT = FB_SMALL_MAX_ROWS;      // counters[0 .. rows): slices arrived; [FB_SMALL_MAX_ROWS]: rows finished
+
+template <class C>
+__global__ void __launch_bounds__(SMALL_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_fb_commit_small(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_coeffs, size_t row_stride,
+                  const Affine<typename C::Fp>* __restrict__ table, int c, int W, uint32_t SL,
+                  XYZZ<typename C::Fp>* __restrict__ part, uint32_t* __restrict__ counters, uint32_t* __restrict__ hdr,
+                  XYZZ<typename C::Fp>* __restrict__ out_sums, uint32_t seq) {
+    using M = typename C::Fp;
+    __shared__ XYZZ<M> pts[SMALL_THREADS];
+    __shared__ uint32_t pat[8];
+    __shared__ uint32_t last_flag;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t r = blockIdx.x / SL, sl = blockIdx.x % SL;
+    if (tid < 8) {
+        uint32_t v = 0;
+        for (uint32_t b = 0; b < 32; b++) if ((32 * tid + b) % (uint32_t)c == (uint32_t)c - 1) v |= 1u << b;
+        pat[tid] = v;
+    }
+    __syncthreads();
+    const uint32_t P = n_coeffs * (uint32_t)W;
+    const uint32_t p0 = (uint32_t)((uint64_t)sl * P / SL), p1 = (uint32_t)((uint64_t)(sl + 1) * P / SL);
+    const uint32_t Bh = 1u << (c - 1);
+    const uint32_t mask = (1u << c) - 1;
+    const uint8_t* row = rows + (size_t)r * row_stride;
+    XYZZ30<M> acc;
+    acc.inf = true;
+    for (uint32_t p = p0 + tid; p < p1; p += SMALL_THREADS) {
+        const uint32_t i = p / (uint32_t)W, w = p % (uint32_t)W;
+        uint32_t t[8];
+        load_be256(t, row + (size_t)i * 32);
+        for (int q = 0; q < C::MAX_Q; q++) {                       // fr.SetBytes: reduced mod the group order (main.go:110)
+            uint32_t d[8];
+            uint32_t br = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                uint64_t x = (uint64_t)t[k] - C::ORDER[k] - br;
+                d[k] = (uint32_t)x;
+                br = (uint32_t)(x >> 63);
+            }
+            if (br) break;
+#pragma unroll
+            for (int k = 0; k < 8; k++) t[k] = d[k];
+        }
+        const uint32_t wc = w * (uint32_t)c;
+        bool gt = false, eq = true;                                // carry into window w (see msm_small.cuh)
+#pragma unroll
+        for (int q = 7; q >= 0; q--) {
+            const uint32_t below = wc > 32u * q ? wc - 32u * q : 0u;
+            const uint32_t m = below >= 32u ? 0xffffffffu : ((1u << below) - 1u);
+            const uint32_t a = t[q] & m, b = pat[q] & m;
+            gt = eq ? (a > b) : gt;
+            eq = eq && (a == b);
+        }
+        uint32_t rawd = gt ? 1u : 0u;
+        if (wc < 256u) {
+            const uint32_t limb = wc >> 5, sh = wc & 31u;
+            uint32_t a = 0, b = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < 8; q++) {
+                a = (q == limb) ? t[q] : a;
+                b = (q == limb + 1) ? t[q] : b;
+            }
+            rawd += (uint32_t)((((uint64_t)b << 32) | a) >> sh) & mask;
+        }
+        uint32_t mag = rawd;
+        bool neg = false;
+        if (rawd > Bh) { mag = (1u << c) - rawd; neg = true; }
+        if (!mag) continue;
+        Affine<M> a = load_affine<M>(table + ((size_t)i * W + w) * Bh, mag - 1);
+        if (aff_is_inf<M>(a)) continue;
+        a = aff_neg_if<M>(a, neg);
+        if constexpr (C::F30_BUCKETS) {
+            xyzz30_madd<M>(acc, f30_from_fe<M>(a.x), f30_from_fe<M>(a.y));
+        } else {
+            static_assert(C::F30_BUCKETS, "k_fb_commit_small needs the reduced-radix form");
+        }
+    }
+    xyzz30_store_lazy<M>(&pts[tid], acc);
+    __syncthreads();
+    for (uint32_t h = 1; h < SMALL_THREADS; h <<= 1) {            // 256 lane sums -> pts[0]
+        small_quad_adds<M>(SMALL_THREADS / (2 * h), [&](uint32_t t, const XYZZ<M>*& pa, const XYZZ<M>*& pb, XYZZ<M>*& out) {
+            pa = &pts[t * 2 * h]; pb = pa + h; out = &pts[t * 2 * h];
+        });
+        __syncthreads();
+    }
+    if (tid < 8) reinterpret_cast<uint4*>(part + blockIdx.x)[tid] = reinterpret_cast<const uint4*>(pts)[tid];
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t old = atomicAdd(&counters[r], 1u);
+        last_flag = (old == SL - 1) ? 1u : 0u;
+        if (last_flag) counters[r] = 0;
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    __threadfence();
+    if (tid < SL * 8) reinterpret_cast<uint4*>(pts)[tid] = reinterpret_cast<const uint4*>(part + (size_t)r * SL)[tid];
+    __syncthreads();
+    for (uint32_t cnt = SL; cnt > 1;) {
+        const uint32_t half = (cnt + 1) / 2, pairs = cnt - half;
+        small_quad_adds<M>(pairs, [&](uint32_t t, const XYZZ<M>*& pa, const XYZZ<M>*& pb, XYZZ<M>*& out) {
+            pa = &pts[t]; pb = &pts[t + half]; out = &pts[t];
+        });
+        __syncthreads();
+        cnt = half;
+    }
+    if (tid == 0) Node<C>::store_final(out_sums + r, Node<C>::load(&pts[0]));
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t old = atomicAdd(&counters[FB_SMALL_DONE_SLOT], 1u);
+        if (old == n_rows - 1) {
+            counters[FB_SMALL_DONE_SLOT] = 0;
+            __threadfence_system();
+            __atomic_store_n(&hdr[0], seq, __ATOMIC_RELEASE);
+        }
+    }
 }
 
 // G lanes per row (G a power of two, 2 <= G <= 64, G <= S): fold the S slice partials of a row into partial[row * S]

@@ -2,7 +2,10 @@
 #pragma once
 #include "engine.hpp"
 #include "fixed_base.cuh"
+#include "host_fold64.hpp"
 #include <cstdlib>
+#include <chrono>
+#include <cstring>
 
 namespace porla {
 
@@ -18,6 +21,11 @@ void FixedBase<C>::release() {
     table = nullptr; partial = nullptr; io_rows = nullptr; io_out = nullptr;
     partial_cap = io_rows_cap = io_out_cap = 0;
     n_points = 0;
+    fence.reset();
+    if (h_small) (void)hipHostFree(h_small);
+    if (d_small) (void)hipFree(d_small);
+    if (small_done) (void)hipEventDestroy(small_done);
+    h_small = nullptr; d_small = nullptr; small_done = nullptr;
 }
 
 // Builds the multiples table for `n` base points (Montgomery affine, device memory).
@@ -27,9 +35,9 @@ int FixedBase<C>::build(const Affine<typename C::Fp>* d_base, size_t n, int wind
     n_points = 0;
     if (n == 0) return PORLA_OK;
     // window_bits = 0 -> automatic: the widest window (<= 20 bits) whose table fits min(a quarter of the free HBM,
-    // PORLA_COMMIT_TABLE_GB, default 64 GB) -- 20 bits = 56 GB for the 128-point BN254 SRS on a 288 GB MI355X.  Wider is
-    // faster (fewer additions per row: 13 windows instead of the 15 of an 18-bit / 16 GB table, 7.4 against 6.65 M
-    // commits/s) and the memory is there; the one-off build grows with it (0.43 s against 0.14 s).
+    // PORLA_COMMIT_TABLE_GB GiB, default 16) -- 18 bits = 15 GiB for the 128-point BN254 SRS: a drop-in library should not take a
+    // fifth of the HBM on its first commit.  A caller that wants the last 10 % asks for it: PORLA_COMMIT_TABLE_GB=64 gives 20-bit
+    // windows (56 GB, 13 additions per coefficient instead of 15: 7.4 against 6.65 M commits/s; build 0.43 s against 0.14 s).
     int cc = window_bits;
     const bool automatic = cc <= 0;
     if (automatic) {
@@ -39,13 +47,17 @@ int FixedBase<C>::build(const Affine<typename C::Fp>* d_base, size_t n, int wind
     if (cc < 2) cc = 2;
     if (cc > 20) cc = 20;
     PORLA_HIP(hipGetDevice(&device));
+    {   // commits that still read the old table: wait for them before it is rebuilt (or freed: hipFree synchronises anyway)
+        int rcf = fence.enter(stream);
+        if (rcf) return rcf;
+    }
     size_t free_b = 0, total_b = 0;
     PORLA_HIP(hipMemGetInfo(&free_b, &total_b));
     free_b += table_cap;
     size_t budget = free_b / 4;
     if (automatic && !getenv("PORLA_COMMIT_WINDOW")) {
         const char* g = getenv("PORLA_COMMIT_TABLE_GB");
-        const size_t cap = (size_t)((g ? atof(g) : 64.0) * 1e9);
+        const size_t cap = (size_t)((g ? atof(g) : 16.0) * 1073741824.0);
         if (cap < budget) budget = cap;
     }
     for (;; cc--) {  // shrink the window until the table fits the budget
@@ -108,7 +120,7 @@ int FixedBase<C>::build(const Affine<typename C::Fp>* d_base, size_t n, int wind
     }
     PORLA_HIP(hipGetLastError());
     n_points = n;
-    return PORLA_OK;
+    return fence.leave(stream);
 }
 
 template <class C>
@@ -119,6 +131,13 @@ int FixedBase<C>::commit_device(const uint8_t* d_rows, size_t n_rows, size_t n_c
     if (!table || n_coeffs > n_points) { set_last_error("porla: fixed base not built / too few base points"); return PORLA_ERR_STATE; }
     if (n_rows > 0xfffffff0u || n_coeffs > 0xffffu) { set_last_error("porla: commit batch too large"); return PORLA_ERR_ARG; }
     if (n_coeffs == 0) { if (d_out) PORLA_HIP(hipMemsetAsync(d_out, 0, n_rows * 64, stream)); return PORLA_OK; }
+    {
+        int cur = -1;
+        PORLA_HIP(hipGetDevice(&cur));
+        if (cur != device) { set_last_error("porla: this fixed-base table lives on another device than the current one"); return PORLA_ERR_STATE; }
+        int rcf = fence.enter(stream);
+        if (rcf) return rcf;
+    }
     // slices per row: enough lanes to fill 256 CUs x 4 SIMDs x 3 waves
     static const size_t target = getenv("PORLA_COMMIT_LANES") ? (size_t)atol(getenv("PORLA_COMMIT_LANES")) : (size_t)196608;
     uint32_t S = 1;
@@ -149,6 +168,75 @@ int FixedBase<C>::commit_device(const uint8_t* d_rows, size_t n_rows, size_t n_c
                            (const XYZZ<M>*)partial, (uint32_t)n_rows, S, d_out);
     }
     PORLA_HIP(hipGetLastError());
+    return fence.leave(stream);
+}
+
+// ---- the single-launch path for a handful of rows
+constexpr size_t FB_SMALL_ROW_BYTES = 8192;          // rows of up to 256 coefficients
+constexpr size_t FB_SMALL_HDR = 128, FB_SMALL_SUMS = FB_SMALL_HDR, FB_SMALL_ROWS = 8192;
+static inline bool fb_small_enabled() {
+    static const bool on = !(getenv("PORLA_COMMIT_SMALL") && getenv("PORLA_COMMIT_SMALL")[0] == '0');
+    return on;
+}
+template <class C>
+bool FixedBase<C>::small_ok(size_t n_rows, size_t n_coeffs) {
+    return fb_small_enabled() && C::F30_BUCKETS && n_rows >= 1 && n_rows <= (size_t)FB_SMALL_MAX_ROWS && n_coeffs >= 1 &&
+           n_coeffs * 32 <= FB_SMALL_ROW_BYTES;
+}
+template <class C>
+int FixedBase<C>::commit_small(const uint8_t* const* row_ptrs, size_t n_rows, size_t n_coeffs, uint8_t* const* outs,
+                               hipStream_t stream) {
+    using M = typename C::Fp;
+    if (!table || n_coeffs > n_points) { set_last_error("porla: fixed base not built / too few base points"); return PORLA_ERR_STATE; }
+    int cur = -1;
+    PORLA_HIP(hipGetDevice(&cur));
+    if (cur != device) { set_last_error("porla: this fixed-base table lives on another device than the current one"); return PORLA_ERR_STATE; }
+    const size_t part_bytes = (size_t)FB_SMALL_MAX_ROWS * FB_SMALL_MAX_SLICES * sizeof(XYZZ<M>);
+    if (!h_small) {
+        PORLA_HIP(hipHostMalloc(&h_small, FB_SMALL_ROWS + FB_SMALL_MAX_ROWS * FB_SMALL_ROW_BYTES, hipHostMallocMapped | hipHostMallocCoherent));
+        PORLA_HIP(hipMalloc(&d_small, part_bytes + 1024));
+        PORLA_HIP(hipMemsetAsync(d_small, 0, part_bytes + 1024, stream));
+        PORLA_HIP(hipEventCreateWithFlags(&small_done, hipEventDisableTiming));
+    }
+    uint8_t* hs = (uint8_t*)h_small;
+    const size_t stride = n_coeffs * 32;
+    for (size_t r = 0; r < n_rows; r++) memcpy(hs + FB_SMALL_ROWS + r * stride, row_ptrs[r], stride);
+    void* h_dev = nullptr;
+    PORLA_HIP(hipHostGetDevicePointer(&h_dev, h_small, 0));
+    if (++small_seq == 0) small_seq = 1;
+    volatile uint32_t* hdr = (volatile uint32_t*)hs;
+    hdr[0] = 0;
+    const uint32_t P = (uint32_t)(n_coeffs * (size_t)W);
+    uint32_t SL = (P + 511) / 512;
+    if (SL < 1) SL = 1;
+    if (SL > (uint32_t)FB_SMALL_MAX_SLICES) SL = FB_SMALL_MAX_SLICES;
+    int rc = fence.enter(stream);
+    if (rc) return rc;
+    {
+        ProfScope ps("fb_commit_small", stream, true);
+        hipLaunchKernelGGL((k_fb_commit_small<C>), dim3((unsigned)(n_rows * SL)), dim3(SMALL_THREADS), 0, stream,
+                           (const uint8_t*)h_dev + FB_SMALL_ROWS, (uint32_t)n_rows, (uint32_t)n_coeffs, stride, (const Affine<M>*)table, c, W, SL,
+                           (XYZZ<M>*)d_small, (uint32_t*)((uint8_t*)d_small + part_bytes), (uint32_t*)h_dev,
+                           (XYZZ<M>*)((uint8_t*)h_dev + FB_SMALL_SUMS), small_seq);
+    }
+    PORLA_HIP(hipGetLastError());
+    PORLA_HIP(hipEventRecord(small_done, stream));
+    if ((rc = fence.leave(stream))) return rc;
+    const auto t_spin = std::chrono::steady_clock::now();
+    bool seen = false;
+    for (uint32_t it = 0;; it++) {
+        if (__atomic_load_n((const uint32_t*)&hdr[0], __ATOMIC_ACQUIRE) == small_seq) { seen = true; break; }
+        __builtin_ia32_pause();
+        if ((it & 1023u) == 1023u && std::chrono::steady_clock::now() - t_spin > std::chrono::milliseconds(2)) break;
+    }
+    if (!seen) {
+        PORLA_HIP(hipEventSynchronize(small_done));
+        if (hdr[0] != small_seq) { set_last_error("porla: the single-launch commitment left no result"); return PORLA_ERR_HIP; }
+    }
+    const XYZZ<M>* sums = (const XYZZ<M>*)(hs + FB_SMALL_SUMS);
+    Affine<M> aff[FB_SMALL_MAX_ROWS];
+    h_batch_xyzz_to_affine64<M>(sums, n_rows, aff);       // one inversion for the whole batch
+    for (size_t r = 0; r < n_rows; r++) h_affine_to_bytes<M>(outs[r], aff[r]);
     return PORLA_OK;
 }
 
@@ -156,6 +244,12 @@ template <class C>
 int FixedBase<C>::commit_host(const uint8_t* rows, size_t n_rows, size_t n_coeffs, size_t row_stride, uint8_t* out,
                               hipStream_t stream) {
     if (n_rows == 0) return PORLA_OK;
+    if (small_ok(n_rows, n_coeffs)) {
+        const uint8_t* rp[FB_SMALL_MAX_ROWS];
+        uint8_t* op[FB_SMALL_MAX_ROWS];
+        for (size_t r = 0; r < n_rows; r++) { rp[r] = rows + r * row_stride; op[r] = out + 64 * r; }
+        return commit_small(rp, n_rows, n_coeffs, op, stream);
+    }
     size_t in_bytes = (n_rows - 1) * row_stride + n_coeffs * 32;
     if (in_bytes > io_rows_cap) {
         if (io_rows) PORLA_HIP(hipFree(io_rows));

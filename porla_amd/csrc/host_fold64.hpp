@@ -108,6 +108,19 @@ struct Fp64 {
         return cond_sub(t, t[4]);
     }
 
+    // a^(p-2) (Fermat; in the Montgomery domain for Montgomery fields: one() is the domain's unit)
+    E one() const { return from(fe_one<M>()); }
+    E inverse(const E& a) const {
+        uint64_t e[4] = {p[0] - 2, p[1], p[2], p[3]};          // p is odd and p[0] >= 2: no borrow
+        E acc = one();
+        for (int l = 3; l >= 0; l--)
+            for (int b = 63; b >= 0; b--) {
+                acc = mul(acc, acc);
+                if ((e[l] >> b) & 1) acc = mul(acc, a);
+            }
+        return acc;
+    }
+
     struct Pt { E x, y, zz, zzz; };
     Pt from(const XYZZ<M>& q) const { Pt r; r.x = from(q.x); r.y = from(q.y); r.zz = from(q.zz); r.zzz = from(q.zzz); return r; }
     XYZZ<M> to(const Pt& q) const { XYZZ<M> r; r.x = to(q.x); r.y = to(q.y); r.zz = to(q.zz); r.zzz = to(q.zzz); return r; }
@@ -141,6 +154,36 @@ struct Fp64 {
         return r;
     }
 };
+
+// n projective sums -> affine with ONE inversion (Montgomery's trick) in 4 x 64-bit limbs: the host tail of a batch of
+// commitments (a row's own inversion costs ~25 us in the portable 8 x 32-bit code, which dominated a coalesced batch of 8)
+template <class M>
+inline void h_batch_xyzz_to_affine64(const XYZZ<M>* in, size_t n, Affine<M>* out) {
+    static const Fp64<M> F;
+    typedef typename Fp64<M>::E E;
+    constexpr size_t MAXN = 64;
+    E d[MAXN], pre[MAXN];
+    for (size_t base = 0; base < n; base += MAXN) {
+        const size_t m = n - base < MAXN ? n - base : MAXN;
+        E acc = F.one();
+        for (size_t i = 0; i < m; i++) {
+            const XYZZ<M>& q = in[base + i];
+            d[i] = xyzz_is_inf<M>(q) ? F.one() : F.mul(Fp64<M>::from(q.zz), Fp64<M>::from(q.zzz));
+            pre[i] = acc;
+            acc = F.mul(acc, d[i]);
+        }
+        E inv = F.inverse(acc);
+        for (size_t i = m; i-- > 0;) {
+            const XYZZ<M>& q = in[base + i];
+            const E di = F.mul(inv, pre[i]);                     // 1 / (ZZ ZZZ) of entry i
+            inv = F.mul(inv, d[i]);
+            Affine<M>& r = out[base + i];
+            if (xyzz_is_inf<M>(q)) { r.x = fe_zero<M>(); r.y = fe_zero<M>(); continue; }
+            r.x = Fp64<M>::to(F.mul(Fp64<M>::from(q.x), F.mul(di, Fp64<M>::from(q.zzz))));     // X / ZZ
+            r.y = Fp64<M>::to(F.mul(Fp64<M>::from(q.y), F.mul(di, Fp64<M>::from(q.zz))));      // Y / ZZZ
+        }
+    }
+}
 
 // Tree form of the bucket reduction (msm.cuh, k_tree_level): window w arrives as fin[w][0] = S (sum of its buckets) and
 // fin[w][1 + k] = M_k (sum of the buckets whose index has bit k set), k < c - 1, and is worth S + sum_k 2^k M_k.

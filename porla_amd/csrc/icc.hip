@@ -15,6 +15,7 @@ struct IccWs {
     Buf work, tw, wpow, in, xo, al, sc;
     uint32_t tw_n = 0;
     int tw_curve = -1;
+    UseFence fence;   // work / twiddle buffers are shared between calls that may come on different streams
 };
 static std::mutex g_icc_mu;
 static std::vector<IccWs*> g_icc_ws;
@@ -55,13 +56,16 @@ template <class Q>
 static int icc_mix_core(IccWs* ws, int curve, const uint8_t* d_a0, const uint8_t* d_a1, size_t len, size_t ncols, size_t n_total,
                         uint8_t* d_out, hipStream_t stream) {
     int rc;
+    if ((rc = ws->fence.enter(stream))) return rc;
     if ((rc = ensure_twiddles<Q>(ws, curve, n_total, stream))) return rc;
     const size_t total = len * ncols;
-    ProfScope ps("icc_mix", stream);
-    hipLaunchKernelGGL((k_icc_mix<Q>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, d_a0, d_a1, (uint32_t)len,
-                       (uint32_t)ncols, (const IccElem<Q>*)ws->tw.p, (uint32_t)(n_total / len), d_out);
+    {
+        ProfScope ps("icc_mix", stream);
+        hipLaunchKernelGGL((k_icc_mix<Q>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, d_a0, d_a1, (uint32_t)len,
+                           (uint32_t)ncols, (const IccElem<Q>*)ws->tw.p, (uint32_t)(n_total / len), d_out);
+    }
     PORLA_HIP(hipGetLastError());
-    return PORLA_OK;
+    return ws->fence.leave(stream);
 }
 
 template <class Q>
@@ -153,10 +157,16 @@ static int icc_encode_core(IccWs* ws, int curve, const uint8_t* d_rows, size_t n
 static int icc_encode_dispatch(IccWs* ws, int curve, const uint8_t* d_rows, size_t n, size_t ncols, unsigned long long ws_step,
                                int part, uint8_t* d_x, uint8_t* d_al, uint8_t* d_sc, int scalar_le, hipStream_t stream,
                                uint8_t* d_qres = nullptr) {
-    if (curve == 0) return icc_encode_core<IccBn254Fr>(ws, 0, d_rows, n, ncols, ws_step, part, d_x, d_al, d_sc, scalar_le, stream, d_qres);
-    if (curve == 1) return icc_encode_core<IccSecp256k1Fn>(ws, 1, d_rows, n, ncols, ws_step, part, d_x, d_al, d_sc, scalar_le, stream, d_qres);
-    set_last_error("porla: curve must be 0 (BN254 / KZG) or 1 (secp256k1 / IPA)");
-    return PORLA_ERR_ARG;
+    if (curve != 0 && curve != 1) {
+        set_last_error("porla: curve must be 0 (BN254 / KZG) or 1 (secp256k1 / IPA)");
+        return PORLA_ERR_ARG;
+    }
+    int rc = ws->fence.enter(stream);      // an earlier encode on another stream may still use work / the twiddles
+    if (rc) return rc;
+    rc = curve == 0 ? icc_encode_core<IccBn254Fr>(ws, 0, d_rows, n, ncols, ws_step, part, d_x, d_al, d_sc, scalar_le, stream, d_qres)
+                    : icc_encode_core<IccSecp256k1Fn>(ws, 1, d_rows, n, ncols, ws_step, part, d_x, d_al, d_sc, scalar_le, stream, d_qres);
+    if (rc) return rc;
+    return ws->fence.leave(stream);
 }
 
 // The butterfly network as a matrix over Z_q: row k = the coefficients F[k][0..n) with out_k = sum_i F[k][i] * in_i
@@ -169,6 +179,7 @@ int icc_network_matrix_device(int curve, size_t n, unsigned long long write_step
     IccWs* ws;
     if ((rc = get_icc_ws(&ws))) return rc;
     if ((rc = ws->in.ensure(n * n * 32))) return rc;
+    if ((rc = ws->fence.enter(stream))) return rc;
     PORLA_HIP(hipMemsetAsync(ws->in.p, 0, n * n * 32, stream));
     hipLaunchKernelGGL(k_icc_identity, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (uint8_t*)ws->in.p, (uint32_t)n);
     return icc_encode_dispatch(ws, curve, (const uint8_t*)ws->in.p, n, n, write_step, part, nullptr, nullptr, nullptr, 0,

@@ -12,8 +12,11 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
+#include <cstring>
 #include <mutex>
 #include <random>
+#include <string>
 #include <vector>
 
 using namespace porla;
@@ -121,23 +124,75 @@ int refresh_srs_locked() {
 
 // kzg.Commit(f, srs) (main.go:114,164) for `n_rows` coefficient rows: fixed-base table path, len <= n_samples
 int commit_rows(const uint8_t* rows, bool device_ptrs, size_t n_rows, size_t len, uint8_t* out, hipStream_t stream) {
-    {
-        std::lock_guard<std::mutex> lk(g.mu);
-        int rc = refresh_srs_locked();
-        if (rc) {
-            if (rc == PORLA_ERR_STATE) set_last_error("porla: SRS not initialised (call init_SRS / init_SRS_from_data first)");
-            return rc;
-        }
-        if (len > g.srs.size()) { set_last_error("porla: more coefficients than SRS points"); return PORLA_ERR_STATE; }
+    // lock order: the state, then the table; the table's mutex is taken BEFORE the state is let go, so that neither
+    // init_SRS_from_data / porla_kzg_set_commit_window nor porla_kzg_release_device_memory can rebuild or free the table between
+    // the checks and the commit (compute_digest_from_srs comes from 8 pool threads, Server.hpp:550-560)
+    std::unique_lock<std::mutex> lk(g.mu);
+    int rc = refresh_srs_locked();
+    if (rc) {
+        if (rc == PORLA_ERR_STATE) set_last_error("porla: SRS not initialised (call init_SRS / init_SRS_from_data first)");
+        return rc;
     }
-    std::lock_guard<std::mutex> lk(g.fb.mu);
+    if (len > g.srs.size()) { set_last_error("porla: more coefficients than SRS points"); return PORLA_ERR_STATE; }
+    std::unique_lock<std::mutex> lkfb(g.fb.mu);
+    lk.unlock();
     if (device_ptrs) return g.fb.commit_device(rows, n_rows, len, len * 32, out, stream);
     return g.fb.commit_host(rows, n_rows, len, len * 32, out, engine_stream());
 }
 
-void commit_gpu(const uint8_t* coeffs_be, size_t len, const char* where, uint8_t out[64]) {
-    int rc = commit_rows(coeffs_be, false, 1, len, out, nullptr);
-    if (rc) die(where, rc);
+// compute_digest_from_srs arrives ONE row per call from up to 8 pool threads at once (Server.hpp:550-560, 1054-1078, 1530-1535):
+// calls that meet here are coalesced -- whoever finds no batch in progress becomes the leader, takes every row queued so far
+// (its own included), commits them in ONE launch (FixedBase::commit_small) and hands the results back; rows that arrive while a
+// batch is in flight form the next one.  A lone caller pays nothing for it (a batch of one).
+struct CommitQueue {
+    struct Item { const uint8_t* row; uint8_t* out; int rc; bool done; std::string err; };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<Item*> q;
+    bool leader = false;
+};
+CommitQueue cq;
+
+int commit_coalesced(const uint8_t* row, uint8_t out[64]) {
+    CommitQueue::Item it{row, out, PORLA_OK, false, std::string()};
+    std::unique_lock<std::mutex> lk(cq.mu);
+    cq.q.push_back(&it);
+    for (;;) {
+        if (it.done) { if (it.rc) set_last_error(it.err); return it.rc; }
+        if (cq.leader) { cq.cv.wait(lk); continue; }
+        cq.leader = true;
+        std::vector<CommitQueue::Item*> batch;
+        const size_t take = cq.q.size() < (size_t)FB_SMALL_MAX_ROWS ? cq.q.size() : (size_t)FB_SMALL_MAX_ROWS;
+        batch.assign(cq.q.begin(), cq.q.begin() + (long)take);
+        cq.q.erase(cq.q.begin(), cq.q.begin() + (long)take);
+        lk.unlock();
+        int rc;
+        std::string err;
+        {
+            std::unique_lock<std::mutex> ls(g.mu);
+            rc = refresh_srs_locked();
+            const size_t len = (size_t)g.n_samples;
+            if (rc == PORLA_ERR_STATE) set_last_error("porla: SRS not initialised (call init_SRS / init_SRS_from_data first)");
+            if (!rc && len > g.srs.size()) { set_last_error("porla: more coefficients than SRS points"); rc = PORLA_ERR_STATE; }
+            if (!rc) {
+                std::unique_lock<std::mutex> lf(g.fb.mu);
+                ls.unlock();
+                const uint8_t* rp[FB_SMALL_MAX_ROWS];
+                uint8_t* op[FB_SMALL_MAX_ROWS];
+                for (size_t i = 0; i < batch.size(); i++) { rp[i] = batch[i]->row; op[i] = batch[i]->out; }
+                if (FixedBase<Bn254G1>::small_ok(batch.size(), len)) {
+                    rc = g.fb.commit_small(rp, batch.size(), len, op, engine_stream());
+                } else {
+                    for (size_t i = 0; i < batch.size() && !rc; i++) rc = g.fb.commit_host(rp[i], 1, len, len * 32, op[i], engine_stream());
+                }
+            }
+            if (rc) err = porla_gpu_last_error();
+        }
+        lk.lock();
+        for (auto* b : batch) { b->rc = rc; b->err = err; b->done = true; }
+        cq.leader = false;
+        cq.cv.notify_all();
+    }
 }
 
 void copy_out(GoSlice* dst, const uint8_t* src, size_t n) {  // Go copy(): min(len(dst), len(src))
@@ -255,7 +310,8 @@ void compute_digest_complement(GoSlice* data_in, GoSlice* data_out) {
 // main.go:103-116: kzg.Commit -- GPU MSM against the resident SRS
 void compute_digest_from_srs(GoSlice* data_in, GoSlice* data_out) {
     uint8_t out[64];
-    commit_gpu((const uint8_t*)data_in->data, (size_t)g.n_samples, "compute_digest_from_srs", out);
+    int rc = commit_coalesced((const uint8_t*)data_in->data, out);
+    if (rc) die("compute_digest_from_srs", rc);
     copy_out(data_out, out, 64);
 }
 
@@ -284,10 +340,6 @@ void create_proof(GoUint64 random_point, GoSlice* data_in, GoSlice* commitment_o
                   GoSlice* proof_point, GoSlice* proof_claim) {
     const uint8_t* d = (const uint8_t*)data_in->data;
     size_t n = (size_t)g.n_samples;
-    uint8_t buf[64];
-    commit_gpu(d, n, "create_proof (commit)", buf);
-    copy_out(commitment_out, buf, 64);
-
     uint8_t zb[32] = {0};
     for (int i = 0; i < 8; i++) zb[31 - i] = (uint8_t)(random_point >> (8 * i));
     Fe<Fr> z = h_fe_from_be<Fr>(zb);
@@ -295,15 +347,22 @@ void create_proof(GoUint64 random_point, GoSlice* data_in, GoSlice* commitment_o
     for (size_t i = 0; i < n; i++) f[i] = h_fe_from_be<Fr>(d + 32 * i);
     Fe<Fr> y = fe_zero<Fr>();
     for (size_t i = n; i-- > 0;) y = fe_add<Fr>(fe_mul<Fr>(y, z), f[i]);
-    // synthetic division: h[n-2] = f[n-1]; h[i-1] = f[i] + z*h[i]
-    std::vector<uint8_t> hb(32 * (n ? n - 1 : 0));
+    // synthetic division: h[n-2] = f[n-1]; h[i-1] = f[i] + z*h[i].  Both commitments go out as ONE batch of two rows of n
+    // coefficients (h padded with a zero top coefficient: the same commitment), one launch instead of two.
+    std::vector<uint8_t> two(2 * 32 * n, 0);
+    memcpy(two.data(), d, 32 * n);
+    uint8_t* hb = two.data() + 32 * n;
     Fe<Fr> carry = fe_zero<Fr>();
     for (size_t i = n; i-- > 1;) {
         carry = fe_add<Fr>(fe_mul<Fr>(carry, z), f[i]);
         fr_plain_be(&hb[32 * (i - 1)], carry);
     }
-    commit_gpu(hb.data(), n ? n - 1 : 0, "create_proof (open)", buf);
-    copy_out(proof_H, buf, 64);
+    uint8_t both[128];
+    int rc = n ? commit_rows(two.data(), false, 2, n, both, nullptr) : PORLA_OK;
+    if (n == 0) memset(both, 0, sizeof both);
+    if (rc) die("create_proof", rc);
+    copy_out(commitment_out, both, 64);
+    copy_out(proof_H, both + 64, 64);
     uint8_t t[32];
     fr_plain_be(t, z); copy_out(proof_point, t, 32);
     fr_plain_be(t, y); copy_out(proof_claim, t, 32);
@@ -432,12 +491,15 @@ int porla_kzg_digest_batch_device(const void* d_rows, size_t n_rows, void* d_out
         g.d_eval_cap = n_rows * 32 + 256;
     }
     hipStream_t stream = (hipStream_t)hip_stream;
+    std::lock_guard<std::mutex> lk2(g.fb_g.mu);
+    // d_eval is read by the commit below: a previous batch on another stream must have finished with it (the table's fence
+    // is recorded after that commit's last kernel)
+    if ((rc = g.fb_g.fence.enter(stream))) return rc;
     {
         ProfScope ps("kzg_eval_rows", stream);
         hipLaunchKernelGGL(k_kzg_eval_rows, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, (const uint8_t*)d_rows,
                            (uint32_t)n_rows, (uint32_t)g.n_samples, g.tau, g.alpha, (uint8_t*)g.d_eval);
     }
-    std::lock_guard<std::mutex> lk2(g.fb_g.mu);
     return g.fb_g.commit_device((const uint8_t*)g.d_eval, n_rows, 1, 32, (uint8_t*)d_out, stream);
 }
 
@@ -474,7 +536,10 @@ int porla_kzg_set_commit_window(int window_bits) {
 // frees the HBM copies that belong to the KZG state (SRS, its window-multiples table -- 56 GB by default --, the one-point
 // tables of the client-side batches and scratch); they are rebuilt by the next call that needs them
 int porla_kzg_release_device_memory(void) {
+    // lock order as everywhere: the state, then the tables -- a commit that has dropped g.mu still holds its table's mutex
+    // (compute_digest_from_srs is called from 8 pool threads, Server.hpp:550-560)
     std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<std::mutex> l1(g.fb.mu), l2(g.fb_g.mu), l3(g.fb_h.mu);
     g.fb.release();
     g.fb_g.release();
     g.fb_h.release();

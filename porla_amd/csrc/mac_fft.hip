@@ -30,6 +30,7 @@ struct MacWs {
     unsigned long long F_wt_exp = 0;
     FixedBase<Bn254G1> fb_bn;
     FixedBase<Secp256k1G> fb_secp;
+    UseFence fence;   // work / twiddle / matrix buffers shared between calls that may come on different streams
 };
 template <class C> struct FbOf;
 template <> struct FbOf<Bn254G1> { static FixedBase<Bn254G1>& get(MacWs* w) { return w->fb_bn; } };
@@ -153,10 +154,16 @@ static int mac_encode_core(MacWs* ws, int curve, const uint8_t* d_in, size_t n, 
 
 static int mac_dispatch(MacWs* ws, int curve, const uint8_t* d_in, size_t n, unsigned long long write_step, int part,
                         uint8_t* d_out, hipStream_t stream) {
-    if (curve == 0) return mac_encode_core<Bn254G1, IccBn254Fr>(ws, 0, d_in, n, write_step, part, d_out, stream);
-    if (curve == 1) return mac_encode_core<Secp256k1G, IccSecp256k1Fn>(ws, 1, d_in, n, write_step, part, d_out, stream);
-    set_last_error("porla: curve must be 0 (BN254) or 1 (secp256k1)");
-    return PORLA_ERR_ARG;
+    if (curve != 0 && curve != 1) {
+        set_last_error("porla: curve must be 0 (BN254) or 1 (secp256k1)");
+        return PORLA_ERR_ARG;
+    }
+    int rc = ws->fence.enter(stream);
+    if (rc) return rc;
+    rc = curve == 0 ? mac_encode_core<Bn254G1, IccBn254Fr>(ws, 0, d_in, n, write_step, part, d_out, stream)
+                    : mac_encode_core<Secp256k1G, IccSecp256k1Fn>(ws, 1, d_in, n, write_step, part, d_out, stream);
+    if (rc) return rc;
+    return ws->fence.leave(stream);
 }
 
 }  // namespace porla
@@ -194,8 +201,11 @@ int porla_icc_mac_mix_device(const void* d_a0, const void* d_a1, size_t len, siz
     std::lock_guard<std::mutex> lk(g_mac_mu);
     MacWs* ws;
     if ((rc = get_mac_ws(&ws))) return rc;
-    if (curve == 0) return mac_mix_core<Bn254G1, IccBn254Fr>(ws, 0, (const uint8_t*)d_a0, (const uint8_t*)d_a1, len, n_total, (uint8_t*)d_out, (hipStream_t)hip_stream);
-    return mac_mix_core<Secp256k1G, IccSecp256k1Fn>(ws, 1, (const uint8_t*)d_a0, (const uint8_t*)d_a1, len, n_total, (uint8_t*)d_out, (hipStream_t)hip_stream);
+    if ((rc = ws->fence.enter((hipStream_t)hip_stream))) return rc;
+    rc = curve == 0 ? mac_mix_core<Bn254G1, IccBn254Fr>(ws, 0, (const uint8_t*)d_a0, (const uint8_t*)d_a1, len, n_total, (uint8_t*)d_out, (hipStream_t)hip_stream)
+                    : mac_mix_core<Secp256k1G, IccSecp256k1Fn>(ws, 1, (const uint8_t*)d_a0, (const uint8_t*)d_a1, len, n_total, (uint8_t*)d_out, (hipStream_t)hip_stream);
+    if (rc) return rc;
+    return ws->fence.leave((hipStream_t)hip_stream);
 }
 
 int porla_icc_mac_mix_host(const uint8_t* a0, const uint8_t* a1, size_t len, size_t n_total, int curve, uint8_t* out) {

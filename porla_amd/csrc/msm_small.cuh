@@ -38,6 +38,10 @@ constexpr int SMALL_MAX_S = 32;                      // slices per window: S * c
 constexpr int SMALL_DONE_SLOT = 255;                 // counters[0 .. W): arrivals per window; [255]: finished windows
 constexpr uint32_t SMALL_HDR_WORDS = 32;             // pinned header in front of fin: [0] = sequence, [1] = W, [2] = c, [3] = glv
 
+// the single-launch commitment of fixed_base.cuh (k_fb_commit_small): rows per launch, slices per row
+constexpr int FB_SMALL_MAX_ROWS = 32;
+constexpr int FB_SMALL_MAX_SLICES = 8;
+
 struct SmallCfg {
     int glv;          // 1: every scalar split in two sub-scalars
     int L;            // bits a sub-scalar can have

@@ -248,3 +248,72 @@ def test_release_device_memory_and_rebuild(mx, srs128):
     assert lib.porla_kzg_release_device_memory() == 0
     assert torch.cuda.mem_get_info()[0] > free0 + (1 << 30)          # the table alone is tens of GB
     assert mx.kzg_commit_batch_host(rows, 3) == a
+
+
+@pytest.mark.parametrize("n_rows", [1, 2, 31, 32, 33])
+def test_few_rows_single_launch_path_and_its_boundary(mx, srs128, n_rows):
+    """<= 32 host rows take the single-launch kernel (k_fb_commit_small: digits, gather, LDS fold, slices folded by the last
+    block, sums polled from pinned memory); 33 rows the batch kernels -- same bytes either way, every table window"""
+    rows = rows_bytes(n_rows, 128, b"few%d" % n_rows)
+    want = common.oracle_commit_batch("bn254", rows, n_rows, 128, srs128)
+    for c in (5, 12, 16):
+        fb = mx.FixedBase("bn254", srs128, 128, window_bits=c)
+        assert fb.commit_host(rows, n_rows, 128) == want
+        # short rows (the 127-coefficient quotient of create_proof) and a padded stride
+        short = b"".join(rows[4096 * r:4096 * r + 32 * 127] + bytes(32) for r in range(n_rows))
+        assert fb.commit_host(short, n_rows, 127, row_stride=4096) == common.oracle_commit_batch("bn254", short, n_rows, 127, srs128, row_stride=4096)
+        fb.close()
+    # edge coefficients through the small path: zero row, r - 1, r, 2^256 - 1
+    vals = [0, 1, R - 1, R, R + 1, (1 << 256) - 1, 5 * R + 7, 1 << 253]
+    row = b"".join(vals[i % len(vals)].to_bytes(32, "big") for i in range(128))
+    edge = bytes(4096) + row
+    fb = mx.FixedBase("bn254", srs128, 128, window_bits=13)
+    got = fb.commit_host(edge, 2, 128)
+    assert got[:64] == bytes(64) and got == common.oracle_commit_batch("bn254", edge, 2, 128, srs128)
+    fb.close()
+
+
+def test_secp256k1_few_rows(mx):
+    pts = common.secp_bench_points(128)
+    rows = common.secp_bench_scalars(128 * 5, start=77)
+    fb = mx.FixedBase("secp256k1", pts, 128, window_bits=10)
+    assert fb.commit_host(rows, 5, 128) == common.oracle_commit_batch("secp256k1", rows, 5, 128, pts)
+    fb.close()
+
+
+def test_sixteen_threads_coalesce_and_a_release_in_between(mx, srs128):
+    """compute_digest_from_srs from 16 threads (calls that meet are committed in one launch) while another thread frees the
+    device copies of the KZG state twice: every result still equals the oracle (the table is rebuilt under the same locks)"""
+    import threading
+    from porla_amd import lib
+    mx.init_key(TAU, ALPHA)
+    blob = mx.init_SRS(128)
+    mx.init_SRS_from_data(128, blob)
+    T = 16
+    rows = rows_bytes(T, 128, b"coal")
+    want = common.oracle_commit_batch("bn254", rows, T, 128, srs128)
+    errors = []
+
+    def worker(t):
+        try:
+            for _ in range(40):
+                if mx.compute_digest_from_srs(rows[4096 * t:4096 * t + 4096]) != want[64 * t:64 * t + 64]:
+                    errors.append(t)
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    def releaser():
+        import time
+        for _ in range(2):
+            time.sleep(0.01)
+            if lib.porla_kzg_release_device_memory() != 0:
+                errors.append("release")
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(T)] + [threading.Thread(target=releaser)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:5]
+    c, h, z, y = mx.create_proof(99, rows[:4096])           # two rows in one batch
+    assert c == want[:64] and mx.verify_proof(c, h, z, y)
