@@ -8,14 +8,16 @@ Default workload (the headline metric): a "step" is ONE 2^20-pair BN254 G1 MSM p
 scheme, single 2^20-point BN254 G1 MSM on 1 MI355X"), inputs resident in HBM in the reference's wire format (32-B
 big-endian scalars + 64-B X||Y points, porla/main.go:118-138) when the timed region starts.  With N > 1 every rank owns
 its own 2^20 pairs (input-range sharding, weak scaling), produces one partial Jacobian sum, the 96-byte partials are
-exchanged with one RCCL all_gather and folded with N-1 group additions: the whole job is one N*2^20-pair
-MSM per step.  Steps are independent MSMs; `--in-flight 2` (default) keeps two of them in flight on two streams through the
+exchanged with ONE ncclAllGather issued from C++ inside libmultiexp.so (porla_dist_*; RCCL over xGMI) and folded with N-1 group
+additions on every host: the whole job is one N*2^20-pair MSM per step.  Steps are independent MSMs; `--in-flight 2` (default) keeps two of them in flight on two streams through the
 two-phase API (porla_bn254_msm_device_begin/_end) -- the audit issues its MSMs in pairs (Server.hpp:900-901) -- so the
 latency-bound tail of one MSM (bucket reduction, host fold) overlaps the bucket accumulation of the next; every step is
 still one complete MSM whose result is produced and checked, and K steps = K results inside the timed region
 (`--in-flight 1` = blocking calls).  The same JSON line carries `kzg_commits`: the second half of BASELINE.json's metric ("KZG commits/s"),
 2^17 rows x 128 coefficients per GPU against the resident SRS (compute_digest_from_srs hoisted over rows), timed
-separately after the MSM region.
+separately after the MSM region, with the per-call figures of the real symbol next to it (one row per call from 1 and 8
+threads of a plain-C caller).  Also on the line, never as `value`: `blocking_ms_per_step` (the same MSM with one in flight) and
+`host_boundary` (compute_multi_exp on caller-owned pageable host buffers, PCIe included).
 
 Other workloads (parity-test configurations of BASELINE.json, selectable for profiling; never the default line):
   kzg_commit      2^17 rows x 128 coefficients per GPU, commits/s                     (SURVEY.md s8(f)-1, config 3 variant)
@@ -29,6 +31,7 @@ launch stream inside the library over the timed region; `traffic` comes from the
 """
 import argparse
 import ctypes
+import subprocess
 import hashlib
 import json
 import os
@@ -84,6 +87,7 @@ def main():
     ap.add_argument("--log2rows", type=int, default=17, help="kzg_commit rows per GPU = 2^log2rows; icc rows = 2^(log2rows-2)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / bit-exact check leg")
     ap.add_argument("--no-commits", action="store_true", help="bn254_msm: skip the kzg_commits leg")
+    ap.add_argument("--no-host-boundary", action="store_true", help="bn254_msm: skip the compute_multi_exp-on-host-buffers leg")
     ap.add_argument("--in-flight", type=int, default=2, help="bn254_msm: independent MSMs in flight (1 = blocking calls; 2 = the "
                     "audit's pair of MSMs, Server.hpp:900-901, overlapped on two streams)")
     args = ap.parse_args()
@@ -113,7 +117,38 @@ def main():
 
     from porla_amd import multiexp as mx
     from porla_amd import sharded
+    mx.lib = __import__("porla_amd.loader", fromlist=["lib"]).lib
     from tests import common  # oracle access is allowed here for input generation + the cpu_baseline leg only
+
+    # N > 1: the 96-byte partials travel through ONE ncclAllGather issued from C++ inside libmultiexp.so (porla_dist_*, RCCL bound
+    # with dlopen); torch.distributed only hands the ncclUniqueId around and keeps the barrier / MAX-over-ranks timing.  Should
+    # the in-library communicator fail to come up on some node, the same exchange runs through torch.distributed's nccl
+    # backend (also RCCL) -- `collective` in the JSON line says which.  With PORLA_DIST_BACKEND=gloo (ranks sharing one GPU,
+    # which RCCL refuses) the partials go over gloo on the host.
+    collective = "none (single GPU)"
+    use_cxx_dist = False
+    if world > 1:
+        collective = "torch.distributed %s all_gather" % backend
+        if backend == "nccl" and os.environ.get("PORLA_DIST_CXX", "1") != "0":
+            ok_t = torch.zeros(1, dtype=torch.int32, device=coll_dev)
+            try:
+                uid = [mx.dist_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                mx.dist_init(uid[0], rank, world)
+                ok_t += 1
+            except Exception as e:  # noqa: BLE001
+                print("rank %d: in-library RCCL communicator unavailable (%s)" % (rank, e), file=sys.stderr)
+            dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+            use_cxx_dist = int(ok_t.item()) == 1
+            if use_cxx_dist:
+                collective = "ncclAllGather from C++ (porla_dist_*, RCCL over xGMI)"
+            elif mx.dist_info()[1]:
+                mx.dist_finalize()
+
+    def fold_across_ranks(curve, part):
+        if use_cxx_dist:
+            return mx.dist_fold(curve, part)
+        return sharded.fold_partials(curve, sharded.gather_partials(part, coll_dev))
 
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -171,6 +206,8 @@ def main():
         ach = algo_bytes_per_launch / (kern[dom] * 1e-3) / 1e9
         r = {"bound": "hbm", "kernel": KERNEL_SYMBOL.get(dom, dom), "achieved": round(ach, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
              "frac": round(ach / HBM_PEAK_GBPS, 6), "traffic": pmc_traffic(dom, workload),
+             "traffic_source": "committed rocprofv3 --pmc passes (profiles/%s), not collected in this run"
+                               % ("pmc_latest.json" if workload == "bn254_msm" else "pmc_latest_%s.json" % workload),
              "kernel_ms": round(kern[dom], 4), "all_kernels_ms": {k: round(v, 4) for k, v in kern.items()}}
         if fe_mults_per_launch:
             # the elliptic-curve kernels are bound by the 32x32->64 multiplier issue rate, which neither "hbm" nor "mfma"
@@ -218,7 +255,27 @@ def main():
         torch.cuda.synchronize()
         build_s = time.perf_counter() - t_build
         el, kern, _ = timed(step)
+        # the reference's own call pattern through the real symbol (one row per compute_digest_from_srs call, 1 and 8 pool threads,
+        # Server.hpp:550-560, 1054-1078): the plain-C harness in a child process, linked with -lmultiexp like the reference
+        per_call = None
+        harness = os.path.join(ROOT, "integration", "kzg_harness", "harness")
+        if rank == 0 and os.path.exists(harness) and not args.no_cpu:
+            per_call = {}
+            for threads in (1, 8):
+                try:
+                    r = subprocess.run([harness, "bench", str(threads), "1500"], capture_output=True, text=True, timeout=180)
+                    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+                    d = json.loads(line)
+                    per_call["threads_%d" % threads] = {"commits_per_s": d["commits_per_s"], "latency_ms_per_call": d["latency_ms_per_call"],
+                                                        "consistent": d["consistent"]}
+                except Exception as e:  # noqa: BLE001
+                    per_call["threads_%d" % threads] = {"error": repr(e)}
+        cshape = mx.kzg_commit_shape()
         out = {"value": round(world * rows_n * args.steps / el, 1), "unit": "commits/s", "rows_per_gpu": rows_n,
+               "table": {"window_bits": cshape[0], "windows_per_coefficient": cshape[1],
+                         "GiB": round(128 * cshape[1] * (1 << (cshape[0] - 1)) * 64 / 2**30, 2) if cshape[0] else None,
+                         "budget": "PORLA_COMMIT_TABLE_GB (default 16 GiB)"},
+               "per_call_compute_digest_from_srs": per_call,
                "coefficients_per_row": 128, "equiv_Mmul_per_s": round(world * rows_n * 128 * args.steps / el / 1e6, 1),
                "ms_per_step": round(el / args.steps * 1e3, 4), "table_build_s": round(build_s, 3),
                "roofline": roofline(kern, COMMIT_BYTES_PER_ROW * rows_n, "kzg_commit",
@@ -264,7 +321,7 @@ def main():
             # additions + one inversion on the host (porla_amd/sharded.py)
             slot = state["inflight"].pop(0)
             part = mx.msm_end(slot, partial=world > 1)
-            return part if world == 1 else sharded.fold_partials("bn254", sharded.gather_partials(part, coll_dev))
+            return part if world == 1 else fold_across_ranks("bn254", part)
 
         def step():
             # every step is one complete 2^20-pair MSM (all kernels + host fold + result); with in_flight > 1 the next
@@ -272,7 +329,9 @@ def main():
             # (bucket reduction, host fold) overlaps the bucket accumulation of the next
             res = None
             if depth == 1:
-                return sharded.sharded_msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n, stream, coll_dev)
+                if world == 1:
+                    return mx.msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n, stream)
+                return fold_across_ranks("bn254", mx.msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n, stream, partial=True))
             if len(state["inflight"]) == depth:
                 res = retire()
             slot = 1 + state["k"] % depth
@@ -288,6 +347,38 @@ def main():
             return res
 
         el, kern, result = timed(step, drain)
+        # the same MSM as blocking calls (one in flight): what a caller that waits for every result sees
+        blocking_ms = None
+        if depth > 1:
+            reps = max(3, args.steps // 4)
+            for _ in range(2):
+                mx.msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n, stream, partial=world > 1)
+            sync()
+            t_b = time.perf_counter()
+            for _ in range(reps):
+                mx.msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n, stream, partial=world > 1)
+            torch.cuda.synchronize()
+            blocking_ms = (time.perf_counter() - t_b) / reps * 1e3
+        # the reference's own boundary: compute_multi_exp on caller-owned pageable HOST buffers (PCIe included; never `value`)
+        host_boundary = None
+        if world == 1 and rank == 0 and not args.no_host_boundary:
+            bs, bp = ctypes.create_string_buffer(sc, 32 * n), ctypes.create_string_buffer(pt, 64 * n)
+            hb_out = ctypes.create_string_buffer(64)
+            from porla_amd.multiexp import _slice
+            ss, sp, so = _slice(bs), _slice(bp), _slice(hb_out)
+            for _ in range(2):
+                mx.lib.compute_multi_exp(ctypes.byref(ss), ctypes.byref(sp), n, ctypes.byref(so))
+            reps = 5
+            t_h = time.perf_counter()
+            for _ in range(reps):
+                mx.lib.compute_multi_exp(ctypes.byref(ss), ctypes.byref(sp), n, ctypes.byref(so))
+            hb_ms = (time.perf_counter() - t_h) / reps * 1e3
+            shards, devs = mx.last_msm_multi()
+            host_boundary = {"entry": "compute_multi_exp(host scalars, host points, n, out) -- porla/main.go:118-138", "ms": round(hb_ms, 3),
+                             "Mmul_s": round(n / hb_ms / 1e3, 1), "pair_ranges": shards, "devices": devs,
+                             "same_result": hb_out.raw == result,
+                             "note": "96 n bytes cross PCIe inside the call; ranges are uploaded under the kernels of the previous range"}
+            del bs, bp
         commits = None if args.no_commits else kzg_commit_leg(1 << args.log2rows)
         if rank == 0:
             cpu = None
@@ -299,8 +390,13 @@ def main():
                 cpu_s = time.perf_counter() - t1
                 verified = (want == result)
                 cpu = {"value": round(n / cpu_s / 1e6, 4), "unit": "Mmul/s", "cores": cores, "kind": "port",
-                       "sample": "the same 2^%d pairs, oracle/bn254_ref.c bucket MSM range-split over %d threads "
-                                 "(CPU restatement, not gnark); %.1f s wall" % (args.log2n, cores, cpu_s)}
+                       "per_thread": round(n / cpu_s / 1e6 / cores, 4),
+                       "sample": "the same 2^%d pairs, oracle/bn254_ref.c bucket MSM (signed windows) range-split over %d threads "
+                                 "(CPU restatement, not gnark); %.1f s wall" % (args.log2n, cores, cpu_s),
+                       "reference_indicative": {"value": 0.143, "unit": "Mmul/s per thread",
+                                                "what": "the reference's OWN CPU path where it could be built: vendored libsecp256k1 "
+                                                        "ecmult_multi_var, 2^18 points, one thread of the survey container (Xeon 2.1 GHz) "
+                                                        "-- BASELINE.md s2; a different machine and the other curve, quoted for scale only"}}
             if not args.no_cpu and world > 1:
                 # whole-job check at N > 1 (no cpu_baseline is reported there): the N * 2^20-pair MSM over every rank's
                 # scalars (rank g: SHA-256 stream starting at g * 2^20) against the oracle
@@ -315,10 +411,13 @@ def main():
                 "config": {"workload": "KZG scheme, single 2^%d-point BN254 G1 MSM per GPU, inputs resident in HBM, "
                                        "output 64-B affine point" % args.log2n,
                            "pairs_per_gpu": n, "msm_in_flight": depth,
-                           "sharding": "input-pair range per rank + RCCL all_gather of 96-B Jacobian partials"
-                           if world > 1 else "single GPU", "input_gen_s": round(gen_s, 1)},
+                           "sharding": "input-pair range per rank + all-gather of 96-B Jacobian partials, folded on every host"
+                           if world > 1 else "single GPU", "collective": collective, "input_gen_s": round(gen_s, 1)},
                 "roofline": roofline(kern, MSM_BYTES_PER_PAIR * n, "bn254_msm", msm_fe_mults(n)), "cpu_baseline": cpu,
-                "bit_exact_vs_oracle": verified, "result": result.hex() if result else None, "kzg_commits": commits,
+                "bit_exact_vs_oracle": verified, "result": result.hex() if result else None,
+                "blocking_ms_per_step": round(blocking_ms, 4) if blocking_ms else None,
+                "blocking_Mmul_s": round(world * n / blocking_ms / 1e3, 1) if blocking_ms else None,
+                "host_boundary": host_boundary, "kzg_commits": commits,
             }
     elif args.workload == "kzg_commit":
         rows_n = 1 << args.log2rows
@@ -351,7 +450,9 @@ def main():
         d_sc, d_pt = to_dev(sc), to_dev(pt)
 
         def step():
-            return sharded.sharded_msm_device("secp256k1", d_sc.data_ptr(), d_pt.data_ptr(), n, stream, coll_dev)
+            if world == 1:
+                return mx.msm_device("secp256k1", d_sc.data_ptr(), d_pt.data_ptr(), n, stream)
+            return fold_across_ranks("secp256k1", mx.msm_device("secp256k1", d_sc.data_ptr(), d_pt.data_ptr(), n, stream, partial=True))
 
         el, kern, result = timed(step)
         if rank == 0:
@@ -435,6 +536,8 @@ def main():
         if failed:
             print("ERROR: GPU result differs from the oracle", file=sys.stderr)
     if world > 1:
+        if use_cxx_dist:
+            mx.dist_finalize()
         dist.barrier()
         dist.destroy_process_group()
     if failed:

@@ -51,6 +51,10 @@ extern "C" {
 int         porla_gpu_device_count(void);
 int         porla_gpu_set_device(int device);
 const char *porla_gpu_last_error(void);
+/* the range rule of every split in the engine (MSM pair ranges, commitment rows, ICC columns): shard `rank` of `world` owns
+ * units [rank n / world, (rank + 1) n / world).  One process per GPU: each rank calls the ordinary entry points on its own
+ * range (rows, columns) -- those paths need no collective. */
+int         porla_shard_range(size_t n, int rank, int world, size_t *begin, size_t *end);
 /* Per-kernel timing with HIP events recorded on the launch stream.  enable=1 starts (and clears) the
  * accumulation for every kernel, enable=2 for each workload's dominant kernel only (two event packets per recorded
  * kernel leave the GPU idle for ~10 us around it -- bench.py times with 2 and takes the full breakdown separately); porla_gpu_profile_get(i, ...) returns kernel name, summed milliseconds and launch count
@@ -158,6 +162,9 @@ void porla_fixed_base_destroy(porla_fixed_base *fb);
 /* KZG: rows of n_samples coefficients (4096 bytes per row for NUM_CHUNKS = 128) against the resident SRS */
 int  porla_kzg_commit_batch_device(const void *d_rows, size_t n_rows, void *d_out, void *hip_stream);
 int  porla_kzg_commit_batch_host(const uint8_t *rows, size_t n_rows, uint8_t *out);
+/* the same with the row range split over `devices` GPUs of this process (0 = every visible one), one host thread and one
+ * resident copy of the SRS table per device; rows are independent, nothing is exchanged (Server.hpp:1077-1078, 2061-2062) */
+int  porla_kzg_commit_batch_host_multi(const uint8_t *rows, size_t n_rows, uint8_t *out, int devices);
 /* frees the HBM copies of the KZG state (SRS + window table, one-point tables, scratch); rebuilt on the next use */
 int  porla_kzg_release_device_memory(void);
 /* Client side, batched (Client::initialize computes both per block, porla/Client/Client.hpp:408-455):
@@ -194,6 +201,16 @@ int porla_icc_encode_device(const void *d_rows_in, size_t n_rows, size_t n_cols,
                             void *hip_stream);
 int porla_icc_encode_host(const uint8_t *rows_in, size_t n_rows, size_t n_cols, int curve, unsigned long long write_step,
                           int part, uint8_t *x_out, uint8_t *aligned_out, uint8_t *scalars_out, int scalar_le);
+/* Column sharding (the reference splits the columns of every stage over its 8 pool threads, Server.hpp:1564-1686; the 128
+ * per-column transforms are independent): only columns [col_begin, col_end) of the row-major input are uploaded (strided),
+ * encoded and written back into the same columns of the full-width outputs.  One process per GPU: rank g passes
+ * porla_shard_range(n_cols, g, G) -- 16 columns each on 8 GPUs; or let _host_multi run `devices` GPUs of this process
+ * (0 = every visible one) from one host thread each.  No collective. */
+int porla_icc_encode_cols_host(const uint8_t *rows_in, size_t n_rows, size_t n_cols, size_t col_begin, size_t col_end, int curve,
+                               unsigned long long write_step, int part, uint8_t *x_out, uint8_t *aligned_out,
+                               uint8_t *scalars_out, int scalar_le);
+int porla_icc_encode_host_multi(const uint8_t *rows_in, size_t n_rows, size_t n_cols, int curve, unsigned long long write_step,
+                                int part, uint8_t *x_out, uint8_t *aligned_out, uint8_t *scalars_out, int scalar_le, int devices);
 
 /* ---- MAC-side ICC encode ("FFT in the exponent": the MAC halves of CRebuild_Cached, Server.hpp:1523-1536 init
  * scaling, :1590-1609 / :1658-1676 butterflies tm = v^j * MAC[k+m2]; MAC[k] = um + tm; MAC[k+m2] = um - tm; client twin
@@ -219,6 +236,29 @@ int porla_icc_mix_device(const void *d_a0, const void *d_a1, size_t len, size_t 
 int porla_icc_mix_host(const uint8_t *a0, const uint8_t *a1, size_t len, size_t n_cols, size_t n_total, int curve, uint8_t *out);
 int porla_icc_mac_mix_device(const void *d_a0, const void *d_a1, size_t len, size_t n_total, int curve, void *d_out, void *hip_stream);
 int porla_icc_mac_mix_host(const uint8_t *a0, const uint8_t *a1, size_t len, size_t n_total, int curve, uint8_t *out);
+
+/* ---- Server::HAdd / Client::HAdd and the HRebuild chains (Server.hpp:1388-1477, 1329-1386; Client.hpp:978-1038) ----
+ * HAdd's arithmetic on ONE incoming block (the level bookkeeping around it stays the caller's):
+ *   porla_icc_hadd_host      data_b2[i] = (data[i] * wt) mod p_icc and the alignment scalars c_i = (data_b2[i] - data[i] * wt) mod q
+ *                            (align_MAC, Server.hpp:531-541 / 495-504), wt = w^reverse_bits(write_step % n_total, height-1);
+ *                            wt_scalar_out: wt as the 32-byte big-endian scalar of the MAC side (convert_ZZ_to_scalar)
+ *   porla_icc_mac_scale_host MAC_B2 = wt * MAC (host: one 64-byte operand; also Client::HAdd, Client.hpp:996-1014)
+ *   porla_kzg_hadd_host      all three outputs of Server::HAdd for the KZG build: data_B2, MAC_B2 and MAC_align_B2 = Commit(c)
+ *                            (IPA: take the scalars of porla_icc_hadd_host with scalar_le = 1 to the generators' fixed base,
+ *                            porla_fixed_base_commit_host, or to secp256k1_ecmult_multi_var through the shim)
+ * HRebuildX / HRebuildY: the chain of mixes that carries the block up to `level`, on the device in one call.  levels[i] points at
+ * level i's rows (i <= level): 2 * 2^i rows, the first 2^i resident, the second 2^i incoming (levels[0] + one row = the new block);
+ * step i mixes the halves of level i (Server::mix / Client::mix) into the incoming half of level i + 1; at the end level
+ * `level`'s incoming half is copied over its resident half, as the reference does.  A row is n_cols 64-byte symbols
+ * (porla_icc_hrebuild_host: the data levels) or one 64-byte affine point (porla_icc_mac_hrebuild_host: MAC commitments,
+ * MAC alignments, the client's complements). */
+int porla_icc_hadd_host(const uint8_t *data_in, size_t n_cols, size_t n_total, unsigned long long write_step, int curve,
+                        uint8_t *data_b2_out, uint8_t *scalars_out, int scalar_le, uint8_t wt_scalar_out[32]);
+int porla_icc_mac_scale_host(const uint8_t mac_in[64], size_t n_total, unsigned long long write_step, int curve, uint8_t mac_out[64]);
+int porla_kzg_hadd_host(const uint8_t *data_in, const uint8_t mac_in[64], size_t n_total, unsigned long long write_step,
+                        uint8_t *data_b2_out, uint8_t mac_b2_out[64], uint8_t mac_align_b2_out[64]);
+int porla_icc_hrebuild_host(uint8_t *const *levels, int level, size_t n_cols, size_t n_total, int curve);
+int porla_icc_mac_hrebuild_host(uint8_t *const *levels, int level, size_t n_total, int curve);
 
 /* ---- audit row combine (Server::audit, Server.hpp:790-828) + the scalar part of align_MAC on the result (:531-541) ----
  * B_j = sum_i coeff_i * row_i[j] (exact integer), then aligned_j = B_j mod p_icc, c_j = (aligned_j - B_j) mod q.

@@ -205,3 +205,28 @@ def mac_mix(a0, a1, n_total, curve="bn254"):
         out[i + length] = ec_add(curve, a0[i], ec_neg(curve, tm))
         vi = vi * v % P_ICC
     return out
+
+
+def hadd(data, mac, n_total, write_step, curve="bn254"):
+    """Server::HAdd up to the level bookkeeping (Server.hpp:1388-1428): wt = w^reverse_bits(write_step % N, height-1);
+    data_B2[i] = data[i] * wt (integer product, :1396-1398), MAC_B2 = wt * MAC (:1400-1417), then align_MAC(data_B2, .) (:1428):
+    data_B2[i] <- data_B2[i] % p_icc and the scalars c_i whose commitment is MAC_align_B2.
+    Returns (data_B2 aligned, c, MAC_B2, wt).  Client::HAdd (Client.hpp:996-1014) is the MAC_B2 part alone."""
+    wt = pow(root_w(n_total), reverse_bits(write_step % n_total, height_of(n_total) - 1), P_ICC)
+    data_b2 = [d * wt for d in data]
+    mods, cs = align(data_b2, curve)
+    return mods, cs, ec_mul(curve, mac, wt), wt
+
+
+def hrebuild(levels, level, n_total, curve="bn254", mac=False):
+    """Server::HRebuildX / HRebuildY (Server.hpp:1329-1386) and Client::HRebuildX / Y (Client.hpp:978-994) on one family of levels:
+    levels[i] = list of 2 * 2^i rows (first half resident, second half incoming); for i < level the halves of level i are mixed
+    (Server::mix :1269-1318 / Client::mix Client.hpp:921-976) into the incoming half of level i + 1; then level `level`'s incoming
+    half is copied over its resident half.  In place; mac = True: rows are affine points (MAC commitments / alignments / complements)."""
+    for i in range(level):
+        ln = 1 << i
+        out = (mac_mix if mac else mix)(levels[i][:ln], levels[i][ln:2 * ln], n_total, curve)
+        levels[i + 1][2 * ln:4 * ln] = out
+    top = 1 << level
+    levels[level][:top] = levels[level][top:2 * top]
+    return levels

@@ -263,6 +263,14 @@ int porla_gpu_release_msm_workspaces(void) {
     (void)hipSetDevice(cur);
     return PORLA_OK;
 }
+// unit u of n belongs to shard u * world / n: shard `rank` owns [rank n / world, (rank+1) n / world) -- the one rule every
+// range split of the engine uses (MSM pair ranges, commitment rows, ICC columns)
+int porla_shard_range(size_t n, int rank, int world, size_t* begin, size_t* end) {
+    if (world < 1 || rank < 0 || rank >= world || !begin || !end) { set_last_error("porla: bad shard"); return PORLA_ERR_ARG; }
+    *begin = (size_t)((unsigned __int128)n * (unsigned)rank / (unsigned)world);
+    *end = (size_t)((unsigned __int128)n * (unsigned)(rank + 1) / (unsigned)world);
+    return PORLA_OK;
+}
 int porla_gpu_set_msm_window(int c) { g_window_override = c; return PORLA_OK; }
 int porla_gpu_last_msm_shape(int* c, int* windows, int* glv) {
     if (c) *c = g_last_shape[0];
@@ -374,6 +382,25 @@ int porla_secp256k1_msm_host(const uint8_t* scalars, const uint8_t* points, size
 }
 int porla_secp256k1_jac_sum(const uint8_t* jacs, size_t count, uint8_t out_affine[64]) {
     return abi_jac_sum<Secp256k1G>(jacs, count, out_affine);
+}
+
+// MAC_B2 = wt * MAC: Server::HAdd (Server.hpp:1400-1417), Client::HAdd (Client.hpp:996-1014), the Y halves of Client::CRebuild
+// (Client.hpp:1066-1075) -- one scalar multiplication on a 64-byte operand: host ("replicas only")
+int porla_icc_mac_scale_host(const uint8_t mac_in[64], size_t n_total, unsigned long long write_step, int curve, uint8_t mac_out[64]) {
+    if (!mac_in || !mac_out || (curve != 0 && curve != 1)) { set_last_error("porla: bad argument"); return PORLA_ERR_ARG; }
+    uint8_t wt[32];
+    int rc = icc_wt_scalar_be(n_total, write_step, wt);
+    if (rc) return rc;
+    uint32_t k[8];
+    h_load_be(k, wt);
+    if (curve == 0) {
+        fe_reduce_plain<Bn254Fr>(k, 8);                 // bn254_mult -> fr.SetBytes reduces mod r (main.go:209)
+        h_affine_to_bytes<Bn254Fp>(mac_out, h_xyzz_to_affine<Bn254Fp>(h_scalar_mul<Bn254Fp>(h_affine_from_bytes<Bn254Fp>(mac_in), k)));
+    } else {
+        fe_reduce_plain<IccSecp256k1FnHost>(k, 2);
+        h_affine_to_bytes<Secp256k1Fp>(mac_out, h_xyzz_to_affine<Secp256k1Fp>(h_scalar_mul<Secp256k1Fp>(h_affine_from_bytes<Secp256k1Fp>(mac_in), k)));
+    }
+    return PORLA_OK;
 }
 
 int porla_fixed_base_create(int curve, const uint8_t* points, size_t n_points, int window_bits, porla_fixed_base** out) {

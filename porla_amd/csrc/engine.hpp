@@ -182,6 +182,9 @@ int get_workspace_slot(int slot, Workspace** out);  // takes g_ws_mu itself
 int lease_blocking_slot(Workspace** out);           // slot 0, or a free pool slot when it is busy; returned LOCKED (ws->mu)
 hipStream_t engine_stream();  // this device's engine-owned non-blocking stream
 
+// icc.hip: wt = w^reverse_bits(write_step % n_total, height - 1) mod p_icc as a 32-byte big-endian integer (the MAC-side scalar of
+// Server::HAdd / Client::HAdd / CRebuild's Y halves)
+int icc_wt_scalar_be(size_t n_total, unsigned long long write_step, uint8_t out[32]);
 // icc.hip: the ICC butterfly network as an n x n matrix of 32-byte big-endian coefficients mod the group order
 int icc_network_matrix_device(int curve, size_t n, unsigned long long write_step, int part, uint8_t* d_rows_out,
                               hipStream_t stream);

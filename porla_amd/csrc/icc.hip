@@ -6,6 +6,9 @@
 #include "icc_host.hpp"
 
 #include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
 #include <vector>
 
 namespace porla {
@@ -16,13 +19,15 @@ struct IccWs {
     uint32_t tw_n = 0;
     int tw_curve = -1;
     UseFence fence;   // work / twiddle buffers are shared between calls that may come on different streams
+    std::mutex mu;    // one encode at a time per device (the column-range splitter runs one host thread per device)
 };
-static std::mutex g_icc_mu;
+static std::mutex g_icc_mu;    // the registry only
 static std::vector<IccWs*> g_icc_ws;
 
 static int get_icc_ws(IccWs** out) {
     int dev = 0;
     PORLA_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_icc_mu);
     for (auto* w : g_icc_ws) if (w->device == dev) { *out = w; return PORLA_OK; }
     IccWs* w = new IccWs();
     w->device = dev;
@@ -68,6 +73,42 @@ static int icc_mix_core(IccWs* ws, int curve, const uint8_t* d_a0, const uint8_t
     return ws->fence.leave(stream);
 }
 
+// wt = w^reverse_bits(write_step % N, height - 1) (Server.hpp:1391, 1494; Client.hpp:998, 1043) as the residue pair the data side
+// multiplies by, and -- plain_be -- as the 32-byte big-endian integer the MAC side uses as a scalar (convert_ZZ_to_scalar)
+template <class Q>
+static IccElem<Q> icc_wt(size_t n, unsigned long long write_step, uint8_t* plain_be) {
+    const int logn = ilog2u(n);
+    const int height = logn + 1;
+    Fe<IccFp> w = icc_root(n);
+    uint64_t ex = rev_bits(write_step % n, height - 1);
+    uint32_t e[8] = {(uint32_t)ex, (uint32_t)(ex >> 32), 0, 0, 0, 0, 0, 0};
+    IccElem<Q> wt;
+    wt.p = h_fe_pow<IccFp>(w, e);
+    Fe<IccFp> plain = fe_from_mont<IccFp>(wt.p);
+    if (plain_be)
+        for (int k = 0; k < 8; k++)
+            for (int b = 0; b < 4; b++) plain_be[31 - (4 * k + b)] = (uint8_t)(plain.v[k] >> (8 * b));
+    Fe<Q> tq;
+    for (int k = 0; k < 8; k++) tq.v[k] = plain.v[k];
+    fe_reduce_plain<Q>(tq.v, 8);
+    wt.q = fe_to_mont<Q>(tq);
+    return wt;
+}
+
+// data side of Server::HAdd on `total` chunks (Server.hpp:1396-1398 data_B2[i] *= wt, then align_MAC's scalar part, :531-541):
+// element-wise, no butterfly -- the load and finish steps of the encode with nothing in between
+template <class Q>
+static int icc_scale_align_core(IccWs* ws, const uint8_t* d_in, size_t total, size_t n_total, unsigned long long write_step,
+                                IccOut out, uint8_t* wt_plain_be, hipStream_t stream) {
+    int rc;
+    if ((rc = ws->work.ensure(total * sizeof(IccElem<Q>)))) return rc;
+    IccElem<Q> wt = icc_wt<Q>(n_total, write_step, wt_plain_be);
+    hipLaunchKernelGGL((k_icc_load<Q>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, d_in, (IccElem<Q>*)ws->work.p, total, wt, 1);
+    hipLaunchKernelGGL((k_icc_finish<Q>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const IccElem<Q>*)ws->work.p, total, out);
+    PORLA_HIP(hipGetLastError());
+    return PORLA_OK;
+}
+
 template <class Q>
 static int icc_encode_core(IccWs* ws, int curve, const uint8_t* d_rows, size_t n, size_t ncols, unsigned long long write_step,
                            int part, uint8_t* d_x, uint8_t* d_al, uint8_t* d_sc, int scalar_le, hipStream_t stream,
@@ -81,24 +122,12 @@ static int icc_encode_core(IccWs* ws, int curve, const uint8_t* d_rows, size_t n
     int rc;
     if ((rc = ws->work.ensure(total * sizeof(IccElem<Q>)))) return rc;
     if ((rc = ensure_twiddles<Q>(ws, curve, n, stream))) return rc;
-    Fe<IccFp> w = icc_root(n);
     // ---- init scaling: wt = w^reverse_bits(write_step % N, height-1) for the Y part (Server.hpp:1494), 1 for X
     IccElem<Q> wt;
     wt.p = fe_one<IccFp>();
     wt.q = fe_one<Q>();
     int use_wt = 0;
-    if (part == 1) {
-        const int height = logn + 1;
-        uint64_t ex = rev_bits(write_step % n, height - 1);
-        uint32_t e[8] = {(uint32_t)ex, (uint32_t)(ex >> 32), 0, 0, 0, 0, 0, 0};
-        wt.p = h_fe_pow<IccFp>(w, e);
-        Fe<IccFp> plain = fe_from_mont<IccFp>(wt.p);
-        Fe<Q> tq;
-        for (int k = 0; k < 8; k++) tq.v[k] = plain.v[k];
-        fe_reduce_plain<Q>(tq.v, 8);
-        wt.q = fe_to_mont<Q>(tq);
-        use_wt = 1;
-    }
+    if (part == 1) { wt = icc_wt<Q>(n, write_step, nullptr); use_wt = 1; }
     static const int fused = !(getenv("PORLA_ICC_FUSED") && getenv("PORLA_ICC_FUSED")[0] == '0');
     IccOut out{d_x, d_al, d_sc, d_qres, scalar_le};
     if (fused) {
@@ -169,15 +198,22 @@ static int icc_encode_dispatch(IccWs* ws, int curve, const uint8_t* d_rows, size
     return ws->fence.leave(stream);
 }
 
+int icc_wt_scalar_be(size_t n_total, unsigned long long write_step, uint8_t out[32]) {
+    const int ln = ilog2u(n_total);
+    if (n_total < 2 || ((size_t)1 << ln) != n_total || !out) { set_last_error("porla: n_total must be a power of two >= 2"); return PORLA_ERR_ARG; }
+    (void)icc_wt<IccBn254Fr>(n_total, write_step, out);
+    return PORLA_OK;
+}
+
 // The butterfly network as a matrix over Z_q: row k = the coefficients F[k][0..n) with out_k = sum_i F[k][i] * in_i
 // (part 1: inputs pre-scaled by wt), 32-byte big-endian each -- the data-side encode applied to the N x N identity.
 int icc_network_matrix_device(int curve, size_t n, unsigned long long write_step, int part, uint8_t* d_rows_out,
                               hipStream_t stream) {
     int rc = ensure_device();
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(g_icc_mu);
     IccWs* ws;
     if ((rc = get_icc_ws(&ws))) return rc;
+    std::lock_guard<std::mutex> lk(ws->mu);
     if ((rc = ws->in.ensure(n * n * 32))) return rc;
     if ((rc = ws->fence.enter(stream))) return rc;
     PORLA_HIP(hipMemsetAsync(ws->in.p, 0, n * n * 32, stream));
@@ -197,36 +233,154 @@ int porla_icc_encode_device(const void* d_rows_in, size_t n_rows, size_t n_cols,
     int rc = ensure_device();
     if (rc) return rc;
     if (!d_rows_in) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
-    std::lock_guard<std::mutex> lk(g_icc_mu);
     IccWs* ws;
     if ((rc = get_icc_ws(&ws))) return rc;
+    std::lock_guard<std::mutex> lk(ws->mu);
     return icc_encode_dispatch(ws, curve, (const uint8_t*)d_rows_in, n_rows, n_cols, write_step, part, (uint8_t*)d_x_out,
                                (uint8_t*)d_aligned_out, (uint8_t*)d_scalars_out, scalar_le, (hipStream_t)stream);
 }
 
-int porla_icc_encode_host(const uint8_t* rows_in, size_t n_rows, size_t n_cols, int curve, unsigned long long write_step,
-                          int part, uint8_t* x_out, uint8_t* aligned_out, uint8_t* scalars_out, int scalar_le) {
+// columns [c0, c1) of row-major host rows: strided upload into a compact n_rows x (c1 - c0) image, encode, strided download into
+// the callers' full-width outputs (only those columns are written)
+static int icc_encode_cols_host(const uint8_t* rows_in, size_t n_rows, size_t n_cols, size_t c0, size_t c1, int curve,
+                                unsigned long long write_step, int part, uint8_t* x_out, uint8_t* aligned_out, uint8_t* scalars_out,
+                                int scalar_le) {
     int rc = ensure_device();
     if (rc) return rc;
-    if (!rows_in) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
-    std::lock_guard<std::mutex> lk(g_icc_mu);
+    if (!rows_in || c0 >= c1 || c1 > n_cols) { set_last_error("porla: bad argument (null rows or empty / out-of-range column range)"); return PORLA_ERR_ARG; }
     IccWs* ws;
     if ((rc = get_icc_ws(&ws))) return rc;
-    const size_t total = n_rows * n_cols;
+    std::lock_guard<std::mutex> lk(ws->mu);
+    const size_t nc = c1 - c0, total = n_rows * nc;
     if ((rc = ws->in.ensure(total * 32))) return rc;
     if (x_out && (rc = ws->xo.ensure(total * 64))) return rc;
     if (aligned_out && (rc = ws->al.ensure(total * 32))) return rc;
     if (scalars_out && (rc = ws->sc.ensure(total * 32))) return rc;
-    hipStream_t s = nullptr;
-    PORLA_HIP(hipMemcpyAsync(ws->in.p, rows_in, total * 32, hipMemcpyHostToDevice, s));
-    rc = icc_encode_dispatch(ws, curve, (const uint8_t*)ws->in.p, n_rows, n_cols, write_step, part,
+    hipStream_t s = engine_stream();
+    if ((rc = ws->fence.enter(s))) return rc;
+    PORLA_HIP(hipMemcpy2DAsync(ws->in.p, nc * 32, rows_in + c0 * 32, n_cols * 32, nc * 32, n_rows, hipMemcpyHostToDevice, s));
+    rc = icc_encode_dispatch(ws, curve, (const uint8_t*)ws->in.p, n_rows, nc, write_step, part,
                              x_out ? (uint8_t*)ws->xo.p : nullptr, aligned_out ? (uint8_t*)ws->al.p : nullptr,
                              scalars_out ? (uint8_t*)ws->sc.p : nullptr, scalar_le, s);
     if (rc) return rc;
-    if (x_out) PORLA_HIP(hipMemcpyAsync(x_out, ws->xo.p, total * 64, hipMemcpyDeviceToHost, s));
-    if (aligned_out) PORLA_HIP(hipMemcpyAsync(aligned_out, ws->al.p, total * 32, hipMemcpyDeviceToHost, s));
-    if (scalars_out) PORLA_HIP(hipMemcpyAsync(scalars_out, ws->sc.p, total * 32, hipMemcpyDeviceToHost, s));
+    if (x_out) PORLA_HIP(hipMemcpy2DAsync(x_out + c0 * 64, n_cols * 64, ws->xo.p, nc * 64, nc * 64, n_rows, hipMemcpyDeviceToHost, s));
+    if (aligned_out) PORLA_HIP(hipMemcpy2DAsync(aligned_out + c0 * 32, n_cols * 32, ws->al.p, nc * 32, nc * 32, n_rows, hipMemcpyDeviceToHost, s));
+    if (scalars_out) PORLA_HIP(hipMemcpy2DAsync(scalars_out + c0 * 32, n_cols * 32, ws->sc.p, nc * 32, nc * 32, n_rows, hipMemcpyDeviceToHost, s));
     PORLA_HIP(hipStreamSynchronize(s));
+    return PORLA_OK;
+}
+
+int porla_icc_encode_host(const uint8_t* rows_in, size_t n_rows, size_t n_cols, int curve, unsigned long long write_step,
+                          int part, uint8_t* x_out, uint8_t* aligned_out, uint8_t* scalars_out, int scalar_le) {
+    return icc_encode_cols_host(rows_in, n_rows, n_cols, 0, n_cols, curve, write_step, part, x_out, aligned_out, scalars_out, scalar_le);
+}
+
+int porla_icc_encode_cols_host(const uint8_t* rows_in, size_t n_rows, size_t n_cols, size_t col_begin, size_t col_end, int curve,
+                               unsigned long long write_step, int part, uint8_t* x_out, uint8_t* aligned_out, uint8_t* scalars_out,
+                               int scalar_le) {
+    return icc_encode_cols_host(rows_in, n_rows, n_cols, col_begin, col_end, curve, write_step, part, x_out, aligned_out, scalars_out,
+                                scalar_le);
+}
+
+// the reference splits the columns of a stage over its 8 pool threads (Server.hpp:1564-1686); here device g of `devices`
+// takes the column block [g C / G, (g+1) C / G) -- 16 columns each for 128 columns on 8 GPUs -- from its own
+// host thread: the 128 transforms are independent, nothing is exchanged
+int porla_icc_encode_host_multi(const uint8_t* rows_in, size_t n_rows, size_t n_cols, int curve, unsigned long long write_step,
+                                int part, uint8_t* x_out, uint8_t* aligned_out, uint8_t* scalars_out, int scalar_le, int devices) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    int visible = 0, first = 0;
+    PORLA_HIP(hipGetDeviceCount(&visible));
+    PORLA_HIP(hipGetDevice(&first));
+    int G = devices <= 0 ? visible : (devices < visible ? devices : visible);
+    if ((size_t)G > n_cols) G = (int)n_cols;
+    if (G < 1) G = 1;
+    std::vector<int> rcs((size_t)G, PORLA_OK);
+    std::vector<std::string> errs((size_t)G);
+    auto worker = [&](int g) {
+        if (hipSetDevice((first + g) % visible) != hipSuccess) { rcs[g] = PORLA_ERR_HIP; errs[g] = "porla: hipSetDevice failed"; return; }
+        size_t col_begin, col_end;
+        porla_shard_range(n_cols, g, G, &col_begin, &col_end);
+        rcs[g] = icc_encode_cols_host(rows_in, n_rows, n_cols, col_begin, col_end, curve, write_step, part, x_out, aligned_out, scalars_out, scalar_le);
+        if (rcs[g]) errs[g] = porla_gpu_last_error();
+    };
+    std::vector<std::thread> th;
+    for (int g = 1; g < G; g++) th.emplace_back(worker, g);
+    worker(0);
+    for (auto& t : th) t.join();
+    if (G > 1) (void)hipSetDevice(first);
+    for (int g = 0; g < G; g++) if (rcs[g]) { set_last_error(errs[g]); return rcs[g]; }
+    return PORLA_OK;
+}
+
+// Server::HAdd, data side of one incoming block (Server.hpp:1388-1398 + align_MAC :531-541 / :495-504)
+int porla_icc_hadd_host(const uint8_t* data_in, size_t n_cols, size_t n_total, unsigned long long write_step, int curve,
+                        uint8_t* data_b2_out, uint8_t* scalars_out, int scalar_le, uint8_t wt_scalar_out[32]) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    const int ln = ilog2u(n_total);
+    if (!data_in || n_cols == 0 || n_total < 2 || ((size_t)1 << ln) != n_total || (curve != 0 && curve != 1)) {
+        set_last_error("porla: bad argument to porla_icc_hadd_host (n_total = num_blocks, a power of two >= 2)");
+        return PORLA_ERR_ARG;
+    }
+    IccWs* ws;
+    if ((rc = get_icc_ws(&ws))) return rc;
+    std::lock_guard<std::mutex> lk(ws->mu);
+    if ((rc = ws->in.ensure(n_cols * 32))) return rc;
+    if ((rc = ws->al.ensure(n_cols * 32))) return rc;
+    if ((rc = ws->sc.ensure(n_cols * 32))) return rc;
+    hipStream_t s = engine_stream();
+    if ((rc = ws->fence.enter(s))) return rc;
+    PORLA_HIP(hipMemcpyAsync(ws->in.p, data_in, n_cols * 32, hipMemcpyHostToDevice, s));
+    IccOut out{nullptr, data_b2_out ? (uint8_t*)ws->al.p : nullptr, scalars_out ? (uint8_t*)ws->sc.p : nullptr, nullptr, scalar_le};
+    rc = curve == 0 ? icc_scale_align_core<IccBn254Fr>(ws, (const uint8_t*)ws->in.p, n_cols, n_total, write_step, out, wt_scalar_out, s)
+                    : icc_scale_align_core<IccSecp256k1Fn>(ws, (const uint8_t*)ws->in.p, n_cols, n_total, write_step, out, wt_scalar_out, s);
+    if (rc) return rc;
+    if (data_b2_out) PORLA_HIP(hipMemcpyAsync(data_b2_out, ws->al.p, n_cols * 32, hipMemcpyDeviceToHost, s));
+    if (scalars_out) PORLA_HIP(hipMemcpyAsync(scalars_out, ws->sc.p, n_cols * 32, hipMemcpyDeviceToHost, s));
+    if ((rc = ws->fence.leave(s))) return rc;
+    PORLA_HIP(hipStreamSynchronize(s));
+    return PORLA_OK;
+}
+
+// Server::HRebuildX / HRebuildY, data part (Server.hpp:1329-1386): the chain of mixes that carries an incoming block up to `level`.
+// levels[i] (i <= level) points at level i's rows: 2 * 2^i rows of n_cols 64-byte symbols, the first 2^i resident, the second 2^i
+// incoming (levels[0][1] = the new block); step i mixes the two halves of level i into the incoming half of level i + 1, and at
+// the end level `level`'s incoming half becomes its resident half -- all on the device, one call instead of `level` mix calls.
+int porla_icc_hrebuild_host(uint8_t* const* levels, int level, size_t n_cols, size_t n_total, int curve) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    const int ln = ilog2u(n_total);
+    if (!levels || level < 0 || level > 30 || n_cols == 0 || n_total < 2 || ((size_t)1 << ln) != n_total || ((size_t)1 << level) > n_total ||
+        (curve != 0 && curve != 1)) {
+        set_last_error("porla: bad argument to porla_icc_hrebuild_host");
+        return PORLA_ERR_ARG;
+    }
+    for (int i = 0; i <= level; i++) if (!levels[i]) { set_last_error("porla: null level"); return PORLA_ERR_ARG; }
+    const size_t row = n_cols * 64, top = (size_t)1 << level;
+    if (level > 0) {
+        void *d_a0 = nullptr, *d_cur = nullptr, *d_next = nullptr;
+        PORLA_HIP(hipMalloc(&d_a0, (top / 2) * row));
+        hipError_t e1 = hipMalloc(&d_cur, top * row), e2 = hipMalloc(&d_next, top * row);
+        if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipFree(d_a0); (void)hipFree(d_cur); (void)hipFree(d_next); return hip_fail(e1 != hipSuccess ? e1 : e2, "hipMalloc", __FILE__, __LINE__); }
+        hipStream_t s = engine_stream();
+        hipError_t e = hipMemcpyAsync(d_cur, levels[0] + row, row, hipMemcpyHostToDevice, s);
+        rc = e == hipSuccess ? PORLA_OK : hip_fail(e, "hipMemcpyAsync", __FILE__, __LINE__);
+        for (int i = 0; i < level && !rc; i++) {
+            const size_t len = (size_t)1 << i;
+            e = hipMemcpyAsync(d_a0, levels[i], len * row, hipMemcpyHostToDevice, s);
+            if (e != hipSuccess) { rc = hip_fail(e, "hipMemcpyAsync", __FILE__, __LINE__); break; }
+            if ((rc = porla_icc_mix_device(d_a0, d_cur, len, n_cols, n_total, curve, d_next, s))) break;
+            e = hipMemcpyAsync(levels[i + 1] + 2 * len * row, d_next, 2 * len * row, hipMemcpyDeviceToHost, s);
+            if (e != hipSuccess) { rc = hip_fail(e, "hipMemcpyAsync", __FILE__, __LINE__); break; }
+            void* t = d_cur; d_cur = d_next; d_next = t;
+        }
+        hipError_t es = hipStreamSynchronize(s);
+        (void)hipFree(d_a0); (void)hipFree(d_cur); (void)hipFree(d_next);
+        if (rc) return rc;
+        if (es != hipSuccess) return hip_fail(es, "hipStreamSynchronize", __FILE__, __LINE__);
+    }
+    memcpy(levels[level], levels[level] + top * row, top * row);
     return PORLA_OK;
 }
 
@@ -240,9 +394,9 @@ int porla_icc_mix_device(const void* d_a0, const void* d_a1, size_t len, size_t 
         set_last_error("porla: bad argument to porla_icc_mix_device (len and n_total must be powers of two, len <= n_total)");
         return PORLA_ERR_ARG;
     }
-    std::lock_guard<std::mutex> lk(g_icc_mu);
     IccWs* ws;
     if ((rc = get_icc_ws(&ws))) return rc;
+    std::lock_guard<std::mutex> lk(ws->mu);
     if (curve == 0) return icc_mix_core<IccBn254Fr>(ws, 0, (const uint8_t*)d_a0, (const uint8_t*)d_a1, len, n_cols, n_total, (uint8_t*)d_out, (hipStream_t)hip_stream);
     return icc_mix_core<IccSecp256k1Fn>(ws, 1, (const uint8_t*)d_a0, (const uint8_t*)d_a1, len, n_cols, n_total, (uint8_t*)d_out, (hipStream_t)hip_stream);
 }

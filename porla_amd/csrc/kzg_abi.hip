@@ -17,6 +17,7 @@
 #include <mutex>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace porla;
@@ -52,16 +53,21 @@ struct KzgState {
     uint8_t tau_raw[32] = {0};    // big.Int of the raw key bytes, reduced mod r, big-endian
     long long n_samples = 0;
     std::vector<Affine<Fp>> srs;  // SRS.G1, Montgomery form (host copy)
-    Affine<Fp>* d_srs = nullptr;  // resident copy in HBM
-    size_t d_srs_cap = 0;
-    int d_srs_device = -1;
-    bool d_srs_dirty = true;      // host copy changed since the last upload
-    FixedBase<Bn254G1> fb;        // window-multiples table of the SRS (fixed_base.cuh), rebuilt when the SRS changes
+    unsigned long long version = 1;   // bumped whenever the SRS, the hiding base or the table window changes
     int commit_window = 0;        // 0 = automatic
-    FixedBase<Bn254G1> fb_g, fb_h;   // one-point tables of G1[0] and of the MAC hiding base (client-side batches)
-    bool fb_g_dirty = true, fb_h_dirty = true;
-    void* d_eval = nullptr;       // scratch: evaluated scalars of a digest batch
-    size_t d_eval_cap = 0;
+    // HBM copies, one set per device that has been used (the row-range splitter of porla_kzg_commit_batch_host_multi runs one
+    // host thread per device; a process pinned to one GPU only ever creates its own)
+    struct Dev {
+        int device = -1;
+        Affine<Fp>* d_srs = nullptr;  // resident Montgomery copy of the SRS
+        size_t d_srs_cap = 0;
+        unsigned long long srs_version = 0, g_version = 0, h_version = 0;   // what the tables below were built from
+        FixedBase<Bn254G1> fb;        // window-multiples table of the SRS (fixed_base.cuh)
+        FixedBase<Bn254G1> fb_g, fb_h;   // one-point tables of G1[0] and of the MAC hiding base (client-side batches)
+        void* d_eval = nullptr;       // scratch: evaluated scalars of a digest batch
+        size_t d_eval_cap = 0;
+    };
+    Dev* devs[16] = {nullptr};
     bool have_g2 = false;
     G2Affine g2[2];               // SRS.G2[0], SRS.G2[1]
     Affine<Fp> h_mac;             // MAC hiding base (main.go:28,58-59)
@@ -93,32 +99,37 @@ Affine<Fp> unmarshal64(const uint8_t* b) {
 
 void fr_plain_be(uint8_t out[32], const Fe<Fr>& a) { h_fe_to_be<Fr>(out, a); }
 
-// upload the SRS to HBM in Montgomery form (done once per init; the base is then resident)
-int upload_srs() {
+// the current device's copies (g.mu held)
+int current_dev(KzgState::Dev** out) {
     int rc = ensure_device();
     if (rc) return rc;
     int dev = 0;
     PORLA_HIP(hipGetDevice(&dev));
-    size_t bytes = g.srs.size() * sizeof(Affine<Fp>);
-    if (g.d_srs && (g.d_srs_cap < bytes || g.d_srs_device != dev)) { PORLA_HIP(hipFree(g.d_srs)); g.d_srs = nullptr; }
-    if (!g.d_srs) { PORLA_HIP(hipMalloc((void**)&g.d_srs, bytes ? bytes : 64)); g.d_srs_cap = bytes; g.d_srs_device = dev; }
-    PORLA_HIP(hipMemcpy(g.d_srs, g.srs.data(), bytes, hipMemcpyHostToDevice));
+    if (dev < 0 || dev >= 16) { set_last_error("porla: device index out of range"); return PORLA_ERR_ARG; }
+    if (!g.devs[dev]) { g.devs[dev] = new KzgState::Dev(); g.devs[dev]->device = dev; }
+    *out = g.devs[dev];
     return PORLA_OK;
 }
 
-// make the HBM copies (Montgomery SRS + its window-multiples table) current; g.mu held by the caller
-int refresh_srs_locked() {
-    if (!g.d_srs_dirty) return PORLA_OK;
-    if (g.srs.empty()) return PORLA_ERR_STATE;
-    int rc = upload_srs();
+// make this device's HBM copies (Montgomery SRS + its window-multiples table) current; g.mu held by the caller
+int refresh_srs_locked(KzgState::Dev** out) {
+    KzgState::Dev* kd;
+    int rc = current_dev(&kd);
     if (rc) return rc;
+    *out = kd;
+    if (kd->srs_version == g.version) return PORLA_OK;
+    if (g.srs.empty()) return PORLA_ERR_STATE;
+    const size_t bytes = g.srs.size() * sizeof(Affine<Fp>);
+    if (kd->d_srs && kd->d_srs_cap < bytes) { PORLA_HIP(hipFree(kd->d_srs)); kd->d_srs = nullptr; }
+    if (!kd->d_srs) { PORLA_HIP(hipMalloc((void**)&kd->d_srs, bytes ? bytes : 64)); kd->d_srs_cap = bytes; }
+    PORLA_HIP(hipMemcpy(kd->d_srs, g.srs.data(), bytes, hipMemcpyHostToDevice));
     hipStream_t s = engine_stream();
     {
-        std::lock_guard<std::mutex> lk(g.fb.mu);
-        rc = g.fb.build(g.d_srs, g.srs.size(), g.commit_window, s);
+        std::lock_guard<std::mutex> lk(kd->fb.mu);
+        rc = kd->fb.build(kd->d_srs, g.srs.size(), g.commit_window, s);
     }
     if (rc) return rc;
-    g.d_srs_dirty = false;
+    kd->srs_version = g.version;
     return PORLA_OK;
 }
 
@@ -128,16 +139,17 @@ int commit_rows(const uint8_t* rows, bool device_ptrs, size_t n_rows, size_t len
     // init_SRS_from_data / porla_kzg_set_commit_window nor porla_kzg_release_device_memory can rebuild or free the table between
     // the checks and the commit (compute_digest_from_srs comes from 8 pool threads, Server.hpp:550-560)
     std::unique_lock<std::mutex> lk(g.mu);
-    int rc = refresh_srs_locked();
+    KzgState::Dev* kd = nullptr;
+    int rc = refresh_srs_locked(&kd);
     if (rc) {
         if (rc == PORLA_ERR_STATE) set_last_error("porla: SRS not initialised (call init_SRS / init_SRS_from_data first)");
         return rc;
     }
     if (len > g.srs.size()) { set_last_error("porla: more coefficients than SRS points"); return PORLA_ERR_STATE; }
-    std::unique_lock<std::mutex> lkfb(g.fb.mu);
+    std::unique_lock<std::mutex> lkfb(kd->fb.mu);
     lk.unlock();
-    if (device_ptrs) return g.fb.commit_device(rows, n_rows, len, len * 32, out, stream);
-    return g.fb.commit_host(rows, n_rows, len, len * 32, out, engine_stream());
+    if (device_ptrs) return kd->fb.commit_device(rows, n_rows, len, len * 32, out, stream);
+    return kd->fb.commit_host(rows, n_rows, len, len * 32, out, engine_stream());
 }
 
 // compute_digest_from_srs arrives ONE row per call from up to 8 pool threads at once (Server.hpp:550-560, 1054-1078, 1530-1535):
@@ -170,20 +182,21 @@ int commit_coalesced(const uint8_t* row, uint8_t out[64]) {
         std::string err;
         {
             std::unique_lock<std::mutex> ls(g.mu);
-            rc = refresh_srs_locked();
+            KzgState::Dev* kd = nullptr;
+            rc = refresh_srs_locked(&kd);
             const size_t len = (size_t)g.n_samples;
             if (rc == PORLA_ERR_STATE) set_last_error("porla: SRS not initialised (call init_SRS / init_SRS_from_data first)");
             if (!rc && len > g.srs.size()) { set_last_error("porla: more coefficients than SRS points"); rc = PORLA_ERR_STATE; }
             if (!rc) {
-                std::unique_lock<std::mutex> lf(g.fb.mu);
+                std::unique_lock<std::mutex> lf(kd->fb.mu);
                 ls.unlock();
                 const uint8_t* rp[FB_SMALL_MAX_ROWS];
                 uint8_t* op[FB_SMALL_MAX_ROWS];
                 for (size_t i = 0; i < batch.size(); i++) { rp[i] = batch[i]->row; op[i] = batch[i]->out; }
                 if (FixedBase<Bn254G1>::small_ok(batch.size(), len)) {
-                    rc = g.fb.commit_small(rp, batch.size(), len, op, engine_stream());
+                    rc = kd->fb.commit_small(rp, batch.size(), len, op, engine_stream());
                 } else {
-                    for (size_t i = 0; i < batch.size() && !rc; i++) rc = g.fb.commit_host(rp[i], 1, len, len * 32, op[i], engine_stream());
+                    for (size_t i = 0; i < batch.size() && !rc; i++) rc = kd->fb.commit_host(rp[i], 1, len, len * 32, op[i], engine_stream());
                 }
             }
             if (rc) err = porla_gpu_last_error();
@@ -255,8 +268,7 @@ void init_SRS(GoInt SRS_size, GoSlice* out, GoInt64* out_len) {
     h_fe_to_plain<Fr>(k, rnd);
     g.h_mac = h_xyzz_to_affine<Fp>(h_scalar_mul<Fp>(g.srs[0], k));
 
-    g.d_srs_dirty = true;  // uploaded to HBM on first use by a commit (the client side never needs the GPU)
-    g.fb_g_dirty = g.fb_h_dirty = true;
+    g.version++;  // the HBM copies are rebuilt on first use by a commit (the client side never needs the GPU)
 }
 
 // main.go:62-68: SRS.ReadFrom
@@ -279,8 +291,7 @@ void init_SRS_from_data(GoInt SRS_size, GoSlice* in) {
     if (len >= 4 + 32 * cnt + 128) {
         g.have_g2 = g2_decompress(b + 4 + 32 * cnt, &g.g2[0]) && g2_decompress(b + 4 + 32 * cnt + 64, &g.g2[1]);
     }
-    g.d_srs_dirty = true;
-    g.fb_g_dirty = true;
+    g.version++;
 }
 
 // main.go:70-89: alpha * f(tau) * G1[0] -- Horner over Fr and ONE scalar multiplication (host)
@@ -465,14 +476,14 @@ int porla_bn254_pairing_product_is_one(const uint8_t p1[64], const uint8_t q1[12
 }
 
 // ---- client side, batched: compute_digest (main.go:70-89) and compute_digest_complement (main.go:91-101) over many rows ----
-static int one_point_table(FixedBase<Bn254G1>& fb, bool& dirty, const Affine<Fp>& point) {
-    if (!dirty) return PORLA_OK;
+static int one_point_table(FixedBase<Bn254G1>& fb, unsigned long long& built_version, const Affine<Fp>& point) {
+    if (built_version == g.version) return PORLA_OK;
     uint8_t be[64];
     h_affine_to_bytes<Fp>(be, point);
     std::lock_guard<std::mutex> lk(fb.mu);
     int rc = fb.build_from_host_bytes(be, 1, 0, engine_stream());
     if (rc) return rc;
-    dirty = false;
+    built_version = g.version;
     return PORLA_OK;
 }
 
@@ -483,24 +494,26 @@ int porla_kzg_digest_batch_device(const void* d_rows, size_t n_rows, void* d_out
     std::lock_guard<std::mutex> lk(g.mu);
     if (!g.have_key || g.srs.empty()) { set_last_error("porla: init_key / init_SRS first"); return PORLA_ERR_STATE; }
     if (n_rows == 0) return PORLA_OK;
-    if ((rc = one_point_table(g.fb_g, g.fb_g_dirty, g.srs[0]))) return rc;
-    if (g.d_eval_cap < n_rows * 32) {
-        if (g.d_eval) PORLA_HIP(hipFree(g.d_eval));
-        g.d_eval = nullptr; g.d_eval_cap = 0;
-        PORLA_HIP(hipMalloc(&g.d_eval, n_rows * 32 + 256));
-        g.d_eval_cap = n_rows * 32 + 256;
-    }
+    KzgState::Dev* kd;
+    if ((rc = current_dev(&kd))) return rc;
+    if ((rc = one_point_table(kd->fb_g, kd->g_version, g.srs[0]))) return rc;
     hipStream_t stream = (hipStream_t)hip_stream;
-    std::lock_guard<std::mutex> lk2(g.fb_g.mu);
+    std::lock_guard<std::mutex> lk2(kd->fb_g.mu);
+    if (kd->d_eval_cap < n_rows * 32) {
+        if (kd->d_eval) PORLA_HIP(hipFree(kd->d_eval));      // hipFree waits for the work that still uses it
+        kd->d_eval = nullptr; kd->d_eval_cap = 0;
+        PORLA_HIP(hipMalloc(&kd->d_eval, n_rows * 32 + 256));
+        kd->d_eval_cap = n_rows * 32 + 256;
+    }
     // d_eval is read by the commit below: a previous batch on another stream must have finished with it (the table's fence
     // is recorded after that commit's last kernel)
-    if ((rc = g.fb_g.fence.enter(stream))) return rc;
+    if ((rc = kd->fb_g.fence.enter(stream))) return rc;
     {
         ProfScope ps("kzg_eval_rows", stream);
         hipLaunchKernelGGL(k_kzg_eval_rows, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, (const uint8_t*)d_rows,
-                           (uint32_t)n_rows, (uint32_t)g.n_samples, g.tau, g.alpha, (uint8_t*)g.d_eval);
+                           (uint32_t)n_rows, (uint32_t)g.n_samples, g.tau, g.alpha, (uint8_t*)kd->d_eval);
     }
-    return g.fb_g.commit_device((const uint8_t*)g.d_eval, n_rows, 1, 32, (uint8_t*)d_out, stream);
+    return kd->fb_g.commit_device((const uint8_t*)kd->d_eval, n_rows, 1, 32, (uint8_t*)d_out, stream);
 }
 
 int porla_kzg_complement_batch_device(const void* d_scalars, size_t n, void* d_out, void* hip_stream) {
@@ -510,9 +523,11 @@ int porla_kzg_complement_batch_device(const void* d_scalars, size_t n, void* d_o
     std::lock_guard<std::mutex> lk(g.mu);
     if (g.srs.empty()) { set_last_error("porla: init_SRS first (it draws the MAC hiding base)"); return PORLA_ERR_STATE; }
     if (n == 0) return PORLA_OK;
-    if ((rc = one_point_table(g.fb_h, g.fb_h_dirty, g.h_mac))) return rc;
-    std::lock_guard<std::mutex> lk2(g.fb_h.mu);
-    return g.fb_h.commit_device((const uint8_t*)d_scalars, n, 1, 32, (uint8_t*)d_out, (hipStream_t)hip_stream);
+    KzgState::Dev* kd;
+    if ((rc = current_dev(&kd))) return rc;
+    if ((rc = one_point_table(kd->fb_h, kd->h_version, g.h_mac))) return rc;
+    std::lock_guard<std::mutex> lk2(kd->fb_h.mu);
+    return kd->fb_h.commit_device((const uint8_t*)d_scalars, n, 1, 32, (uint8_t*)d_out, (hipStream_t)hip_stream);
 }
 
 // ---- batched form of compute_digest_from_srs (include/porla_gpu.h) ----
@@ -528,9 +543,55 @@ int porla_kzg_commit_batch_host(const uint8_t* rows, size_t n_rows, uint8_t* out
     if (rc) return rc;
     return commit_rows(rows, false, n_rows, (size_t)g.n_samples, out, nullptr);
 }
+// Server::HAdd for the KZG build, everything it computes before the level bookkeeping (Server.hpp:1388-1428): data_B2 = data * wt
+// aligned mod p_icc, MAC_B2 = wt * MAC, MAC_align_B2 = Commit(alignment scalars of data_B2) -- align_MAC's compute_digest_from_srs
+// (Server.hpp:531-560) on the scalars the device derived.  n_cols = NUM_CHUNKS = the SRS size.
+int porla_kzg_hadd_host(const uint8_t* data_in, const uint8_t mac_in[64], size_t n_total, unsigned long long write_step,
+                        uint8_t* data_b2_out, uint8_t mac_b2_out[64], uint8_t mac_align_b2_out[64]) {
+    if (!data_in || !mac_in || !data_b2_out || !mac_b2_out || !mac_align_b2_out) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    const size_t n_cols = (size_t)g.n_samples;
+    if (n_cols == 0) { set_last_error("porla: SRS not initialised"); return PORLA_ERR_STATE; }
+    std::vector<uint8_t> scalars(32 * n_cols);
+    uint8_t wt[32];
+    int rc = porla_icc_hadd_host(data_in, n_cols, n_total, write_step, 0, data_b2_out, scalars.data(), 0, wt);
+    if (rc) return rc;
+    if ((rc = porla_icc_mac_scale_host(mac_in, n_total, write_step, 0, mac_b2_out))) return rc;
+    return commit_coalesced(scalars.data(), mac_align_b2_out);      // infinity + Commit(c) (bn254_add(B, align_value), B = infinity)
+}
+
+// rows are independent: device g of `devices` commits the row range [g R / G, (g+1) R / G) from its own host thread against its
+// own resident copy of the SRS table; the results land in the caller's `out`, nothing is exchanged
+int porla_kzg_commit_batch_host_multi(const uint8_t* rows, size_t n_rows, uint8_t* out, int devices) {
+    if (n_rows && (!rows || !out)) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    int visible = 0, first = 0;
+    PORLA_HIP(hipGetDeviceCount(&visible));
+    PORLA_HIP(hipGetDevice(&first));
+    int G = devices <= 0 ? visible : (devices < visible ? devices : visible);
+    if ((size_t)G > n_rows) G = (int)n_rows;
+    if (G < 1) G = 1;
+    const size_t len = (size_t)g.n_samples;
+    std::vector<int> rcs((size_t)G, PORLA_OK);
+    std::vector<std::string> errs((size_t)G);
+    auto worker = [&](int d) {
+        if (hipSetDevice((first + d) % visible) != hipSuccess) { rcs[d] = PORLA_ERR_HIP; errs[d] = "porla: hipSetDevice failed"; return; }
+        size_t lo, hi;
+        porla_shard_range(n_rows, d, G, &lo, &hi);
+        rcs[d] = commit_rows(rows + lo * len * 32, false, hi - lo, len, out + 64 * lo, nullptr);
+        if (rcs[d]) errs[d] = porla_gpu_last_error();
+    };
+    std::vector<std::thread> th;
+    for (int d = 1; d < G; d++) th.emplace_back(worker, d);
+    worker(0);
+    for (auto& t : th) t.join();
+    if (G > 1) (void)hipSetDevice(first);
+    for (int d = 0; d < G; d++) if (rcs[d]) { set_last_error(errs[d]); return rcs[d]; }
+    return PORLA_OK;
+}
 int porla_kzg_set_commit_window(int window_bits) {
     std::lock_guard<std::mutex> lk(g.mu);
-    if (window_bits != g.commit_window) { g.commit_window = window_bits; g.d_srs_dirty = true; }
+    if (window_bits != g.commit_window) { g.commit_window = window_bits; g.version++; }
     return PORLA_OK;
 }
 // frees the HBM copies that belong to the KZG state (SRS, its window-multiples table -- 56 GB by default --, the one-point
@@ -539,23 +600,32 @@ int porla_kzg_release_device_memory(void) {
     // lock order as everywhere: the state, then the tables -- a commit that has dropped g.mu still holds its table's mutex
     // (compute_digest_from_srs is called from 8 pool threads, Server.hpp:550-560)
     std::lock_guard<std::mutex> lk(g.mu);
-    std::lock_guard<std::mutex> l1(g.fb.mu), l2(g.fb_g.mu), l3(g.fb_h.mu);
-    g.fb.release();
-    g.fb_g.release();
-    g.fb_h.release();
-    g.fb_g_dirty = g.fb_h_dirty = true;
-    if (g.d_srs) (void)hipFree(g.d_srs);
-    g.d_srs = nullptr; g.d_srs_cap = 0; g.d_srs_device = -1;
-    g.d_srs_dirty = true;
-    if (g.d_eval) (void)hipFree(g.d_eval);
-    g.d_eval = nullptr; g.d_eval_cap = 0;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (KzgState::Dev* kd : g.devs) {
+        if (!kd) continue;
+        std::lock_guard<std::mutex> l1(kd->fb.mu), l2(kd->fb_g.mu), l3(kd->fb_h.mu);
+        (void)hipSetDevice(kd->device);
+        kd->fb.release();
+        kd->fb_g.release();
+        kd->fb_h.release();
+        if (kd->d_srs) (void)hipFree(kd->d_srs);
+        kd->d_srs = nullptr; kd->d_srs_cap = 0;
+        if (kd->d_eval) (void)hipFree(kd->d_eval);
+        kd->d_eval = nullptr; kd->d_eval_cap = 0;
+        kd->srs_version = kd->g_version = kd->h_version = 0;
+    }
+    (void)hipSetDevice(cur);
     return PORLA_OK;
 }
 
 int porla_kzg_commit_shape(int* window_bits, int* windows) {
     std::lock_guard<std::mutex> lk(g.mu);
-    if (window_bits) *window_bits = g.fb.c;
-    if (windows) *windows = g.fb.W;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const KzgState::Dev* kd = dev >= 0 && dev < 16 ? g.devs[dev] : nullptr;
+    if (window_bits) *window_bits = kd ? kd->fb.c : 0;
+    if (windows) *windows = kd ? kd->fb.W : 0;
     return PORLA_OK;
 }
 

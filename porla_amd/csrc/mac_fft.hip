@@ -10,6 +10,7 @@
 // Patch site in the reference (no function boundary exists there): the MAC halves of Server::CRebuild_Cached,
 // porla/Server/Server.hpp:1523-1536, 1590-1609, 1658-1676 and the Y-part twins; see INTEGRATION.md.
 #include "engine.hpp"
+#include <cstring>
 #include "mac_fft.cuh"
 #include "icc_host.hpp"
 
@@ -224,6 +225,44 @@ int porla_icc_mac_mix_host(const uint8_t* a0, const uint8_t* a1, size_t len, siz
     (void)hipFree(d0); (void)hipFree(d1); (void)hipFree(dout);
     if (rc) return rc;
     if (e3 != hipSuccess) return hip_fail(e3, "hipMemcpy", __FILE__, __LINE__);
+    return PORLA_OK;
+}
+
+// MAC side of Server::HRebuildX / HRebuildY (MAC commitments and alignments, Server.hpp:1329-1386) and Client::HRebuildX / Y
+// (Client.hpp:978-994): the same chain as porla_icc_hrebuild_host on 64-byte affine points, Client::mix (Client.hpp:921-976) per step
+int porla_icc_mac_hrebuild_host(uint8_t* const* levels, int level, size_t n_total, int curve) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    const int ln = ilog2u(n_total);
+    if (!levels || level < 0 || level > 30 || n_total < 2 || ((size_t)1 << ln) != n_total || ((size_t)1 << level) > n_total || (curve != 0 && curve != 1)) {
+        set_last_error("porla: bad argument to porla_icc_mac_hrebuild_host");
+        return PORLA_ERR_ARG;
+    }
+    for (int i = 0; i <= level; i++) if (!levels[i]) { set_last_error("porla: null level"); return PORLA_ERR_ARG; }
+    const size_t row = 64, top = (size_t)1 << level;
+    if (level > 0) {
+        void *d_a0 = nullptr, *d_cur = nullptr, *d_next = nullptr;
+        PORLA_HIP(hipMalloc(&d_a0, (top / 2) * row));
+        hipError_t e1 = hipMalloc(&d_cur, top * row), e2 = hipMalloc(&d_next, top * row);
+        if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipFree(d_a0); (void)hipFree(d_cur); (void)hipFree(d_next); return hip_fail(e1 != hipSuccess ? e1 : e2, "hipMalloc", __FILE__, __LINE__); }
+        hipStream_t s = engine_stream();
+        hipError_t e = hipMemcpyAsync(d_cur, levels[0] + row, row, hipMemcpyHostToDevice, s);
+        rc = e == hipSuccess ? PORLA_OK : hip_fail(e, "hipMemcpyAsync", __FILE__, __LINE__);
+        for (int i = 0; i < level && !rc; i++) {
+            const size_t len = (size_t)1 << i;
+            e = hipMemcpyAsync(d_a0, levels[i], len * row, hipMemcpyHostToDevice, s);
+            if (e != hipSuccess) { rc = hip_fail(e, "hipMemcpyAsync", __FILE__, __LINE__); break; }
+            if ((rc = porla_icc_mac_mix_device(d_a0, d_cur, len, n_total, curve, d_next, s))) break;
+            e = hipMemcpyAsync(levels[i + 1] + 2 * len * row, d_next, 2 * len * row, hipMemcpyDeviceToHost, s);
+            if (e != hipSuccess) { rc = hip_fail(e, "hipMemcpyAsync", __FILE__, __LINE__); break; }
+            void* t = d_cur; d_cur = d_next; d_next = t;
+        }
+        hipError_t es = hipStreamSynchronize(s);
+        (void)hipFree(d_a0); (void)hipFree(d_cur); (void)hipFree(d_next);
+        if (rc) return rc;
+        if (es != hipSuccess) return hip_fail(es, "hipStreamSynchronize", __FILE__, __LINE__);
+    }
+    memcpy(levels[level], levels[level] + top * row, top * row);
     return PORLA_OK;
 }
 

@@ -29,6 +29,26 @@ def crebuild_host(rows, n_rows, n_cols=NUM_CHUNKS, curve="bn254", write_step=0, 
     return (x.raw if x else None, al.raw if al else None, sc.raw if sc else None)
 
 
+def crebuild_cols_host(rows, n_rows, n_cols, col_begin, col_end, x, aligned, scalars, curve="bn254", write_step=0, part=0,
+                       scalar_le=False):
+    """column sharding: encode columns [col_begin, col_end) of the row-major `rows` into the same columns of the caller's
+    full-width ctypes buffers x / aligned / scalars (each may be None)"""
+    vp = ctypes.c_void_p
+    _check(lib.porla_icc_encode_cols_host(bytes(rows), n_rows, n_cols, col_begin, col_end, CURVE[curve], write_step, part,
+                                          ctypes.cast(x, vp) if x else None, ctypes.cast(aligned, vp) if aligned else None,
+                                          ctypes.cast(scalars, vp) if scalars else None, 1 if scalar_le else 0))
+
+
+def crebuild_host_multi(rows, n_rows, n_cols=NUM_CHUNKS, curve="bn254", write_step=0, part=0, devices=0, scalar_le=False):
+    """the whole encode with the columns split over `devices` GPUs of this process (0 = every visible one)"""
+    total = n_rows * n_cols
+    x, al, sc = (ctypes.create_string_buffer(64 * total), ctypes.create_string_buffer(32 * total), ctypes.create_string_buffer(32 * total))
+    vp = ctypes.c_void_p
+    _check(lib.porla_icc_encode_host_multi(bytes(rows), n_rows, n_cols, CURVE[curve], write_step, part, ctypes.cast(x, vp),
+                                           ctypes.cast(al, vp), ctypes.cast(sc, vp), 1 if scalar_le else 0, devices))
+    return x.raw, al.raw, sc.raw
+
+
 def crebuild_device(d_rows, n_rows, n_cols, curve, write_step, part, d_x=0, d_aligned=0, d_scalars=0, scalar_le=False,
                     stream=0):
     """device-pointer form (integers, e.g. torch tensor .data_ptr()); asynchronous on `stream`."""
@@ -71,3 +91,42 @@ def mac_mix_host(a0, a1, length, n_total, curve="bn254"):
     out = ctypes.create_string_buffer(2 * length * 64)
     _check(lib.porla_icc_mac_mix_host(bytes(a0), bytes(a1), length, n_total, CURVE[curve], out))
     return out.raw
+
+
+# ---- Server::HAdd / Client::HAdd and the HRebuild chains (Server.hpp:1388-1477, 1329-1386; Client.hpp:978-1038) ----
+def hadd_host(data, n_total, write_step, curve="bn254", n_cols=NUM_CHUNKS, scalar_le=False):
+    """data side of HAdd on one block: (data_B2 aligned mod p_icc [32-B LE each], alignment scalars, wt as 32-byte BE scalar)"""
+    b2, sc, wt = ctypes.create_string_buffer(32 * n_cols), ctypes.create_string_buffer(32 * n_cols), ctypes.create_string_buffer(32)
+    _check(lib.porla_icc_hadd_host(bytes(data), n_cols, n_total, write_step, CURVE[curve], b2, sc, 1 if scalar_le else 0, wt))
+    return b2.raw, sc.raw, wt.raw
+
+
+def mac_scale_host(mac, n_total, write_step, curve="bn254"):
+    """MAC_B2 = wt * MAC (Server.hpp:1400-1417; Client::HAdd, Client.hpp:996-1014)"""
+    out = ctypes.create_string_buffer(64)
+    _check(lib.porla_icc_mac_scale_host(bytes(mac), n_total, write_step, CURVE[curve], out))
+    return out.raw
+
+
+def kzg_hadd_host(data, mac, n_total, write_step, n_cols=NUM_CHUNKS):
+    """Server::HAdd for the KZG build: (data_B2, MAC_B2, MAC_align_B2)"""
+    b2, m2, ma = ctypes.create_string_buffer(32 * n_cols), ctypes.create_string_buffer(64), ctypes.create_string_buffer(64)
+    _check(lib.porla_kzg_hadd_host(bytes(data), bytes(mac), n_total, write_step, b2, m2, ma))
+    return b2.raw, m2.raw, ma.raw
+
+
+def _level_ptrs(bufs):
+    arr = (ctypes.c_void_p * len(bufs))()
+    for i, b in enumerate(bufs):
+        arr[i] = ctypes.cast(b, ctypes.c_void_p)
+    return arr
+
+
+def hrebuild_host(level_bufs, level, n_total, curve="bn254", n_cols=NUM_CHUNKS):
+    """level_bufs[i]: ctypes buffer of 2 * 2^i rows x n_cols x 64 bytes (resident half, incoming half); rebuilt in place"""
+    _check(lib.porla_icc_hrebuild_host(_level_ptrs(level_bufs), level, n_cols, n_total, CURVE[curve]))
+
+
+def mac_hrebuild_host(level_bufs, level, n_total, curve="bn254"):
+    """the same for 64-byte affine points (MAC commitments, MAC alignments, the client's complements)"""
+    _check(lib.porla_icc_mac_hrebuild_host(_level_ptrs(level_bufs), level, n_total, CURVE[curve]))

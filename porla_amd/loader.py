@@ -74,6 +74,17 @@ def _declare(L):
         f = getattr(L, "porla_%s_msm_device_dist" % curve); f.argtypes = [vp, vp, sz, u8p, vp]; f.restype = ctypes.c_int
         f = getattr(L, "porla_%s_jac_sum" % curve); f.argtypes = [u8p, sz, u8p]; f.restype = ctypes.c_int
         f = getattr(L, "porla_%s_tree_fold" % curve); f.argtypes = [u8p, ctypes.c_int, ctypes.c_int, u8p]; f.restype = ctypes.c_int
+    L.porla_icc_hadd_host.argtypes = [u8p, sz, sz, ctypes.c_ulonglong, ctypes.c_int, u8p, u8p, ctypes.c_int, u8p]; L.porla_icc_hadd_host.restype = ctypes.c_int
+    L.porla_icc_mac_scale_host.argtypes = [u8p, sz, ctypes.c_ulonglong, ctypes.c_int, u8p]; L.porla_icc_mac_scale_host.restype = ctypes.c_int
+    L.porla_kzg_hadd_host.argtypes = [u8p, u8p, sz, ctypes.c_ulonglong, u8p, u8p, u8p]; L.porla_kzg_hadd_host.restype = ctypes.c_int
+    L.porla_icc_hrebuild_host.argtypes = [ctypes.POINTER(vp), ctypes.c_int, sz, sz, ctypes.c_int]; L.porla_icc_hrebuild_host.restype = ctypes.c_int
+    L.porla_icc_mac_hrebuild_host.argtypes = [ctypes.POINTER(vp), ctypes.c_int, sz, ctypes.c_int]; L.porla_icc_mac_hrebuild_host.restype = ctypes.c_int
+    L.porla_shard_range.argtypes = [sz, ctypes.c_int, ctypes.c_int, ctypes.POINTER(sz), ctypes.POINTER(sz)]; L.porla_shard_range.restype = ctypes.c_int
+    L.porla_kzg_commit_batch_host_multi.argtypes = [u8p, sz, u8p, ctypes.c_int]; L.porla_kzg_commit_batch_host_multi.restype = ctypes.c_int
+    L.porla_icc_encode_cols_host.argtypes = [u8p, sz, sz, sz, sz, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_int, vp, vp, vp, ctypes.c_int]
+    L.porla_icc_encode_cols_host.restype = ctypes.c_int
+    L.porla_icc_encode_host_multi.argtypes = [u8p, sz, sz, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_int, vp, vp, vp, ctypes.c_int, ctypes.c_int]
+    L.porla_icc_encode_host_multi.restype = ctypes.c_int
     L.porla_gpu_last_msm_multi.argtypes = [ctypes.POINTER(ctypes.c_int)] * 2; L.porla_gpu_last_msm_multi.restype = ctypes.c_int
     L.porla_dist_unique_id.argtypes = [u8p]; L.porla_dist_unique_id.restype = ctypes.c_int
     L.porla_dist_init.argtypes = [u8p, ctypes.c_int, ctypes.c_int]; L.porla_dist_init.restype = ctypes.c_int

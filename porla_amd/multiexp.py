@@ -273,6 +273,20 @@ def kzg_commit_batch_host(rows, n_rows):
     return out.raw[:64 * n_rows]
 
 
+def kzg_commit_batch_host_multi(rows, n_rows, devices=0):
+    """row range split over `devices` GPUs of this process (0 = every visible one)"""
+    out = ctypes.create_string_buffer(64 * max(n_rows, 1))
+    _check(lib.porla_kzg_commit_batch_host_multi(bytes(rows), n_rows, out, devices))
+    return out.raw[:64 * n_rows]
+
+
+def shard_range(n, rank, world):
+    """[begin, end) of shard `rank` of `world` over n units -- the engine's own range rule (porla_shard_range)"""
+    b, e = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    _check(lib.porla_shard_range(n, rank, world, ctypes.byref(b), ctypes.byref(e)))
+    return b.value, e.value
+
+
 def kzg_commit_batch_device(d_rows, n_rows, d_out, stream=0):
     _check(lib.porla_kzg_commit_batch_device(ctypes.c_void_p(d_rows), n_rows, ctypes.c_void_p(d_out), ctypes.c_void_p(stream)))
 

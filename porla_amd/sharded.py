@@ -44,3 +44,29 @@ def affine_to_partial(affine64):
     if bytes(affine64) == bytes(64):
         return (1).to_bytes(32, "big") * 2 + bytes(32)
     return bytes(affine64) + (1).to_bytes(32, "big")
+
+
+# ---- the paths that shard with NO collective: every rank works on its own range and keeps its results
+def my_range(n):
+    """this rank's [begin, end) of n units (porla_shard_range: rows of a commitment batch, columns of an ICC encode)"""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    return mx.shard_range(n, rank, world)
+
+
+def sharded_commit_rows(rows, n_rows, commit=None):
+    """this rank's row range of a commitment batch -> (first row, its 64-byte commitments).  `commit(rows, n)` defaults to the
+    engine (porla_kzg_commit_batch_host); the CPU tests pass the oracle in its place."""
+    lo, hi = my_range(n_rows)
+    fn = commit or mx.kzg_commit_batch_host
+    return lo, fn(rows[4096 * lo:4096 * hi], hi - lo)
+
+
+def gather_objects(obj):
+    """test / bookkeeping helper: every rank's object (NOT part of the data path -- the results stay where they are produced)"""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return [obj]
+    out = [None] * world
+    dist.all_gather_object(out, obj)
+    return out

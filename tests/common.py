@@ -26,8 +26,25 @@ def oracle():
 
 
 def ncpu():
-    """threads of the CPU restatement: every hardware thread of the box (hardware_concurrency())"""
-    return max(1, os.cpu_count() or 1)
+    """threads of the CPU restatement: every hardware thread this process may use (hardware_concurrency()),
+    i.e. the CPU count cut down to the scheduler affinity and to a cgroup CPU quota where one is set (a GPU box hands a
+    one-GPU job 16 of its 256 hardware threads: 256 runnable threads on them only thrash)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: [t.strip(), None])):
+        try:
+            quota, period = parse(open(path).read())
+            if period is None:
+                period = open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
 
 
 def synth_scalars(n, start=0):

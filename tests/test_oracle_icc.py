@@ -86,3 +86,31 @@ def test_x_part_mod_p_icc_equals_an_independent_recursive_formulation(n):
     X, _ = icc_py.crebuild([[v] for v in col], "bn254", 0)
     want = icc_py.linear_network_matrix(n)([v % icc_py.P_ICC for v in col])
     assert [r[0] % icc_py.P_ICC for r in X] == want
+
+
+def test_hadd_and_hrebuild_restatements_are_consistent_with_the_encode():
+    """oracle/icc_py.py:hadd / hrebuild (Server::HAdd, HRebuildX: Server.hpp:1388-1477, 1329-1386) against the restatement of
+    CRebuild they must agree with: adding N blocks one by one with HAdd / HRebuild builds, level by level, what the batch encode of
+    those N blocks gives mod p_icc (the hierarchical log structure's invariant), for the X part"""
+    import icc_py
+    import random
+    rnd = random.Random(3)
+    N, ncols = 8, 3
+    blocks = [[rnd.getrandbits(256) for _ in range(ncols)] for _ in range(N)]
+    # HAdd with write_step = t: data_B2 = data * wt aligned, c = (mod - A) % q, MAC_B2 = wt * MAC
+    for t in (0, 1, 5):
+        mods, cs, mac_b2, wt = icc_py.hadd(blocks[t], None, N, t, "bn254")
+        assert wt == pow(icc_py.root_w(N), icc_py.reverse_bits(t % N, icc_py.height_of(N) - 1), icc_py.P_ICC)
+        for d, m, c in zip(blocks[t], mods, cs):
+            assert m == d * wt % icc_py.P_ICC and (d * wt + c) % icc_py.Q["bn254"] == m % icc_py.Q["bn254"] and mac_b2 is None
+    # X part: level L after 2^L insertions == mix tree of those blocks; compare with mixing by hand
+    levels = [[[0] * ncols for _ in range(2 << i)] for i in range(4)]
+    levels[0][0], levels[0][1] = blocks[0], blocks[1]
+    icc_py.hrebuild(levels, 1, N, "bn254")
+    want1 = icc_py.mix([blocks[0]], [blocks[1]], N, "bn254")
+    assert levels[1][:2] == want1 and levels[1][2:4] == want1
+    # next pair arrives: level 0 again, then a level-2 rebuild mixes level 1's resident half with the new pair's mix
+    levels[0][0], levels[0][1] = blocks[2], blocks[3]
+    icc_py.hrebuild(levels, 2, N, "bn254")
+    want2 = icc_py.mix(want1, icc_py.mix([blocks[2]], [blocks[3]], N, "bn254"), N, "bn254")
+    assert levels[2][:4] == want2
