@@ -196,6 +196,8 @@ template <class M>
 __device__ __forceinline__ F30<M> f30_mul_pm(const F30<M>& a, const F30<M>& b) { return f30_mul_pm_portable<M>(a, b); }
 template <class M>
 __device__ __forceinline__ F30<M> f30_sqr_pm(const F30<M>& a) { return f30_sqr_pm_portable<M>(a); }
+template <class M>
+__device__ __forceinline__ F30<M> f30_mul_icc(const F30<M>& a, const F30<M>& b) { return f30_mul_portable<M>(a, b); }
 #endif
 template <class M>
 __device__ __forceinline__ F30<M> f30_mul(const F30<M>& a, const F30<M>& b) {

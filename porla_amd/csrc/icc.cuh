@@ -8,11 +8,16 @@
 // element-wise over 128-wide rows, natural order in, no permutation, w = GENERATOR^((p_icc-1)/(2N)) (order N).
 //
 // HOW (MI355X): Z/LCM = Z/p_icc x Z/q (both prime), so every element is carried as a pair of 256-bit Montgomery
-// residues (64 B) -- two 8-limb products per butterfly instead of one 16-limb product plus a 768->512-bit
-// reduction -- and recombined once at the end with p_icc = 207*2^248 + 1 (a shift-and-add CRT).  The network is
-// HBM-bound: one thread owns 4 rows x 1 column and fuses TWO stages per pass in registers (radix-4), lanes run along
-// the 128 columns of a row so every access is a fully coalesced 64-B-per-lane stream, and the N-entry twiddle
-// table (N * 64 B) stays L2-resident.  No MFMA: there is no contraction.
+// residues -- two 256-bit products per butterfly instead of one 512-bit product plus a 768->512-bit reduction -- and
+// recombined once at the end with p_icc = 207*2^248 + 1 (a shift-and-add CRT).  The encode is bound by the integer
+// multiplier, not by HBM: a block keeps a tile of 512 symbols (2^ns rows x 2^(9-ns) columns) in LDS through ns <= 8 stages, so
+// 15 stages are two passes over the working set (32 B in + 2 x 64..72 B between the passes + the outputs per symbol), against
+// ~1 000 vector instructions per symbol and pass.  The first pass converts the raw 32-byte chunks on the way in, the last writes
+// the CRT / alignment outputs; the N-entry twiddle table stays L2-resident; lanes run along the columns of a row, so global
+// accesses are coalesced.  Two kernels share this tiling: k_icc_fused below (8 x 32-bit limbs, Montgomery radix 2^256) and the
+// default k_icc_fused30 of icc30.cuh (9 x 30-bit limbs, radix 2^270, sparse reduction for p_icc).  The element-wise kernels of
+// this file (k_icc_load, k_icc_finish, k_icc_stages, k_icc_mix) serve the unfused fallback, Server::mix and HAdd.
+// No MFMA: there is no contraction.
 #pragma once
 #include "fe.cuh"
 

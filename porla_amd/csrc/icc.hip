@@ -3,6 +3,7 @@
 // porla/Server/Server.hpp:1544-1833; see INTEGRATION.md.
 #include "engine.hpp"
 #include "icc.cuh"
+#include "icc30.cuh"
 #include "icc_host.hpp"
 
 #include <cstdlib>
@@ -15,8 +16,9 @@ namespace porla {
 
 struct IccWs {
     int device = -1;
-    Buf work, tw, wpow, in, xo, al, sc;
-    uint32_t tw_n = 0;
+    Buf work, tw, tw30, wpow, in, xo, al, sc;
+    uint32_t tw_n = 0, tw30_n = 0;   // tw30: the same table in the reduced-radix form of icc30.cuh (80-byte slots)
+    int tw30_curve = -1;
     int tw_curve = -1;
     UseFence fence;   // work / twiddle buffers are shared between calls that may come on different streams
     std::mutex mu;    // one encode at a time per device (the column-range splitter runs one host thread per device)
@@ -54,6 +56,7 @@ static int ensure_twiddles(IccWs* ws, int curve, size_t n, hipStream_t stream) {
                        (uint32_t)n, (const Fe<IccFp>*)ws->wpow.p, logn);
     ws->tw_n = (uint32_t)n;
     ws->tw_curve = curve;
+    ws->tw30_n = 0;
     return PORLA_OK;
 }
 
@@ -129,10 +132,22 @@ static int icc_encode_core(IccWs* ws, int curve, const uint8_t* d_rows, size_t n
     int use_wt = 0;
     if (part == 1) { wt = icc_wt<Q>(n, write_step, nullptr); use_wt = 1; }
     static const int fused = !(getenv("PORLA_ICC_FUSED") && getenv("PORLA_ICC_FUSED")[0] == '0');
+    static const int f30 = !(getenv("PORLA_ICC_F30") && getenv("PORLA_ICC_F30")[0] == '0');
     IccOut out{d_x, d_al, d_sc, d_qres, scalar_le};
     if (fused) {
         // ceil(logn / 8) passes of (almost) equal stage counts, each through LDS tiles of 512 symbols; the first pass reads
-        // the raw chunks, the last one writes the outputs: the residue-pair working set only travels between passes
+        // the raw chunks, the last one writes the outputs: the residue-pair working set only travels between passes.
+        // Default: the reduced-radix kernel of icc30.cuh (72 bytes per symbol between the passes); PORLA_ICC_F30=0: icc.cuh's.
+        if (f30) {
+            if ((rc = ws->work.ensure(total * ICC30_PACK_WORDS * 4))) return rc;
+            if (ws->tw30_n != n || ws->tw30_curve != curve) {
+                if ((rc = ws->tw30.ensure(n * ICC30_SLOT_WORDS * 4))) return rc;
+                hipLaunchKernelGGL((k_icc_twiddles30<Q>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                                   (const IccElem<Q>*)ws->tw.p, (uint32_t)n, (uint32_t*)ws->tw30.p);
+                ws->tw30_n = (uint32_t)n;
+                ws->tw30_curve = curve;
+            }
+        }
         const int passes = (logn + 7) / 8;
         int s = 1;
         for (int pz = 0; pz < passes; pz++) {
@@ -144,8 +159,14 @@ static int icc_encode_core(IccWs* ws, int curve, const uint8_t* d_rows, size_t n
             const bool first = pz == 0, last = pz == passes - 1;
             ProfScope ps("icc_fused", stream, true);
 #define PORLA_ICC_LAUNCH(F, L)                                                                                              \
-    hipLaunchKernelGGL((k_icc_fused<Q, F, L>), grid, dim3(256), 0, stream, (IccElem<Q>*)ws->work.p,                         \
-                       (const IccElem<Q>*)ws->tw.p, (uint32_t)n, (uint32_t)ncols, s, ns, cc_log, d_rows, wt, use_wt, out)
+    do {                                                                                                                    \
+        if (f30)                                                                                                            \
+            hipLaunchKernelGGL((k_icc_fused30<Q, F, L>), grid, dim3(256), 0, stream, (uint32_t*)ws->work.p,                 \
+                               (const uint32_t*)ws->tw30.p, (uint32_t)n, (uint32_t)ncols, s, ns, cc_log, d_rows, wt, use_wt, out); \
+        else                                                                                                                \
+            hipLaunchKernelGGL((k_icc_fused<Q, F, L>), grid, dim3(256), 0, stream, (IccElem<Q>*)ws->work.p,                 \
+                               (const IccElem<Q>*)ws->tw.p, (uint32_t)n, (uint32_t)ncols, s, ns, cc_log, d_rows, wt, use_wt, out); \
+    } while (0)
             if (first && last) PORLA_ICC_LAUNCH(true, true);
             else if (first) PORLA_ICC_LAUNCH(true, false);
             else if (last) PORLA_ICC_LAUNCH(false, true);

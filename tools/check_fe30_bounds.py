@@ -6,10 +6,18 @@ MODULI = {
     "bn254_r": 21888242871839275222246405745257275088548364400416034343698204186575808495617,
     "p_icc": 207 * 2**248 + 1,
 }
+# the ICC kernel of icc30.cuh multiplies an UNREDUCED butterfly output (< 2^263: limb 8 < 2^23) by a twiddle (a product's result,
+# < p + 2^248: limb 8 < 2^17) modulo p_icc, the BN254 group order and the secp256k1 group order
+ICC_MODULI = {
+    "p_icc": 207 * 2**248 + 1,
+    "bn254_r": 21888242871839275222246405745257275088548364400416034343698204186575808495617,
+    "secp256k1_n": 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141,
+}
 MASK = 2**30 - 1
-def check(name, p, top_bits=18):
+def check(name, p, top_bits=18, top_bits_b=None):
     P = [(p >> (30 * i)) & MASK for i in range(9)]
     amax = [MASK] * 8 + [2**top_bits - 1]
+    bmax = [MASK] * 8 + [2**(top_bits_b or top_bits) - 1]
     carry = 0
     worst = 0
     for k in range(17):
@@ -17,7 +25,7 @@ def check(name, p, top_bits=18):
         for i in range(9):
             j = k - i
             if 0 <= j <= 8:
-                t += amax[i] * amax[j]
+                t += amax[i] * bmax[j]
                 if not (k < 9 and i == k):
                     pass
         # reduction products m_i * P_{k-i}, i <= min(k, 8); for k < 9 this includes m_k * P_0
@@ -32,4 +40,7 @@ def check(name, p, top_bits=18):
     return ok
 if __name__ == "__main__":
     import sys
-    sys.exit(0 if all([check(n, p) for n, p in MODULI.items()]) else 1)
+    ok = all([check(n, p) for n, p in MODULI.items()])
+    ok = all([check("icc:" + n, p, 23, 17) for n, p in ICC_MODULI.items()]) and ok
+    # result bound of the ICC product: a b / 2^270 + p < p + 2^249 for a < 2^263, b < 2^256: limb 8 stays far below 2^30
+    sys.exit(0 if ok else 1)
