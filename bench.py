@@ -53,7 +53,7 @@ FE_MUL_PEAK_G = {"bn254_msm": 186.5, "kzg_commit": 186.5, "secp256k1_msm": 199.9
 KERNEL_SYMBOL = {  # profile slot -> substring of the kernel symbol in the rocprofv3 output
     "bucket_sum": "k_bucket_sum30", "tree_levels": "k_tree_level", "tree_tail": "k_tree_tail", "partition_sort": "k_partition_sort",
     "fb_commit": "k_fb_commit", "digits_partition": "k_digits_partition", "points_to_mont": "k_points_to_mont",
-    "icc_fused": "k_icc_fused", "icc_stages_r4": "k_icc_stages", "icc_stages_r2": "k_icc_stages", "icc_load": "k_icc_load", "icc_finish": "k_icc_finish",
+    "icc_fused": "k_icc_fused30", "icc_stages_r4": "k_icc_stages", "icc_stages_r2": "k_icc_stages", "icc_load": "k_icc_load", "icc_finish": "k_icc_finish",
 }
 
 
@@ -67,10 +67,18 @@ def pmc_traffic(slot, workload):
         write = [v for k, v in d["write"].items() if sym in k and "WRITE_SIZE" in k]
         if not fetch or not write:
             return None
-        # rocprofv3 reports KiB; gfx950 FETCH_SIZE counts 128-B requests as 64 B -> doubled (MI355X_MICROARCH.md, HBM)
-        return int((2 * fetch[0]["per_dispatch"] + write[0]["per_dispatch"]) * 1024)
+        # per launch, averaged over every instantiation of the kernel that ran (the ICC encode launches a first-pass and a
+        # last-pass variant): sum / dispatches.  rocprofv3 reports KiB; gfx950 FETCH_SIZE counts 128-B requests as 64 B ->
+        # doubled (MI355X_MICROARCH.md, HBM)
+        per = lambda rows: sum(r["sum"] for r in rows) / max(1, sum(r["dispatches"] for r in rows))
+        return int((2 * per(fetch) + per(write)) * 1024)
     except (OSError, KeyError, ValueError):
         return None
+
+
+def child_env():
+    """environment for the measurement children (plain-C harness, host-boundary script): the parent's, minus a preloaded profiler"""
+    return {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCPROF", "ROCPROFILER", "ROCP_"))}
 
 
 def sha_rows(seed, count):
@@ -130,20 +138,31 @@ def main():
     if world > 1:
         collective = "torch.distributed %s all_gather" % backend
         if backend == "nccl" and os.environ.get("PORLA_DIST_CXX", "1") != "0":
-            ok_t = torch.zeros(1, dtype=torch.int32, device=coll_dev)
+            def all_ok(flag):
+                t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=coll_dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                return int(t.item()) == 1
+            # 1. every rank checks that RCCL can be bound at all BEFORE anyone enters the collective ncclCommInitRank
+            #    (a rank that fails early would leave the others waiting there)
+            probe = None
             try:
-                uid = [mx.dist_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(uid, src=0)
-                mx.dist_init(uid[0], rank, world)
-                ok_t += 1
+                probe = mx.dist_unique_id()
             except Exception as e:  # noqa: BLE001
-                print("rank %d: in-library RCCL communicator unavailable (%s)" % (rank, e), file=sys.stderr)
-            dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
-            use_cxx_dist = int(ok_t.item()) == 1
-            if use_cxx_dist:
-                collective = "ncclAllGather from C++ (porla_dist_*, RCCL over xGMI)"
-            elif mx.dist_info()[1]:
-                mx.dist_finalize()
+                print("rank %d: in-library RCCL unavailable (%s)" % (rank, e), file=sys.stderr)
+            if all_ok(probe is not None):
+                uid = [probe if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                inited = False
+                try:
+                    mx.dist_init(uid[0], rank, world)
+                    inited = True
+                except Exception as e:  # noqa: BLE001
+                    print("rank %d: ncclCommInitRank from C++ failed (%s)" % (rank, e), file=sys.stderr)
+                use_cxx_dist = all_ok(inited)
+                if use_cxx_dist:
+                    collective = "ncclAllGather from C++ (porla_dist_*, RCCL over xGMI)"
+                elif inited:
+                    mx.dist_finalize()
 
     def fold_across_ranks(curve, part):
         if use_cxx_dist:
@@ -263,7 +282,7 @@ def main():
             per_call = {}
             for threads in (1, 8):
                 try:
-                    r = subprocess.run([harness, "bench", str(threads), "1500"], capture_output=True, text=True, timeout=180)
+                    r = subprocess.run([harness, "bench", str(threads), "1500"], capture_output=True, text=True, timeout=180, env=child_env())
                     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
                     d = json.loads(line)
                     per_call["threads_%d" % threads] = {"commits_per_s": d["commits_per_s"], "latency_ms_per_call": d["latency_ms_per_call"],
@@ -362,23 +381,15 @@ def main():
         # the reference's own boundary: compute_multi_exp on caller-owned pageable HOST buffers (PCIe included; never `value`)
         host_boundary = None
         if world == 1 and rank == 0 and not args.no_host_boundary:
-            bs, bp = ctypes.create_string_buffer(sc, 32 * n), ctypes.create_string_buffer(pt, 64 * n)
-            hb_out = ctypes.create_string_buffer(64)
-            from porla_amd.multiexp import _slice
-            ss, sp, so = _slice(bs), _slice(bp), _slice(hb_out)
-            for _ in range(2):
-                mx.lib.compute_multi_exp(ctypes.byref(ss), ctypes.byref(sp), n, ctypes.byref(so))
-            reps = 5
-            t_h = time.perf_counter()
-            for _ in range(reps):
-                mx.lib.compute_multi_exp(ctypes.byref(ss), ctypes.byref(sp), n, ctypes.byref(so))
-            hb_ms = (time.perf_counter() - t_h) / reps * 1e3
-            shards, devs = mx.last_msm_multi()
-            host_boundary = {"entry": "compute_multi_exp(host scalars, host points, n, out) -- porla/main.go:118-138", "ms": round(hb_ms, 3),
-                             "Mmul_s": round(n / hb_ms / 1e3, 1), "pair_ranges": shards, "devices": devs,
-                             "same_result": hb_out.raw == result,
-                             "note": "96 n bytes cross PCIe inside the call; ranges are uploaded under the kernels of the previous range"}
-            del bs, bp
+            # in a child process (its launches at other sizes stay out of this process's kernel statistics; a profiler
+            # preloaded into this process is not handed down)
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_host_boundary.py"), "--json", str(args.log2n)],
+                                   capture_output=True, text=True, timeout=600, env=child_env())
+                host_boundary = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                host_boundary["same_result"] = host_boundary.pop("result") == result.hex()
+            except Exception as e:  # noqa: BLE001
+                host_boundary = {"error": repr(e)}
         commits = None if args.no_commits else kzg_commit_leg(1 << args.log2rows)
         if rank == 0:
             cpu = None
@@ -518,8 +529,11 @@ def main():
                        "CRebuild_Cached + align_MAC scalars in Z/LCM, not NTL) over %d threads; %.2f s wall"
                        % (sample_rows, cores, cpu_s)}
             failed = verified is False
-            rl = roofline(kern, ICC_BYTES_PER_ELEMENT * n_rows * n_cols, "icc")
+            passes = max(1, ((n_rows.bit_length() - 1) + 7) // 8)      # LDS-fused passes per encode = launches of the dominant kernel
+            rl = roofline(kern, ICC_BYTES_PER_ELEMENT * n_rows * n_cols / passes, "icc")
             if rl:
+                rl["note"] = ("an encode is %d launches of the dominant kernel; `achieved` prices the encode's algorithmic bytes / %d "
+                              "per launch, `traffic` is the per-launch average of the counters" % (passes, passes))
                 rl["launches_per_encode"] = {k: round(timed.totals[k] / v) for k, v in kern.items() if v > 0}
                 rl["whole_encode_kernels_ms"] = round(total_ms, 4)
                 rl["whole_encode_achieved_GBps"] = round(ICC_BYTES_PER_ELEMENT * n_rows * n_cols / (total_ms * 1e-3) / 1e9, 2)

@@ -9,6 +9,25 @@ import ctypes
 from porla_amd import multiexp as mx, lib
 from porla_amd.multiexp import _slice
 from tests import common
+if len(sys.argv) > 1 and sys.argv[1] == "--json":
+    # one line for bench.py's `host_boundary` object: compute_multi_exp on caller-owned pageable host buffers at 2^log2n pairs
+    log2n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    n = 1 << log2n
+    sc, pt = common.cached_inputs(n)
+    bs, bp, out = ctypes.create_string_buffer(sc, 32 * n), ctypes.create_string_buffer(pt, 64 * n), ctypes.create_string_buffer(64)
+    ss, sp, so = _slice(bs), _slice(bp), _slice(out)
+    for _ in range(3):
+        lib.compute_multi_exp(ctypes.byref(ss), ctypes.byref(sp), n, ctypes.byref(so))
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        lib.compute_multi_exp(ctypes.byref(ss), ctypes.byref(sp), n, ctypes.byref(so))
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    shards, devs = mx.last_msm_multi()
+    print(json.dumps({"entry": "compute_multi_exp(host scalars, host points, n, out) -- porla/main.go:118-138", "ms": round(ms, 3),
+                      "Mmul_s": round(n / ms / 1e3, 1), "pair_ranges": shards, "devices": devs, "result": out.raw.hex(),
+                      "note": "96 n bytes cross PCIe inside the call; ranges are uploaded under the kernels of the previous range"}))
+    sys.exit(0)
 sc, pt = common.cached_inputs(1 << 20)
 d_sc = torch.frombuffer(bytearray(sc), dtype=torch.uint8).cuda()
 d_pt = torch.frombuffer(bytearray(pt), dtype=torch.uint8).cuda()

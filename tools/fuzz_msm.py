@@ -57,14 +57,19 @@ while time.time() < t_end:
         pt = b"".join(out)
     c = rnd.choice([0, 0, 0, rnd.randrange(2, 21)])
     glv = rnd.choice([-1, 0, 1])
+    # the single-launch path for n <= 4096 (automatic or forced window width), or switched off; sometimes the range-sharded entry
+    small_on, small_c = rnd.choice([(1, 0), (1, 0), (1, rnd.randrange(1, 9)), (0, 0)])
+    shards = rnd.choice([0, 0, 0, 0, rnd.randrange(1, 7)])
     lib.porla_gpu_set_msm_window(c)
     lib.porla_gpu_set_msm_glv(glv)
-    got = mx.msm_host(curve, sc, pt, n)
+    lib.porla_gpu_set_msm_small(small_on, small_c)
+    got = mx.msm_host_multi(curve, sc, pt, n, shards=shards, devices=1) if shards else mx.msm_host(curve, sc, pt, n)
     want = common.oracle_msm(sc, pt, n) if curve == "bn254" else common.oracle_secp_msm(sc, pt, n)
     cases += 1
     if got != want:
         fails += 1
-        print("MISMATCH", curve, "n=%d" % n, dist, pmode, "c=%d" % c, "glv=%d" % glv, flush=True)
+        print("MISMATCH", curve, "n=%d" % n, dist, pmode, "c=%d" % c, "glv=%d" % glv, "small=%d/%d" % (small_on, small_c), "shards=%d" % shards, flush=True)
+lib.porla_gpu_set_msm_small(1, 0)
 lib.porla_gpu_set_msm_window(0)
 lib.porla_gpu_set_msm_glv(-1)
 print("fuzz: %d cases, %d mismatches (seed %d)" % (cases, fails, seed))
