@@ -31,6 +31,9 @@ typedef GoInt64 GoInt;
 typedef struct { void *data; GoInt len; GoInt cap; } GoSlice;
 #endif
 
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)   /* the engine itself is built with -fvisibility=hidden: only this ABI is exported */
+#endif
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -67,5 +70,8 @@ extern void set_inf_point(GoSlice* point);
 
 #ifdef __cplusplus
 }
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility pop
 #endif
 #endif

@@ -34,6 +34,9 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)   /* the engine itself is built with -fvisibility=hidden: only this ABI is exported */
+#endif
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -275,5 +278,8 @@ int porla_audit_combine_device(const void *d_rows64, const uint64_t *d_idx64, co
 
 #ifdef __cplusplus
 }
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility pop
 #endif
 #endif
