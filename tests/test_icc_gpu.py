@@ -88,3 +88,40 @@ def test_full_size_2_22_elements():
     assert d_x.cpu().numpy().tobytes() == want[0]
     assert d_al.cpu().numpy().tobytes() == want[1]
     assert d_sc.cpu().numpy().tobytes() == want[2]
+
+
+@pytest.mark.parametrize("curve", ["bn254", "secp256k1"])
+@pytest.mark.parametrize("n,ncols,part,ws", [(1 << 17, 3, 0, 0), (1 << 18, 1, 1, 99991), (1 << 16, 5, 1, 7)])
+def test_three_passes_and_worst_case_operand_growth(curve, n, ncols, part, ws):
+    """more than 16 stages = three LDS-fused passes (the middle-pass instantiation of the kernel) and the longest chains of
+    unreduced butterflies of the reduced-radix kernel (icc30.cuh: rows that meet only unit twiddles are brought back every fourth
+    stage); inputs at the top of the range (every chunk 2^256 - 1 or p_icc - 1) make every sum as large as it can get"""
+    from porla_amd import icc
+    import icc_py
+    big = [(1 << 256) - 1, icc_py.P_ICC - 1, icc_py.Q[curve] - 1]
+    rows = b"".join(big[(r * 7 + c) % 3].to_bytes(32, "little") for r in range(n) for c in range(ncols))
+    got = icc.crebuild_host(rows, n, ncols, curve, ws, part)
+    assert got == oracle_crebuild(rows, n, ncols, icc.CURVE[curve], part, ws)
+    rows = rows_bytes(n, ncols, seed=n + ws)
+    got = icc.crebuild_host(rows, n, ncols, curve, ws, part, want_x=False)
+    want = oracle_crebuild(rows, n, ncols, icc.CURVE[curve], part, ws)
+    assert got[1] == want[1] and got[2] == want[2]
+
+
+def test_both_field_forms_agree(monkeypatch):
+    """the 8 x 32-bit kernel (PORLA_ICC_F30=0, read once per process) is kept: a child process runs it on the same input"""
+    import os
+    import subprocess
+    import sys
+    from porla_amd import icc
+    n, ncols = 512, 128
+    rows = rows_bytes(n, ncols, seed=4242)
+    a = icc.crebuild_host(rows, n, ncols, "bn254", 11, 1)
+    code = ("import sys, hashlib; sys.path.insert(0, %r)\n"
+            "from tests.test_icc_gpu import rows_bytes\nfrom porla_amd import icc\n"
+            "r = icc.crebuild_host(rows_bytes(%d, %d, seed=4242), %d, %d, 'bn254', 11, 1)\n"
+            "print(hashlib.sha256(r[0] + r[1] + r[2]).hexdigest())\n" % (common.ROOT, n, ncols, n, ncols))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, PORLA_ICC_F30="0"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == hashlib.sha256(a[0] + a[1] + a[2]).hexdigest()
