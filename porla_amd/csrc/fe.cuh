@@ -46,6 +46,9 @@ struct Bn254Fp {
                                           0xdf1160f4u, 0x9e7d8ca3u, 0xed6d3304u, 0x279be39au};
     static constexpr uint32_t R2_30[8] = {0x5b61e465u, 0x0c82ea1du, 0xf298bc82u, 0x87f2ef02u,
                                           0x4050e665u, 0x9938cdbeu, 0xdf213851u, 0x2c026cedu};
+    // 2^540 mod p: a plain residue times this in the reduced-radix product (radix 2^270) is the residue's 2^270 form
+    static constexpr uint32_t RR_30[8] = {0x2e53b794u, 0x242db528u, 0x301f5ed1u, 0xa3522573u,
+                                          0x9d4e3aa6u, 0x93560daau, 0x51b66a12u, 0x0d15816du};
 };
 
 // secp256k1 base field p = 2^256 - 2^32 - 977 (field_5x52.h:13-15 of the vendored tree).  Like the reference's own field
@@ -64,6 +67,7 @@ struct Secp256k1Fp {
     // reduced-radix form (fe30.cuh): plain residues there too, so both conversion factors are 1
     static constexpr uint32_t R1_30[8] = {1, 0, 0, 0, 0, 0, 0, 0};
     static constexpr uint32_t R2_30[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+    static constexpr uint32_t RR_30[8] = {1, 0, 0, 0, 0, 0, 0, 0};
 };
 
 // ---------------------------------------------------------------- element type

@@ -19,6 +19,8 @@ namespace porla {
 //   proven bound (|a1|+|a2|)/2, (|b1|+|b2|)/2 (+ rounding): 126 / 126 bits; worst seen over the self-check: 126 bits
 struct GlvBn254 {
     static constexpr uint32_t BETA[8] = {0x607cfd48u, 0xe4bd44e5u, 0xbb966e3du, 0xc28f069fu, 0xe0acccb0u, 0x5e6dd9e7u, 0xe131a029u, 0x30644e72u};   // plain
+    // beta in the field form the reduced-radix kernels compute in (fe30.cuh): beta * 2^270 mod p
+    static constexpr uint32_t BETA_30[8] = {0x553ba9feu, 0xf084d174u, 0x425467c7u, 0x743dbd42u, 0xac1030d9u, 0x64efb88du, 0x788d0b37u, 0x24f261b7u};
     static constexpr int SHIFT = 382;
     static constexpr uint32_t G1[8] = {0xf2d2e698u, 0x058ed210u, 0xf5792573u, 0x45275503u, 0xc03fd959u, 0x94e63f40u, 0x29dcf4b4u, 0x9333bc05u};     // round(2^SHIFT |b2| / n)
     static constexpr uint32_t G2[8] = {0x4bebee99u, 0xa3e9f4cbu, 0x1dce9bbcu, 0xdbae71c5u, 0xb1f82cf5u, 0xb64748cbu, 0x00000000u, 0x00000000u};     // round(2^SHIFT |b1| / n)
@@ -34,6 +36,7 @@ struct GlvBn254 {
 //   proven bound (|a1|+|a2|)/2, (|b1|+|b2|)/2 (+ rounding): 128 / 128 bits; worst seen over the self-check: 128 bits
 struct GlvSecp256k1 {
     static constexpr uint32_t BETA[8] = {0x719501eeu, 0xc1396c28u, 0x12f58995u, 0x9cf04975u, 0xac3434e9u, 0x6e64479eu, 0x657c0710u, 0x7ae96a2bu};   // plain
+    static constexpr uint32_t BETA_30[8] = {0x719501eeu, 0xc1396c28u, 0x12f58995u, 0x9cf04975u, 0xac3434e9u, 0x6e64479eu, 0x657c0710u, 0x7ae96a2bu};   // plain residues in that form too
     static constexpr int SHIFT = 384;
     static constexpr uint32_t G1[8] = {0x45dbb031u, 0xe893209au, 0x71e8ca7fu, 0x3daa8a14u, 0x9284eb15u, 0xe86c90e4u, 0xa7d46bcdu, 0x3086d221u};     // round(2^SHIFT |b2| / n)
     static constexpr uint32_t G2[8] = {0x8ac47f71u, 0x1571b4aeu, 0x9df506c6u, 0x221208acu, 0x0abfe4c4u, 0x6f547fa9u, 0x010e8828u, 0xe4437ed6u};     // round(2^SHIFT |b1| / n)

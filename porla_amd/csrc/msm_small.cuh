@@ -285,29 +285,37 @@ k_small_msm(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ poi
     {
         XYZZ30<M> acc;
         acc.inf = true;
+        // the next entry's point is in flight while this one is converted and added (a gather is an L2 / HBM round trip)
+        uint32_t en = 0;
+        Affine<M> nx;
+        if (my_t < my_cnt) {
+            en = ent[my_start + my_t];
+            const uint32_t i = g.glv ? (en & 0x7fffffffu) >> 1 : (en & 0x7fffffffu);
+            load_be256(nx.x.v, points + (size_t)i * 64);
+            load_be256(nx.y.v, points + (size_t)i * 64 + 32);
+        }
         for (uint32_t e = my_t; e < my_cnt; e += T) {
-            const uint32_t en = ent[my_start + e];
-            const uint32_t u = en & 0x7fffffffu;
-            const uint32_t i = g.glv ? u >> 1 : u;
-            Affine<M> a;
-            load_be256(a.x.v, points + (size_t)i * 64);
-            load_be256(a.y.v, points + (size_t)i * 64 + 32);
+            const uint32_t cur = en;
+            Affine<M> a = nx;
+            if (e + T < my_cnt) {
+                en = ent[my_start + e + T];
+                const uint32_t i = g.glv ? (en & 0x7fffffffu) >> 1 : (en & 0x7fffffffu);
+                load_be256(nx.x.v, points + (size_t)i * 64);
+                load_be256(nx.y.v, points + (size_t)i * 64 + 32);
+            }
             fe_reduce_plain<M>(a.x.v, 6);                      // G1Affine.Unmarshal: SetBytes reduces (main.go:130)
             fe_reduce_plain<M>(a.y.v, 6);
             if (aff_is_inf<M>(a)) continue;
-            Fe<M> r2;
-#pragma unroll
-            for (int q = 0; q < 8; q++) r2.v[q] = M::R2_30[q];
-            a.x = fe_mul<M>(a.x, r2);                          // the 2^270 form the reduced-radix addition computes in
-            a.y = fe_mul<M>(a.y, r2);
-            if (g.glv && (u & 1u)) {                           // phi(P) = (beta x, y)
-                Fe<M> beta;
-#pragma unroll
-                for (int q = 0; q < 8; q++) beta.v[q] = C::Glv::BETA[q];
-                a.x = fe_mul<M>(a.x, fe_to_mont<M>(beta));
+            a = aff_neg_if<M>(a, (cur >> 31) != 0);            // on the plain residue: -y = p - y in any form
+            // into the 2^270 form the reduced-radix addition computes in: one product by 2^540 mod p per coordinate (the special-form
+            // field keeps plain residues: nothing to do); phi(P) = (beta x, y) for the second sub-scalar
+            F30<M> ax = f30_from_fe<M>(a.x), ay = f30_from_fe<M>(a.y);
+            if constexpr (!M::PSEUDO_MERSENNE) {
+                ax = f30_mul<M>(ax, f30_const<M>(M::RR_30));
+                ay = f30_mul<M>(ay, f30_const<M>(M::RR_30));
             }
-            a = aff_neg_if<M>(a, (en >> 31) != 0);
-            xyzz30_madd<M>(acc, f30_from_fe<M>(a.x), f30_from_fe<M>(a.y));
+            if (g.glv && (cur & 1u)) ax = f30_mul<M>(ax, f30_const<M>(C::Glv::BETA_30));
+            xyzz30_madd<M>(acc, ax, ay);
         }
         xyzz30_store_lazy<M>(&pts[tid], acc);
     }
