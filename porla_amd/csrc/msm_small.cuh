@@ -67,24 +67,27 @@ __host__ __device__ inline SmallCfg small_cfg(uint32_t n, int used_bits, int c_f
     // 7 per tree level, 4 (split) or 2 per scalar a lane recodes; a bucket's load is taken at its mean + 3 sigma.
     int best_c = 0;
     float best_cost = 1e30f;
+    // (every block evaluates this before it can start: the loop is unrolled so that the divisions by c are by constants, and the
+    // two by run-time values are float divisions -- exact here: blocks <= 256, n <= 4096 and the quotients are floored)
+#pragma unroll
     for (int c = 1; c <= SMALL_MAX_C; c++) {
         if (c_override >= 1 && c_override <= SMALL_MAX_C && c != c_override) continue;
-        const int W = (g.L + 1 + c - 1) / c;
+        const int W = (g.L + c) / c;
         if (W > blocks || W >= SMALL_DONE_SLOT) continue;
-        uint32_t S = (uint32_t)(blocks / W);
+        uint32_t S = (uint32_t)((float)blocks / (float)W);
         const uint32_t by_size = (g.n_sub + 7) / 8;      // a slice of fewer than 8 sub-scalars is not worth a fold level
         if (S > by_size) S = by_size;
         if (S > (uint32_t)SMALL_MAX_S) S = SMALL_MAX_S;
         if (S < 1) S = 1;
         const float Bf = (float)(1u << (c > 1 ? c - 1 : 0));
-        const float per_bucket = (float)g.n_sub / (float)S * (1.0f - 1.0f / (float)(1u << c)) / Bf;
+        const float per_bucket = (float)g.n_sub / (float)S * ((1.0f - 1.0f / (float)(1u << c)) / Bf);
         const float lanes = 256.0f / Bf;
         float per_lane = (per_bucket + 3.0f * __builtin_sqrtf(per_bucket)) / lanes;
         int chain = (int)per_lane;
         if ((float)chain < per_lane) chain++;
         int lv = 0;
         while ((1u << lv) < S) lv++;
-        const int recode = (int)((n / S + 255u) / 256u);
+        const int recode = (int)(((uint32_t)((float)n / (float)S) + 255u) / 256u);
         const float cost = 18.0f * (float)(chain > 1 ? chain - 1 : 0) + 7.0f * (float)(8 + lv) + (g.glv ? 4.0f : 2.0f) * (float)recode +
                            0.01f * (float)W;
         if (cost < best_cost) { best_cost = cost; best_c = c; g.c = c; g.W = W; g.S = (int)S; }
@@ -177,9 +180,9 @@ k_small_msm(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ poi
     const uint32_t i0 = (uint32_t)((uint64_t)s * n / g.S), i1 = (uint32_t)((uint64_t)(s + 1) * n / g.S);   // the slice's scalars
 
     const uint32_t wc = w * (uint32_t)c;                          // first bit of the window
-    if (tid < 8) {
+    if (tid < 8) {                                             // bits p of limb tid with p mod c == c - 1
         uint32_t v = 0;
-        for (uint32_t b = 0; b < 32; b++) if ((32 * tid + b) % (uint32_t)c == (uint32_t)c - 1) v |= 1u << b;
+        for (uint32_t b = (uint32_t)c - 1 - (32 * tid) % (uint32_t)c; b < 32; b += (uint32_t)c) v |= 1u << b;
         pat[tid] = v;
     }
     __syncthreads();
