@@ -257,7 +257,7 @@ int porla_gpu_release_msm_workspaces(void) {
         (void)hipSetDevice(w->device);
         Buf* bufs[] = {&w->pts, &w->keys, &w->entries, &w->counts, &w->starts, &w->fill, &w->cursor, &w->buckets, &w->in_scalars,
                        &w->in_points, &w->order, &w->blk_hist, &w->blk_off, &w->tile_off, &w->heavy, &w->chunk_out, &w->tree_s,
-                       &w->tree_m, &w->tree_mt, &w->small_part};
+                       &w->tree_m, &w->tree_mt, &w->small_part, &w->multi_acc};
         for (Buf* b : bufs) b->release();
     }
     (void)hipSetDevice(cur);

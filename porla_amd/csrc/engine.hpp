@@ -108,6 +108,8 @@ struct Workspace {
     Buf small_part;               // single-launch path: the blocks' sums + the per-window arrival counters
     uint32_t small_seq = 0;
     Buf tree_s, tree_m, tree_mt;  // bucket reduction tree: S levels, M ping-pong halves (all windows / tail-private)
+    Buf multi_acc;                // msm_host_multi: the bucket sums of a device's ranges, merged before one reduction
+    hipEvent_t merged = nullptr;  // ... recorded after this slot's range has been merged into multi_acc
     void* h_windows = nullptr;  // pinned, device-mapped: the tree's last level writes [W][c] (S, M_0 .. M_(c-2)) per window
     size_t h_windows_cap = 0;
     hipStream_t own_stream = nullptr;

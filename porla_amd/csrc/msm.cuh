@@ -530,7 +530,8 @@ k_size_scan(const uint32_t* __restrict__ blk_hist, uint32_t* __restrict__ blk_of
     if (tid == 0) ctrl[4 + row] = run;
 }
 
-// order[pos] = (bucket, item index inside the bucket); empty buckets are written as infinity (zz = 0) here.
+// order[pos] = (bucket, item index inside the bucket); empty buckets are written as infinity (zz = 0) here (buckets_raw ==
+// nullptr: the bucket array already holds sums this launch adds to, and empty buckets keep theirs).
 static __global__ void __launch_bounds__(1024)
 k_size_order(const uint32_t* __restrict__ counts, uint32_t nb, const uint32_t* __restrict__ blk_off, uint32_t nblocks,
              uint2* __restrict__ order, uint32_t* __restrict__ chunk_base, uint32_t* __restrict__ heavy_list,
@@ -551,7 +552,7 @@ k_size_order(const uint32_t* __restrict__ counts, uint32_t nb, const uint32_t* _
     uint32_t cnt = counts[i];
     uint32_t full = cnt / CHUNK, rem = cnt % CHUNK;
     uint32_t items = full + (rem ? 1u : 0u);
-    if (items == 0) {
+    if (items == 0 && buckets_raw) {
         uint4 z = make_uint4(0, 0, 0, 0);
         uint4* d = buckets_raw + (size_t)i * 8;
 #pragma unroll
@@ -613,7 +614,7 @@ k_bucket_sum30(const Affine<typename C::Fp>* __restrict__ pts, const uint32_t* _
                const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
                const uint2* __restrict__ order, const uint32_t* __restrict__ chunk_base,
                const uint32_t* __restrict__ ctrl, XYZZ<typename C::Fp>* __restrict__ buckets,
-               XYZZ<typename C::Fp>* __restrict__ chunk_out) {
+               XYZZ<typename C::Fp>* __restrict__ chunk_out, uint32_t accumulate) {
     using M = typename C::Fp;
     uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= ctrl[3]) return;
@@ -623,8 +624,14 @@ k_bucket_sum30(const Affine<typename C::Fp>* __restrict__ pts, const uint32_t* _
     uint32_t cnt = counts[b] - first;
     if (cnt > CHUNK) cnt = CHUNK;
     const uint32_t* e = entries + starts[b] + first;
+    const uint32_t cb = chunk_base[b];
     XYZZ30<M> acc;
     acc.inf = true;
+    // accumulate: the bucket array holds the sums of earlier pair ranges of the same input (msm_host_multi) -- the bucket's only
+    // item continues from that sum (multi-item buckets: k_bucket_combine adds it)
+    if constexpr (C::F30_LAZY) {
+        if (accumulate && cb == NO_CHUNK) acc = xyzz30_load_lazy<M>(buckets + b);
+    }
     uint32_t ent = e[0];
     for (uint32_t k = 0; k < cnt; k++) {
         uint32_t cur = ent;
@@ -634,7 +641,6 @@ k_bucket_sum30(const Affine<typename C::Fp>* __restrict__ pts, const uint32_t* _
         a = aff_neg_if<M>(a, (cur >> 31) != 0);
         xyzz30_madd<M>(acc, f30_from_fe<M>(a.x), f30_from_fe<M>(a.y));
     }
-    const uint32_t cb = chunk_base[b];
     XYZZ<M>* dst = cb == NO_CHUNK ? buckets + b : chunk_out + cb + item.y;
     if constexpr (C::F30_LAZY) xyzz30_store_lazy<M>(dst, acc);
     else store_xyzz<M>(dst, xyzz30_to_xyzz<M>(acc));
@@ -849,7 +855,8 @@ template <class C>
 __global__ void __launch_bounds__(64)
 k_bucket_combine(const uint32_t* __restrict__ heavy_list, const uint32_t* __restrict__ chunk_base,
                  const uint32_t* __restrict__ counts, const uint32_t* __restrict__ ctrl,
-                 const XYZZ<typename C::Fp>* __restrict__ chunk_out, XYZZ<typename C::Fp>* __restrict__ buckets) {
+                 const XYZZ<typename C::Fp>* __restrict__ chunk_out, XYZZ<typename C::Fp>* __restrict__ buckets,
+                 uint32_t accumulate) {
     using M = typename C::Fp;
     using N = Node<C>;
     __shared__ XYZZ<M> stage[64];
@@ -859,6 +866,7 @@ k_bucket_combine(const uint32_t* __restrict__ heavy_list, const uint32_t* __rest
         const uint32_t items = (counts[b] + CHUNK - 1) / CHUNK;
         const XYZZ<M>* src = chunk_out + chunk_base[b];
         typename N::T acc = N::inf();
+        if (accumulate && threadIdx.x == 0) acc = N::load(buckets + b);      // the sums of earlier ranges (k_bucket_sum30)
         for (uint32_t k = threadIdx.x; k < items; k += 64) {
             typename N::T p = N::load(src + k);
             N::add(acc, p);

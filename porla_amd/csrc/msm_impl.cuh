@@ -136,21 +136,44 @@ static int msm_small_launch(Workspace* ws, const uint8_t* d_scalars, const uint8
 
 #define PORLA_TRACE(tag) do { if (trace_on) { auto now = std::chrono::steady_clock::now(); \
     fprintf(stderr, "[trace slot %d] %-18s %8.1f us\n", ws->slot, tag, std::chrono::duration<double, std::micro>(now - t_tr).count()); t_tr = now; } } while (0)
+// The shape several ranges of one input share when their bucket sums are merged before ONE reduction (msm_host_multi): the
+// split flag and the scalar length are those of the whole input, the window width is given.
+struct MsmShape {
+    bool glv;
+    int bits, c, W;
+};
 template <class C>
-static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_points_be, size_t n, hipStream_t stream) {
+static inline MsmShape msm_full_shape(size_t n_range) {
+    MsmShape sh;
+    sh.glv = g_use_glv < 0 ? C::GLV_DEFAULT : g_use_glv != 0;
+    sh.bits = sh.glv ? C::Glv::BITS : C::SCALAR_BITS;
+    sh.c = choose_window(sh.glv ? 2 * n_range : n_range, sh.bits);
+    sh.W = (sh.bits + 1 + sh.c - 1) / sh.c;
+    return sh;
+}
+template <class C>
+static int msm_tree_launch(Workspace* ws, const XYZZ<typename C::Fp>* buckets, int c, int W, bool glv, hipStream_t stream);
+
+// forced != nullptr: bucket sums only, in the given shape, into bucket_out; `accumulate`: bucket_out already holds the sums
+// of earlier ranges and this range adds to them, after `after` (the previous range's last write to bucket_out) has happened.
+// The caller runs msm_tree_launch once.  Otherwise the complete MSM up to the per-window sums in pinned memory.
+template <class C>
+static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_points_be, size_t n, hipStream_t stream,
+                      const MsmShape* forced = nullptr, XYZZ<typename C::Fp>* bucket_out = nullptr, bool accumulate = false,
+                      hipEvent_t after = nullptr) {
     using M = typename C::Fp;
     static const bool trace_on = getenv("PORLA_TRACE_LAUNCH") != nullptr;
     auto t_tr = std::chrono::steady_clock::now();
     ws->pend_W = 0;
     if (n == 0) return PORLA_OK;
     if (n >= (1ull << 30)) { set_last_error("porla: MSM length must be < 2^30 per call (range-split larger inputs)"); return PORLA_ERR_ARG; }
-    if (n <= SMALL_MAX_N && g_small_mode != 0 && g_window_override == 0) return msm_small_launch<C>(ws, d_scalars, d_points_be, n, stream);
-    const bool glv = g_use_glv < 0 ? C::GLV_DEFAULT : g_use_glv != 0;
+    if (!forced && n <= SMALL_MAX_N && g_small_mode != 0 && g_window_override == 0) return msm_small_launch<C>(ws, d_scalars, d_points_be, n, stream);
+    const bool glv = forced ? forced->glv : (g_use_glv < 0 ? C::GLV_DEFAULT : g_use_glv != 0);
     int bits = glv ? C::Glv::BITS : C::SCALAR_BITS;
     // Small and medium inputs: look at the scalars first.  If none of them exceeds b bits (and b is below the group order's
     // length, so SetBytes does not reduce anything) only ceil((b + 1) / c) windows exist -- the audit's abs(int32)
     // coefficients need 2 windows of 16 bits, not 16.  One extra launch and an 8-word read-back (~15 us).
-    if (n <= MSM_SCAN_MAX) {
+    if (!forced && n <= MSM_SCAN_MAX) {
         if (ws->h_windows_cap < 64 * 1024) {
             if (ws->h_windows) PORLA_HIP(hipHostFree(ws->h_windows));
             ws->h_windows_cap = 64 * 1024;
@@ -173,7 +196,7 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
     }
     const size_t n_sub = glv ? 2 * n : n;                 // sub-scalars = entries per window at most
     const uint32_t tile_cap = glv ? 2 * TILE : TILE;
-    const int c = choose_window(n_sub, bits);
+    const int c = forced ? forced->c : choose_window(n_sub, bits);
     const int W = (bits + 1 + c - 1) / c;
     const uint32_t B = 1u << (c - 1);
     const size_t nb = (size_t)W * B;
@@ -200,21 +223,11 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
     if ((rc = ws->chunk_out.ensure(max_chunk_out * sizeof(XYZZ<M>)))) return rc;
     if ((rc = ws->blk_hist.ensure((size_t)CHUNK * nblk * 4))) return rc;
     if ((rc = ws->blk_off.ensure((size_t)CHUNK * nblk * 4))) return rc;
-    if ((rc = ws->buckets.ensure(nb * sizeof(XYZZ<M>)))) return rc;
-    const uint32_t nlev = (uint32_t)(c - 1);
-    {
-        if ((rc = ws->tree_s.ensure((nb + 1) * sizeof(XYZZ<M>)))) return rc;               // all S levels: nb/2 + nb/4 + ...
-        if ((rc = ws->tree_m.ensure((2 * (nb / 4) + 2) * sizeof(XYZZ<M>)))) return rc;     // two ping-pong halves
-        if ((rc = ws->tree_mt.ensure((2 * (size_t)W * (B / 4 + 1) + 2) * sizeof(XYZZ<M>)))) return rc;  // the tail's private halves
+    XYZZ<M>* bk = bucket_out;
+    if (!bk) {
+        if ((rc = ws->buckets.ensure(nb * sizeof(XYZZ<M>)))) return rc;
+        bk = (XYZZ<M>*)ws->buckets.p;
     }
-    if (ws->h_windows_cap < (size_t)W * c * sizeof(XYZZ<M>)) {
-        if (ws->h_windows) PORLA_HIP(hipHostFree(ws->h_windows));
-        ws->h_windows_cap = 64 * 1024;
-        PORLA_HIP(hipHostMalloc(&ws->h_windows, ws->h_windows_cap, hipHostMallocMapped | hipHostMallocCoherent));
-    }
-    void* h_windows_dev = nullptr;
-    PORLA_HIP(hipHostGetDevicePointer(&h_windows_dev, ws->h_windows, 0));
-
     PORLA_TRACE("alloc");
     uint32_t* ctrl = (uint32_t*)ws->cursor.p;
     PORLA_HIP(hipMemsetAsync(ctrl, 0, CTRL_WORDS * 4, stream));
@@ -233,10 +246,12 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
     const int P = 1 << (c - 1 - lowbits);
     {
         ProfScope ps("digits_partition", stream);
-        // blocks per tile: small inputs (a few tiles) split the windows of a tile over up to 32 blocks; large inputs keep
-        // one block per tile (every extra block re-reads the tile's scalars: 0.08 -> 0.19 ms at 2^20 with four)
-        unsigned wg = T_tiles <= 16 ? 32u / T_tiles : 1u;
-        if (wg < 1) wg = 1;
+        // blocks per tile: up to 2^19 pairs the windows of a tile are split over enough blocks to give every CU one (a block
+        // walks its windows one after the other: 74 -> 50 us at 2^18 with four blocks per tile); larger inputs keep one block
+        // per tile -- every extra block re-reads the tile's scalars: 0.07 -> 0.18 ms at 2^20 with four
+        // (profiles/r02_g_digits_blocks_per_tile.jsonl)
+        unsigned wg = T_tiles < 256 ? 256u / T_tiles : 1u;
+        if (wg > 16) wg = 16;
         if (wg > (unsigned)W) wg = (unsigned)W;
         if (getenv("PORLA_DIGITS_WG")) wg = (unsigned)atoi(getenv("PORLA_DIGITS_WG"));
         if (glv)
@@ -261,30 +276,60 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
                            (uint32_t*)ws->blk_off.p, nblk, ctrl);
         hipLaunchKernelGGL(k_size_order, dim3(nblk), dim3(1024), 0, stream, (const uint32_t*)ws->counts.p, (uint32_t)nb,
                            (const uint32_t*)ws->blk_off.p, nblk, (uint2*)ws->order.p, (uint32_t*)ws->fill.p,
-                           (uint32_t*)ws->heavy.p, ctrl, (uint4*)ws->buckets.p);
+                           (uint32_t*)ws->heavy.p, ctrl, accumulate ? (uint4*)nullptr : (uint4*)bk);
     }
     PORLA_TRACE("size_order");
+    if (accumulate) {
+        if (!C::F30_LAZY) { set_last_error("porla: merged pair ranges need the reduced-radix bucket form"); return PORLA_ERR_STATE; }
+        if (after) PORLA_HIP(hipStreamWaitEvent(stream, after, 0));
+    }
     {
         ProfScope ps("bucket_sum", stream, true);
         if constexpr (C::F30_BUCKETS)
             hipLaunchKernelGGL((k_bucket_sum30<C>), dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, stream, pts,
                                (const uint32_t*)ws->entries.p, (const uint32_t*)ws->starts.p,
                                (const uint32_t*)ws->counts.p, (const uint2*)ws->order.p, (const uint32_t*)ws->fill.p,
-                               (const uint32_t*)ctrl, (XYZZ<M>*)ws->buckets.p, (XYZZ<M>*)ws->chunk_out.p);
+                               (const uint32_t*)ctrl, bk, (XYZZ<M>*)ws->chunk_out.p, accumulate ? 1u : 0u);
         else
             hipLaunchKernelGGL((k_bucket_sum<C>), dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, stream, pts,
                                (const uint32_t*)ws->entries.p, (const uint32_t*)ws->starts.p,
                                (const uint32_t*)ws->counts.p, (const uint2*)ws->order.p, (const uint32_t*)ws->fill.p,
-                               (const uint32_t*)ctrl, (XYZZ<M>*)ws->buckets.p, (XYZZ<M>*)ws->chunk_out.p);
+                               (const uint32_t*)ctrl, bk, (XYZZ<M>*)ws->chunk_out.p);
     }
     PORLA_TRACE("bucket_sum");
     {
         ProfScope ps("bucket_combine", stream);
         hipLaunchKernelGGL((k_bucket_combine<C>), dim3(2048), dim3(64), 0, stream, (const uint32_t*)ws->heavy.p,
                            (const uint32_t*)ws->fill.p, (const uint32_t*)ws->counts.p, (const uint32_t*)ctrl,
-                           (const XYZZ<M>*)ws->chunk_out.p, (XYZZ<M>*)ws->buckets.p);
+                           (const XYZZ<M>*)ws->chunk_out.p, bk, accumulate ? 1u : 0u);
     }
     PORLA_TRACE("combine");
+    PORLA_HIP(hipGetLastError());
+    if (forced) return PORLA_OK;
+    return msm_tree_launch<C>(ws, bk, c, W, glv, stream);
+}
+
+// bucket reduction of W windows of 2^(c-1) buckets each (the bit-sliced tree of msm.cuh) into the workspace's pinned buffer;
+// records ws->done and leaves the shape for msm_finish
+template <class C>
+static int msm_tree_launch(Workspace* ws, const XYZZ<typename C::Fp>* buckets, int c, int W, bool glv, hipStream_t stream) {
+    using M = typename C::Fp;
+    static const bool trace_on = getenv("PORLA_TRACE_LAUNCH") != nullptr;
+    auto t_tr = std::chrono::steady_clock::now();
+    int rc;
+    const uint32_t B = 1u << (c - 1);
+    const size_t nb = (size_t)W * B;
+    const uint32_t nlev = (uint32_t)(c - 1);
+    if ((rc = ws->tree_s.ensure((nb + 1) * sizeof(XYZZ<M>)))) return rc;               // all S levels: nb/2 + nb/4 + ...
+    if ((rc = ws->tree_m.ensure((2 * (nb / 4) + 2) * sizeof(XYZZ<M>)))) return rc;     // two ping-pong halves
+    if ((rc = ws->tree_mt.ensure((2 * (size_t)W * (B / 4 + 1) + 2) * sizeof(XYZZ<M>)))) return rc;  // the tail's private halves
+    if (ws->h_windows_cap < (size_t)W * c * sizeof(XYZZ<M>) || ws->h_windows_cap < 64 * 1024) {
+        if (ws->h_windows) PORLA_HIP(hipHostFree(ws->h_windows));
+        ws->h_windows_cap = 64 * 1024;
+        PORLA_HIP(hipHostMalloc(&ws->h_windows, ws->h_windows_cap, hipHostMallocMapped | hipHostMallocCoherent));
+    }
+    void* h_windows_dev = nullptr;
+    PORLA_HIP(hipHostGetDevicePointer(&h_windows_dev, ws->h_windows, 0));
     {
         // S level l at tree_s + (nb - (nb >> l)) (nb/2 + ... + nb/2^l entries before it); M slots of level l in half l & 1
         XYZZ<M>* s_base = (XYZZ<M>*)ws->tree_s.p;
@@ -296,8 +341,8 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
             ProfScope ps("tree_levels", stream);
             for (uint32_t l = 0; l < l0; l++) {
                 TreeLevelArgs<M> a;
-                a.s_prev = l ? s_level(l - 1) : (const XYZZ<M>*)ws->buckets.p;
-                a.s_prev2 = l >= 2 ? s_level(l - 2) : (const XYZZ<M>*)ws->buckets.p;
+                a.s_prev = l ? s_level(l - 1) : buckets;
+                a.s_prev2 = l >= 2 ? s_level(l - 2) : buckets;
                 a.m_prev = m_half[(l + 1) & 1];
                 a.s_out = s_level(l);
                 a.m_out = m_half[l & 1];
@@ -320,7 +365,7 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
         {
             ProfScope ps("tree_tail", stream);
             TreeTailArgs<M> t;
-            t.buckets = (const XYZZ<M>*)ws->buckets.p;
+            t.buckets = buckets;
             for (uint32_t l = 0; l < 24; l++) t.s_lev[l] = l < nlev ? s_level(l) : nullptr;
             t.m_global = m_half[(l0 + 1) & 1];
             t.per_window = B / 4 + 1;
@@ -456,7 +501,10 @@ static inline int msm_multi_pipeline() {   // ranges per device when the caller 
     return v < 1 ? 1 : (v > 64 ? 64 : v);
 }
 extern std::mutex g_multi_mu;
-
+static inline bool msm_multi_shared_buckets() {
+    static const bool v = !(getenv("PORLA_MSM_SHARED_BUCKETS") && getenv("PORLA_MSM_SHARED_BUCKETS")[0] == '0');
+    return v;
+}
 template <class C>
 int msm_host_multi(const uint8_t* scalars, const uint8_t* points, size_t n, int shards, int devices,
                    XYZZ<typename C::Fp>* total) {
@@ -485,46 +533,109 @@ int msm_host_multi(const uint8_t* scalars, const uint8_t* points, size_t n, int 
     }
     if ((size_t)S > n) S = (int)n;
     if (S < G) G = S;
-    // range s = pairs [s n / S, (s+1) n / S); device g owns the contiguous ranges [g S / G, (g+1) S / G)
-    std::vector<XYZZ<M>> part((size_t)S, xyzz_inf<M>());
+    // Device g owns the contiguous ranges [g S / G, (g+1) S / G) of the S ranges (range s = pairs [s n / S, (s+1) n / S)).
+    // A device's R ranges share ONE shape and ONE bucket array: each range runs digits and sort on its own slot and then
+    // accumulates into the buckets where the previous range left them; the reduction tree + host fold run once per device -- a
+    // tree costs the same whatever the range size, so R of them were most of the work after the last upload
+    // (PORLA_MSM_SHARED_BUCKETS=0: one complete MSM per range, as before).
+    std::vector<XYZZ<M>> part((size_t)G, xyzz_inf<M>());
     std::vector<int> dev_rc((size_t)G, PORLA_OK);
     std::vector<std::string> dev_err((size_t)G);
     std::lock_guard<std::mutex> lk_multi(g_multi_mu);
     auto worker = [&](int g) {
         int r = PORLA_OK;
-        auto fail = [&](int code) { r = code; dev_err[g] = porla_gpu_last_error(); };
-        if (hipSetDevice((first + g) % visible) != hipSuccess) { set_last_error("porla: hipSetDevice failed"); fail(PORLA_ERR_HIP); dev_rc[g] = r; return; }
-        const int s0 = (int)((long long)g * S / G), s1 = (int)((long long)(g + 1) * S / G);
+        auto fail = [&](int code) { if (!r) { r = code; dev_err[g] = porla_gpu_last_error(); } };
+        const int dev = (first + g) % visible;
+        if (hipSetDevice(dev) != hipSuccess) { set_last_error("porla: hipSetDevice failed"); fail(PORLA_ERR_HIP); dev_rc[g] = r; return; }
+        const int s0 = (int)((long long)g * S / G), s1 = (int)((long long)(g + 1) * S / G), R = s1 - s0;
+        std::vector<size_t> bound((size_t)R + 1);
+        size_t max_cnt = 0;
+        for (int j = 0; j <= R; j++) {
+            bound[(size_t)j] = (size_t)((unsigned __int128)(s0 + j) * n / (unsigned)S);
+            if (j && bound[(size_t)j] - bound[(size_t)j - 1] > max_cnt) max_cnt = bound[(size_t)j] - bound[(size_t)j - 1];
+        }
         constexpr int PIPE = MSM_MULTI_SLOTS;
         Workspace* slot_ws[PIPE] = {nullptr, nullptr, nullptr, nullptr};
-        int slot_shard[PIPE] = {-1, -1, -1, -1};
-        auto retire = [&](int k) {
-            if (slot_shard[k] < 0) return;
-            int rr = msm_finish<C>(slot_ws[k], &part[(size_t)slot_shard[k]]);
-            if (rr && !r) fail(rr);
-            slot_shard[k] = -1;
-        };
-        for (int s = s0; s < s1 && !r; s++) {
-            const int k = (s - s0) % PIPE;
-            if (!slot_ws[k]) {
-                int rr = get_workspace_slot(MSM_MULTI_SLOT0 + k, &slot_ws[k]);
-                if (rr) { fail(rr); break; }
-                slot_ws[k]->mu.lock();
+        const int used_slots = R < PIPE ? R : PIPE;
+        for (int k = 0; k < used_slots && !r; k++) {
+            int rr = get_workspace_slot(MSM_MULTI_SLOT0 + k, &slot_ws[k]);
+            if (rr) { slot_ws[k] = nullptr; fail(rr); break; }
+            slot_ws[k]->mu.lock();
+            slot_ws[k]->pend_W = 0;
+            // staging sized for the largest range before any copy is in flight (growing it later would free a buffer in use)
+            if ((rr = slot_ws[k]->in_scalars.ensure(max_cnt * 32)) || (rr = slot_ws[k]->in_points.ensure(max_cnt * 64))) { fail(rr); break; }
+            if (!slot_ws[k]->merged && hipEventCreateWithFlags(&slot_ws[k]->merged, hipEventDisableTiming) != hipSuccess) {
+                set_last_error("porla: hipEventCreate failed"); fail(PORLA_ERR_HIP); break;
             }
-            retire(k);
-            const size_t lo = (size_t)((unsigned __int128)s * n / (unsigned)S), hi = (size_t)((unsigned __int128)(s + 1) * n / (unsigned)S);
-            int rr = msm_host_launch<C>(slot_ws[k], scalars + 32 * lo, points + 64 * lo, hi - lo);
-            if (rr) { fail(rr); break; }
-            slot_shard[k] = s;
+        }
+        const bool shared = R >= 2 && msm_multi_shared_buckets();
+        MsmShape shape = msm_full_shape<C>(max_cnt);
+        if (getenv("PORLA_MSM_MULTI_C")) { int cc = atoi(getenv("PORLA_MSM_MULTI_C")); if (cc >= 2 && cc <= 20) { shape.c = cc; shape.W = (shape.bits + 1 + cc - 1) / cc; } }
+        const size_t nb = (size_t)shape.W << (shape.c - 1);
+        XYZZ<M>* acc = nullptr;
+        if (!r && shared) {
+            int rr = slot_ws[0]->multi_acc.ensure(nb * sizeof(XYZZ<M>));
+            if (rr) fail(rr);
+            acc = (XYZZ<M>*)slot_ws[0]->multi_acc.p;
+        }
+        // (measured and dropped: the uploads on a thread of their own, so that a range's kernels are enqueued while the next range
+        // is copied, and ranges of unequal size -- neither moved the 2^20 figure, profiles/r02_g_host_boundary_sweep.txt)
+        auto upload = [&](int j) -> int {                // copies of local range j into its slot's staging buffers
+            Workspace* ws = slot_ws[j % PIPE];
+            const size_t lo = bound[(size_t)j], cnt = bound[(size_t)j + 1] - lo;
+            if (cnt == 0) return PORLA_OK;
+            PORLA_HIP(hipMemcpyAsync(ws->in_scalars.p, scalars + 32 * lo, cnt * 32, hipMemcpyHostToDevice, ws->own_stream));
+            PORLA_HIP(hipMemcpyAsync(ws->in_points.p, points + 64 * lo, cnt * 64, hipMemcpyHostToDevice, ws->own_stream));
+            return PORLA_OK;
+        };
+        Workspace* last_ws = nullptr;                    // the slot whose stream carries the reduction
+        int prev_merged = -1;                            // slot of the last range that has been merged (its `merged` event is recorded)
+        XYZZ<M> unshared_sum = xyzz_inf<M>();
+        for (int j = 0; j < R && !r; j++) {
+            const int k = j % PIPE;
+            Workspace* ws = slot_ws[k];
+            if (!shared && ws->pend_W) {                 // one complete MSM per range: fold the slot's previous range first
+                XYZZ<M> t;
+                int rr = msm_finish<C>(ws, &t);
+                if (rr) { fail(rr); break; }
+                xyzz_add<M>(unshared_sum, t);
+            }
+            {
+                int rr = upload(j);
+                if (rr) { fail(rr); break; }
+            }
+            const size_t cnt = bound[(size_t)j + 1] - bound[(size_t)j];
+            hipStream_t st = ws->own_stream;
+            if (cnt) {
+                int rr;
+                if (!shared) {
+                    rr = msm_launch<C>(ws, (const uint8_t*)ws->in_scalars.p, (const uint8_t*)ws->in_points.p, cnt, st);
+                } else {
+                    const bool first_range = prev_merged < 0;
+                    rr = msm_launch<C>(ws, (const uint8_t*)ws->in_scalars.p, (const uint8_t*)ws->in_points.p, cnt, st, &shape, acc,
+                                       !first_range, first_range ? nullptr : slot_ws[prev_merged]->merged);
+                    if (!rr && hipEventRecord(ws->merged, st) != hipSuccess) { set_last_error("porla: hipEventRecord failed"); rr = PORLA_ERR_HIP; }
+                    if (!rr) { prev_merged = k; last_ws = ws; }
+                }
+                if (rr) { fail(rr); break; }
+            }
+        }
+        if (!r && shared && last_ws) {
+            int rr = msm_tree_launch<C>(last_ws, acc, shape.c, shape.W, shape.glv, last_ws->own_stream);
+            if (!rr) rr = msm_finish<C>(last_ws, &part[(size_t)g]);
+            if (rr) fail(rr);
         }
         for (int k = 0; k < PIPE; k++) {
             if (!slot_ws[k]) continue;
-            if (slot_shard[k] >= 0) {
-                if (!r) retire(k);
-                else { (void)hipEventSynchronize(slot_ws[k]->done); slot_ws[k]->pend_W = 0; }   // drain what was enqueued
+            if (r) { (void)hipStreamSynchronize(slot_ws[k]->own_stream); slot_ws[k]->pend_W = 0; }   // drain what was enqueued
+            else if (!shared && slot_ws[k]->pend_W) {
+                XYZZ<M> t;
+                int rr = msm_finish<C>(slot_ws[k], &t);
+                if (rr) fail(rr); else xyzz_add<M>(unshared_sum, t);
             }
             slot_ws[k]->mu.unlock();
         }
+        if (!r && !shared) part[(size_t)g] = unshared_sum;
         dev_rc[g] = r;
     };
     if (G == 1) {
@@ -538,7 +649,7 @@ int msm_host_multi(const uint8_t* scalars, const uint8_t* points, size_t n, int 
     }
     for (int g = 0; g < G; g++) if (dev_rc[g]) { set_last_error(dev_err[g]); return dev_rc[g]; }
     XYZZ<M> acc = xyzz_inf<M>();
-    for (int s = 0; s < S; s++) xyzz_add<M>(acc, part[(size_t)s]);
+    for (int g = 0; g < G; g++) xyzz_add<M>(acc, part[(size_t)g]);
     *total = acc;
     g_last_multi[0] = S; g_last_multi[1] = G;
     return PORLA_OK;
