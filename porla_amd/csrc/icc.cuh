@@ -220,12 +220,18 @@ k_icc_stages(IccElem<Q>* __restrict__ work, const IccElem<Q>* __restrict__ tw, u
 
 // value in [0, LCM) as 64 bytes little-endian from the residue pair: P = A mod p_icc (plain), pq_m = P mod q (Montgomery)
 template <class Q>
+__device__ __forceinline__ void icc_store_lcm_pt(const Fe<IccFp>& P, const Fe<Q>& t, uint8_t* dst);
+template <class Q>
 __device__ __forceinline__ void icc_store_lcm(const IccElem<Q>& e, const Fe<IccFp>& P, const Fe<Q>& pq_m, uint8_t* dst) {
         // A = P + p_icc * t,  t = (a_q - P) * p_icc^-1 mod q;  p_icc * t = t + (207 t << 248)
     Fe<Q> pinv;
 #pragma unroll
     for (int k = 0; k < 8; k++) pinv.v[k] = Q::PINV[k];
-    Fe<Q> t = fe_mul<Q>(fe_sub<Q>(e.q, pq_m), pinv);   // Montgomery(d) * plain -> plain product
+    icc_store_lcm_pt<Q>(P, fe_mul<Q>(fe_sub<Q>(e.q, pq_m), pinv), dst);   // Montgomery(d) * plain -> plain product
+}
+// A = P + t + (207 t << 248) as 64 bytes little-endian (P = A mod p_icc, t = the CRT coefficient, both plain)
+template <class Q>
+__device__ __forceinline__ void icc_store_lcm_pt(const Fe<IccFp>& P, const Fe<Q>& t, uint8_t* dst) {
     uint32_t u[9];
     uint32_t carry = 0;
 #pragma unroll
