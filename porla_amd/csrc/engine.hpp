@@ -127,6 +127,7 @@ constexpr int MSM_MULTI_SLOT0 = 4;
 constexpr int MSM_MULTI_SLOTS = 4;
 constexpr int MSM_POOL_SLOT0 = 8;
 constexpr size_t MSM_SCAN_MAX = 1u << 16;  // inputs up to this size are scanned for their longest scalar first
+constexpr size_t MSM_RANGE_MAX = 1u << 22; // larger inputs run as ranges of this size into one bucket array (msm_launch)
 // Batched fixed-base commitments (fixed_base.cuh): resident table of window multiples of one base.
 // Calls on one object are serialised by `mu`; the *_device form leaves its kernels in flight on the caller's stream, and a
 // later call on another stream waits (on the device, through `fence`) for them before it reuses the slice-partial scratch.

@@ -168,6 +168,22 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
     if (n == 0) return PORLA_OK;
     if (n >= (1ull << 30)) { set_last_error("porla: MSM length must be < 2^30 per call (range-split larger inputs)"); return PORLA_ERR_ARG; }
     if (!forced && n <= SMALL_MAX_N && g_small_mode != 0 && g_window_override == 0) return msm_small_launch<C>(ws, d_scalars, d_points_be, n, stream);
+    // Above 2^22 pairs the window model would ask for 18 bits and more, where a partition of the counting sort no longer fits its
+    // LDS staging area (scattered 4-byte stores: 5.5 of 26 ms at 2^24).  Instead the input goes through in ranges of <= 2^22
+    // pairs that accumulate into ONE bucket array (as the ranges of msm_host_multi do) with one reduction at the end; the scratch
+    // is that of a 2^22-pair MSM.
+    if (!forced && n > MSM_RANGE_MAX && C::F30_LAZY && g_window_override == 0) {
+        const size_t R = (n + MSM_RANGE_MAX - 1) / MSM_RANGE_MAX;
+        const MsmShape shape = msm_full_shape<C>((n + R - 1) / R);
+        int rc2;
+        if ((rc2 = ws->multi_acc.ensure(((size_t)shape.W << (shape.c - 1)) * sizeof(XYZZ<M>)))) return rc2;
+        XYZZ<M>* acc = (XYZZ<M>*)ws->multi_acc.p;
+        for (size_t r = 0; r < R; r++) {
+            const size_t lo = (size_t)((unsigned __int128)r * n / R), hi = (size_t)((unsigned __int128)(r + 1) * n / R);
+            if ((rc2 = msm_launch<C>(ws, d_scalars + 32 * lo, d_points_be + 64 * lo, hi - lo, stream, &shape, acc, r > 0, nullptr))) return rc2;
+        }
+        return msm_tree_launch<C>(ws, acc, shape.c, shape.W, shape.glv, stream);
+    }
     const bool glv = forced ? forced->glv : (g_use_glv < 0 ? C::GLV_DEFAULT : g_use_glv != 0);
     int bits = glv ? C::Glv::BITS : C::SCALAR_BITS;
     // Small and medium inputs: look at the scalars first.  If none of them exceeds b bits (and b is below the group order's

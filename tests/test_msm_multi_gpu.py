@@ -100,12 +100,29 @@ def test_2p24_config3_whole_job(mx):
     assert mx.last_msm_multi() == (4 * G, G)
     assert mx.bn254_multi_exp(pt, sc, n) == want     # compute_multi_exp, automatic split
     if G == 1:
-        # the same job as ONE launch on one GPU (c = 20 windows), device-resident -- the single-range baseline
+        # the same job device-resident on one GPU: ranges of 2^22 pairs into one bucket array (17-bit windows, the sort's staged
+        # path), and as ONE pass with 20-bit windows (the sort's scattered-store fallback) -- msm_impl.cuh:msm_launch
+        import time
         import torch
         d_sc = torch.frombuffer(bytearray(sc), dtype=torch.uint8).cuda()
         d_pt = torch.frombuffer(bytearray(pt), dtype=torch.uint8).cuda()
-        assert mx.msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n, torch.cuda.current_stream().cuda_stream) == want
+        s = torch.cuda.current_stream().cuda_stream
+        assert mx.msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n, s) == want
+        assert mx.last_msm_shape()[0] == 17
+        t0 = time.perf_counter()
+        mx.msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n, s)
+        t_ranges = time.perf_counter() - t0
         from porla_amd import lib
+        lib.porla_gpu_set_msm_window(20)
+        try:
+            assert mx.msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n, s) == want
+            assert mx.last_msm_shape()[0] == 20
+            t0 = time.perf_counter()
+            mx.msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n, s)
+            t_single = time.perf_counter() - t0
+        finally:
+            lib.porla_gpu_set_msm_window(0)
+        print("2^24 pairs, device-resident: %.2f ms in 4 ranges (c = 17), %.2f ms in one pass (c = 20)" % (t_ranges * 1e3, t_single * 1e3))
         lib.porla_gpu_release_msm_workspaces()
 
 
