@@ -315,17 +315,28 @@ k_digits_partition(const uint8_t* __restrict__ scalars, uint32_t n, int c, int W
         uint32_t key[NSUB];
         const int lo = w * c;
         const int limb = lo >> 5, sh = lo & 31;
+        // the two words the window straddles: `limb` is the same for the whole block, so this is a scalar branch to one of
+        // LIMBS copies (a select chain over the limbs cost 2 * LIMBS instructions per sub-scalar and window)
+        uint32_t wa[NSUB], wb[NSUB];
+#pragma unroll
+        for (int u = 0; u < NSUB; u++) { wa[u] = 0; wb[u] = 0; }
+#define PORLA_DIGIT_WORDS(k)                                                                              \
+        if constexpr ((k) < LIMBS) {                                                                          \
+            if (limb == (k)) {                                                                                \
+                _Pragma("unroll") for (int u = 0; u < NSUB; u++) {                                            \
+                    wa[u] = t[u][(k)];                                                                        \
+                    wb[u] = ((k) + 1 < LIMBS) ? t[u][((k) + 1 < LIMBS) ? (k) + 1 : (k)] : 0u;                 \
+                }                                                                                             \
+            }                                                                                                 \
+        }
+        PORLA_DIGIT_WORDS(0) PORLA_DIGIT_WORDS(1) PORLA_DIGIT_WORDS(2) PORLA_DIGIT_WORDS(3)
+        PORLA_DIGIT_WORDS(4) PORLA_DIGIT_WORDS(5) PORLA_DIGIT_WORDS(6) PORLA_DIGIT_WORDS(7)
+#undef PORLA_DIGIT_WORDS
 #pragma unroll
         for (int u = 0; u < NSUB; u++) {
             uint32_t raw = 0;
             if (lo < 32 * LIMBS) {
-                uint32_t a = 0, b = 0;
-#pragma unroll
-                for (int q = 0; q < LIMBS; q++) {
-                    a = (q == limb) ? t[u][q] : a;
-                    b = (q == limb + 1) ? t[u][q] : b;
-                }
-                uint64_t v = ((uint64_t)b << 32) | a;
+                uint64_t v = ((uint64_t)wb[u] << 32) | wa[u];
                 raw = (uint32_t)(v >> sh) & mask;
             }
             raw += (carry >> u) & 1u;
@@ -346,28 +357,29 @@ k_digits_partition(const uint8_t* __restrict__ scalars, uint32_t n, int c, int W
         }
         if (!mine) continue;
         __syncthreads();
-        // exclusive scan over P <= 128 partitions (Hillis-Steele in LDS)
+        // exclusive scan over P <= 128 partitions: two waves scan their 64 counters with shuffles, one barrier to pass the first
+        // wave's total on (a Hillis-Steele scan in LDS took 14 barriers of a 1024-thread block per window)
+        uint32_t pv = 0, pincl = 0;
         if (tid < MAX_PARTS) {
-            uint32_t v = (tid < (uint32_t)P) ? hist[tid] : 0;
-            cursor[tid] = v;
+            pv = (tid < (uint32_t)P) ? hist[tid] : 0;
+            pincl = pv;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(pincl, d, 64);
+                if ((tid & 63u) >= (uint32_t)d) pincl += o;
+            }
+            if (tid == 63) cursor[0] = pincl;
         }
         __syncthreads();
-        for (int d = 1; d < MAX_PARTS; d <<= 1) {
-            uint32_t v = 0;
-            if (tid < MAX_PARTS && tid >= (uint32_t)d) v = cursor[tid - d];
-            __syncthreads();
-            if (tid < MAX_PARTS) cursor[tid] += v;
-            __syncthreads();
-        }
         uint16_t* off = tile_off + ((size_t)w * T + tile) * (MAX_PARTS + 1);
-        uint32_t total = cursor[MAX_PARTS - 1];
         if (tid < MAX_PARTS) {
-            uint32_t excl = cursor[tid] - ((tid < (uint32_t)P) ? hist[tid] : 0);
+            const uint32_t excl = (tid >= 64 ? cursor[0] : 0u) + pincl - pv;
             off[tid] = (uint16_t)excl;
-            if (tid == 0) off[MAX_PARTS] = (uint16_t)total;
             hist[tid] = excl;  // becomes the running cursor
+            if (tid == MAX_PARTS - 1) { off[MAX_PARTS] = (uint16_t)(excl + pv); cursor[1] = excl + pv; }
         }
         __syncthreads();
+        const uint32_t total = cursor[1];
 #pragma unroll
         for (int u = 0; u < NSUB; u++) {
             if (key[u] != KEY_NONE) {
