@@ -23,3 +23,9 @@ for _ in range(reps):
     r = mx.msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n, s)
 el = (time.perf_counter() - t0) / reps
 print("blocking 2^%d MSM: %.4f ms, %.1f Mmul/s, shape %s" % (log2n, el * 1e3, n / el / 1e6, mx.last_msm_shape()))
+if os.environ.get("PORLA_LOOP_PROFILE"):
+    mx.profile_enable(True)
+    for _ in range(5):
+        mx.msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n, s)
+    print("kernels (ms per MSM):", {k: round(ms / max(c, 1), 4) for k, ms, c in mx.profile_get()})
+    mx.profile_enable(False)
