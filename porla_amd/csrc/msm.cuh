@@ -412,21 +412,52 @@ k_partition_sort(const uint32_t* __restrict__ tile_items, const uint16_t* __rest
     const uint32_t lowmask = nlow - 1;
     for (uint32_t i = tid; i < nlow; i += 1024) cnt[i] = 0;
     __syncthreads();
-    for (uint32_t t = wv; t < T; t += 16) {
-        const uint16_t* off = tile_off + ((size_t)w * T + t) * (MAX_PARTS + 1);
-        const uint32_t lo = off[p], hi = (p + 1 < (uint32_t)P) ? off[p + 1] : off[MAX_PARTS];
-        const uint32_t* it = tile_items + ((size_t)w * T + t) * tile_cap;
-        for (uint32_t i0 = lo; i0 < hi; i0 += 64) {
-            const bool active = i0 + lane < hi;
-            const uint32_t low = active ? (it[i0 + lane] & lowmask) : 0xffffffffu;
-            // skewed digits (a sparsely populated top window): lanes that hit the first lane's bucket share one atomic
-            const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)low);
-            const unsigned long long same = __ballot(low == first);
-            if (__popcll(same) >= 8) {
-                if (lane == (uint32_t)(__ffsll((long long)same) - 1)) atomicAdd(&cnt[first], (uint32_t)__popcll(same));
-                if (active && low != first) atomicAdd(&cnt[low], 1u);
-            } else if (active) {
-                atomicAdd(&cnt[low], 1u);
+    // A wave walks the runs of its tiles t = wv, wv + 16, ...: offsets -> items -> LDS atomics is a chain of two global loads
+    // per run, so the run bounds are fetched two tiles ahead and the first 128 items of a run one tile ahead (runs are 128
+    // items at 2^20 pairs): the loads of the next tiles are in flight while this one is counted / placed.
+    auto run_bounds = [&](uint32_t t, uint32_t& lo, uint32_t& hi) {
+        lo = 0; hi = 0;
+        if (t < T) {
+            const uint16_t* off = tile_off + ((size_t)w * T + t) * (MAX_PARTS + 1);
+            lo = off[p];
+            hi = (p + 1 < (uint32_t)P) ? off[p + 1] : off[MAX_PARTS];
+        }
+    };
+    auto run_items = [&](uint32_t t, uint32_t lo, uint32_t hi, uint32_t& a, uint32_t& b) {
+        a = 0; b = 0;
+        if (t < T) {
+            const uint32_t* it = tile_items + ((size_t)w * T + t) * tile_cap;
+            if (lo + lane < hi) a = it[lo + lane];
+            if (lo + 64 + lane < hi) b = it[lo + 64 + lane];
+        }
+    };
+    auto count_chunk = [&](bool active, uint32_t item) {
+        const uint32_t low = active ? (item & lowmask) : 0xffffffffu;
+        // skewed digits (a sparsely populated top window): lanes that hit the first lane's bucket share one atomic
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)low);
+        const unsigned long long same = __ballot(low == first);
+        if (__popcll(same) >= 8) {
+            if (lane == (uint32_t)(__ffsll((long long)same) - 1)) atomicAdd(&cnt[first], (uint32_t)__popcll(same));
+            if (active && low != first) atomicAdd(&cnt[low], 1u);
+        } else if (active) {
+            atomicAdd(&cnt[low], 1u);
+        }
+    };
+    {
+        uint32_t lo1, hi1, lo2, hi2, a1, b1;
+        run_bounds(wv, lo1, hi1);
+        run_bounds(wv + 16, lo2, hi2);
+        run_items(wv, lo1, hi1, a1, b1);
+        for (uint32_t t = wv; t < T; t += 16) {
+            const uint32_t lo = lo1, hi = hi1, a = a1, b = b1;
+            lo1 = lo2; hi1 = hi2;
+            run_bounds(t + 32, lo2, hi2);
+            run_items(t + 16, lo1, hi1, a1, b1);
+            const uint32_t* it = tile_items + ((size_t)w * T + t) * tile_cap;
+            for (uint32_t i0 = lo; i0 < hi; i0 += 64) {
+                const bool active = i0 + lane < hi;
+                const uint32_t item = i0 == lo ? a : (i0 == lo + 64 ? b : (active ? it[i0 + lane] : 0u));
+                count_chunk(active, item);
             }
         }
     }
@@ -457,13 +488,19 @@ k_partition_sort(const uint32_t* __restrict__ tile_items, const uint16_t* __rest
         }
     }
     __syncthreads();
+    uint32_t lo1, hi1, lo2, hi2, a1, b1;
+    run_bounds(wv, lo1, hi1);
+    run_bounds(wv + 16, lo2, hi2);
+    run_items(wv, lo1, hi1, a1, b1);
     for (uint32_t t = wv; t < T; t += 16) {
-        const uint16_t* off = tile_off + ((size_t)w * T + t) * (MAX_PARTS + 1);
-        const uint32_t lo = off[p], hi = (p + 1 < (uint32_t)P) ? off[p + 1] : off[MAX_PARTS];
+        const uint32_t lo = lo1, hi = hi1, a = a1, b = b1;
+        lo1 = lo2; hi1 = hi2;
+        run_bounds(t + 32, lo2, hi2);
+        run_items(t + 16, lo1, hi1, a1, b1);
         const uint32_t* it = tile_items + ((size_t)w * T + t) * tile_cap;
         for (uint32_t i0 = lo; i0 < hi; i0 += 64) {
             const bool active = i0 + lane < hi;
-            const uint32_t item = active ? it[i0 + lane] : 0u;
+            const uint32_t item = i0 == lo ? a : (i0 == lo + 64 ? b : (active ? it[i0 + lane] : 0u));
             const uint32_t low = active ? (item & lowmask) : 0xffffffffu;
             const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)low);
             const unsigned long long same = __ballot(low == first);
