@@ -46,6 +46,7 @@ struct Bn254G1 {
     // 254-bit scalars fill 16 windows of 16 bits exactly; the GLV split would halve the windows but double the entries per
     // bucket and the gathered point set (measured: 3.31 ms vs 2.85 ms at 2^20) -- off by default, on with porla_gpu_set_msm_glv(1)
     static constexpr bool GLV_DEFAULT = false;
+    static constexpr size_t GLV_BELOW = (size_t)1 << 17;   // ... but on up to this many pairs (msm_impl.cuh:msm_use_glv)
     // bucket accumulation in the reduced-radix field form (fe30.cuh / ec30.cuh): 1.35-1.6x the field-product rate
     static constexpr bool F30_BUCKETS = true;
     // ... and the sums stay in that form ("lazy" memory form of ec30.cuh: unreduced residues, X <= 5p < 2^256) through the
@@ -63,6 +64,7 @@ struct Secp256k1G {
     // 256-bit scalars need a carry-only 17th window at c = 16 (one bucket with half of all entries); the GLV split (which
     // the reference's secp256k1 path also applies, ecmult_impl.h:621-634) gives 8 windows of 17 bits instead
     static constexpr bool GLV_DEFAULT = true;
+    static constexpr size_t GLV_BELOW = 0;
     static constexpr bool F30_BUCKETS = true;    // special-form product on 30-bit limbs: 194 against 133 G products/s
     static constexpr bool F30_LAZY = true;       // memory form: canonical residues (5p > 2^256: an unreduced X does not fit 32 bytes)
     static constexpr int BUCKET_SUM_WAVES = 3;   // the fold's temporaries do not fit 128 registers

@@ -142,10 +142,19 @@ struct MsmShape {
     bool glv;
     int bits, c, W;
 };
+// Split the scalars with the endomorphism?  The caller's choice (porla_gpu_set_msm_glv), else the curve's default -- and for a
+// curve whose default is "no" still up to GLV_BELOW pairs: there the launch chain and the host fold weigh more than the
+// accumulation, and the split halves the windows and the fold (BN254: 0.39 / 0.43 / 0.48 / 0.57 / 0.58 ms against 0.45 / 0.48 /
+// 0.52 / 0.62 / 0.62 ms at 2^13 .. 2^17 pairs, 0.78 against 0.76 ms at 2^18: profiles/r02_l_glv_mid_sizes.jsonl)
+template <class C>
+static inline bool msm_use_glv(size_t n) {
+    if (g_use_glv >= 0) return g_use_glv != 0;
+    return C::GLV_DEFAULT || n <= C::GLV_BELOW;
+}
 template <class C>
 static inline MsmShape msm_full_shape(size_t n_range) {
     MsmShape sh;
-    sh.glv = g_use_glv < 0 ? C::GLV_DEFAULT : g_use_glv != 0;
+    sh.glv = msm_use_glv<C>(n_range);
     sh.bits = sh.glv ? C::Glv::BITS : C::SCALAR_BITS;
     sh.c = choose_window(sh.glv ? 2 * n_range : n_range, sh.bits);
     sh.W = (sh.bits + 1 + sh.c - 1) / sh.c;
@@ -184,7 +193,7 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
         }
         return msm_tree_launch<C>(ws, acc, shape.c, shape.W, shape.glv, stream);
     }
-    const bool glv = forced ? forced->glv : (g_use_glv < 0 ? C::GLV_DEFAULT : g_use_glv != 0);
+    bool glv = forced ? forced->glv : msm_use_glv<C>(n);
     int bits = glv ? C::Glv::BITS : C::SCALAR_BITS;
     // Small and medium inputs: look at the scalars first.  If none of them exceeds b bits (and b is below the group order's
     // length, so SetBytes does not reduce anything) only ceil((b + 1) / c) windows exist -- the audit's abs(int32)
@@ -208,6 +217,7 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
         int top = 7;
         while (top > 0 && h_or[top] == 0) top--;
         int used = h_or[top] ? 32 * top + (32 - __builtin_clz(h_or[top])) : 1;
+        if (glv && g_use_glv < 0 && used <= C::Glv::BITS) { glv = false; bits = C::SCALAR_BITS; }   // short scalars: nothing to split
         if (used < 250 && used < bits) bits = used;       // < 2^250 < both group orders: no reduction happens
     }
     const size_t n_sub = glv ? 2 * n : n;                 // sub-scalars = entries per window at most

@@ -20,6 +20,8 @@ d_sc = torch.frombuffer(bytearray(sc), dtype=torch.uint8).cuda()
 d_pt = torch.frombuffer(bytearray(pt), dtype=torch.uint8).cuda()
 s = torch.cuda.current_stream().cuda_stream
 sizes = (128, 1408, 3200, 1 << 14, 1 << 16) if kind == "int32" else (128, 1408, 3200, 1 << 14, 1 << 17, 1 << 20)
+if len(sys.argv) > 3:   # explicit log2 sizes: sweep_window_sizes.py secp256k1 full 13,14,15,16,17,18,19
+    sizes = tuple(1 << int(x) for x in sys.argv[3].split(","))
 
 def run(n, reps):
     for _ in range(2):
@@ -34,7 +36,7 @@ for n in sizes:
     t_auto, ref = run(n, 10)
     c_auto, w_auto, glv = mx.last_msm_shape()
     row = {}
-    for c in range(max(2, c_auto - 4), min(20, c_auto + 4) + 1):
+    for c in range(max(2, c_auto - 6), min(20, c_auto + 4) + 1):
         lib.porla_gpu_set_msm_window(c)
         t, r = run(n, 10)
         assert r == ref
