@@ -126,6 +126,32 @@ def test_2p24_config3_whole_job(mx):
         lib.porla_gpu_release_msm_workspaces()
 
 
+def test_device_resident_ranges_share_one_bucket_array(mx):
+    """above 2^22 pairs a device-resident MSM runs as ranges into one bucket array (msm_impl.cuh:msm_launch): 2^22 + 12 345 pairs =
+    two ranges; the same scalar repeated 300 000 times across the range boundary makes one bucket per window a multi-item
+    bucket in BOTH ranges (k_bucket_combine adds the earlier range's sum), and a block of zero scalars leaves buckets that
+    only one range touches"""
+    import torch
+    n = (1 << 22) + 12345
+    distinct = 1 << 14
+    pt = (common.synth_points(distinct) * (n // distinct + 1))[:64 * n]
+    sc = bytearray(np.random.default_rng(7).bytes(32 * n))
+    lo = (n // 2) - 150000
+    sc[32 * lo:32 * (lo + 300000)] = bytes(sc[0:32]) * 300000
+    sc[32 * 1000:32 * 51000] = bytes(32 * 50000)
+    sc = bytes(sc)
+    want = common.oracle_msm(sc, pt, n)
+    d_sc = torch.frombuffer(bytearray(sc), dtype=torch.uint8).cuda()
+    d_pt = torch.frombuffer(bytearray(pt), dtype=torch.uint8).cuda()
+    assert mx.msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n, torch.cuda.current_stream().cuda_stream) == want
+    assert mx.last_msm_shape()[0] == 17
+    # the same input from host buffers: 4 ranges on one device into one bucket array
+    assert mx.msm_host_multi("bn254", sc, pt, n, shards=0, devices=1) == want
+    assert mx.last_msm_multi() == (4, 1)
+    from porla_amd import lib
+    lib.porla_gpu_release_msm_workspaces()
+
+
 def test_rccl_from_cxx_world_of_one(mx, inputs):
     """porla_dist_*: ncclGetUniqueId / ncclCommInitRank / ncclAllGather bound with dlopen and issued from C++ (a world of one
     rank here; the two-rank form runs wherever two devices are visible)"""
