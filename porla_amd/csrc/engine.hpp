@@ -113,9 +113,12 @@ struct Workspace {
     void* h_windows = nullptr;  // pinned, device-mapped: the tree's last level writes [W][c] (S, M_0 .. M_(c-2)) per window
     size_t h_windows_cap = 0;
     hipStream_t own_stream = nullptr;
+    hipStream_t aux_stream = nullptr;            // second stream of the reduction tree (msm_tree_launch)
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     int slot = 0;
     hipEvent_t done = nullptr;  // recorded after the last kernel + D2H copy of a launched MSM
     int pend_W = 0, pend_c = 0; // window count / width of the launched, not yet folded MSM (0 = none)
+    bool lone = false;          // the caller waits for this MSM (blocking entry points): the reduction tree may use two streams
     bool begun = false;         // two-phase API: a begin without its end (also set for n == 0, where pend_W stays 0)
 };
 // workspace slots per device -- 0: blocking calls, 1..3: the two-phase C ABI, 4..7: msm_host_multi's pipeline,

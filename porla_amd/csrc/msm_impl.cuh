@@ -346,9 +346,10 @@ static int msm_tree_launch(Workspace* ws, const XYZZ<typename C::Fp>* buckets, i
     const uint32_t B = 1u << (c - 1);
     const size_t nb = (size_t)W * B;
     const uint32_t nlev = (uint32_t)(c - 1);
-    if ((rc = ws->tree_s.ensure((nb + 1) * sizeof(XYZZ<M>)))) return rc;               // all S levels: nb/2 + nb/4 + ...
-    if ((rc = ws->tree_m.ensure((2 * (nb / 4) + 2) * sizeof(XYZZ<M>)))) return rc;     // two ping-pong halves
-    if ((rc = ws->tree_mt.ensure((2 * (size_t)W * (B / 4 + 1) + 2) * sizeof(XYZZ<M>)))) return rc;  // the tail's private halves
+    // (sizes for the two halves of the window set, each with its own end slack)
+    if ((rc = ws->tree_s.ensure((nb + 2) * sizeof(XYZZ<M>)))) return rc;               // all S levels: nb/2 + nb/4 + ...
+    if ((rc = ws->tree_m.ensure((2 * (nb / 4) + 6) * sizeof(XYZZ<M>)))) return rc;     // two ping-pong halves
+    if ((rc = ws->tree_mt.ensure((2 * (size_t)W * (B / 4 + 1) + 4) * sizeof(XYZZ<M>)))) return rc;  // the tail's private halves
     if (ws->h_windows_cap < (size_t)W * c * sizeof(XYZZ<M>) || ws->h_windows_cap < 64 * 1024) {
         if (ws->h_windows) PORLA_HIP(hipHostFree(ws->h_windows));
         ws->h_windows_cap = 64 * 1024;
@@ -356,63 +357,89 @@ static int msm_tree_launch(Workspace* ws, const XYZZ<typename C::Fp>* buckets, i
     }
     void* h_windows_dev = nullptr;
     PORLA_HIP(hipHostGetDevicePointer(&h_windows_dev, ws->h_windows, 0));
-    {
-        // S level l at tree_s + (nb - (nb >> l)) (nb/2 + ... + nb/2^l entries before it); M slots of level l in half l & 1
-        XYZZ<M>* s_base = (XYZZ<M>*)ws->tree_s.p;
-        XYZZ<M>* m_half[2] = {(XYZZ<M>*)ws->tree_m.p, (XYZZ<M>*)ws->tree_m.p + nb / 4 + 1};
-        auto s_level = [&](uint32_t l) { return s_base + (nb - (nb >> l)); };
+    // The windows are independent trees.  With enough buckets they run as TWO halves on two streams: the first levels of a tree
+    // are throughput bound, the last ones (quad levels, the tail) latency bound -- side by side the latency-bound levels of one
+    // half run under the large levels of the other.
+    static const int split_env = getenv("PORLA_TREE_SPLIT") ? atoi(getenv("PORLA_TREE_SPLIT")) : 2;
+    // (only for a caller that waits for this one device-resident MSM: -1.7 % at 2^18 and 2^20 pairs; with a second MSM in
+    // flight -- the two-phase API -- the other MSM already fills those gaps and the extra stream costs 5 % of the pipelined rate)
+    const int parts = (split_env >= 2 && ws->lone && W >= 4 && nb >= ((size_t)1 << 18)) ? 2 : 1;
+    if (parts == 2) {
+        if (!ws->aux_stream) PORLA_HIP(hipStreamCreateWithFlags(&ws->aux_stream, hipStreamNonBlocking));
+        if (!ws->fork_ev) PORLA_HIP(hipEventCreateWithFlags(&ws->fork_ev, hipEventDisableTiming));
+        if (!ws->join_ev) PORLA_HIP(hipEventCreateWithFlags(&ws->join_ev, hipEventDisableTiming));
+        PORLA_HIP(hipEventRecord(ws->fork_ev, stream));
+        PORLA_HIP(hipStreamWaitEvent(ws->aux_stream, ws->fork_ev, 0));
+    }
+    size_t s_off = 0, m_off = 0, mt_off = 0;
+    for (int part = 0, w0 = 0; part < parts; part++) {
+        const int Wp = parts == 1 ? W : (part == 0 ? W / 2 : W - W / 2);
+        hipStream_t st = part == 0 ? stream : ws->aux_stream;
+        const size_t nbp = (size_t)Wp * B;
+        const XYZZ<M>* bk = buckets + (size_t)w0 * B;
+        // S level l at s_base + (nbp - (nbp >> l)) (nbp/2 + ... + nbp/2^l entries before it); M slots of level l in half l & 1
+        XYZZ<M>* s_base = (XYZZ<M>*)ws->tree_s.p + s_off;
+        XYZZ<M>* m_half[2] = {(XYZZ<M>*)ws->tree_m.p + m_off, (XYZZ<M>*)ws->tree_m.p + m_off + nbp / 4 + 1};
+        XYZZ<M>* mt_base = (XYZZ<M>*)ws->tree_mt.p + mt_off;
+        auto s_level = [&](uint32_t l) { return s_base + (nbp - (nbp >> l)); };
         const bool quad = C::F30_LAZY && tree_quad();
         const uint32_t l0 = tree_tail_start(B, nlev, quad);
         {
-            ProfScope ps("tree_levels", stream);
+            ProfScope ps("tree_levels", st);
             for (uint32_t l = 0; l < l0; l++) {
                 TreeLevelArgs<M> a;
-                a.s_prev = l ? s_level(l - 1) : buckets;
-                a.s_prev2 = l >= 2 ? s_level(l - 2) : buckets;
+                a.s_prev = l ? s_level(l - 1) : bk;
+                a.s_prev2 = l >= 2 ? s_level(l - 2) : bk;
                 a.m_prev = m_half[(l + 1) & 1];
                 a.s_out = s_level(l);
                 a.m_out = m_half[l & 1];
                 a.fin = nullptr;   // only the tail holds the last level
-                a.n = (uint32_t)(nb >> (l + 1));
+                a.n = (uint32_t)(nbp >> (l + 1));
                 a.m_prev_stride = 2 * a.n; a.m_out_stride = a.n;
                 a.l = l; a.nlev = nlev; a.last = 0;
                 const size_t tasks = (size_t)(l + 1) * a.n;
                 if constexpr (C::F30_LAZY) {
                     if (quad && tasks <= TREE_QUAD_MAX_TASKS) {
-                        hipLaunchKernelGGL((k_tree_level_quad<C>), dim3((unsigned)((4 * tasks + 255) / 256)), dim3(256), 0, stream, a);
+                        hipLaunchKernelGGL((k_tree_level_quad<C>), dim3((unsigned)((4 * tasks + 255) / 256)), dim3(256), 0, st, a);
                         PORLA_TRACE("tree_level");
                         continue;
                     }
                 }
-                hipLaunchKernelGGL((k_tree_level<C>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, stream, a);
+                hipLaunchKernelGGL((k_tree_level<C>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, st, a);
                 PORLA_TRACE("tree_level");
             }
         }
         {
-            ProfScope ps("tree_tail", stream);
+            ProfScope ps("tree_tail", st);
             TreeTailArgs<M> t;
-            t.buckets = buckets;
+            t.buckets = bk;
             for (uint32_t l = 0; l < 24; l++) t.s_lev[l] = l < nlev ? s_level(l) : nullptr;
             t.m_global = m_half[(l0 + 1) & 1];
             t.per_window = B / 4 + 1;
-            t.m_tail[0] = (XYZZ<M>*)ws->tree_mt.p; t.m_tail[1] = (XYZZ<M>*)ws->tree_mt.p + (size_t)W * t.per_window + 1;
-            t.fin = (XYZZ<M>*)h_windows_dev;
-            t.nb = (uint32_t)nb; t.B = B; t.l0 = l0; t.nlev = nlev;
+            t.m_tail[0] = mt_base; t.m_tail[1] = mt_base + (size_t)Wp * t.per_window + 1;
+            t.fin = (XYZZ<M>*)h_windows_dev + (size_t)w0 * c;
+            t.nb = (uint32_t)nbp; t.B = B; t.l0 = l0; t.nlev = nlev;
             uint32_t need = (l0 + 2) * (B >> (l0 + 1)) * (quad ? 4u : 1u);
             uint32_t threads = (need + 63) / 64 * 64;
             if (threads > tree_tail_threads()) threads = tree_tail_threads();
             if (threads < 64) threads = 64;
             if constexpr (C::F30_LAZY) {
-                if (quad) hipLaunchKernelGGL((k_tree_tail<C, true>), dim3(W), dim3(threads), 0, stream, t);
-                else hipLaunchKernelGGL((k_tree_tail<C, false>), dim3(W), dim3(threads), 0, stream, t);
+                if (quad) hipLaunchKernelGGL((k_tree_tail<C, true>), dim3(Wp), dim3(threads), 0, st, t);
+                else hipLaunchKernelGGL((k_tree_tail<C, false>), dim3(Wp), dim3(threads), 0, st, t);
             } else {
-                hipLaunchKernelGGL((k_tree_tail<C, false>), dim3(W), dim3(threads), 0, stream, t);
+                hipLaunchKernelGGL((k_tree_tail<C, false>), dim3(Wp), dim3(threads), 0, st, t);
             }
             PORLA_TRACE("tree_tail");
         }
         // no copy packet: the last level stores its W * c results straight into the pinned host buffer (a D2H hipMemcpyAsync
         // was seen to block the launching thread for milliseconds while another MSM is in flight)
         PORLA_HIP(hipGetLastError());
+        s_off += nbp + 1; m_off += 2 * (nbp / 4) + 2; mt_off += 2 * (size_t)Wp * (B / 4 + 1) + 2;
+        w0 += Wp;
+    }
+    if (parts == 2) {
+        PORLA_HIP(hipEventRecord(ws->join_ev, ws->aux_stream));
+        PORLA_HIP(hipStreamWaitEvent(stream, ws->join_ev, 0));
     }
     if (!ws->done) PORLA_HIP(hipEventCreateWithFlags(&ws->done, hipEventDisableTiming));
     PORLA_HIP(hipEventRecord(ws->done, stream));
@@ -472,6 +499,7 @@ int msm_device(const uint8_t* d_scalars, const uint8_t* d_points, size_t n, hipS
     Workspace* ws;
     if ((rc = lease_blocking_slot(&ws))) return rc;
     std::lock_guard<std::mutex> lk(ws->mu, std::adopt_lock);
+    ws->lone = true;
     return msm_core<C>(ws, d_scalars, d_points, n, stream, total);
 }
 // Two-phase form: several MSMs in flight on different streams, each in its own workspace slot (1 .. MSM_USER_SLOTS-1; slot 0
@@ -485,6 +513,7 @@ int msm_device_begin(int slot, const uint8_t* d_scalars, const uint8_t* d_points
     if ((rc = get_workspace_slot(slot, &ws))) return rc;
     std::lock_guard<std::mutex> lk(ws->mu);
     if (ws->begun) { set_last_error("porla: MSM slot still has a pending result (call the matching _end first)"); return PORLA_ERR_STATE; }
+    ws->lone = false;
     rc = msm_launch<C>(ws, d_scalars, d_points, n, stream);
     if (rc == PORLA_OK) ws->begun = true;
     return rc;
@@ -588,6 +617,7 @@ int msm_host_multi(const uint8_t* scalars, const uint8_t* points, size_t n, int 
             if (rr) { slot_ws[k] = nullptr; fail(rr); break; }
             slot_ws[k]->mu.lock();
             slot_ws[k]->pend_W = 0;
+            slot_ws[k]->lone = false;       // (the two-stream tree made the host-buffer call slower: 2.72 -> 2.90 ms at 2^20)
             // staging sized for the largest range before any copy is in flight (growing it later would free a buffer in use)
             if ((rr = slot_ws[k]->in_scalars.ensure(max_cnt * 32)) || (rr = slot_ws[k]->in_points.ensure(max_cnt * 64))) { fail(rr); break; }
             if (!slot_ws[k]->merged && hipEventCreateWithFlags(&slot_ws[k]->merged, hipEventDisableTiming) != hipSuccess) {
@@ -695,6 +725,7 @@ int msm_host(const uint8_t* scalars, const uint8_t* points, size_t n, XYZZ<typen
     if ((rc = lease_blocking_slot(&ws))) return rc;
     std::lock_guard<std::mutex> lk(ws->mu, std::adopt_lock);
     if (n == 0) { *total = xyzz_inf<typename C::Fp>(); return PORLA_OK; }
+    ws->lone = true;
     if ((rc = msm_host_launch<C>(ws, scalars, points, n))) return rc;
     return msm_finish<C>(ws, total);
 }
