@@ -10,8 +10,12 @@ seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 pools = {"bn254": common.synth_points(256), "secp256k1": common.secp_bench_points(256)}
 t_end = time.time() + seconds
+t_note = time.time() + 60          # a progress line per minute: a silent GPU command is taken to be hung
 cases = fails = 0
 while time.time() < t_end:
+    if time.time() > t_note:
+        print("... %d cases so far" % cases, flush=True)
+        t_note = time.time() + 60
     curve = rnd.choice(["bn254", "secp256k1"])
     nb = rnd.choice([1, 2, 3, 17, 64, 127, 128, 200])
     c = rnd.choice([2, 3, 5, 8, 9, 12, 13])

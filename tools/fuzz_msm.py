@@ -15,8 +15,12 @@ ORD = {"bn254": 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f00000
 LAM = {"bn254": 0x30644e72e131a029048b6e193fd84104cc37a73fec2bc5e9b8ca0b2d36636f23,
        "secp256k1": 0x5363ad4cc05c30e0a5261c028812645a122e22ea20816678df02967c1b23bd72}
 t_end = time.time() + seconds
+t_note = time.time() + 60          # a progress line per minute: a silent GPU command is taken to be hung
 cases = fails = 0
 while time.time() < t_end:
+    if time.time() > t_note:
+        print("... %d cases so far" % cases, flush=True)
+        t_note = time.time() + 60
     curve = rnd.choice(["bn254", "secp256k1"])
     n = rnd.choice([1, 2, 3, 7, 64, 65, 127, 128, 129, 500, 1408, 3200, rnd.randrange(1, NMAX)])
     dist = rnd.choice(["uniform", "small", "fewvals", "edge", "bits"])
