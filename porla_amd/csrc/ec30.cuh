@@ -347,6 +347,48 @@ __device__ __forceinline__ void xyzz30_add_quad(const XYZZ<M>* pa, const XYZZ<M>
     else if (r == 2u) xyzz30_store_coord<M>(out, 3, M4, final);
 }
 
+// *out = 2 * *p on the four lanes of a quad (dbl-2008-s-1, a = 0; bounds as xyzz30_double_body): the 9 products in 3 rounds.
+//   lane          0                    1                  2               3
+//   loads     X                    Y                  ZZ              ZZZ
+//   round 1   XX = X^2             V = (2Y)^2         -               -
+//   round 2   S = X V              W = 2Y V           ZZ3 = ZZ V      MM = (3 XX)^2
+//   round 3   T1 = 3XX (S - X3)    T2 = W Y           -               ZZZ3 = ZZZ W       X3 = MM - 2S
+//   result    X3, Y3 = T1 - T2                        ZZ3             ZZZ3
+// Called by ALL FOUR lanes of a quad with the same arguments (out may be p); infinity stays infinity.
+template <class M>
+__device__ __forceinline__ void xyzz30_dbl_quad(const XYZZ<M>* p, XYZZ<M>* out, bool live, uint32_t lane) {
+    const uint32_t r = lane & 3u;
+    bool zero;
+    const F30<M> A = xyzz30_load_coord<M>(p, (int)r, &zero);
+    const uint32_t qz = (uint32_t)(__ballot(zero && r == 2u) >> (lane & 60u)) & 0xfu;      // ZZ = 0: infinity
+    if (qz) {
+        if (live && out != p) {
+            uint4* d = reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(out) + 8 * r);
+            d[0] = make_uint4(0, 0, 0, 0); d[1] = d[0];
+        }
+        return;
+    }
+    const F30<M> U = f30_small_mul<M, 2>(A);                               // lane 1: 2Y
+    const F30<M> O1 = f30_sel<M>(r == 1u, U, A);
+    const F30<M> M1 = f30_mul<M>(O1, O1);                                  // XX, V, -, -
+    const F30<M> bV = f30_quad<M, 0x55>(M1);
+    const F30<M> bXX = f30_quad<M, 0x00>(M1);
+    const F30<M> Mm = f30_small_mul<M, 3>(bXX);                            // 3 X^2 (lanes 0 and 3 use it)
+    const F30<M> M2 = f30_mul<M>(r == 3u ? Mm : O1, r == 3u ? Mm : bV);    // S, W, ZZ3, MM
+    const F30<M> bW = f30_quad<M, 0x55>(M2);
+    const F30<M> bMM = f30_quad<M, 0xFF>(M2);
+    const F30<M> S2 = f30_small_mul<M, 2>(M2);                             // lane 0: 2S
+    const F30<M> X3 = f30_sub<M, 3>(bMM, S2);                              // lane 0
+    const F30<M> D = f30_sub<M, 5>(M2, X3);                                // lane 0: S - X3
+    const F30<M> M3 = f30_mul<M>(r == 0u ? Mm : bW, r == 0u ? D : A);      // T1, T2 = W Y, (W ZZ), ZZZ3 = W ZZZ
+    const F30<M> bT2 = f30_quad<M, 0x55>(M3);
+    const F30<M> Y3 = f30_sub<M, 2>(M3, bT2);                              // lane 0
+    if (!live) return;
+    if (r == 0u) { xyzz30_store_coord<M>(out, 0, X3, false); xyzz30_store_coord<M>(out, 1, Y3, false); }
+    else if (r == 2u) xyzz30_store_coord<M>(out, 2, M2, false);
+    else if (r == 3u) xyzz30_store_coord<M>(out, 3, M3, false);
+}
+
 // the accumulator as an ec.cuh XYZZ in the 2^256 Montgomery form (canonical residues); infinity = all zero
 template <class M>
 __device__ __forceinline__ XYZZ<M> xyzz30_to_xyzz(const XYZZ30<M>& p) {

@@ -226,6 +226,111 @@ k_mac_stage30(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restric
     store_xyzz<M>(work + k + m2, dif);
 }
 
+// ---------------------------------------------------------------- the butterfly stage with FOUR LANES per butterfly
+// Below N = 2^16 rows a stage is one lone wave per SIMD walking a ladder of ~200 dependent group operations: its time is the
+// latency of those operations (1.08 ms with one lane per butterfly).  Here every group operation runs on the four lanes of a
+// quad (ec30.cuh: xyzz30_add_quad 3.6 us instead of 7, xyzz30_dbl_quad 3 rounds of products instead of 9 in sequence); the
+// ladder is the same (endomorphism split, 33 signed 4-bit windows, one table of multiples, phi(P)'s entries by scaling X with
+// beta), its state -- table, accumulator, the operand being added -- lives in LDS, and the control flow is the same for every
+// butterfly of the block (a zero digit computes its addition and does not store it), so block barriers order the LDS traffic.
+constexpr int MACQ_BF = 32;                       // butterflies per block (128 lanes): 11 slots of 128 B each = 44 KiB of LDS
+
+// signed 4-bit digit i (0 .. 32) of the 128-bit magnitude m: ((m >> 4i) & 15) + carry, minus 16 above 8.  The carry into
+// window i is 1 exactly when the bits below it exceed 0x88..8 (the recoding with digits in (-8, 8] is unique: msm_small.cuh).
+__device__ __forceinline__ int mac_signed_digit(const uint32_t m[4], int i) {
+    bool gt = false, eq = true;
+#pragma unroll
+    for (int q = 3; q >= 0; q--) {
+        const int below = 4 * i - 32 * q;                                  // bits of limb q below the window
+        const uint32_t mask = below <= 0 ? 0u : (below >= 32 ? 0xffffffffu : ((1u << below) - 1u));
+        const uint32_t a = m[q] & mask, b = 0x88888888u & mask;
+        gt = eq ? (a > b) : gt;
+        eq = eq && (a == b);
+    }
+    uint32_t raw = gt ? 1u : 0u;
+    if (i < 32) {
+        uint32_t limb = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) limb = (q == (i >> 3)) ? m[q] : limb;
+        raw += (limb >> ((i & 7) * 4)) & 15u;
+    }
+    return raw > 8u ? (int)raw - 16 : (int)raw;
+}
+
+template <class C>
+__global__ void __launch_bounds__(4 * MACQ_BF)
+k_mac_stage30_quad(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restrict__ tws, uint32_t n, int s) {
+    using M = typename C::Fp;
+    using G = typename C::Glv;
+    __shared__ XYZZ<M> tbl[MACQ_BF][8];
+    __shared__ XYZZ<M> acc[MACQ_BF], tmp[MACQ_BF], um[MACQ_BF];
+    const uint32_t q = threadIdx.x >> 2, r = threadIdx.x & 3u, lane = threadIdx.x & 63u;
+    uint32_t t = blockIdx.x * MACQ_BF + q;
+    const bool valid = t < n / 2;
+    if (!valid) t = 0;                                                     // padding quads compute butterfly 0 and store nothing
+    const uint32_t m2 = 1u << (s - 1);
+    const uint32_t j = t & (m2 - 1);
+    const uint32_t k = ((t >> (s - 1)) << s) + j;
+    const uint32_t e = j * (n >> (s - 1));
+    uint32_t sc[8];
+    {
+        const uint4* w4 = reinterpret_cast<const uint4*>(tws + (size_t)e * 8);
+        const uint4 a = w4[0], b = w4[1];
+        sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
+    }
+    uint32_t m[2][4];
+    bool ng[2];
+    glv_split<G>(sc, m[0], ng[0], m[1], ng[1]);
+    const F30<M> beta30 = f30_const<M>(G::BETA_30);
+    // every lane moves "its" coordinate (32 bytes) of a point
+    auto copy_coord = [&](XYZZ<M>* dst, const XYZZ<M>* src) {
+        const uint4* a = reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(src) + 8 * r);
+        uint4* d = reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(dst) + 8 * r);
+        const uint4 v0 = a[0], v1 = a[1];
+        d[0] = v0; d[1] = v1;
+    };
+    // tmp = (neg ? -1 : 1) * (phi ? (beta X, Y, ZZ, ZZZ) : (X, Y, ZZ, ZZZ)) of *src; infinity stays infinity (ZZ = ZZZ = 0)
+    auto prepare = [&](const XYZZ<M>* src, bool neg, bool phi) {
+        bool z;
+        F30<M> v = xyzz30_load_coord<M>(src, (int)r, &z);
+        const uint32_t qz = (uint32_t)(__ballot(z && r == 2u) >> (lane & 60u)) & 0xfu;
+        if (qz) { copy_coord(&tmp[q], src); return; }
+        if (r == 0u && phi) v = f30_mul<M>(v, beta30);
+        if (r == 1u && neg) v = f30_sub<M, 4>(F30<M>{}, v);
+        xyzz30_store_coord<M>(&tmp[q], (int)r, v, false);
+    };
+    copy_coord(&tbl[q][0], work + k + m2);
+    copy_coord(&um[q], work + k);
+    {
+        uint4* d = reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(&acc[q]) + 8 * r);
+        d[0] = make_uint4(0, 0, 0, 0); d[1] = d[0];                        // infinity
+    }
+    __syncthreads();
+    for (int i = 1; i < 8; i++) {                                          // tbl[i] = (i + 1) P
+        xyzz30_add_quad<M>(&tbl[q][i - 1], &tbl[q][0], &tbl[q][i], false, true, lane);
+        __syncthreads();
+    }
+    for (int i = 32; i >= 0; i--) {
+        for (int d = 0; d < 4; d++) {
+            xyzz30_dbl_quad<M>(&acc[q], &acc[q], true, lane);
+            __syncthreads();
+        }
+        for (int h = 0; h < 2; h++) {
+            const int dg = mac_signed_digit(m[h], i);
+            const int mag = dg < 0 ? -dg : dg;
+            prepare(&tbl[q][mag ? mag - 1 : 0], (dg < 0) != ng[h], h != 0);
+            __syncthreads();
+            xyzz30_add_quad<M>(&acc[q], &tmp[q], &acc[q], false, mag != 0, lane);
+            __syncthreads();
+        }
+    }
+    // MAC[k] = um + tm, MAC[k + m2] = um - tm
+    xyzz30_add_quad<M>(&um[q], &acc[q], work + k, false, valid, lane);
+    prepare(&acc[q], true, false);
+    __syncthreads();
+    xyzz30_add_quad<M>(&um[q], &tmp[q], work + k + m2, false, valid, lane);
+}
+
 // 64-byte big-endian affine MACs -> XYZZ work array; part 1 (Y): times wt (Server.hpp:1528-1536)
 template <class C>
 __global__ void __launch_bounds__(64)

@@ -37,7 +37,7 @@ template <class C> struct FbOf;
 template <> struct FbOf<Bn254G1> { static FixedBase<Bn254G1>& get(MacWs* w) { return w->fb_bn; } };
 template <> struct FbOf<Secp256k1G> { static FixedBase<Secp256k1G>& get(MacWs* w) { return w->fb_secp; } };
 static std::mutex g_mac_mu;
-static size_t g_matrix_max = getenv("PORLA_MAC_MATRIX_MAX") ? (size_t)atol(getenv("PORLA_MAC_MATRIX_MAX")) : 1024;
+static size_t g_matrix_max = getenv("PORLA_MAC_MATRIX_MAX") ? (size_t)atol(getenv("PORLA_MAC_MATRIX_MAX")) : 512;
 static std::vector<MacWs*> g_mac_ws;
 
 static int get_mac_ws(MacWs** out) {
@@ -137,10 +137,17 @@ static int mac_encode_core(MacWs* ws, int curve, const uint8_t* d_in, size_t n, 
     }
     for (int s = 1; s <= logn; s++) {
         ProfScope ps("mac_stage", stream);
-        if constexpr (C::F30_LAZY)
-            hipLaunchKernelGGL((k_mac_stage30<C>), dim3((unsigned)((n / 2 + 63) / 64)), dim3(64), 0, stream, (XYZZ<M>*)ws->work.p,
-                               (const uint32_t*)ws->tws.p, (uint32_t)n, s);
-        else
+        if constexpr (C::F30_LAZY) {
+            // up to 2^15 rows a stage is latency bound (one wave per SIMD even with four lanes per butterfly): the quad-lane ladder
+            // (2^16 rows: 22.2 ms against 18.8 ms with one lane per butterfly)
+            static const bool quad = !(getenv("PORLA_MAC_QUAD") && getenv("PORLA_MAC_QUAD")[0] == '0');
+            if (quad && n <= ((size_t)1 << 15))
+                hipLaunchKernelGGL((k_mac_stage30_quad<C>), dim3((unsigned)((n / 2 + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), 0, stream,
+                                   (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->tws.p, (uint32_t)n, s);
+            else
+                hipLaunchKernelGGL((k_mac_stage30<C>), dim3((unsigned)((n / 2 + 63) / 64)), dim3(64), 0, stream, (XYZZ<M>*)ws->work.p,
+                                   (const uint32_t*)ws->tws.p, (uint32_t)n, s);
+        } else
             hipLaunchKernelGGL((k_mac_stage<C>), dim3((unsigned)((n / 2 + 63) / 64)), dim3(64), 0, stream, (XYZZ<M>*)ws->work.p,
                                (const uint32_t*)ws->tws.p, (uint32_t)n, s);
     }
