@@ -257,13 +257,70 @@ __device__ __forceinline__ int mac_signed_digit(const uint32_t m[4], int i) {
     return raw > 8u ? (int)raw - 16 : (int)raw;
 }
 
+// LDS state of a block of MACQ_BF quads: table of multiples, accumulator, the operand being added, the butterfly's upper input
+template <class M>
+struct MacQuadLds {
+    XYZZ<M> tbl[MACQ_BF][8];
+    XYZZ<M> acc[MACQ_BF], tmp[MACQ_BF], um[MACQ_BF];
+};
+// every lane of a quad moves "its" coordinate (32 bytes) of a point
+template <class M>
+__device__ __forceinline__ void macq_copy_coord(XYZZ<M>* dst, const XYZZ<M>* src, uint32_t r) {
+    const uint4* a = reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(src) + 8 * r);
+    uint4* d = reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(dst) + 8 * r);
+    const uint4 v0 = a[0], v1 = a[1];
+    d[0] = v0; d[1] = v1;
+}
+// *dst = (neg ? -1 : 1) * (phi ? (beta X, Y, ZZ, ZZZ) : (X, Y, ZZ, ZZZ)) of *src; infinity stays infinity (ZZ = ZZZ = 0)
+template <class M>
+__device__ __forceinline__ void macq_prepare(XYZZ<M>* dst, const XYZZ<M>* src, bool neg, bool phi, const F30<M>& beta30, uint32_t r,
+                                             uint32_t lane) {
+    bool z;
+    F30<M> v = xyzz30_load_coord<M>(src, (int)r, &z);
+    const uint32_t qz = (uint32_t)(__ballot(z && r == 2u) >> (lane & 60u)) & 0xfu;
+    if (qz) { macq_copy_coord<M>(dst, src, r); return; }
+    if (r == 0u && phi) v = f30_mul<M>(v, beta30);
+    if (r == 1u && neg) v = f30_sub<M, 4>(F30<M>{}, v);
+    xyzz30_store_coord<M>(dst, (int)r, v, false);
+}
+// L.acc[q] = sc * L.tbl[q][0]  (all lanes of the block; L.tbl[q][0] written and a barrier passed; ends behind a barrier)
+template <class C>
+__device__ __forceinline__ void macq_ladder(MacQuadLds<typename C::Fp>& L, uint32_t q, uint32_t r, uint32_t lane, const uint32_t sc[8]) {
+    using M = typename C::Fp;
+    using G = typename C::Glv;
+    uint32_t m[2][4];
+    bool ng[2];
+    glv_split<G>(sc, m[0], ng[0], m[1], ng[1]);
+    const F30<M> beta30 = f30_const<M>(G::BETA_30);
+    {
+        uint4* d = reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(&L.acc[q]) + 8 * r);
+        d[0] = make_uint4(0, 0, 0, 0); d[1] = d[0];                        // infinity
+    }
+    for (int i = 1; i < 8; i++) {                                          // tbl[i] = (i + 1) P
+        xyzz30_add_quad<M>(&L.tbl[q][i - 1], &L.tbl[q][0], &L.tbl[q][i], false, true, lane);
+        __syncthreads();
+    }
+    for (int i = 32; i >= 0; i--) {
+        for (int d = 0; d < 4; d++) {
+            xyzz30_dbl_quad<M>(&L.acc[q], &L.acc[q], true, lane);
+            __syncthreads();
+        }
+        for (int h = 0; h < 2; h++) {
+            const int dg = mac_signed_digit(m[h], i);
+            const int mag = dg < 0 ? -dg : dg;
+            macq_prepare<M>(&L.tmp[q], &L.tbl[q][mag ? mag - 1 : 0], (dg < 0) != ng[h], h != 0, beta30, r, lane);
+            __syncthreads();
+            xyzz30_add_quad<M>(&L.acc[q], &L.tmp[q], &L.acc[q], false, mag != 0, lane);
+            __syncthreads();
+        }
+    }
+}
+
 template <class C>
 __global__ void __launch_bounds__(4 * MACQ_BF)
 k_mac_stage30_quad(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restrict__ tws, uint32_t n, int s) {
     using M = typename C::Fp;
-    using G = typename C::Glv;
-    __shared__ XYZZ<M> tbl[MACQ_BF][8];
-    __shared__ XYZZ<M> acc[MACQ_BF], tmp[MACQ_BF], um[MACQ_BF];
+    __shared__ MacQuadLds<M> L;
     const uint32_t q = threadIdx.x >> 2, r = threadIdx.x & 3u, lane = threadIdx.x & 63u;
     uint32_t t = blockIdx.x * MACQ_BF + q;
     const bool valid = t < n / 2;
@@ -278,57 +335,67 @@ k_mac_stage30_quad(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __re
         const uint4 a = w4[0], b = w4[1];
         sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
     }
-    uint32_t m[2][4];
-    bool ng[2];
-    glv_split<G>(sc, m[0], ng[0], m[1], ng[1]);
-    const F30<M> beta30 = f30_const<M>(G::BETA_30);
-    // every lane moves "its" coordinate (32 bytes) of a point
-    auto copy_coord = [&](XYZZ<M>* dst, const XYZZ<M>* src) {
-        const uint4* a = reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(src) + 8 * r);
-        uint4* d = reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(dst) + 8 * r);
-        const uint4 v0 = a[0], v1 = a[1];
-        d[0] = v0; d[1] = v1;
-    };
-    // tmp = (neg ? -1 : 1) * (phi ? (beta X, Y, ZZ, ZZZ) : (X, Y, ZZ, ZZZ)) of *src; infinity stays infinity (ZZ = ZZZ = 0)
-    auto prepare = [&](const XYZZ<M>* src, bool neg, bool phi) {
-        bool z;
-        F30<M> v = xyzz30_load_coord<M>(src, (int)r, &z);
-        const uint32_t qz = (uint32_t)(__ballot(z && r == 2u) >> (lane & 60u)) & 0xfu;
-        if (qz) { copy_coord(&tmp[q], src); return; }
-        if (r == 0u && phi) v = f30_mul<M>(v, beta30);
-        if (r == 1u && neg) v = f30_sub<M, 4>(F30<M>{}, v);
-        xyzz30_store_coord<M>(&tmp[q], (int)r, v, false);
-    };
-    copy_coord(&tbl[q][0], work + k + m2);
-    copy_coord(&um[q], work + k);
-    {
-        uint4* d = reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(&acc[q]) + 8 * r);
-        d[0] = make_uint4(0, 0, 0, 0); d[1] = d[0];                        // infinity
-    }
+    macq_copy_coord<M>(&L.tbl[q][0], work + k + m2, r);
+    macq_copy_coord<M>(&L.um[q], work + k, r);
     __syncthreads();
-    for (int i = 1; i < 8; i++) {                                          // tbl[i] = (i + 1) P
-        xyzz30_add_quad<M>(&tbl[q][i - 1], &tbl[q][0], &tbl[q][i], false, true, lane);
-        __syncthreads();
-    }
-    for (int i = 32; i >= 0; i--) {
-        for (int d = 0; d < 4; d++) {
-            xyzz30_dbl_quad<M>(&acc[q], &acc[q], true, lane);
-            __syncthreads();
-        }
-        for (int h = 0; h < 2; h++) {
-            const int dg = mac_signed_digit(m[h], i);
-            const int mag = dg < 0 ? -dg : dg;
-            prepare(&tbl[q][mag ? mag - 1 : 0], (dg < 0) != ng[h], h != 0);
-            __syncthreads();
-            xyzz30_add_quad<M>(&acc[q], &tmp[q], &acc[q], false, mag != 0, lane);
-            __syncthreads();
-        }
-    }
+    macq_ladder<C>(L, q, r, lane, sc);
     // MAC[k] = um + tm, MAC[k + m2] = um - tm
-    xyzz30_add_quad<M>(&um[q], &acc[q], work + k, false, valid, lane);
-    prepare(&acc[q], true, false);
+    xyzz30_add_quad<M>(&L.um[q], &L.acc[q], work + k, false, valid, lane);
+    macq_prepare<M>(&L.tmp[q], &L.acc[q], true, false, F30<M>{}, r, lane);
     __syncthreads();
-    xyzz30_add_quad<M>(&um[q], &tmp[q], work + k + m2, false, valid, lane);
+    xyzz30_add_quad<M>(&L.um[q], &L.tmp[q], work + k + m2, false, valid, lane);
+}
+
+// init scaling of the Y part (k_mac_load30 with use_wt) with four lanes per MAC: work[i] = wt * MAC[i]
+template <class C>
+__global__ void __launch_bounds__(4 * MACQ_BF)
+k_mac_load30_quad(const uint8_t* __restrict__ in, uint32_t n, XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restrict__ wt) {
+    using M = typename C::Fp;
+    __shared__ MacQuadLds<M> L;
+    const uint32_t q = threadIdx.x >> 2, r = threadIdx.x & 3u, lane = threadIdx.x & 63u;
+    uint32_t i = blockIdx.x * MACQ_BF + q;
+    const bool valid = i < n;
+    if (!valid) i = 0;
+    uint32_t sc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) sc[j] = wt[j];
+    if (r == 0u) store_xyzz<M>(&L.tbl[q][0], load_affine_be_lazy<M>(in + (size_t)i * 64));
+    __syncthreads();
+    macq_ladder<C>(L, q, r, lane, sc);
+    if (valid) macq_copy_coord<M>(work + i, &L.acc[q], r);
+}
+
+template <class M>
+__device__ __forceinline__ void store_affine_be(uint8_t* dst, const XYZZ<M>& p);     // below
+
+// Server::mix's MAC part (k_mac_mix below) with four lanes per i: the butterfly out[i] = A0[i] + v^i A1[i], out[i + len] = A0[i] -
+// v^i A1[i] on 64-byte affine points -- lanes 0 / 1 convert the two inputs on the way in and invert for the two outputs
+template <class C>
+__global__ void __launch_bounds__(4 * MACQ_BF)
+k_mac_mix_quad(const uint8_t* __restrict__ a0, const uint8_t* __restrict__ a1, uint32_t len, const uint32_t* __restrict__ tws,
+               uint32_t tw_step, uint8_t* __restrict__ out) {
+    using M = typename C::Fp;
+    __shared__ MacQuadLds<M> L;
+    const uint32_t q = threadIdx.x >> 2, r = threadIdx.x & 3u, lane = threadIdx.x & 63u;
+    uint32_t i = blockIdx.x * MACQ_BF + q;
+    const bool valid = i < len;
+    if (!valid) i = 0;
+    uint32_t sc[8];
+    {
+        const uint4* w4 = reinterpret_cast<const uint4*>(tws + (size_t)i * tw_step * 8);
+        const uint4 a = w4[0], b = w4[1];
+        sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
+    }
+    if (r < 2u) store_xyzz<M>(r ? &L.um[q] : &L.tbl[q][0], load_affine_be_lazy<M>((r ? a0 : a1) + (size_t)i * 64));   // lanes 0 and 1 side by side
+    __syncthreads();
+    macq_ladder<C>(L, q, r, lane, sc);
+    xyzz30_add_quad<M>(&L.um[q], &L.acc[q], &L.tbl[q][1], false, true, lane);      // sum
+    macq_prepare<M>(&L.tmp[q], &L.acc[q], true, false, F30<M>{}, r, lane);
+    __syncthreads();
+    xyzz30_add_quad<M>(&L.um[q], &L.tmp[q], &L.tbl[q][2], false, true, lane);      // difference
+    __syncthreads();
+    if (valid && r < 2u)                                                           // the two inversions side by side
+        store_affine_be<M>(out + ((size_t)i + (r ? len : 0)) * 64, xyzz30_to_xyzz<M>(xyzz30_load_lazy<M>(&L.tbl[q][1 + r])));
 }
 
 // 64-byte big-endian affine MACs -> XYZZ work array; part 1 (Y): times wt (Server.hpp:1528-1536)

@@ -78,6 +78,15 @@ static int mac_mix_core(MacWs* ws, int curve, const uint8_t* d_a0, const uint8_t
     int rc;
     if ((rc = ensure_mac_twiddles<Q>(ws, curve, n_total, stream))) return rc;
     ProfScope ps("mac_mix", stream);
+    static const bool quad = !(getenv("PORLA_MAC_QUAD") && getenv("PORLA_MAC_QUAD")[0] == '0');
+    if constexpr (C::F30_LAZY) {
+        if (quad && len <= ((size_t)1 << 14)) {        // latency bound: four lanes per element (k_mac_stage30_quad's ladder)
+            hipLaunchKernelGGL((k_mac_mix_quad<C>), dim3((unsigned)((len + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), 0, stream, d_a0,
+                               d_a1, (uint32_t)len, (const uint32_t*)ws->tws.p, (uint32_t)(n_total / len), d_out);
+            PORLA_HIP(hipGetLastError());
+            return PORLA_OK;
+        }
+    }
     hipLaunchKernelGGL((k_mac_mix<C>), dim3((unsigned)((len + 63) / 64)), dim3(64), 0, stream, d_a0, d_a1, (uint32_t)len,
                        (const uint32_t*)ws->tws.p, (uint32_t)(n_total / len), d_out);
     PORLA_HIP(hipGetLastError());
@@ -128,10 +137,15 @@ static int mac_encode_core(MacWs* ws, int curve, const uint8_t* d_in, size_t n, 
     }
     {
         ProfScope ps("mac_load", stream);
-        if constexpr (C::F30_LAZY)
-            hipLaunchKernelGGL((k_mac_load30<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_in, (uint32_t)n,
-                               (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->wt.p, use_wt);
-        else
+        if constexpr (C::F30_LAZY) {
+            static const bool quad = !(getenv("PORLA_MAC_QUAD") && getenv("PORLA_MAC_QUAD")[0] == '0');
+            if (use_wt && quad && n <= ((size_t)1 << 14))
+                hipLaunchKernelGGL((k_mac_load30_quad<C>), dim3((unsigned)((n + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), 0, stream, d_in,
+                                   (uint32_t)n, (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->wt.p);
+            else
+                hipLaunchKernelGGL((k_mac_load30<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_in, (uint32_t)n,
+                                   (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->wt.p, use_wt);
+        } else
             hipLaunchKernelGGL((k_mac_load<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_in, (uint32_t)n,
                                (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->wt.p, use_wt);
     }
