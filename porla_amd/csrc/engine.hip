@@ -149,7 +149,7 @@ static int abi_msm_device(const void* d_scalars, const void* d_points, size_t n,
     int rc = msm_device<C>((const uint8_t*)d_scalars, (const uint8_t*)d_points, n, (hipStream_t)stream, &tot);
     if (rc) return rc;
     if (jac) h_xyzz_to_jac_bytes<M>(out, tot);
-    else h_affine_to_bytes<M>(out, h_xyzz_to_affine<M>(tot));
+    else h_affine_to_bytes<M>(out, h_xyzz_to_affine64<M>(tot));
     return PORLA_OK;
 }
 template <class C>
@@ -159,7 +159,7 @@ static int abi_msm_host(const uint8_t* scalars, const uint8_t* points, size_t n,
     XYZZ<M> tot;
     int rc = msm_host<C>(scalars, points, n, &tot);
     if (rc) return rc;
-    h_affine_to_bytes<M>(out, h_xyzz_to_affine<M>(tot));
+    h_affine_to_bytes<M>(out, h_xyzz_to_affine64<M>(tot));
     return PORLA_OK;
 }
 template <class C>
@@ -169,7 +169,7 @@ static int abi_msm_host_multi(const uint8_t* scalars, const uint8_t* points, siz
     XYZZ<M> tot;
     int rc = msm_host_multi<C>(scalars, points, n, shards, devices, &tot);
     if (rc) return rc;
-    h_affine_to_bytes<M>(out, h_xyzz_to_affine<M>(tot));
+    h_affine_to_bytes<M>(out, h_xyzz_to_affine64<M>(tot));
     return PORLA_OK;
 }
 template <class C>
@@ -178,7 +178,7 @@ static int abi_tree_fold(const uint8_t* sums, int W, int c, uint8_t* out) {
     if (W < 1 || c < 2 || c > 20 || !sums || !out) { set_last_error("porla: bad argument"); return PORLA_ERR_ARG; }
     std::vector<XYZZ<M>> fin((size_t)W * c);
     for (size_t i = 0; i < fin.size(); i++) fin[i] = xyzz_from_affine<M>(h_affine_from_bytes<M>(sums + 64 * i));
-    h_affine_to_bytes<M>(out, h_xyzz_to_affine<M>(h_fold_tree64<M>(fin.data(), W, c)));
+    h_affine_to_bytes<M>(out, h_xyzz_to_affine64<M>(h_fold_tree64<M>(fin.data(), W, c)));
     return PORLA_OK;
 }
 template <class C>
@@ -190,7 +190,7 @@ static int abi_jac_sum(const uint8_t* jacs, size_t count, uint8_t* out) {
         XYZZ<M> p = h_xyzz_from_jac_bytes<M>(jacs + 96 * i);
         xyzz_add<M>(acc, p);
     }
-    h_affine_to_bytes<M>(out, h_xyzz_to_affine<M>(acc));
+    h_affine_to_bytes<M>(out, h_xyzz_to_affine64<M>(acc));
     return PORLA_OK;
 }
 
@@ -351,7 +351,7 @@ int porla_bn254_msm_device_end(int slot, uint8_t* out, int jacobian) {
     int rc = msm_device_end<Bn254G1>(slot, &tot);
     if (rc) return rc;
     if (jacobian) h_xyzz_to_jac_bytes<Bn254Fp>(out, tot);
-    else h_affine_to_bytes<Bn254Fp>(out, h_xyzz_to_affine<Bn254Fp>(tot));
+    else h_affine_to_bytes<Bn254Fp>(out, h_xyzz_to_affine64<Bn254Fp>(tot));
     return PORLA_OK;
 }
 
@@ -367,7 +367,7 @@ int porla_secp256k1_msm_device_end(int slot, uint8_t* out, int jacobian) {
     int rc = msm_device_end<Secp256k1G>(slot, &tot);
     if (rc) return rc;
     if (jacobian) h_xyzz_to_jac_bytes<Secp256k1Fp>(out, tot);
-    else h_affine_to_bytes<Secp256k1Fp>(out, h_xyzz_to_affine<Secp256k1Fp>(tot));
+    else h_affine_to_bytes<Secp256k1Fp>(out, h_xyzz_to_affine64<Secp256k1Fp>(tot));
     return PORLA_OK;
 }
 
@@ -395,10 +395,10 @@ int porla_icc_mac_scale_host(const uint8_t mac_in[64], size_t n_total, unsigned 
     h_load_be(k, wt);
     if (curve == 0) {
         fe_reduce_plain<Bn254Fr>(k, 8);                 // bn254_mult -> fr.SetBytes reduces mod r (main.go:209)
-        h_affine_to_bytes<Bn254Fp>(mac_out, h_xyzz_to_affine<Bn254Fp>(h_scalar_mul<Bn254Fp>(h_affine_from_bytes<Bn254Fp>(mac_in), k)));
+        h_affine_to_bytes<Bn254Fp>(mac_out, h_xyzz_to_affine64<Bn254Fp>(h_scalar_mul<Bn254Fp>(h_affine_from_bytes<Bn254Fp>(mac_in), k)));
     } else {
         fe_reduce_plain<IccSecp256k1FnHost>(k, 2);
-        h_affine_to_bytes<Secp256k1Fp>(mac_out, h_xyzz_to_affine<Secp256k1Fp>(h_scalar_mul<Secp256k1Fp>(h_affine_from_bytes<Secp256k1Fp>(mac_in), k)));
+        h_affine_to_bytes<Secp256k1Fp>(mac_out, h_xyzz_to_affine64<Secp256k1Fp>(h_scalar_mul<Secp256k1Fp>(h_affine_from_bytes<Secp256k1Fp>(mac_in), k)));
     }
     return PORLA_OK;
 }

@@ -274,7 +274,7 @@ int FixedBase<C>::commit_host(const uint8_t* rows, size_t n_rows, size_t n_coeff
         for (size_t r = 0; r < n_rows; r++)
             PORLA_HIP(hipMemcpyAsync(&sums[r], partial + r * last_S, sizeof(XYZZ<M>), hipMemcpyDeviceToHost, stream));
         PORLA_HIP(hipStreamSynchronize(stream));
-        for (size_t r = 0; r < n_rows; r++) h_affine_to_bytes<M>(out + 64 * r, h_xyzz_to_affine<M>(sums[r]));
+        for (size_t r = 0; r < n_rows; r++) h_affine_to_bytes<M>(out + 64 * r, h_xyzz_to_affine64<M>(sums[r]));
         return PORLA_OK;
     }
     int rc = commit_device(io_rows, n_rows, n_coeffs, row_stride, io_out, stream);

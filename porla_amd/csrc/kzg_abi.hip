@@ -7,6 +7,7 @@
 //   single-point ops, Horner evaluation, pairing check               -> host (latency-bound, 64-byte operands)
 #include "engine.hpp"
 #include "pairing_host.hpp"
+#include "host_fold64.hpp"
 #include "../../include/libmultiexp.h"
 #include "../../include/porla_gpu.h"
 
@@ -243,7 +244,7 @@ void init_SRS(GoInt SRS_size, GoSlice* out, GoInt64* out_len) {
         proj[(size_t)i] = h_scalar_mul<Fp>(G, k);
         t = fe_mul<Fr>(t, g.tau);
     }
-    for (long long i = 0; i < SRS_size; i++) g.srs[(size_t)i] = h_xyzz_to_affine<Fp>(proj[(size_t)i]);
+    for (long long i = 0; i < SRS_size; i++) g.srs[(size_t)i] = h_xyzz_to_affine64<Fp>(proj[(size_t)i]);
     uint32_t tau_plain[8];
     h_fe_to_plain<Fr>(tau_plain, g.tau);
     g.g2[0] = g2_generator();
@@ -266,7 +267,7 @@ void init_SRS(GoInt SRS_size, GoSlice* out, GoInt64* out_len) {
     Fe<Fr> rnd = h_fe_from_be<Fr>(rb);
     uint32_t k[8];
     h_fe_to_plain<Fr>(k, rnd);
-    g.h_mac = h_xyzz_to_affine<Fp>(h_scalar_mul<Fp>(g.srs[0], k));
+    g.h_mac = h_xyzz_to_affine64<Fp>(h_scalar_mul<Fp>(g.srs[0], k));
 
     g.version++;  // the HBM copies are rebuilt on first use by a commit (the client side never needs the GPU)
 }
@@ -304,7 +305,7 @@ void compute_digest(GoSlice* data_in, GoSlice* data_out) {
     uint32_t k[8];
     h_fe_to_plain<Fr>(k, acc);
     uint8_t out[64];
-    h_affine_to_bytes<Fp>(out, h_xyzz_to_affine<Fp>(h_scalar_mul<Fp>(g.srs[0], k)));
+    h_affine_to_bytes<Fp>(out, h_xyzz_to_affine64<Fp>(h_scalar_mul<Fp>(g.srs[0], k)));
     copy_out(data_out, out, 64);
 }
 
@@ -314,7 +315,7 @@ void compute_digest_complement(GoSlice* data_in, GoSlice* data_out) {
     uint32_t k[8];
     h_fe_to_plain<Fr>(k, s);
     uint8_t out[64];
-    h_affine_to_bytes<Fp>(out, h_xyzz_to_affine<Fp>(h_scalar_mul<Fp>(g.h_mac, k)));
+    h_affine_to_bytes<Fp>(out, h_xyzz_to_affine64<Fp>(h_scalar_mul<Fp>(g.h_mac, k)));
     copy_out(data_out, out, 64);
 }
 
@@ -396,7 +397,7 @@ GoUint8 verify_proof(GoSlice* commitment_in, GoSlice* proof_H, GoSlice* proof_po
     XYZZ<Fp> A = h_scalar_mul<Fp>(g.srs.empty() ? generator() : g.srs[0], yk);
     A.y = fe_neg<Fp>(A.y);
     xyzz_madd<Fp>(A, C);
-    Affine<Fp> Aaff = h_xyzz_to_affine<Fp>(A);
+    Affine<Fp> Aaff = h_xyzz_to_affine64<Fp>(A);
     // Q = tau*G2 - z*G2
     G2Affine zG2 = g2_scalar_mul(g.g2[0], zk);
     G2Affine Q = g2_add(g.g2[1], g2_neg(zG2));
@@ -418,7 +419,7 @@ void add_point(GoSlice* point_a, GoSlice* point_b) {
     XYZZ<Fp> p = xyzz_from_affine<Fp>(a);
     xyzz_madd<Fp>(p, b);
     uint8_t out[64];
-    h_affine_to_bytes<Fp>(out, h_xyzz_to_affine<Fp>(p));
+    h_affine_to_bytes<Fp>(out, h_xyzz_to_affine64<Fp>(p));
     copy_out(point_a, out, 64);
 }
 
@@ -429,7 +430,7 @@ void mult_point(GoSlice* point_a, GoSlice* scalar) {
     uint32_t k[8];
     h_fe_to_plain<Fr>(k, s);
     uint8_t out[64];
-    h_affine_to_bytes<Fp>(out, h_xyzz_to_affine<Fp>(h_scalar_mul<Fp>(a, k)));
+    h_affine_to_bytes<Fp>(out, h_xyzz_to_affine64<Fp>(h_scalar_mul<Fp>(a, k)));
     copy_out(point_a, out, 64);
 }
 
