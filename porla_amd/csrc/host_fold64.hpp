@@ -213,6 +213,40 @@ inline Affine<M> h_xyzz_to_affine64(const XYZZ<M>& q) {
     return r;
 }
 
+// k * a on the host in 4 x 64-bit limbs, signed 4-bit windows (65 digits cover the carry): 256 doublings + <= 65 additions.
+// The single-point operations of the plug-in (mult_point, compute_digest: porla/main.go:70-89, 205-213) -- the reference issues
+// them one cgo call at a time from 8 threads; host_curve.hpp:h_scalar_mul is the same by double-and-add on 8 x 32-bit limbs.
+template <class M>
+inline XYZZ<M> h_scalar_mul64(const Affine<M>& a, const uint32_t k[8]) {
+    static const Fp64<M> F;
+    typedef typename Fp64<M>::Pt Pt;
+    if (aff_is_inf<M>(a)) return xyzz_inf<M>();
+    uint32_t nz = 0;
+    for (int i = 0; i < 8; i++) nz |= k[i];
+    if (!nz) return xyzz_inf<M>();
+    Pt tbl[8];
+    tbl[0].x = Fp64<M>::from(a.x); tbl[0].y = Fp64<M>::from(a.y); tbl[0].zz = F.one(); tbl[0].zzz = F.one();
+    for (int i = 1; i < 8; i++) tbl[i] = F.padd(tbl[i - 1], tbl[0]);
+    int8_t dig[65];
+    uint32_t carry = 0;
+    for (int i = 0; i < 64; i++) {
+        const uint32_t d = ((k[i >> 3] >> ((i & 7) * 4)) & 15u) + carry;
+        if (d > 8) { dig[i] = (int8_t)((int)d - 16); carry = 1; }
+        else { dig[i] = (int8_t)d; carry = 0; }
+    }
+    dig[64] = (int8_t)carry;
+    Pt acc = F.inf();
+    typename Fp64<M>::E zero;
+    for (int i = 0; i < 4; i++) zero.v[i] = 0;
+    for (int i = 64; i >= 0; i--) {
+        if (!Fp64<M>::is_zero(acc.zz)) for (int d = 0; d < 4; d++) acc = F.dbl(acc);
+        const int d = dig[i];
+        if (d > 0) acc = F.padd(acc, tbl[d - 1]);
+        else if (d < 0) { Pt t = tbl[-d - 1]; t.y = F.sub(zero, t.y); acc = F.padd(acc, t); }
+    }
+    return F.to(acc);
+}
+
 // n projective sums -> affine with ONE inversion (Montgomery's trick) in 4 x 64-bit limbs: the host tail of a batch of
 // commitments (a row's own inversion costs ~25 us in the portable 8 x 32-bit code, which dominated a coalesced batch of 8)
 template <class M>

@@ -241,7 +241,7 @@ void init_SRS(GoInt SRS_size, GoSlice* out, GoInt64* out_len) {
     for (long long i = 0; i < SRS_size; i++) {
         uint32_t k[8];
         h_fe_to_plain<Fr>(k, t);
-        proj[(size_t)i] = h_scalar_mul<Fp>(G, k);
+        proj[(size_t)i] = h_scalar_mul64<Fp>(G, k);
         t = fe_mul<Fr>(t, g.tau);
     }
     for (long long i = 0; i < SRS_size; i++) g.srs[(size_t)i] = h_xyzz_to_affine64<Fp>(proj[(size_t)i]);
@@ -267,7 +267,7 @@ void init_SRS(GoInt SRS_size, GoSlice* out, GoInt64* out_len) {
     Fe<Fr> rnd = h_fe_from_be<Fr>(rb);
     uint32_t k[8];
     h_fe_to_plain<Fr>(k, rnd);
-    g.h_mac = h_xyzz_to_affine64<Fp>(h_scalar_mul<Fp>(g.srs[0], k));
+    g.h_mac = h_xyzz_to_affine64<Fp>(h_scalar_mul64<Fp>(g.srs[0], k));
 
     g.version++;  // the HBM copies are rebuilt on first use by a commit (the client side never needs the GPU)
 }
@@ -305,7 +305,7 @@ void compute_digest(GoSlice* data_in, GoSlice* data_out) {
     uint32_t k[8];
     h_fe_to_plain<Fr>(k, acc);
     uint8_t out[64];
-    h_affine_to_bytes<Fp>(out, h_xyzz_to_affine64<Fp>(h_scalar_mul<Fp>(g.srs[0], k)));
+    h_affine_to_bytes<Fp>(out, h_xyzz_to_affine64<Fp>(h_scalar_mul64<Fp>(g.srs[0], k)));
     copy_out(data_out, out, 64);
 }
 
@@ -315,7 +315,7 @@ void compute_digest_complement(GoSlice* data_in, GoSlice* data_out) {
     uint32_t k[8];
     h_fe_to_plain<Fr>(k, s);
     uint8_t out[64];
-    h_affine_to_bytes<Fp>(out, h_xyzz_to_affine64<Fp>(h_scalar_mul<Fp>(g.h_mac, k)));
+    h_affine_to_bytes<Fp>(out, h_xyzz_to_affine64<Fp>(h_scalar_mul64<Fp>(g.h_mac, k)));
     copy_out(data_out, out, 64);
 }
 
@@ -394,7 +394,7 @@ GoUint8 verify_proof(GoSlice* commitment_in, GoSlice* proof_H, GoSlice* proof_po
     h_fe_to_plain<Fr>(yk, y);
     h_fe_to_plain<Fr>(zk, z);
     // A = C - y*G1
-    XYZZ<Fp> A = h_scalar_mul<Fp>(g.srs.empty() ? generator() : g.srs[0], yk);
+    XYZZ<Fp> A = h_scalar_mul64<Fp>(g.srs.empty() ? generator() : g.srs[0], yk);
     A.y = fe_neg<Fp>(A.y);
     xyzz_madd<Fp>(A, C);
     Affine<Fp> Aaff = h_xyzz_to_affine64<Fp>(A);
@@ -430,7 +430,7 @@ void mult_point(GoSlice* point_a, GoSlice* scalar) {
     uint32_t k[8];
     h_fe_to_plain<Fr>(k, s);
     uint8_t out[64];
-    h_affine_to_bytes<Fp>(out, h_xyzz_to_affine64<Fp>(h_scalar_mul<Fp>(a, k)));
+    h_affine_to_bytes<Fp>(out, h_xyzz_to_affine64<Fp>(h_scalar_mul64<Fp>(a, k)));
     copy_out(point_a, out, 64);
 }
 
