@@ -110,8 +110,8 @@ struct Fp64 {
 
     E one() const { return from(fe_one<M>()); }
     // 1 / a in the field's own domain (Montgomery form in, Montgomery form out; plain for the special-form modulus): binary
-    // extended Euclid on the stored integer -- ~4 us against ~9 us for Fermat's a^(p-2) in these limbs and ~18 us in the
-    // portable 8 x 32-bit code, and it sits at the end of EVERY MSM / commitment call (the affine result).  The stored integer
+    // extended Euclid on the stored integer -- the whole affine conversion takes 2.6 us with it against 13.8 us with Fermat's
+    // a^(p-2) in the portable 8 x 32-bit code (build container), and it sits at the end of EVERY MSM / commitment call.  The stored integer
     // of a is a R, its plain inverse a^-1 R^-1; two products with R^2 bring that to a^-1 R (R^2 = 1 for the plain domain).
     E inverse(const E& a) const {
         if (is_zero(a)) return a;
@@ -199,7 +199,7 @@ struct Fp64 {
 };
 
 // one projective sum -> affine in 4 x 64-bit limbs (host_curve.hpp:h_xyzz_to_affine is the same on 8 x 32-bit limbs with Fermat's
-// inversion: ~18 us at the end of every call)
+// inversion: 13.8 us at the end of every call, 2.6 us here)
 template <class M>
 inline Affine<M> h_xyzz_to_affine64(const XYZZ<M>& q) {
     static const Fp64<M> F;
