@@ -6,6 +6,13 @@
 #pragma once
 #include "ec.cuh"
 
+// the x86-64 host pass gets a hand-written product (mulx, adcx, adox); everything else (the device pass, other hosts) the portable one
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__) && (defined(__clang__) || defined(__GNUC__))
+#define PORLA_FP64_ADX 1
+#else
+#define PORLA_FP64_ADX 0
+#endif
+
 namespace porla {
 
 template <class M>
@@ -18,7 +25,13 @@ struct Fp64 {
         uint64_t x = 1;  // Newton: x <- x * (2 - p0 * x), doubles the number of correct low bits
         for (int i = 0; i < 6; i++) x *= 2 - p[0] * x;
         inv = 0 - x;
+        adx = false;
+#if PORLA_FP64_ADX
+        // the mulx / adcx / adox product below: needs those instructions and a modulus whose top bit is clear
+        adx = !M::PSEUDO_MERSENNE && (p[3] >> 63) == 0 && __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("adx");
+#endif
     }
+    bool adx;
     struct E { uint64_t v[4]; };
 
     static E from(const Fe<M>& a) {
@@ -35,36 +48,38 @@ struct Fp64 {
 
     // t - p if t >= p (t given with an extra carry word)
     E cond_sub(const uint64_t t[4], uint64_t carry) const {
-        uint64_t s[4];
-        u128 br = 0;
-        for (int i = 0; i < 4; i++) {
-            u128 d = (u128)t[i] - p[i] - (uint64_t)br;
-            s[i] = (uint64_t)d;
-            br = (d >> 64) & 1;
-        }
+        unsigned long long s0, s1, s2, s3, br;
+        s0 = __builtin_subcll(t[0], p[0], 0, &br);
+        s1 = __builtin_subcll(t[1], p[1], br, &br);
+        s2 = __builtin_subcll(t[2], p[2], br, &br);
+        s3 = __builtin_subcll(t[3], p[3], br, &br);
+        const bool ge = carry != 0 || br == 0;
         E r;
-        bool ge = carry != 0 || br == 0;
-        for (int i = 0; i < 4; i++) r.v[i] = ge ? s[i] : t[i];
+        r.v[0] = ge ? s0 : t[0]; r.v[1] = ge ? s1 : t[1]; r.v[2] = ge ? s2 : t[2]; r.v[3] = ge ? s3 : t[3];
         return r;
     }
     E add(const E& a, const E& b) const {
+        unsigned long long c;
         uint64_t t[4];
-        u128 c = 0;
-        for (int i = 0; i < 4; i++) { c += (u128)a.v[i] + b.v[i]; t[i] = (uint64_t)c; c >>= 64; }
-        return cond_sub(t, (uint64_t)c);
+        t[0] = __builtin_addcll(a.v[0], b.v[0], 0, &c);
+        t[1] = __builtin_addcll(a.v[1], b.v[1], c, &c);
+        t[2] = __builtin_addcll(a.v[2], b.v[2], c, &c);
+        t[3] = __builtin_addcll(a.v[3], b.v[3], c, &c);
+        return cond_sub(t, c);
     }
     E sub(const E& a, const E& b) const {
+        unsigned long long br, c;
         uint64_t t[4];
-        u128 br = 0;
-        for (int i = 0; i < 4; i++) {
-            u128 d = (u128)a.v[i] - b.v[i] - (uint64_t)br;
-            t[i] = (uint64_t)d;
-            br = (d >> 64) & 1;
-        }
+        t[0] = __builtin_subcll(a.v[0], b.v[0], 0, &br);
+        t[1] = __builtin_subcll(a.v[1], b.v[1], br, &br);
+        t[2] = __builtin_subcll(a.v[2], b.v[2], br, &br);
+        t[3] = __builtin_subcll(a.v[3], b.v[3], br, &br);
+        const uint64_t mask = 0 - (uint64_t)br;                 // borrowed: add p back
         E r;
-        u128 c = 0;
-        uint64_t mask = 0 - (uint64_t)br;
-        for (int i = 0; i < 4; i++) { c += (u128)t[i] + (p[i] & mask); r.v[i] = (uint64_t)c; c >>= 64; }
+        r.v[0] = __builtin_addcll(t[0], p[0] & mask, 0, &c);
+        r.v[1] = __builtin_addcll(t[1], p[1] & mask, c, &c);
+        r.v[2] = __builtin_addcll(t[2], p[2] & mask, c, &c);
+        r.v[3] = __builtin_addcll(t[3], p[3] & mask, c, &c);
         return r;
     }
     // special-form product for p = 2^256 - 2^32 - FOLD on plain residues (fe_mul_pseudo_mersenne in fe.cuh)
@@ -91,9 +106,46 @@ struct Fp64 {
         }
         return cond_sub(r, 0);
     }
+#if PORLA_FP64_ADX
+    // One round of the Montgomery product with two carry chains (adcx / adox), the modulus' top bit clear so that no sixth word is
+    // needed: T0..T4 += a * b[i]; m = T0 * inv; T += m * p; the round's result is (T1..T4).
+#define PORLA_MM_ROUND(BI, T0, T1, T2, T3, T4)                                                  \
+    "movq " BI "(%[b]), %%rdx\n\t"                                                              \
+    "movq $0, " T4 "\n\t"                                                                       \
+    "xorl %%eax, %%eax\n\t"                                                                     \
+    "mulxq 0(%[a]), %[l], %[h]\n\t"  "adoxq %[l], " T0 "\n\t" "adcxq %[h], " T1 "\n\t"            \
+    "mulxq 8(%[a]), %[l], %[h]\n\t"  "adoxq %[l], " T1 "\n\t" "adcxq %[h], " T2 "\n\t"            \
+    "mulxq 16(%[a]), %[l], %[h]\n\t" "adoxq %[l], " T2 "\n\t" "adcxq %[h], " T3 "\n\t"            \
+    "mulxq 24(%[a]), %[l], %[h]\n\t" "adoxq %[l], " T3 "\n\t" "adcxq %[h], " T4 "\n\t"            \
+    "adoxq %%rax, " T4 "\n\t"                                                                   \
+    "movq " T0 ", %%rdx\n\t"                                                                    \
+    "imulq %[inv], %%rdx\n\t"                                                                   \
+    "xorl %%eax, %%eax\n\t"                                                                     \
+    "mulxq 0(%[p]), %[l], %[h]\n\t"  "adoxq %[l], " T0 "\n\t" "adcxq %[h], " T1 "\n\t"            \
+    "mulxq 8(%[p]), %[l], %[h]\n\t"  "adoxq %[l], " T1 "\n\t" "adcxq %[h], " T2 "\n\t"            \
+    "mulxq 16(%[p]), %[l], %[h]\n\t" "adoxq %[l], " T2 "\n\t" "adcxq %[h], " T3 "\n\t"            \
+    "mulxq 24(%[p]), %[l], %[h]\n\t" "adoxq %[l], " T3 "\n\t" "adcxq %[h], " T4 "\n\t"            \
+    "adoxq %%rax, " T4 "\n\t"
+    __attribute__((target("bmi2,adx"))) E mul_adx(const E& a, const E& b) const {
+        uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, l, h;
+        asm(PORLA_MM_ROUND("0", "%[t0]", "%[t1]", "%[t2]", "%[t3]", "%[t4]")
+            PORLA_MM_ROUND("8", "%[t1]", "%[t2]", "%[t3]", "%[t4]", "%[t0]")
+            PORLA_MM_ROUND("16", "%[t2]", "%[t3]", "%[t4]", "%[t0]", "%[t1]")
+            PORLA_MM_ROUND("24", "%[t3]", "%[t4]", "%[t0]", "%[t1]", "%[t2]")
+            : [t0] "+&r"(t0), [t1] "+&r"(t1), [t2] "+&r"(t2), [t3] "+&r"(t3), [t4] "+&r"(t4), [l] "=&r"(l), [h] "=&r"(h)
+            : [a] "r"(a.v), [b] "r"(b.v), [p] "r"(p), [inv] "r"(inv), "m"(a), "m"(b), "m"(p)
+            : "rax", "rdx", "cc");
+        const uint64_t t[4] = {t4, t0, t1, t2};      // after the fourth round the result is its (T1..T4) = (t4, t0, t1, t2)
+        return cond_sub(t, 0);
+    }
+#undef PORLA_MM_ROUND
+#endif
     // CIOS Montgomery product
     E mul(const E& a, const E& b) const {
         if (M::PSEUDO_MERSENNE) return mul_pseudo_mersenne(a, b);
+#if PORLA_FP64_ADX
+        if (adx) return mul_adx(a, b);     // 25 against 36 ns per dependent product, 18 against 28 ns with four products in flight (build container)
+#endif
         uint64_t t[6] = {0, 0, 0, 0, 0, 0};
         for (int i = 0; i < 4; i++) {
             u128 c = 0;
