@@ -29,9 +29,10 @@ struct Fp64 {
 #if PORLA_FP64_ADX
         // the mulx / adcx / adox product below: needs those instructions and a modulus whose top bit is clear
         adx = !M::PSEUDO_MERSENNE && (p[3] >> 63) == 0 && __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("adx");
+        adx_pm = M::PSEUDO_MERSENNE && __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("adx");
 #endif
     }
-    bool adx;
+    bool adx, adx_pm = false;
     struct E { uint64_t v[4]; };
 
     static E from(const Fe<M>& a) {
@@ -82,10 +83,38 @@ struct Fp64 {
         r.v[3] = __builtin_addcll(t[3], p[3] & mask, c, &c);
         return r;
     }
+#if PORLA_FP64_ADX
+    // 256 x 256 -> 512-bit schoolbook product, one row per b[i] with two carry chains: T[i..i+4] += a * b[i]
+#define PORLA_MUL_ROW(BI, T0, T1, T2, T3, T4)                                                   \
+    "movq " BI "(%[b]), %%rdx\n\t"                                                              \
+    "xorl %%eax, %%eax\n\t"                                                                     \
+    "mulxq 0(%[a]), %[l], %[h]\n\t"  "adoxq %[l], " T0 "\n\t" "adcxq %[h], " T1 "\n\t"            \
+    "mulxq 8(%[a]), %[l], %[h]\n\t"  "adoxq %[l], " T1 "\n\t" "adcxq %[h], " T2 "\n\t"            \
+    "mulxq 16(%[a]), %[l], %[h]\n\t" "adoxq %[l], " T2 "\n\t" "adcxq %[h], " T3 "\n\t"            \
+    "mulxq 24(%[a]), %[l], %[h]\n\t" "adoxq %[l], " T3 "\n\t" "adcxq %[h], " T4 "\n\t"            \
+    "adoxq %%rax, " T4 "\n\t"
+    __attribute__((target("bmi2,adx"))) static void mul512_adx(uint64_t t[8], const E& a, const E& b) {
+        uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0, t7 = 0, l, h;
+        asm(PORLA_MUL_ROW("0", "%[t0]", "%[t1]", "%[t2]", "%[t3]", "%[t4]")
+            PORLA_MUL_ROW("8", "%[t1]", "%[t2]", "%[t3]", "%[t4]", "%[t5]")
+            PORLA_MUL_ROW("16", "%[t2]", "%[t3]", "%[t4]", "%[t5]", "%[t6]")
+            PORLA_MUL_ROW("24", "%[t3]", "%[t4]", "%[t5]", "%[t6]", "%[t7]")
+            : [t0] "+&r"(t0), [t1] "+&r"(t1), [t2] "+&r"(t2), [t3] "+&r"(t3), [t4] "+&r"(t4), [t5] "+&r"(t5), [t6] "+&r"(t6),
+              [t7] "+&r"(t7), [l] "=&r"(l), [h] "=&r"(h)
+            : [a] "r"(a.v), [b] "r"(b.v), "m"(a), "m"(b)
+            : "rax", "rdx", "cc");
+        t[0] = t0; t[1] = t1; t[2] = t2; t[3] = t3; t[4] = t4; t[5] = t5; t[6] = t6; t[7] = t7;
+    }
+#undef PORLA_MUL_ROW
+#endif
     // special-form product for p = 2^256 - 2^32 - FOLD on plain residues (fe_mul_pseudo_mersenne in fe.cuh)
     E mul_pseudo_mersenne(const E& a, const E& b) const {
         const uint64_t c = ((uint64_t)1 << 32) + M::FOLD;
         uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#if PORLA_FP64_ADX
+        if (adx_pm) mul512_adx(t, a, b);
+        else
+#endif
         for (int i = 0; i < 4; i++) {
             u128 carry = 0;
             for (int j = 0; j < 4; j++) { carry += (u128)a.v[i] * b.v[j] + t[i + j]; t[i + j] = (uint64_t)carry; carry >>= 64; }
