@@ -146,11 +146,19 @@ k_small_msm(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ poi
     __syncthreads();
     {
         uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (uint32_t i = tid; i < n; i += SMALL_THREADS) {
-            uint32_t t[8];
-            load_be256(t, scalars + (size_t)i * 32);
+        // four scalars per lane and trip, loaded before the first is used: the loop is a chain of L2 round trips otherwise
+        // (13 trips of ~0.6 us at 3 200 scalars)
+        for (uint32_t i = tid; i < n; i += 4 * SMALL_THREADS) {
+            uint32_t t[4][8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) acc[k] |= t[k];
+            for (int u = 0; u < 4; u++) {
+                const uint32_t j = i + (uint32_t)u * SMALL_THREADS;
+                load_be256(t[u], scalars + (size_t)(j < n ? j : i) * 32);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int k = 0; k < 8; k++) acc[k] |= t[u][k];
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
