@@ -354,20 +354,45 @@ void create_proof(GoUint64 random_point, GoSlice* data_in, GoSlice* commitment_o
     size_t n = (size_t)g.n_samples;
     uint8_t zb[32] = {0};
     for (int i = 0; i < 8; i++) zb[31 - i] = (uint8_t)(random_point >> (8 * i));
-    Fe<Fr> z = h_fe_from_be<Fr>(zb);
-    std::vector<Fe<Fr>> f(n);
-    for (size_t i = 0; i < n; i++) f[i] = h_fe_from_be<Fr>(d + 32 * i);
-    Fe<Fr> y = fe_zero<Fr>();
-    for (size_t i = n; i-- > 0;) y = fe_add<Fr>(fe_mul<Fr>(y, z), f[i]);
+    // Horner and the synthetic division in 4 x 64-bit limbs (host_fold64.hpp): the coefficients and the running values stay
+    // PLAIN residues, only z is in the Montgomery form -- a Montgomery product of a plain value with z R is the plain product,
+    // so the 2 n products need no conversion on either side (510 products in the 8 x 32-bit code before)
+    static const Fp64<Fr> F;
+    typedef Fp64<Fr>::E E64;
+    auto from_be_plain = [&](const uint8_t* b) {          // fr.SetBytes: big-endian, reduced mod r
+        uint64_t t[4];
+        for (int i = 0; i < 4; i++) {
+            uint64_t w = 0;
+            for (int k = 0; k < 8; k++) w = (w << 8) | b[8 * (3 - i) + k];
+            t[i] = w;
+        }
+        E64 v = F.cond_sub(t, 0);
+        for (int q = 0; q < 5; q++) v = F.cond_sub(v.v, 0);      // 2^256 < 6 r
+        return v;
+    };
+    auto to_be = [&](uint8_t* out, const E64& a) {
+        for (int i = 0; i < 4; i++)
+            for (int k = 0; k < 8; k++) out[8 * (3 - i) + k] = (uint8_t)(a.v[i] >> (8 * (7 - k)));
+    };
+    Fe<Fr> r2f;
+    for (int i = 0; i < 8; i++) r2f.v[i] = Fr::R2[i];
+    const E64 z = from_be_plain(zb);
+    const E64 zM = F.mul(z, Fp64<Fr>::from(r2f));          // z R
+    std::vector<E64> f(n);
+    for (size_t i = 0; i < n; i++) f[i] = from_be_plain(d + 32 * i);
+    E64 y;
+    for (int i = 0; i < 4; i++) y.v[i] = 0;
+    for (size_t i = n; i-- > 0;) y = F.add(F.mul(y, zM), f[i]);
     // synthetic division: h[n-2] = f[n-1]; h[i-1] = f[i] + z*h[i].  Both commitments go out as ONE batch of two rows of n
     // coefficients (h padded with a zero top coefficient: the same commitment), one launch instead of two.
     std::vector<uint8_t> two(2 * 32 * n, 0);
     memcpy(two.data(), d, 32 * n);
     uint8_t* hb = two.data() + 32 * n;
-    Fe<Fr> carry = fe_zero<Fr>();
+    E64 carry;
+    for (int i = 0; i < 4; i++) carry.v[i] = 0;
     for (size_t i = n; i-- > 1;) {
-        carry = fe_add<Fr>(fe_mul<Fr>(carry, z), f[i]);
-        fr_plain_be(&hb[32 * (i - 1)], carry);
+        carry = F.add(F.mul(carry, zM), f[i]);
+        to_be(&hb[32 * (i - 1)], carry);
     }
     uint8_t both[128];
     int rc = n ? commit_rows(two.data(), false, 2, n, both, nullptr) : PORLA_OK;
@@ -376,8 +401,8 @@ void create_proof(GoUint64 random_point, GoSlice* data_in, GoSlice* commitment_o
     copy_out(commitment_out, both, 64);
     copy_out(proof_H, both + 64, 64);
     uint8_t t[32];
-    fr_plain_be(t, z); copy_out(proof_point, t, 32);
-    fr_plain_be(t, y); copy_out(proof_claim, t, 32);
+    to_be(t, z); copy_out(proof_point, t, 32);
+    to_be(t, y); copy_out(proof_claim, t, 32);
 }
 
 // main.go:177-193: kzg.Verify -- e(C - y*G1, G2) == e(H, tau*G2 - z*G2), as one product of two pairings
