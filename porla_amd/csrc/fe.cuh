@@ -118,8 +118,48 @@ PORLA_HD uint32_t sub_p(uint32_t s[8], const uint32_t t[8]) {
     return br;
 }
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+// host pass: the limbs taken two at a time (little-endian host: the same bytes), carries through the compiler's builtins --
+// the pairing of verify_proof is as many additions as products
+template <class M>
+inline void fe_host64_load(unsigned long long w[4], const uint32_t v[8]) {
+    for (int i = 0; i < 4; i++) w[i] = ((unsigned long long)v[2 * i + 1] << 32) | v[2 * i];
+}
+template <class M>
+inline Fe<M> fe_add_host64(const Fe<M>& a, const Fe<M>& b) {
+    unsigned long long A[4], B[4], Pm[4], t[4], s[4], c, br;
+    fe_host64_load<M>(A, a.v); fe_host64_load<M>(B, b.v); fe_host64_load<M>(Pm, M::P);
+    t[0] = __builtin_addcll(A[0], B[0], 0, &c); t[1] = __builtin_addcll(A[1], B[1], c, &c);
+    t[2] = __builtin_addcll(A[2], B[2], c, &c); t[3] = __builtin_addcll(A[3], B[3], c, &c);
+    s[0] = __builtin_subcll(t[0], Pm[0], 0, &br); s[1] = __builtin_subcll(t[1], Pm[1], br, &br);
+    s[2] = __builtin_subcll(t[2], Pm[2], br, &br); s[3] = __builtin_subcll(t[3], Pm[3], br, &br);
+    const bool ge = c != 0 || br == 0;
+    Fe<M> r;
+    for (int i = 0; i < 4; i++) { const unsigned long long w = ge ? s[i] : t[i]; r.v[2 * i] = (uint32_t)w; r.v[2 * i + 1] = (uint32_t)(w >> 32); }
+    return r;
+}
+template <class M>
+inline Fe<M> fe_sub_host64(const Fe<M>& a, const Fe<M>& b) {
+    unsigned long long A[4], B[4], Pm[4], t[4], c, br;
+    fe_host64_load<M>(A, a.v); fe_host64_load<M>(B, b.v); fe_host64_load<M>(Pm, M::P);
+    t[0] = __builtin_subcll(A[0], B[0], 0, &br); t[1] = __builtin_subcll(A[1], B[1], br, &br);
+    t[2] = __builtin_subcll(A[2], B[2], br, &br); t[3] = __builtin_subcll(A[3], B[3], br, &br);
+    const unsigned long long mask = 0ull - br;
+    Fe<M> r;
+    unsigned long long w;
+    w = __builtin_addcll(t[0], Pm[0] & mask, 0, &c); r.v[0] = (uint32_t)w; r.v[1] = (uint32_t)(w >> 32);
+    w = __builtin_addcll(t[1], Pm[1] & mask, c, &c); r.v[2] = (uint32_t)w; r.v[3] = (uint32_t)(w >> 32);
+    w = __builtin_addcll(t[2], Pm[2] & mask, c, &c); r.v[4] = (uint32_t)w; r.v[5] = (uint32_t)(w >> 32);
+    w = __builtin_addcll(t[3], Pm[3] & mask, c, &c); r.v[6] = (uint32_t)w; r.v[7] = (uint32_t)(w >> 32);
+    return r;
+}
+#endif
+
 template <class M>
 PORLA_HD Fe<M> fe_add(const Fe<M>& a, const Fe<M>& b) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    return fe_add_host64<M>(a, b);
+#endif
     uint32_t t[8], s[8];
     uint32_t c = 0;
 #pragma unroll
@@ -138,6 +178,9 @@ PORLA_HD Fe<M> fe_add(const Fe<M>& a, const Fe<M>& b) {
 
 template <class M>
 PORLA_HD Fe<M> fe_sub(const Fe<M>& a, const Fe<M>& b) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    return fe_sub_host64<M>(a, b);
+#endif
     uint32_t t[8];
     uint32_t br = 0;
 #pragma unroll
@@ -287,6 +330,53 @@ PORLA_HD Fe<M> fe_mul_pseudo_mersenne(const Fe<M>& a, const Fe<M>& b) {
     return out;
 }
 
+// the x86-64 host pass gets a hand-written product (mulx, adcx, adox); everything else (the device pass, other hosts) the portable one
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__) && (defined(__clang__) || defined(__GNUC__))
+#define PORLA_FP64_ADX 1
+#else
+#define PORLA_FP64_ADX 0
+#endif
+#if PORLA_FP64_ADX
+inline bool host_has_adx() {
+    static const bool v = __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("adx");
+    return v;
+}
+// One round of the Montgomery product with two carry chains (adcx / adox), the modulus' top bit clear so that no sixth word is
+// needed: T0..T4 += a * b[i]; m = T0 * inv; T += m * p; the round's result is (T1..T4).
+#define PORLA_MM_ROUND(BI, T0, T1, T2, T3, T4)                                                  \
+    "movq " BI "(%[b]), %%rdx\n\t"                                                              \
+    "movq $0, " T4 "\n\t"                                                                       \
+    "xorl %%eax, %%eax\n\t"                                                                     \
+    "mulxq 0(%[a]), %[l], %[h]\n\t"  "adoxq %[l], " T0 "\n\t" "adcxq %[h], " T1 "\n\t"            \
+    "mulxq 8(%[a]), %[l], %[h]\n\t"  "adoxq %[l], " T1 "\n\t" "adcxq %[h], " T2 "\n\t"            \
+    "mulxq 16(%[a]), %[l], %[h]\n\t" "adoxq %[l], " T2 "\n\t" "adcxq %[h], " T3 "\n\t"            \
+    "mulxq 24(%[a]), %[l], %[h]\n\t" "adoxq %[l], " T3 "\n\t" "adcxq %[h], " T4 "\n\t"            \
+    "adoxq %%rax, " T4 "\n\t"                                                                   \
+    "movq " T0 ", %%rdx\n\t"                                                                    \
+    "imulq %[inv], %%rdx\n\t"                                                                   \
+    "xorl %%eax, %%eax\n\t"                                                                     \
+    "mulxq 0(%[p]), %[l], %[h]\n\t"  "adoxq %[l], " T0 "\n\t" "adcxq %[h], " T1 "\n\t"            \
+    "mulxq 8(%[p]), %[l], %[h]\n\t"  "adoxq %[l], " T1 "\n\t" "adcxq %[h], " T2 "\n\t"            \
+    "mulxq 16(%[p]), %[l], %[h]\n\t" "adoxq %[l], " T2 "\n\t" "adcxq %[h], " T3 "\n\t"            \
+    "mulxq 24(%[p]), %[l], %[h]\n\t" "adoxq %[l], " T3 "\n\t" "adcxq %[h], " T4 "\n\t"            \
+    "adoxq %%rax, " T4 "\n\t"
+// t = a b / 2^256 mod p, below 2p (the caller subtracts p once if needed); p's top bit must be clear; needs BMI2 + ADX
+__attribute__((target("bmi2,adx"))) inline void mont_mul4_adx(uint64_t t[4], const uint64_t a[4], const uint64_t b[4], const uint64_t p[4],
+                                                               uint64_t inv) {
+    uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, l, h;
+    asm(PORLA_MM_ROUND("0", "%[t0]", "%[t1]", "%[t2]", "%[t3]", "%[t4]")
+        PORLA_MM_ROUND("8", "%[t1]", "%[t2]", "%[t3]", "%[t4]", "%[t0]")
+        PORLA_MM_ROUND("16", "%[t2]", "%[t3]", "%[t4]", "%[t0]", "%[t1]")
+        PORLA_MM_ROUND("24", "%[t3]", "%[t4]", "%[t0]", "%[t1]", "%[t2]")
+        : [t0] "+&r"(t0), [t1] "+&r"(t1), [t2] "+&r"(t2), [t3] "+&r"(t3), [t4] "+&r"(t4), [l] "=&r"(l), [h] "=&r"(h)
+        : [a] "r"(a), [b] "r"(b), [p] "r"(p), [inv] "r"(inv), "m"(*(const uint64_t(*)[4])a), "m"(*(const uint64_t(*)[4])b),
+          "m"(*(const uint64_t(*)[4])p)
+        : "rax", "rdx", "cc");
+    t[0] = t4; t[1] = t0; t[2] = t1; t[3] = t2;      // after the fourth round the result is its (T1..T4) = (t4, t0, t1, t2)
+}
+#undef PORLA_MM_ROUND
+#endif
+
 #if !defined(__HIP_DEVICE_COMPILE__)
 // Host pass: the same Montgomery product (radix 2^256) with 4 x 64-bit limbs and 128-bit products (CIOS) -- about 2.5x the
 // speed of the 32-bit form above on x86-64; it carries every host-side tail (window fold, single-point operations, the
@@ -306,6 +396,10 @@ inline Fe<M> fe_mul_host64(const Fe<M>& a, const Fe<M>& b) {
         B[i] = ((uint64_t)b.v[2 * i + 1] << 32) | b.v[2 * i];
         Pm[i] = ((uint64_t)M::P[2 * i + 1] << 32) | M::P[2 * i];
     }
+#if PORLA_FP64_ADX
+    if ((Pm[3] >> 63) == 0 && host_has_adx()) mont_mul4_adx(t, A, B, Pm, inv);     // the hand-written product (t[4] stays 0)
+    else
+#endif
     for (int i = 0; i < 4; i++) {
         u128 c = 0;
         for (int j = 0; j < 4; j++) { c += (u128)A[j] * B[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }

@@ -6,13 +6,6 @@
 #pragma once
 #include "ec.cuh"
 
-// the x86-64 host pass gets a hand-written product (mulx, adcx, adox); everything else (the device pass, other hosts) the portable one
-#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__) && (defined(__clang__) || defined(__GNUC__))
-#define PORLA_FP64_ADX 1
-#else
-#define PORLA_FP64_ADX 0
-#endif
-
 namespace porla {
 
 template <class M>
@@ -28,8 +21,8 @@ struct Fp64 {
         adx = false;
 #if PORLA_FP64_ADX
         // the mulx / adcx / adox product below: needs those instructions and a modulus whose top bit is clear
-        adx = !M::PSEUDO_MERSENNE && (p[3] >> 63) == 0 && __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("adx");
-        adx_pm = M::PSEUDO_MERSENNE && __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("adx");
+        adx = !M::PSEUDO_MERSENNE && (p[3] >> 63) == 0 && host_has_adx();
+        adx_pm = M::PSEUDO_MERSENNE && host_has_adx();
 #endif
     }
     bool adx, adx_pm = false;
@@ -136,38 +129,11 @@ struct Fp64 {
         return cond_sub(r, 0);
     }
 #if PORLA_FP64_ADX
-    // One round of the Montgomery product with two carry chains (adcx / adox), the modulus' top bit clear so that no sixth word is
-    // needed: T0..T4 += a * b[i]; m = T0 * inv; T += m * p; the round's result is (T1..T4).
-#define PORLA_MM_ROUND(BI, T0, T1, T2, T3, T4)                                                  \
-    "movq " BI "(%[b]), %%rdx\n\t"                                                              \
-    "movq $0, " T4 "\n\t"                                                                       \
-    "xorl %%eax, %%eax\n\t"                                                                     \
-    "mulxq 0(%[a]), %[l], %[h]\n\t"  "adoxq %[l], " T0 "\n\t" "adcxq %[h], " T1 "\n\t"            \
-    "mulxq 8(%[a]), %[l], %[h]\n\t"  "adoxq %[l], " T1 "\n\t" "adcxq %[h], " T2 "\n\t"            \
-    "mulxq 16(%[a]), %[l], %[h]\n\t" "adoxq %[l], " T2 "\n\t" "adcxq %[h], " T3 "\n\t"            \
-    "mulxq 24(%[a]), %[l], %[h]\n\t" "adoxq %[l], " T3 "\n\t" "adcxq %[h], " T4 "\n\t"            \
-    "adoxq %%rax, " T4 "\n\t"                                                                   \
-    "movq " T0 ", %%rdx\n\t"                                                                    \
-    "imulq %[inv], %%rdx\n\t"                                                                   \
-    "xorl %%eax, %%eax\n\t"                                                                     \
-    "mulxq 0(%[p]), %[l], %[h]\n\t"  "adoxq %[l], " T0 "\n\t" "adcxq %[h], " T1 "\n\t"            \
-    "mulxq 8(%[p]), %[l], %[h]\n\t"  "adoxq %[l], " T1 "\n\t" "adcxq %[h], " T2 "\n\t"            \
-    "mulxq 16(%[p]), %[l], %[h]\n\t" "adoxq %[l], " T2 "\n\t" "adcxq %[h], " T3 "\n\t"            \
-    "mulxq 24(%[p]), %[l], %[h]\n\t" "adoxq %[l], " T3 "\n\t" "adcxq %[h], " T4 "\n\t"            \
-    "adoxq %%rax, " T4 "\n\t"
-    __attribute__((target("bmi2,adx"))) E mul_adx(const E& a, const E& b) const {
-        uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, l, h;
-        asm(PORLA_MM_ROUND("0", "%[t0]", "%[t1]", "%[t2]", "%[t3]", "%[t4]")
-            PORLA_MM_ROUND("8", "%[t1]", "%[t2]", "%[t3]", "%[t4]", "%[t0]")
-            PORLA_MM_ROUND("16", "%[t2]", "%[t3]", "%[t4]", "%[t0]", "%[t1]")
-            PORLA_MM_ROUND("24", "%[t3]", "%[t4]", "%[t0]", "%[t1]", "%[t2]")
-            : [t0] "+&r"(t0), [t1] "+&r"(t1), [t2] "+&r"(t2), [t3] "+&r"(t3), [t4] "+&r"(t4), [l] "=&r"(l), [h] "=&r"(h)
-            : [a] "r"(a.v), [b] "r"(b.v), [p] "r"(p), [inv] "r"(inv), "m"(a), "m"(b), "m"(p)
-            : "rax", "rdx", "cc");
-        const uint64_t t[4] = {t4, t0, t1, t2};      // after the fourth round the result is its (T1..T4) = (t4, t0, t1, t2)
+    E mul_adx(const E& a, const E& b) const {          // fe.cuh:mont_mul4_adx
+        uint64_t t[4];
+        mont_mul4_adx(t, a.v, b.v, p, inv);
         return cond_sub(t, 0);
     }
-#undef PORLA_MM_ROUND
 #endif
     // CIOS Montgomery product
     E mul(const E& a, const E& b) const {

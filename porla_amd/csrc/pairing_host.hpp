@@ -74,7 +74,10 @@ inline Fp2 f2_mul(const Fp2& a, const Fp2& b) {
     FpE s = fe_mul<Bn254Fp>(fe_add<Bn254Fp>(a.a0, a.a1), fe_add<Bn254Fp>(b.a0, b.a1));
     return Fp2{fe_sub<Bn254Fp>(t0, t1), fe_sub<Bn254Fp>(fe_sub<Bn254Fp>(s, t0), t1)};
 }
-inline Fp2 f2_sqr(const Fp2& a) { return f2_mul(a, a); }
+inline Fp2 f2_sqr(const Fp2& a) {   // (a0 + a1)(a0 - a1) + 2 a0 a1 u
+    FpE t = fe_mul<Bn254Fp>(a.a0, a.a1);
+    return Fp2{fe_mul<Bn254Fp>(fe_add<Bn254Fp>(a.a0, a.a1), fe_sub<Bn254Fp>(a.a0, a.a1)), fe_dbl<Bn254Fp>(t)};
+}
 inline Fp2 f2_mul_fp(const Fp2& a, const FpE& k) { return Fp2{fe_mul<Bn254Fp>(a.a0, k), fe_mul<Bn254Fp>(a.a1, k)}; }
 inline Fp2 f2_inv(const Fp2& a) {
     FpE n = fe_add<Bn254Fp>(fe_sqr<Bn254Fp>(a.a0), fe_sqr<Bn254Fp>(a.a1));
@@ -204,19 +207,50 @@ inline bool g2_decompress(const uint8_t in[64], G2Affine* p) {
 // ---------------------------------------------------------------- Fp12 = Fp2[w]/(w^6 - xi)
 struct Fp12 { Fp2 c[6]; };
 inline Fp12 f12_one() { Fp12 r; for (int i = 0; i < 6; i++) r.c[i] = f2_zero(); r.c[0] = f2_one(); return r; }
+// Fp6 = Fp2[v]/(v^3 - xi), v = w^2; an Fp12 element is A + w B with A = (c0, c2, c4), B = (c1, c3, c5)
+struct Fp6 { Fp2 a0, a1, a2; };
+inline Fp6 f6_add(const Fp6& a, const Fp6& b) { return Fp6{f2_add(a.a0, b.a0), f2_add(a.a1, b.a1), f2_add(a.a2, b.a2)}; }
+inline Fp6 f6_sub(const Fp6& a, const Fp6& b) { return Fp6{f2_sub(a.a0, b.a0), f2_sub(a.a1, b.a1), f2_sub(a.a2, b.a2)}; }
+inline Fp6 f6_mul_v(const Fp6& a) { return Fp6{f2_mul_xi(a.a2), a.a0, a.a1}; }
+inline Fp6 f6_mul(const Fp6& a, const Fp6& b) {   // Karatsuba: 6 products in Fp2
+    Fp2 t0 = f2_mul(a.a0, b.a0), t1 = f2_mul(a.a1, b.a1), t2 = f2_mul(a.a2, b.a2);
+    Fp2 c0 = f2_add(t0, f2_mul_xi(f2_sub(f2_sub(f2_mul(f2_add(a.a1, a.a2), f2_add(b.a1, b.a2)), t1), t2)));
+    Fp2 c1 = f2_add(f2_sub(f2_sub(f2_mul(f2_add(a.a0, a.a1), f2_add(b.a0, b.a1)), t0), t1), f2_mul_xi(t2));
+    Fp2 c2 = f2_add(f2_sub(f2_sub(f2_mul(f2_add(a.a0, a.a2), f2_add(b.a0, b.a2)), t0), t2), t1);
+    return Fp6{c0, c1, c2};
+}
+inline void f12_split(const Fp12& a, Fp6* A, Fp6* B) { *A = Fp6{a.c[0], a.c[2], a.c[4]}; *B = Fp6{a.c[1], a.c[3], a.c[5]}; }
+inline Fp12 f12_join(const Fp6& A, const Fp6& B) {
+    Fp12 r;
+    r.c[0] = A.a0; r.c[2] = A.a1; r.c[4] = A.a2; r.c[1] = B.a0; r.c[3] = B.a1; r.c[5] = B.a2;
+    return r;
+}
+// (A0 + w A1)(B0 + w B1) = (A0 B0 + v A1 B1) + w ((A0 + A1)(B0 + B1) - A0 B0 - A1 B1): 3 products in Fp6 = 18 in Fp2 (the
+// schoolbook form over the six Fp2 coefficients took 36, plus five products by xi that are additions in f2_mul_xi)
 inline Fp12 f12_mul(const Fp12& a, const Fp12& b) {
+    Fp6 A0, A1, B0, B1;
+    f12_split(a, &A0, &A1); f12_split(b, &B0, &B1);
+    const Fp6 t0 = f6_mul(A0, B0), t1 = f6_mul(A1, B1), t2 = f6_mul(f6_add(A0, A1), f6_add(B0, B1));
+    return f12_join(f6_add(t0, f6_mul_v(t1)), f6_sub(f6_sub(t2, t0), t1));
+}
+// (A0 + w A1)^2 = ((A0 + A1)(A0 + v A1) - t - v t) + w 2t, t = A0 A1: 2 products in Fp6
+inline Fp12 f12_sqr(const Fp12& a) {
+    Fp6 A0, A1;
+    f12_split(a, &A0, &A1);
+    const Fp6 t = f6_mul(A0, A1);
+    const Fp6 r0 = f6_sub(f6_sub(f6_mul(f6_add(A0, A1), f6_add(A0, f6_mul_v(A1))), t), f6_mul_v(t));
+    return f12_join(r0, f6_add(t, t));
+}
+// a times a SPARSE element (a line value: three of its six coefficients are zero): schoolbook over the non-zero coefficients
+inline Fp12 f12_mul_sparse(const Fp12& a, const Fp12& b) {
     Fp2 t[11];
     for (int i = 0; i < 11; i++) t[i] = f2_zero();
-    for (int i = 0; i < 6; i++) {
-        if (f2_is_zero(a.c[i])) continue;
-        for (int j = 0; j < 6; j++) {
-            if (f2_is_zero(b.c[j])) continue;
-            t[i + j] = f2_add(t[i + j], f2_mul(a.c[i], b.c[j]));
-        }
+    for (int j = 0; j < 6; j++) {
+        if (f2_is_zero(b.c[j])) continue;
+        for (int i = 0; i < 6; i++) t[i + j] = f2_add(t[i + j], f2_mul(a.c[i], b.c[j]));
     }
-    Fp2 xi = f2_xi();
     Fp12 r;
-    for (int i = 0; i < 6; i++) r.c[i] = (i + 6 < 11) ? f2_add(t[i], f2_mul(t[i + 6], xi)) : t[i];
+    for (int i = 0; i < 6; i++) r.c[i] = (i + 6 < 11) ? f2_add(t[i], f2_mul_xi(t[i + 6])) : t[i];
     return r;
 }
 inline bool f12_is_one(const Fp12& a) {
@@ -231,17 +265,6 @@ inline Fp12 f12_conj(const Fp12& a) {
     r.c[1] = f2_neg(a.c[1]); r.c[3] = f2_neg(a.c[3]); r.c[5] = f2_neg(a.c[5]);
     return r;
 }
-// Fp6 = Fp2[v]/(v^3 - xi), v = w^2: helpers for the Fp12 inversion
-struct Fp6 { Fp2 a0, a1, a2; };
-inline Fp6 f6_mul(const Fp6& a, const Fp6& b) {
-    Fp2 t0 = f2_mul(a.a0, b.a0), t1 = f2_mul(a.a1, b.a1), t2 = f2_mul(a.a2, b.a2);
-    Fp2 c0 = f2_add(t0, f2_mul_xi(f2_add(f2_mul(a.a1, b.a2), f2_mul(a.a2, b.a1))));
-    Fp2 c1 = f2_add(f2_add(f2_mul(a.a0, b.a1), f2_mul(a.a1, b.a0)), f2_mul_xi(t2));
-    Fp2 c2 = f2_add(f2_add(f2_mul(a.a0, b.a2), f2_mul(a.a2, b.a0)), t1);
-    return Fp6{c0, c1, c2};
-}
-inline Fp6 f6_sub(const Fp6& a, const Fp6& b) { return Fp6{f2_sub(a.a0, b.a0), f2_sub(a.a1, b.a1), f2_sub(a.a2, b.a2)}; }
-inline Fp6 f6_mul_v(const Fp6& a) { return Fp6{f2_mul_xi(a.a2), a.a0, a.a1}; }
 inline Fp6 f6_inv(const Fp6& a) {
     Fp2 t0 = f2_sub(f2_sqr(a.a0), f2_mul_xi(f2_mul(a.a1, a.a2)));
     Fp2 t1 = f2_sub(f2_mul_xi(f2_sqr(a.a2)), f2_mul(a.a0, a.a1));
@@ -289,7 +312,7 @@ inline Fp12 f12_pow_x(const Fp12& a) {
     const uint64_t x = 4965661367192848881ull;
     Fp12 acc = a;
     for (int i = 61; i >= 0; i--) {   // bit 62 is the top bit of x
-        acc = f12_mul(acc, acc);
+        acc = f12_sqr(acc);
         if ((x >> i) & 1) acc = f12_mul(acc, a);
     }
     return acc;
@@ -371,9 +394,43 @@ inline Fp12 miller_ate(const Affine<Bn254Fp>& P, const G2Affine& Q) {
     int top = 127;
     while (!((S[top >> 5] >> (top & 31)) & 1)) top--;
     for (int i = top - 1; i >= 0; i--) {
-        f = f12_mul(f, f);
-        f = f12_mul(f, line_double_proj(&T, P));
-        if ((S[i >> 5] >> (i & 31)) & 1) f = f12_mul(f, line_add_proj(&T, Q, P));
+        f = f12_sqr(f);
+        f = f12_mul_sparse(f, line_double_proj(&T, P));
+        if ((S[i >> 5] >> (i & 31)) & 1) f = f12_mul_sparse(f, line_add_proj(&T, Q, P));
+    }
+    return f;
+}
+
+// The p-power Frobenius on the twist: psi^-1 o pi o psi (x', y') = (conj(x') gamma^2, conj(y') gamma^3), gamma = xi^((p-1)/6)
+inline G2Affine g2_frob(const G2Affine& q) {
+    const Fp2* g = f12_frob_gammas();
+    return G2Affine{f2_mul(f2_conj(q.x), g[2]), f2_mul(f2_conj(q.y), g[3]), q.inf};
+}
+// OPTIMAL ate Miller function of the two pairs in ONE loop (the squaring of the running value is shared):
+//   f_{6x+2,Q}(P) * l_{[6x+2]Q, pi(Q)}(P) * l_{[6x+2]Q + pi(Q), -pi^2(Q)}(P),   6x + 2 = 0x19d797039be763ba8 (65 bits)
+// -- half the iterations of the plain ate function f_{6x^2,Q} (miller_ate, 127 bits), which stays as the form the slow reference
+// is compared with.  Both are non-degenerate bilinear pairings, so the predicate "product == 1" is the same.
+inline Fp12 miller_opt_ate2(const Affine<Bn254Fp>& P1, const G2Affine& Q1, const Affine<Bn254Fp>& P2, const G2Affine& Q2) {
+    static const uint32_t S[3] = {0xbe763ba8u, 0x9d797039u, 0x1u};    // 6x + 2, little-endian words
+    const bool on[2] = {!(aff_is_inf<Bn254Fp>(P1) || Q1.inf), !(aff_is_inf<Bn254Fp>(P2) || Q2.inf)};
+    const Affine<Bn254Fp>* P[2] = {&P1, &P2};
+    const G2Affine* Q[2] = {&Q1, &Q2};
+    Fp12 f = f12_one();
+    if (!on[0] && !on[1]) return f;
+    G2Proj T[2] = {G2Proj{Q1.x, Q1.y, f2_one()}, G2Proj{Q2.x, Q2.y, f2_one()}};
+    for (int i = 63; i >= 0; i--) {                      // bit 64 is the top bit
+        f = f12_sqr(f);
+        for (int k = 0; k < 2; k++) if (on[k]) f = f12_mul_sparse(f, line_double_proj(&T[k], *P[k]));
+        if ((S[i >> 5] >> (i & 31)) & 1)
+            for (int k = 0; k < 2; k++) if (on[k]) f = f12_mul_sparse(f, line_add_proj(&T[k], *Q[k], *P[k]));
+    }
+    for (int k = 0; k < 2; k++) {
+        if (!on[k]) continue;
+        const G2Affine q1 = g2_frob(*Q[k]);
+        G2Affine q2 = g2_frob(q1);
+        q2.y = f2_neg(q2.y);
+        f = f12_mul_sparse(f, line_add_proj(&T[k], q1, *P[k]));
+        f = f12_mul_sparse(f, line_add_proj(&T[k], q2, *P[k]));
     }
     return f;
 }
@@ -426,14 +483,14 @@ inline Fp12 f12_final_exp(const Fp12& a) {
     Fp12 y4 = f12_conj(f12_mul(fx, f12_frob(fx2)));
     Fp12 y5 = f12_conj(fx2);
     Fp12 y6 = f12_conj(f12_mul(fx3, f12_frob(fx3)));
-    Fp12 t0 = f12_mul(f12_mul(f12_mul(y6, y6), y4), y5);
+    Fp12 t0 = f12_mul(f12_mul(f12_sqr(y6), y4), y5);
     Fp12 t1 = f12_mul(f12_mul(y3, y5), t0);
     t0 = f12_mul(t0, y2);
-    t1 = f12_mul(f12_mul(t1, t1), t0);
-    t1 = f12_mul(t1, t1);
+    t1 = f12_mul(f12_sqr(t1), t0);
+    t1 = f12_sqr(t1);
     t0 = f12_mul(t1, y1);
     t1 = f12_mul(t1, y0);
-    t0 = f12_mul(t0, t0);
+    t0 = f12_sqr(t0);
     return f12_mul(t0, t1);
 }
 
@@ -441,7 +498,7 @@ inline Fp12 f12_final_exp(const Fp12& a) {
 inline bool pairing_product_is_one(const Affine<Bn254Fp>& P1, const G2Affine& Q1, const Affine<Bn254Fp>& P2,
                                    const G2Affine& Q2, bool slow = false) {
     if (slow) return f12_is_one(f12_pow_final(f12_mul(miller_ate_affine(P1, Q1), miller_ate_affine(P2, Q2))));
-    return f12_is_one(f12_final_exp(f12_mul(miller_ate(P1, Q1), miller_ate(P2, Q2))));
+    return f12_is_one(f12_final_exp(miller_opt_ate2(P1, Q1, P2, Q2)));
 }
 
 }  // namespace porla
