@@ -399,28 +399,53 @@ k_fb_fold(XYZZ<typename C::Fp>* __restrict__ partial, uint32_t n_rows, uint32_t 
     if (sub == 0 && row < n_rows) store_xyzz<M>(partial + (size_t)row * S, acc);
 }
 
-// one lane per row: partial[row * S] -> affine (one inversion), Montgomery -> big-endian X||Y (64 zero bytes = infinity)
+// a lane takes FB_FINISH_ROWS rows: partial[row * S] -> affine with ONE inversion for the lane's rows (Montgomery's trick: the
+// inversion is a chain of ~380 dependent products, a row's share of the trick three), Montgomery -> big-endian X||Y (64 zero
+// bytes = infinity).  Rows of a lane are block-strided so that neighbouring lanes still read neighbouring rows.
+constexpr int FB_FINISH_ROWS = 4;
 template <class C>
 __global__ void __launch_bounds__(64)
 k_fb_finish(const XYZZ<typename C::Fp>* __restrict__ partial, uint32_t n_rows, uint32_t S, uint8_t* __restrict__ out) {
     using M = typename C::Fp;
-    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= n_rows) return;
-    XYZZ<M> acc = load_xyzz<M>(partial + (size_t)row * S);
-    uint8_t* dst = out + (size_t)row * 64;
-    if (xyzz_is_inf<M>(acc)) {
-        uint4 z = make_uint4(0, 0, 0, 0);
-        uint4* q = reinterpret_cast<uint4*>(dst);
-        q[0] = z; q[1] = z; q[2] = z; q[3] = z;
-        return;
+    const uint32_t base = blockIdx.x * (64u * FB_FINISH_ROWS) + threadIdx.x;
+    Fe<M> zzz[FB_FINISH_ROWS], pre[FB_FINISH_ROWS];
+    bool live[FB_FINISH_ROWS];
+    Fe<M> acc = fe_one<M>();
+#pragma unroll
+    for (int k = 0; k < FB_FINISH_ROWS; k++) {
+        const uint32_t row = base + 64u * k;
+        live[k] = false;
+        zzz[k] = fe_one<M>();
+        if (row < n_rows) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(partial + (size_t)row * S) + 24;     // ZZZ
+            Fe<M> z = load_fe<M>(src);
+            if (!fe_is_zero<M>(z)) { live[k] = true; zzz[k] = z; }
+        }
+        pre[k] = acc;
+        acc = fe_mul_call<M>(acc, zzz[k]);
     }
-    Fe<M> inv = fe_inv_dev<M>(acc.zzz);
-    Affine<M> a = xyzz_to_affine_with_inv<M>(acc, inv);
+    Fe<M> inv = fe_inv_dev<M>(acc);
     Fe<M> one = fe_zero<M>();
     one.v[0] = 1;
-    Fe<M> x = fe_mul_call<M>(a.x, one), y = fe_mul_call<M>(a.y, one);  // out of Montgomery form
-    store_be256(dst, x.v);
-    store_be256(dst + 32, y.v);
+#pragma unroll
+    for (int k = FB_FINISH_ROWS - 1; k >= 0; k--) {
+        const uint32_t row = base + 64u * k;
+        const Fe<M> inv_k = fe_mul_call<M>(inv, pre[k]);             // 1 / ZZZ of row k
+        inv = fe_mul_call<M>(inv, zzz[k]);
+        if (row >= n_rows) continue;
+        uint8_t* dst = out + (size_t)row * 64;
+        if (!live[k]) {
+            uint4 z = make_uint4(0, 0, 0, 0);
+            uint4* q = reinterpret_cast<uint4*>(dst);
+            q[0] = z; q[1] = z; q[2] = z; q[3] = z;
+            continue;
+        }
+        const XYZZ<M> p = load_xyzz<M>(partial + (size_t)row * S);
+        Affine<M> a = xyzz_to_affine_with_inv<M>(p, inv_k);
+        Fe<M> x = fe_mul_call<M>(a.x, one), y = fe_mul_call<M>(a.y, one);  // out of Montgomery form
+        store_be256(dst, x.v);
+        store_be256(dst + 32, y.v);
+    }
 }
 
 }  // namespace porla

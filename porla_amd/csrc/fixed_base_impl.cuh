@@ -164,7 +164,7 @@ int FixedBase<C>::commit_device(const uint8_t* d_rows, size_t n_rows, size_t n_c
     last_S = S;
     if (d_out) {
         ProfScope ps("fb_finish", stream);
-        hipLaunchKernelGGL((k_fb_finish<C>), dim3((unsigned)((n_rows + 63) / 64)), dim3(64), 0, stream,
+        hipLaunchKernelGGL((k_fb_finish<C>), dim3((unsigned)((n_rows + 64 * FB_FINISH_ROWS - 1) / (64 * FB_FINISH_ROWS))), dim3(64), 0, stream,
                            (const XYZZ<M>*)partial, (uint32_t)n_rows, S, d_out);
     }
     PORLA_HIP(hipGetLastError());
