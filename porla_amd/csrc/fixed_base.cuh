@@ -181,9 +181,27 @@ k_fb_commit(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_coeffs
     Acc acc;
     if constexpr (C::F30_BUCKETS) acc.inf = true;
     else acc = xyzz_inf<M>();
+    // One software pipeline over all (coefficient, window) pairs of the lane: the gather of a window's table entry is issued
+    // before the addition of the previous one -- also across the boundary between two coefficients -- and the next
+    // coefficient's 32 bytes are requested a whole coefficient ahead (a pipeline that restarted per coefficient left one
+    // gather and one row read exposed per 15 additions).
+    auto madd_entry = [&](const Affine<M>& e, bool neg) {
+        Affine<M> a = aff_neg_if<M>(e, neg);
+        if constexpr (C::F30_BUCKETS) {
+            if (!aff_is_inf<M>(a)) xyzz30_madd<M>(acc, f30_from_fe<M>(a.x), f30_from_fe<M>(a.y));
+        } else {
+            xyzz_madd<M>(acc, a);
+        }
+    };
+    Affine<M> cur;
+    bool cur_valid = false, cur_neg = false;
+    uint32_t tn[8];
+    if (i0 < i1) load_be256(tn, row + (size_t)i0 * 32);
     for (uint32_t i = i0; i < i1; i++) {
         uint32_t t[8];
-        load_be256(t, row + (size_t)i * 32);
+#pragma unroll
+        for (int k = 0; k < 8; k++) t[k] = tn[k];
+        if (i + 1 < i1) load_be256(tn, row + (size_t)(i + 1) * 32);
         for (int q = 0; q < C::MAX_Q; q++) {
             uint32_t d[8];
             uint32_t br = 0;
@@ -199,48 +217,37 @@ k_fb_commit(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_coeffs
         }
         const Affine<M>* tab_i = table + (size_t)i * W * Bh;
         uint32_t carry = 0;
-        // software pipeline: the gather of window w+1 is issued before the addition of window w
-        Affine<M> cur;
-        bool cur_valid = false, cur_neg = false;
-        for (int w = 0; w <= W; w++) {
+        for (int w = 0; w < W; w++) {
             Affine<M> nxt;
             bool nxt_valid = false, nxt_neg = false;
-            if (w < W) {
-                const int lo = w * c;
-                uint32_t raw = 0;
-                if (lo < 256) {
-                    const int limb = lo >> 5, sh = lo & 31;
-                    uint32_t a = 0, b = 0;
+            const int lo = w * c;
+            uint32_t raw = 0;
+            if (lo < 256) {
+                const int limb = lo >> 5, sh = lo & 31;
+                uint32_t a = 0, b = 0;
 #pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        a = (k == limb) ? t[k] : a;
-                        b = (k == limb + 1) ? t[k] : b;
-                    }
-                    uint64_t v = ((uint64_t)b << 32) | a;
-                    raw = (uint32_t)(v >> sh) & mask;
+                for (int k = 0; k < 8; k++) {
+                    a = (k == limb) ? t[k] : a;
+                    b = (k == limb + 1) ? t[k] : b;
                 }
-                raw += carry;
-                uint32_t mag;
-                if (raw > Bh) { carry = 1; mag = (1u << c) - raw; nxt_neg = true; }
-                else { carry = 0; mag = raw; }
-                if (mag) {
-                    nxt_valid = true;
-                    nxt = load_affine<M>(tab_i + (size_t)w * Bh, mag - 1);
-                }
+                uint64_t v = ((uint64_t)b << 32) | a;
+                raw = (uint32_t)(v >> sh) & mask;
             }
-            if (cur_valid) {
-                Affine<M> a = aff_neg_if<M>(cur, cur_neg);
-                if constexpr (C::F30_BUCKETS) {
-                    if (!aff_is_inf<M>(a)) xyzz30_madd<M>(acc, f30_from_fe<M>(a.x), f30_from_fe<M>(a.y));
-                } else {
-                    xyzz_madd<M>(acc, a);
-                }
+            raw += carry;
+            uint32_t mag;
+            if (raw > Bh) { carry = 1; mag = (1u << c) - raw; nxt_neg = true; }
+            else { carry = 0; mag = raw; }
+            if (mag) {
+                nxt_valid = true;
+                nxt = load_affine<M>(tab_i + (size_t)w * Bh, mag - 1);
             }
+            if (cur_valid) madd_entry(cur, cur_neg);
             if (nxt_valid) cur = nxt;
             cur_valid = nxt_valid;
             cur_neg = nxt_neg;
         }
     }
+    if (cur_valid) madd_entry(cur, cur_neg);
     if constexpr (C::F30_BUCKETS) store_xyzz<M>(partial + (size_t)r * S + s, xyzz30_to_xyzz<M>(acc));
     else store_xyzz<M>(partial + (size_t)r * S + s, acc);
 }
