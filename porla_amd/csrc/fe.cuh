@@ -14,6 +14,7 @@
 //    host pass runs and what tools/fe_check.hip compares the assembly against.
 //  * All loops are fully unrolled with compile-time indices: limbs never leave registers.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -337,8 +338,9 @@ PORLA_HD Fe<M> fe_mul_pseudo_mersenne(const Fe<M>& a, const Fe<M>& b) {
 #define PORLA_FP64_ADX 0
 #endif
 #if PORLA_FP64_ADX
-inline bool host_has_adx() {
-    static const bool v = __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("adx");
+inline bool host_has_adx() {      // PORLA_NO_ADX=1 forces the portable products (the path of a host without BMI2 / ADX)
+    static const bool v = __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("adx") &&
+                          !(getenv("PORLA_NO_ADX") && getenv("PORLA_NO_ADX")[0] == '1');
     return v;
 }
 // One round of the Montgomery product with two carry chains (adcx / adox), the modulus' top bit clear so that no sixth word is
