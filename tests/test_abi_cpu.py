@@ -135,3 +135,18 @@ def test_eip196_vectors_through_the_host_side_symbols():
         assert mx.bn254_add(bytes.fromhex(e["b"]), bytes.fromhex(e["a"])).hex() == e["sum"], e["name"]
     for e in kat["mul"]:
         assert mx.bn254_mult(bytes.fromhex(e["p"]), bytes.fromhex(e["k"])).hex() == e["r"], e["name"]
+
+
+def test_host_field_arithmetic_without_adx_instructions():
+    """the x86-64 host pass multiplies with mulx / adcx / adox where the CPU has them (fe.cuh:mont_mul4_adx,
+    host_fold64.hpp:mul512_adx); PORLA_NO_ADX=1 takes the portable products instead -- the path of any other host.  The known
+    answers, the tree fold and the pairing self-check must come out the same there (a child process: the switch is read once)"""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, PORLA_NO_ADX="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", os.path.join(here, "test_abi_cpu.py"), os.path.join(here, "test_pairing_cpu.py"),
+                        "-k", "eip196 or tree_fold or point_ops or kzg_host_side or bilinearity"],
+                       env=env, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
