@@ -35,8 +35,8 @@ int FixedBase<C>::build(const Affine<typename C::Fp>* d_base, size_t n, int wind
     n_points = 0;
     if (n == 0) return PORLA_OK;
     // window_bits = 0 -> automatic: the widest window (<= 20 bits) whose table fits min(a quarter of the free HBM,
-    // PORLA_COMMIT_TABLE_GB GiB, default 16) -- 18 bits = 15 GiB for the 128-point BN254 SRS: a drop-in library should not take a
-    // fifth of the HBM on its first commit.  A caller that wants the last 10 % asks for it: PORLA_COMMIT_TABLE_GB=64 gives 20-bit
+    // PORLA_COMMIT_TABLE_GB GiB, default 16), then the narrowest one with the same window count -- 17 bits = 7.5 GiB for the
+    // 128-point BN254 SRS: a drop-in library should not take a fifth of the HBM on its first commit.  A caller that wants the last 10 % asks for it: PORLA_COMMIT_TABLE_GB=64 gives 20-bit
     // windows (56 GB, 13 additions per coefficient instead of 15: 7.4 against 6.65 M commits/s; build 0.43 s against 0.14 s).
     int cc = window_bits;
     const bool automatic = cc <= 0;
@@ -65,6 +65,10 @@ int FixedBase<C>::build(const Affine<typename C::Fp>* d_base, size_t n, int wind
         size_t bytes = n * (size_t)Wc * ((size_t)1 << (cc - 1)) * sizeof(Affine<M>);
         if (bytes <= budget || cc <= 4) break;
     }
+    // a narrower window that needs no more windows per coefficient halves the table for the same number of additions
+    // (BN254: 255 signed bits are 15 windows of 18 bits -- and 15 of 17)
+    if (automatic && !getenv("PORLA_COMMIT_WINDOW"))
+        while (cc > 4 && (C::SCALAR_BITS + 1 + (cc - 1) - 1) / (cc - 1) == (C::SCALAR_BITS + 1 + cc - 1) / cc) cc--;
     c = cc;
     W = (C::SCALAR_BITS + 1 + c - 1) / c;
     const uint32_t H = 1u << (c - 1);
