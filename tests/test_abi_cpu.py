@@ -150,3 +150,20 @@ def test_host_field_arithmetic_without_adx_instructions():
                        env=env, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_mult_point_against_the_c_oracle_on_random_and_edge_scalars():
+    """mult_point runs signed 4-bit windows in 64-bit limbs on the host (host_fold64.hpp:h_scalar_mul64): every digit value, the
+    carry into the 65th digit, scalars at and above the group order, the point at infinity -- against oracle/bn254_ref.c"""
+    import random
+    from porla_amd import multiexp as mx
+    R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    pts = common.synth_points(6, start=4242)
+    rnd = random.Random(20261004)
+    scalars = [0, 1, 2, 7, 8, 9, 15, 16, 17, 0x88888888, R - 1, R, R + 1, (1 << 256) - 1, (1 << 255), int("8" * 64, 16), int("f" * 63 + "8", 16),
+               int("7" * 64, 16), int("9" * 64, 16)] + [rnd.getrandbits(256) for _ in range(40)] + [rnd.getrandbits(64) for _ in range(10)]
+    for i, k in enumerate(scalars):
+        p = pts[64 * (i % 6):64 * (i % 6) + 64]
+        kb = k.to_bytes(32, "big")
+        assert mx.bn254_mult(p, kb) == common.oracle_msm(kb, p, 1), hex(k)
+    assert mx.bn254_mult(bytes(64), (12345).to_bytes(32, "big")) == bytes(64)
