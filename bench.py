@@ -16,7 +16,8 @@ still one complete MSM whose result is produced and checked, and K steps = K res
 (`--in-flight 1` = blocking calls).  The same JSON line carries `kzg_commits`: the second half of BASELINE.json's metric ("KZG commits/s"),
 2^17 rows x 128 coefficients per GPU against the resident SRS (compute_digest_from_srs hoisted over rows), timed
 separately after the MSM region, with the per-call figures of the real symbol next to it (one row per call from 1 and 8
-threads of a plain-C caller).  Also on the line, never as `value`: `blocking_ms_per_step` (the same MSM with one in flight) and
+threads of a plain-C caller).  Also on the line, never as `value`: `blocking_ms_per_step` (the same MSM with one in flight),
+`audit_size_msm` (128 / 1 408 / 3 200 pairs: the sizes the reference issues) and
 `host_boundary` (compute_multi_exp on caller-owned pageable host buffers, PCIe included).
 
 Other workloads (parity-test configurations of BASELINE.json, selectable for profiling; never the default line):
@@ -379,6 +380,27 @@ def main():
             torch.cuda.synchronize()
             blocking_ms = (time.perf_counter() - t_b) / reps * 1e3
         # the reference's own boundary: compute_multi_exp on caller-owned pageable HOST buffers (PCIe included; never `value`)
+        # ---- the sizes the reference really issues (n_points <= 3 200, Server.hpp:585-587; coefficients abs(int32), utils.h:271-275):
+        # latency of one blocking call on device-resident inputs, each checked against the oracle
+        audit = None
+        if world == 1 and rank == 0 and not args.no_cpu:
+            try:
+                import random
+                rnd = random.Random(5)
+                a_sc = b"".join(mx.bn254_scalar_set_int(rnd.getrandbits(31)) for _ in range(3200))
+                d_a = to_dev(a_sc)
+                audit = {"what": "one blocking MSM on device-resident inputs, ms per call", "abs_int32_coefficients": {}, "256_bit_scalars": {}}
+                for label, host_sc, dev_sc in (("abs_int32_coefficients", a_sc, d_a), ("256_bit_scalars", sc, d_sc)):
+                    for m in (128, 1408, 3200):
+                        for _ in range(3):
+                            r = mx.msm_device("bn254", dev_sc.data_ptr(), d_pt.data_ptr(), m, stream)
+                        t1 = time.perf_counter()
+                        for _ in range(20):
+                            r = mx.msm_device("bn254", dev_sc.data_ptr(), d_pt.data_ptr(), m, stream)
+                        ms = (time.perf_counter() - t1) / 20 * 1e3
+                        audit[label][str(m)] = {"ms": round(ms, 4), "bit_exact_vs_oracle": r == common.oracle_msm(host_sc, pt, m)}
+            except Exception as e:  # noqa: BLE001
+                audit = {"error": repr(e)}
         host_boundary = None
         if world == 1 and rank == 0 and not args.no_host_boundary:
             # in a child process (its launches at other sizes stay out of this process's kernel statistics; a profiler
@@ -428,7 +450,7 @@ def main():
                 "bit_exact_vs_oracle": verified, "result": result.hex() if result else None,
                 "blocking_ms_per_step": round(blocking_ms, 4) if blocking_ms else None,
                 "blocking_Mmul_s": round(world * n / blocking_ms / 1e3, 1) if blocking_ms else None,
-                "host_boundary": host_boundary, "kzg_commits": commits,
+                "host_boundary": host_boundary, "audit_size_msm": audit, "kzg_commits": commits,
             }
     elif args.workload == "kzg_commit":
         rows_n = 1 << args.log2rows
