@@ -5,6 +5,9 @@
 // secp256k1_ecmult_pippenger_wnaf (porla/Utils/secp256k1_lib/ecmult_impl.h:544-564).
 #pragma once
 #include "ec.cuh"
+#include <memory>
+#include <mutex>
+#include <vector>
 
 namespace porla {
 
@@ -323,6 +326,69 @@ inline void h_batch_xyzz_to_affine64(const XYZZ<M>* in, size_t n, Affine<M>* out
         }
     }
 }
+
+// k * B for a base point B that stays the same over many calls (compute_digest multiplies SRS.G1[0], compute_digest_complement
+// the MAC hiding base: porla/main.go:87-88, 99-100): a table of j * 16^i * B (i < 65 signed 4-bit digits, j = 1 .. 8, affine)
+// turns the multiplication into <= 65 mixed additions and NO doublings.  The table (33 KB) is rebuilt when the base changes.
+template <class M>
+struct HostFixedBase {
+    typedef std::vector<Affine<M>> Table;          // [65][8]
+    std::mutex mu;                                  // guards base / tab; the multiplication itself runs on a snapshot
+    Affine<M> base;
+    std::shared_ptr<const Table> tab;
+    static bool same(const Affine<M>& a, const Affine<M>& b) {
+        for (int i = 0; i < 8; i++) if (a.x.v[i] != b.x.v[i] || a.y.v[i] != b.y.v[i]) return false;
+        return true;
+    }
+    static std::shared_ptr<const Table> build(const Affine<M>& b) {
+        static const Fp64<M> F;
+        typedef typename Fp64<M>::Pt Pt;
+        std::vector<XYZZ<M>> proj(65 * 8);
+        Pt P;
+        P.x = Fp64<M>::from(b.x); P.y = Fp64<M>::from(b.y); P.zz = F.one(); P.zzz = F.one();
+        for (int i = 0; i < 65; i++) {
+            Pt acc = P;
+            for (int j = 0; j < 8; j++) {
+                proj[(size_t)i * 8 + j] = F.to(acc);
+                if (j < 7) acc = F.padd(acc, P);
+            }
+            for (int d = 0; d < 4; d++) P = F.dbl(P);          // 16^(i+1) B
+        }
+        auto t = std::make_shared<Table>(65 * 8);
+        h_batch_xyzz_to_affine64<M>(proj.data(), proj.size(), t->data());
+        return t;
+    }
+    XYZZ<M> mul(const Affine<M>& b, const uint32_t k[8]) {
+        static const Fp64<M> F;
+        typedef typename Fp64<M>::Pt Pt;
+        typedef typename Fp64<M>::E E;
+        if (aff_is_inf<M>(b)) return xyzz_inf<M>();
+        std::shared_ptr<const Table> t;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!tab || !same(base, b)) { tab = build(b); base = b; }
+            t = tab;
+        }
+        Pt acc = F.inf();
+        E zero;
+        for (int i = 0; i < 4; i++) zero.v[i] = 0;
+        uint32_t carry = 0;
+        for (int i = 0; i < 65; i++) {
+            uint32_t d = carry;
+            if (i < 64) d += (k[i >> 3] >> ((i & 7) * 4)) & 15u;
+            int dg;
+            if (d > 8) { dg = (int)d - 16; carry = 1; } else { dg = (int)d; carry = 0; }
+            if (dg == 0) continue;
+            const Affine<M>& e = (*t)[(size_t)i * 8 + (size_t)((dg < 0 ? -dg : dg) - 1)];
+            if (aff_is_inf<M>(e)) continue;
+            Pt q;
+            q.x = Fp64<M>::from(e.x); q.y = Fp64<M>::from(e.y); q.zz = F.one(); q.zzz = F.one();
+            if (dg < 0) q.y = F.sub(zero, q.y);
+            acc = F.padd(acc, q);
+        }
+        return F.to(acc);
+    }
+};
 
 // Tree form of the bucket reduction (msm.cuh, k_tree_level): window w arrives as fin[w][0] = S (sum of its buckets) and
 // fin[w][1 + k] = M_k (sum of the buckets whose index has bit k set), k < c - 1, and is worth S + sum_k 2^k M_k.

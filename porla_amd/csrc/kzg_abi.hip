@@ -305,7 +305,9 @@ void compute_digest(GoSlice* data_in, GoSlice* data_out) {
     uint32_t k[8];
     h_fe_to_plain<Fr>(k, acc);
     uint8_t out[64];
-    h_affine_to_bytes<Fp>(out, h_xyzz_to_affine64<Fp>(h_scalar_mul64<Fp>(g.srs[0], k)));
+    static HostFixedBase<Fp> fbG;                 // table of multiples of SRS.G1[0] (rebuilt when the SRS changes)
+    const XYZZ<Fp> prod = fbG.mul(g.srs[0], k);
+    h_affine_to_bytes<Fp>(out, h_xyzz_to_affine64<Fp>(prod));
     copy_out(data_out, out, 64);
 }
 
@@ -315,7 +317,9 @@ void compute_digest_complement(GoSlice* data_in, GoSlice* data_out) {
     uint32_t k[8];
     h_fe_to_plain<Fr>(k, s);
     uint8_t out[64];
-    h_affine_to_bytes<Fp>(out, h_xyzz_to_affine64<Fp>(h_scalar_mul64<Fp>(g.h_mac, k)));
+    static HostFixedBase<Fp> fbH;                 // table of multiples of the MAC hiding base
+    const XYZZ<Fp> prod = fbH.mul(g.h_mac, k);
+    h_affine_to_bytes<Fp>(out, h_xyzz_to_affine64<Fp>(prod));
     copy_out(data_out, out, 64);
 }
 
