@@ -11,6 +11,8 @@
 #include "../../include/libmultiexp.h"
 #include "../../include/porla_gpu.h"
 
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <condition_variable>
@@ -158,25 +160,51 @@ int commit_rows(const uint8_t* rows, bool device_ptrs, size_t n_rows, size_t len
 // (its own included), commits them in ONE launch (FixedBase::commit_small) and hands the results back; rows that arrive while a
 // batch is in flight form the next one.  A lone caller pays nothing for it (a batch of one).
 struct CommitQueue {
-    struct Item { const uint8_t* row; uint8_t* out; int rc; bool done; std::string err; };
+    struct Item { const uint8_t* row; uint8_t* out; int rc; std::atomic<bool> done; std::string err; };
     std::mutex mu;
     std::condition_variable cv;
     std::vector<Item*> q;
-    bool leader = false;
+    std::atomic<bool> leader{false};
+    bool contended = false;      // a caller found a batch in flight since the last batch was formed
 };
 CommitQueue cq;
+inline int commit_linger_us() {
+    static const int v = getenv("PORLA_COMMIT_LINGER_US") ? atoi(getenv("PORLA_COMMIT_LINGER_US")) : 12;
+    return v < 0 ? 0 : (v > 1000 ? 1000 : v);
+}
 
 int commit_coalesced(const uint8_t* row, uint8_t out[64]) {
-    CommitQueue::Item it{row, out, PORLA_OK, false, std::string()};
+    CommitQueue::Item it;
+    it.row = row; it.out = out; it.rc = PORLA_OK; it.done.store(false);
     std::unique_lock<std::mutex> lk(cq.mu);
     cq.q.push_back(&it);
     for (;;) {
-        if (it.done) { if (it.rc) set_last_error(it.err); return it.rc; }
-        if (cq.leader) { cq.cv.wait(lk); continue; }
+        if (it.done.load()) { if (it.rc) set_last_error(it.err); return it.rc; }
+        if (cq.leader.load()) { cq.contended = true; cq.cv.wait(lk); continue; }
         cq.leader = true;
+        if (cq.contended) {
+            // Several threads are calling (the reference's pool threads, Server.hpp:550-560): the callers of the batch that just
+            // finished are on their way back.  Without a pause the first one back leads a batch of whoever happens to be queued
+            // (sizes 1 .. 8 evenly, PORLA_COMMIT_STATS=1 prints the histogram); 12 us let them form ONE batch: 59 k -> 87 k
+            // commits/s from 8 C threads, 33 k -> 46 k from 4 (profiles/r02_t_commit_queue_linger.txt).  A lone caller never waits.
+            cq.contended = false;
+            lk.unlock();
+            const auto t0 = std::chrono::steady_clock::now();
+            while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(commit_linger_us())) __builtin_ia32_pause();
+            lk.lock();
+        }
         std::vector<CommitQueue::Item*> batch;
         const size_t take = cq.q.size() < (size_t)FB_SMALL_MAX_ROWS ? cq.q.size() : (size_t)FB_SMALL_MAX_ROWS;
         batch.assign(cq.q.begin(), cq.q.begin() + (long)take);
+        {   // PORLA_COMMIT_STATS=1: batch-size histogram on stderr at exit (measurement aid)
+            static const bool stats = getenv("PORLA_COMMIT_STATS") != nullptr;
+            if (stats) {
+                static unsigned long hist[FB_SMALL_MAX_ROWS + 1];
+                static bool reg = false;
+                hist[take]++;
+                if (!reg) { reg = true; atexit([] { for (int i = 1; i <= FB_SMALL_MAX_ROWS; i++) if (hist[i]) fprintf(stderr, "[commit queue] batches of %d rows: %lu\n", i, hist[i]); }); }
+            }
+        }
         cq.q.erase(cq.q.begin(), cq.q.begin() + (long)take);
         lk.unlock();
         int rc;
@@ -203,8 +231,8 @@ int commit_coalesced(const uint8_t* row, uint8_t out[64]) {
             if (rc) err = porla_gpu_last_error();
         }
         lk.lock();
-        for (auto* b : batch) { b->rc = rc; b->err = err; b->done = true; }
-        cq.leader = false;
+        for (auto* b : batch) { b->rc = rc; b->err = err; b->done.store(true, std::memory_order_release); }
+        cq.leader.store(false, std::memory_order_release);
         cq.cv.notify_all();
     }
 }
