@@ -69,7 +69,7 @@ int         porla_gpu_profile_get(int slot, char *name, size_t name_cap, double 
 int         porla_gpu_release_msm_workspaces(void);
 /* MSM tuning override (0 = automatic): window bits c */
 int         porla_gpu_set_msm_window(int c);
-/* inputs of up to 4096 pairs (every MSM the reference issues: n_points <= 3200, Server.hpp:585-587) take a single-launch path;
+/* inputs of up to 32768 pairs (every MSM the reference issues: n_points <= 3200, Server.hpp:585-587) take a single-launch path;
  * on = 0 sends them through the general path instead, window_bits in 2..8 fixes its window width (0 = automatic) */
 int         porla_gpu_set_msm_small(int on, int window_bits);
 /* 1: split every scalar with the curve endomorphism (half the windows); 0: plain windows over the full scalar;

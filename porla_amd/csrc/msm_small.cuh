@@ -1,4 +1,4 @@
-// Single-launch MSM for the sizes the reference actually issues (n <= 4096 pairs: the audit's n_points <= 3 200,
+// Single-launch MSM for the sizes the reference actually issues and a margin (n <= 32 768 pairs; the audit's n_points <= 3 200,
 // porla/Server/Server.hpp:585-587, 838-848, 900-901; the client's 176- and 1 408-point calls, porla/Client/Client.hpp:664-669,
 // 756-787) on both curves.
 //
@@ -28,12 +28,12 @@
 
 namespace porla {
 
-constexpr uint32_t SMALL_MAX_N = 4096;
+constexpr uint32_t SMALL_MAX_N = 32768;             // (the reference stops at 3 200; up to here one launch still beats the general path's ~25)
 constexpr int SMALL_THREADS = 256;
 constexpr int SMALL_BLOCKS = 256;
 constexpr int SMALL_MAX_C = 8;                       // <= 128 buckets per window
 constexpr int SMALL_MAX_B = 1 << (SMALL_MAX_C - 1);
-constexpr uint32_t SMALL_MAX_SUB = 2 * SMALL_MAX_N;
+constexpr uint32_t SMALL_MAX_SUB = 8192;             // sub-scalars ONE block (a slice of a window) can hold: LDS, 13-bit local index
 constexpr int SMALL_MAX_S = 32;                      // slices per window: S * c <= 256 sums fit the LDS fold
 constexpr int SMALL_DONE_SLOT = 255;                 // counters[0 .. W): arrivals per window; [255]: finished windows
 constexpr uint32_t SMALL_HDR_WORDS = 32;             // pinned header in front of fin: [0] = sequence, [1] = W, [2] = c, [3] = glv
@@ -68,7 +68,7 @@ __host__ __device__ inline SmallCfg small_cfg(uint32_t n, int used_bits, int c_f
     int best_c = 0;
     float best_cost = 1e30f;
     // (every block evaluates this before it can start: the loop is unrolled so that the divisions by c are by constants, and the
-    // two by run-time values are float divisions -- exact here: blocks <= 256, n <= 4096 and the quotients are floored)
+    // two by run-time values are float divisions -- exact here: blocks <= 256, n <= 32 768, S <= 32 and the quotients are floored)
 #pragma unroll
     for (int c = 1; c <= SMALL_MAX_C; c++) {
         if (c_override >= 1 && c_override <= SMALL_MAX_C && c != c_override) continue;
@@ -79,6 +79,7 @@ __host__ __device__ inline SmallCfg small_cfg(uint32_t n, int used_bits, int c_f
         if (S > by_size) S = by_size;
         if (S > (uint32_t)SMALL_MAX_S) S = SMALL_MAX_S;
         if (S < 1) S = 1;
+        if ((g.n_sub + S - 1) / S > SMALL_MAX_SUB) continue;      // a slice must fit the block's LDS
         const float Bf = (float)(1u << (c > 1 ? c - 1 : 0));
         const float per_bucket = (float)g.n_sub / (float)S * ((1.0f - 1.0f / (float)(1u << c)) / Bf);
         const float lanes = 256.0f / Bf;
@@ -92,8 +93,9 @@ __host__ __device__ inline SmallCfg small_cfg(uint32_t n, int used_bits, int c_f
                            0.01f * (float)W;
         if (cost < best_cost) { best_cost = cost; best_c = c; g.c = c; g.W = W; g.S = (int)S; }
     }
-    if (best_c == 0) {                                   // cannot happen for blocks >= 128 (W <= 129 at c = 2); keep a valid shape
-        g.c = SMALL_MAX_C; g.W = (g.L + 1 + g.c - 1) / g.c; g.S = 1;
+    if (best_c == 0) {                                   // cannot happen for 256 blocks (c = 8: W <= 32, S >= 8 slices of <= 4096); keep a valid shape
+        g.c = SMALL_MAX_C; g.W = (g.L + 1 + g.c - 1) / g.c;
+        g.S = blocks / g.W < 1 ? 1 : (blocks / g.W > SMALL_MAX_S ? SMALL_MAX_S : blocks / g.W);
     }
     return g;
 }

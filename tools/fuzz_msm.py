@@ -9,7 +9,7 @@ from tests import common
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rnd = random.Random(seed)
-NMAX = 1 << 13
+NMAX = 40000          # spans the single-launch path (<= 32768 pairs) and the general one
 pools = {"bn254": common.synth_points(NMAX), "secp256k1": common.secp_bench_points(NMAX)}
 ORD = {"bn254": 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001, "secp256k1": common.SECP_N}
 LAM = {"bn254": 0x30644e72e131a029048b6e193fd84104cc37a73fec2bc5e9b8ca0b2d36636f23,
