@@ -276,9 +276,9 @@ k_fb_commit_small(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_
     __shared__ uint32_t last_flag;
     const uint32_t tid = threadIdx.x;
     const uint32_t r = blockIdx.x / SL, sl = blockIdx.x % SL;
-    if (tid < 8) {
+    if (tid < 8) {                                             // bits p of limb tid with p mod c == c - 1
         uint32_t v = 0;
-        for (uint32_t b = 0; b < 32; b++) if ((32 * tid + b) % (uint32_t)c == (uint32_t)c - 1) v |= 1u << b;
+        for (uint32_t b = (uint32_t)c - 1 - (32 * tid) % (uint32_t)c; b < 32; b += (uint32_t)c) v |= 1u << b;
         pat[tid] = v;
     }
     __syncthreads();

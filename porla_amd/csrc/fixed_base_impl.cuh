@@ -177,7 +177,9 @@ int FixedBase<C>::commit_device(const uint8_t* d_rows, size_t n_rows, size_t n_c
 
 // ---- the single-launch path for a handful of rows
 constexpr size_t FB_SMALL_ROW_BYTES = 8192;          // rows of up to 256 coefficients
-constexpr size_t FB_SMALL_HDR = 128, FB_SMALL_SUMS = FB_SMALL_HDR, FB_SMALL_ROWS = 8192;
+// staging layout: header | row sums (one 128-byte XYZZ per row) | rows, the rows on a 4 KB boundary past the sums
+constexpr size_t FB_SMALL_HDR = 128, FB_SMALL_SUMS = FB_SMALL_HDR, FB_SMALL_SUM_BYTES = 128;
+constexpr size_t FB_SMALL_ROWS = (FB_SMALL_SUMS + (size_t)FB_SMALL_MAX_ROWS * FB_SMALL_SUM_BYTES + 4095) / 4096 * 4096;
 static inline bool fb_small_enabled() {
     static const bool on = !(getenv("PORLA_COMMIT_SMALL") && getenv("PORLA_COMMIT_SMALL")[0] == '0');
     return on;
@@ -195,6 +197,7 @@ int FixedBase<C>::commit_small(const uint8_t* const* row_ptrs, size_t n_rows, si
     int cur = -1;
     PORLA_HIP(hipGetDevice(&cur));
     if (cur != device) { set_last_error("porla: this fixed-base table lives on another device than the current one"); return PORLA_ERR_STATE; }
+    static_assert(sizeof(XYZZ<M>) == FB_SMALL_SUM_BYTES, "staging layout: the row sums must end before the rows begin");
     const size_t part_bytes = (size_t)FB_SMALL_MAX_ROWS * FB_SMALL_MAX_SLICES * sizeof(XYZZ<M>);
     if (!h_small) {
         PORLA_HIP(hipHostMalloc(&h_small, FB_SMALL_ROWS + FB_SMALL_MAX_ROWS * FB_SMALL_ROW_BYTES, hipHostMallocMapped | hipHostMallocCoherent));

@@ -39,7 +39,7 @@ constexpr int SMALL_DONE_SLOT = 255;                 // counters[0 .. W): arriva
 constexpr uint32_t SMALL_HDR_WORDS = 32;             // pinned header in front of fin: [0] = sequence, [1] = W, [2] = c, [3] = glv
 
 // the single-launch commitment of fixed_base.cuh (k_fb_commit_small): rows per launch, slices per row
-constexpr int FB_SMALL_MAX_ROWS = 32;
+constexpr int FB_SMALL_MAX_ROWS = 64;            // 64 rows x 4 slices = 256 blocks: one round on the chip (96 rows: 0.19 ms, the batch kernels 0.22)
 constexpr int FB_SMALL_MAX_SLICES = 8;
 
 struct SmallCfg {

@@ -250,10 +250,10 @@ def test_release_device_memory_and_rebuild(mx, srs128):
     assert mx.kzg_commit_batch_host(rows, 3) == a
 
 
-@pytest.mark.parametrize("n_rows", [1, 2, 31, 32, 33])
+@pytest.mark.parametrize("n_rows", [1, 2, 31, 32, 33, 63, 64, 65])
 def test_few_rows_single_launch_path_and_its_boundary(mx, srs128, n_rows):
-    """<= 32 host rows take the single-launch kernel (k_fb_commit_small: digits, gather, LDS fold, slices folded by the last
-    block, sums polled from pinned memory); 33 rows the batch kernels -- same bytes either way, every table window"""
+    """<= 64 host rows take the single-launch kernel (k_fb_commit_small: digits, gather, LDS fold, slices folded by the last
+    block, sums polled from pinned memory); 65 rows the batch kernels -- same bytes either way, every table window"""
     rows = rows_bytes(n_rows, 128, b"few%d" % n_rows)
     want = common.oracle_commit_batch("bn254", rows, n_rows, 128, srs128)
     for c in (5, 12, 16):
@@ -271,6 +271,21 @@ def test_few_rows_single_launch_path_and_its_boundary(mx, srs128, n_rows):
     got = fb.commit_host(edge, 2, 128)
     assert got[:64] == bytes(64) and got == common.oracle_commit_batch("bn254", edge, 2, 128, srs128)
     fb.close()
+
+
+@pytest.mark.parametrize("n_rows", [1024, 1025])
+def test_host_and_device_normalisation_meet_at_1024_rows(mx, srs128, n_rows):
+    """batches of <= 1024 rows are normalised on the host (engine.hpp:HOST_FINISH_MAX_ROWS: one batched inversion in 64-bit limbs
+    beats the finish kernel's fixed 0.32 ms up to there), larger ones by k_fb_finish; rows with a zero sum on both sides"""
+    rows = bytearray(rows_bytes(n_rows, 128, b"finish%d" % n_rows))
+    rows[4096 * 7:4096 * 8] = bytes(4096)
+    rows[4096 * (n_rows - 1):4096 * n_rows] = bytes(4096)
+    rows = bytes(rows)
+    fb = mx.FixedBase("bn254", srs128, 128)
+    got = fb.commit_host(rows, n_rows, 128)
+    fb.close()
+    assert got[64 * 7:64 * 8] == bytes(64) and got[-64:] == bytes(64)
+    assert got == common.oracle_commit_batch("bn254", rows, n_rows, 128, srs128)
 
 
 def test_secp256k1_few_rows(mx):
