@@ -367,6 +367,7 @@ def main():
             return res
 
         el, kern, result = timed(step, drain)
+        fe_mults = msm_fe_mults(n)        # read now: the audit-size MSMs below run with another (window, GLV) shape
         # the same MSM as blocking calls (one in flight): what a caller that waits for every result sees
         blocking_ms = None
         if depth > 1:
@@ -446,7 +447,7 @@ def main():
                            "pairs_per_gpu": n, "msm_in_flight": depth,
                            "sharding": "input-pair range per rank + all-gather of 96-B Jacobian partials, folded on every host"
                            if world > 1 else "single GPU", "collective": collective, "input_gen_s": round(gen_s, 1)},
-                "roofline": roofline(kern, MSM_BYTES_PER_PAIR * n, "bn254_msm", msm_fe_mults(n)), "cpu_baseline": cpu,
+                "roofline": roofline(kern, MSM_BYTES_PER_PAIR * n, "bn254_msm", fe_mults), "cpu_baseline": cpu,
                 "bit_exact_vs_oracle": verified, "result": result.hex() if result else None,
                 "blocking_ms_per_step": round(blocking_ms, 4) if blocking_ms else None,
                 "blocking_Mmul_s": round(world * n / blocking_ms / 1e3, 1) if blocking_ms else None,
@@ -488,6 +489,7 @@ def main():
             return fold_across_ranks("secp256k1", mx.msm_device("secp256k1", d_sc.data_ptr(), d_pt.data_ptr(), n, stream, partial=True))
 
         el, kern, result = timed(step)
+        fe_mults = msm_fe_mults(n)
         if rank == 0:
             cpu = None
             verified = None
@@ -509,7 +511,7 @@ def main():
                    "config": {"workload": "IPA scheme, 2^%d-point secp256k1 ecmult_multi per GPU (points 2^i*G, scalars "
                                           "SHA-256(\"ecmult\"||i) as bench_ecmult.c), inputs resident in HBM" % args.log2n,
                               "pairs_per_gpu": n, "input_gen_s": round(gen_s, 1)},
-                   "roofline": roofline(kern, MSM_BYTES_PER_PAIR * n, "secp256k1_msm", msm_fe_mults(n)), "cpu_baseline": cpu,
+                   "roofline": roofline(kern, MSM_BYTES_PER_PAIR * n, "secp256k1_msm", fe_mults), "cpu_baseline": cpu,
                    "bit_exact_vs_oracle": verified, "result": result.hex() if result else None}
     else:  # icc
         from porla_amd import icc
