@@ -43,6 +43,30 @@ __device__ __noinline__ Fe<M> fe_inv_dev(Fe<M> a) {
     return acc;
 }
 
+// The same on 30-bit limbs (fe30.cuh) for the curves that have the reduced-radix product: the chain's ~380 dependent products
+// take 0.28 / 0.36 us each there (square / product, one wave alone) against 0.85 us for the out-of-line 8 x 32-bit product --
+// k_fb_finish is nothing but this chain's latency.  a: a residue in the Fe form (radix 2^256); the integer V it holds goes into
+// the reduced-radix form (V 2^270 through the factor 2^540; plain for the special-form modulus), V^(p-2) comes back times
+// R2 = 2^512 (1): (A 2^256)^-1 2^512 = A^-1 2^256.
+template <class M>
+__device__ __noinline__ Fe<M> fe_inv_dev30(Fe<M> a) {
+    const F30<M> x = f30_mul<M>(f30_unpack<M>(a.v), f30_const<M>(M::RR_30));
+    F30<M> acc = x;                                       // the exponent's top bit
+    bool started = false;
+#pragma unroll 1
+    for (int l = 7; l >= 0; l--) {
+        const uint32_t limb = (l == 0) ? M::P[0] - 2u : M::P[l];
+#pragma unroll 1
+        for (int b = 31; b >= 0; b--) {
+            const bool bit = (limb >> b) & 1u;
+            if (!started) { started = bit; continue; }
+            acc = f30_sqr<M>(acc);
+            if (bit) acc = f30_mul<M>(acc, x);
+        }
+    }
+    return f30_to_fe_canonical<M>(f30_mul<M>(acc, f30_const<M>(M::R2)));
+}
+
 // XYZZ -> affine on the device (cold path): x = X * (ZZ*I)^2, y = Y * I with I = 1/ZZZ  (ZZ^3 = ZZZ^2)
 template <class M>
 __device__ __forceinline__ Affine<M> xyzz_to_affine_with_inv(const XYZZ<M>& p, const Fe<M>& inv_zzz) {
@@ -248,8 +272,14 @@ k_fb_commit(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_coeffs
         }
     }
     if (cur_valid) madd_entry(cur, cur_neg);
-    if constexpr (C::F30_BUCKETS) store_xyzz<M>(partial + (size_t)r * S + s, xyzz30_to_xyzz<M>(acc));
-    else store_xyzz<M>(partial + (size_t)r * S + s, acc);
+    if constexpr (C::F30_BUCKETS) {
+        // a slice partial goes to k_fb_fold in the reduced-radix memory form (no conversion products here, reduced-radix additions
+        // there); a whole row's sum (S = 1) in the 2^256 form k_fb_finish and the host read
+        if (C::F30_LAZY && S > 1) xyzz30_store_lazy<M>(partial + (size_t)r * S + s, acc);
+        else store_xyzz<M>(partial + (size_t)r * S + s, xyzz30_to_xyzz<M>(acc));
+    } else {
+        store_xyzz<M>(partial + (size_t)r * S + s, acc);
+    }
 }
 
 // ---------------------------------------------------------------- a handful of rows, latency-bound (the reference's real pattern)
@@ -406,6 +436,34 @@ k_fb_fold(XYZZ<typename C::Fp>* __restrict__ partial, uint32_t n_rows, uint32_t 
     if (sub == 0 && row < n_rows) store_xyzz<M>(partial + (size_t)row * S, acc);
 }
 
+// The same fold where the partials are in the reduced-radix memory form (k_fb_commit with S > 1): a pairwise tree in place --
+// level n adds partial[q + n] to partial[q] for q < n on the four lanes of quad q (ec30.cuh:xyzz30_add_quad: ~2 us per level
+// against ~6 us for a one-lane addition and ~12 us for the out-of-line 8 x 32-bit one above), a barrier between levels; the
+// last level leaves the row's sum in the 2^256 form k_fb_finish and the host read.  S a power of two (2 .. 128); a row takes
+// S / 2 quads, a block of 256 lanes 128 / S rows.
+template <class C>
+__global__ void __launch_bounds__(256)
+k_fb_fold_quad(XYZZ<typename C::Fp>* __restrict__ partial, uint32_t n_rows, uint32_t S) {
+    using M = typename C::Fp;
+    const uint32_t half = S >> 1;                        // quads per row
+    const uint32_t quad = threadIdx.x >> 2;
+    const uint32_t q = quad % half;
+    uint32_t row = blockIdx.x * (64u / half) + quad / half;
+    const bool row_ok = row < n_rows;
+    if (!row_ok) row = n_rows - 1;                       // padding quads compute on a valid pair and store nothing
+    XYZZ<M>* base = partial + (size_t)row * S;
+    const uint32_t wave_q0 = ((threadIdx.x & ~63u) >> 2) % half;     // the wave's first quad inside its row (half >= 16), else 0
+#pragma unroll 1
+    for (uint32_t n = half; n >= 1; n >>= 1) {
+        if (half < 16u || wave_q0 < n) {                 // wave-uniform: this wave holds at least one quad with work
+            const bool live = row_ok && q < n;
+            const uint32_t qq = q < n ? q : 0u;
+            xyzz30_add_quad<M>(base + qq, base + qq + n, base + qq, n == 1u, live, threadIdx.x & 63u);
+        }
+        __syncthreads();
+    }
+}
+
 // a lane takes FB_FINISH_ROWS rows: partial[row * S] -> affine with ONE inversion for the lane's rows (Montgomery's trick: the
 // inversion is a chain of ~380 dependent products, a row's share of the trick three), Montgomery -> big-endian X||Y (64 zero
 // bytes = infinity).  Rows of a lane are block-strided so that neighbouring lanes still read neighbouring rows.
@@ -431,7 +489,9 @@ k_fb_finish(const XYZZ<typename C::Fp>* __restrict__ partial, uint32_t n_rows, u
         pre[k] = acc;
         acc = fe_mul_call<M>(acc, zzz[k]);
     }
-    Fe<M> inv = fe_inv_dev<M>(acc);
+    Fe<M> inv;
+    if constexpr (C::F30_BUCKETS) inv = fe_inv_dev30<M>(acc);
+    else inv = fe_inv_dev<M>(acc);
     Fe<M> one = fe_zero<M>();
     one.v[0] = 1;
 #pragma unroll

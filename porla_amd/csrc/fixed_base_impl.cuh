@@ -161,9 +161,15 @@ int FixedBase<C>::commit_device(const uint8_t* d_rows, size_t n_rows, size_t n_c
     }
     if (S > 1) {
         ProfScope ps("fb_fold", stream);
-        uint32_t rows_per_wave = 64 / G;
-        hipLaunchKernelGGL((k_fb_fold<C>), dim3((unsigned)((n_rows + rows_per_wave - 1) / rows_per_wave)), dim3(64), 0,
-                           stream, partial, (uint32_t)n_rows, S, G);
+        if constexpr (C::F30_BUCKETS && C::F30_LAZY) {
+            const uint32_t rows_per_block = 128 / S;          // S / 2 quads per row, 64 quads per block
+            hipLaunchKernelGGL((k_fb_fold_quad<C>), dim3((unsigned)((n_rows + rows_per_block - 1) / rows_per_block)), dim3(256), 0, stream,
+                               partial, (uint32_t)n_rows, S);
+        } else {
+            uint32_t rows_per_wave = 64 / G;
+            hipLaunchKernelGGL((k_fb_fold<C>), dim3((unsigned)((n_rows + rows_per_wave - 1) / rows_per_wave)), dim3(64), 0,
+                               stream, partial, (uint32_t)n_rows, S, G);
+        }
     }
     last_S = S;
     if (d_out) {

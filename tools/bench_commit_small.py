@@ -7,7 +7,7 @@ from porla_amd import multiexp as mx
 TAU = bytes.fromhex("ffeeddccbbaa99887766554433221100"); ALPHA = bytes.fromhex("00112233445566778899aabbccddeeff")
 mx.init_key(TAU, ALPHA)
 mx.init_SRS_from_data(128, mx.init_SRS(128))
-for rows in (1, 8, 32, 64, 65, 128, 256, 512, 1024, 1025, 2048, 4096):
+for rows in (1, 8, 32, 64, 65, 128, 256, 512, 1024, 1025, 2048, 4096, 8192):
     data = os.urandom(4096 * rows)
     for _ in range(3):
         r = mx.kzg_commit_batch_host(data, rows)
