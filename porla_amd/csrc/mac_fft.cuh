@@ -284,6 +284,17 @@ __device__ __forceinline__ void macq_prepare(XYZZ<M>* dst, const XYZZ<M>* src, b
     xyzz30_store_coord<M>(dst, (int)r, v, false);
 }
 // L.acc[q] = sc * L.tbl[q][0]  (all lanes of the block; L.tbl[q][0] written and a barrier passed; ends behind a barrier)
+// A quad's LDS state is private to its four lanes, which sit in one wave: LDS operations of a wave complete in order, so between a
+// lane's store and another lane's load only the compiler has to be held back -- no s_barrier across the block's waves
+// (PORLA_MACQ_BLOCK_SYNC at build time brings the block-wide barrier back)
+__device__ __forceinline__ void macq_sync() {
+#ifdef PORLA_MACQ_BLOCK_SYNC
+    __syncthreads();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#endif
+}
 template <class C>
 __device__ __forceinline__ void macq_ladder(MacQuadLds<typename C::Fp>& L, uint32_t q, uint32_t r, uint32_t lane, const uint32_t sc[8]) {
     using M = typename C::Fp;
@@ -298,20 +309,20 @@ __device__ __forceinline__ void macq_ladder(MacQuadLds<typename C::Fp>& L, uint3
     }
     for (int i = 1; i < 8; i++) {                                          // tbl[i] = (i + 1) P
         xyzz30_add_quad<M>(&L.tbl[q][i - 1], &L.tbl[q][0], &L.tbl[q][i], false, true, lane);
-        __syncthreads();
+        macq_sync();
     }
     for (int i = 32; i >= 0; i--) {
         for (int d = 0; d < 4; d++) {
             xyzz30_dbl_quad<M>(&L.acc[q], &L.acc[q], true, lane);
-            __syncthreads();
+            macq_sync();
         }
         for (int h = 0; h < 2; h++) {
             const int dg = mac_signed_digit(m[h], i);
             const int mag = dg < 0 ? -dg : dg;
             macq_prepare<M>(&L.tmp[q], &L.tbl[q][mag ? mag - 1 : 0], (dg < 0) != ng[h], h != 0, beta30, r, lane);
-            __syncthreads();
+            macq_sync();
             xyzz30_add_quad<M>(&L.acc[q], &L.tmp[q], &L.acc[q], false, mag != 0, lane);
-            __syncthreads();
+            macq_sync();
         }
     }
 }
@@ -457,7 +468,7 @@ __device__ __forceinline__ void store_affine_be(uint8_t* dst, const XYZZ<M>& p) 
         q[0] = z; q[1] = z; q[2] = z; q[3] = z;
         return;
     }
-    Fe<M> inv = fe_inv_dev<M>(p.zzz);
+    Fe<M> inv = fe_inv_dev30<M>(p.zzz);
     Affine<M> a = xyzz_to_affine_with_inv<M>(p, inv);
     Fe<M> one = fe_zero<M>();
     one.v[0] = 1;
@@ -529,7 +540,7 @@ k_mac_finish(const XYZZ<typename C::Fp>* __restrict__ work, uint32_t n, uint8_t*
         q[0] = z; q[1] = z; q[2] = z; q[3] = z;
         return;
     }
-    Fe<M> inv = fe_inv_dev<M>(p.zzz);
+    Fe<M> inv = fe_inv_dev30<M>(p.zzz);
     Affine<M> a = xyzz_to_affine_with_inv<M>(p, inv);
     Fe<M> one = fe_zero<M>();
     one.v[0] = 1;
