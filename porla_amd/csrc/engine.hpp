@@ -154,7 +154,7 @@ struct FixedBase {
     size_t io_out_cap = 0;
     uint32_t last_S = 1;                      // slices per row of the last commit_device (layout of `partial`)
     UseFence fence;                           // orders `partial` (and the table after a rebuild) between calls on different streams
-    static constexpr size_t HOST_FINISH_MAX_ROWS = 1024;  // batches up to this size are normalised on the host (commit_host)
+    static constexpr size_t HOST_FINISH_MAX_ROWS = 256;   // batches up to this size are normalised on the host (commit_host)
     // single-launch path for a handful of host rows (fixed_base.cuh:k_fb_commit_small): pinned staging (header, row sums,
     // rows) + the blocks' partial sums and arrival counters in HBM
     void* h_small = nullptr;

@@ -50,6 +50,10 @@ struct Bn254Fp {
     // 2^540 mod p: a plain residue times this in the reduced-radix product (radix 2^270) is the residue's 2^270 form
     static constexpr uint32_t RR_30[8] = {0x2e53b794u, 0x242db528u, 0x301f5ed1u, 0xa3522573u,
                                           0x9d4e3aa6u, 0x93560daau, 0x51b66a12u, 0x0d15816du};
+    // 2^782 mod p = 2^(512 + 270): the plain inverse of the INTEGER a residue's Fe form holds (A 2^256), times this in the
+    // reduced-radix product, is A^-1 2^256 -- the inverse in the Fe form (fixed_base.cuh:fe_inv_safegcd)
+    static constexpr uint32_t INV_OUT_30[8] = {0x27118959u, 0x136c05cau, 0x42d79087u, 0x7eef37ccu,
+                                               0x568e8d6du, 0x5c91832eu, 0x53347fadu, 0x13616943u};
 };
 
 // secp256k1 base field p = 2^256 - 2^32 - 977 (field_5x52.h:13-15 of the vendored tree).  Like the reference's own field
@@ -69,6 +73,7 @@ struct Secp256k1Fp {
     static constexpr uint32_t R1_30[8] = {1, 0, 0, 0, 0, 0, 0, 0};
     static constexpr uint32_t R2_30[8] = {1, 0, 0, 0, 0, 0, 0, 0};
     static constexpr uint32_t RR_30[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+    static constexpr uint32_t INV_OUT_30[8] = {1, 0, 0, 0, 0, 0, 0, 0};
 };
 
 // ---------------------------------------------------------------- element type

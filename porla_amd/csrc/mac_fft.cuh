@@ -468,7 +468,7 @@ __device__ __forceinline__ void store_affine_be(uint8_t* dst, const XYZZ<M>& p) 
         q[0] = z; q[1] = z; q[2] = z; q[3] = z;
         return;
     }
-    Fe<M> inv = fe_inv_dev30<M>(p.zzz);
+    Fe<M> inv = fe_inv_safegcd<M>(p.zzz);
     Affine<M> a = xyzz_to_affine_with_inv<M>(p, inv);
     Fe<M> one = fe_zero<M>();
     one.v[0] = 1;
@@ -540,7 +540,7 @@ k_mac_finish(const XYZZ<typename C::Fp>* __restrict__ work, uint32_t n, uint8_t*
         q[0] = z; q[1] = z; q[2] = z; q[3] = z;
         return;
     }
-    Fe<M> inv = fe_inv_dev30<M>(p.zzz);
+    Fe<M> inv = fe_inv_safegcd<M>(p.zzz);
     Affine<M> a = xyzz_to_affine_with_inv<M>(p, inv);
     Fe<M> one = fe_zero<M>();
     one.v[0] = 1;

@@ -167,3 +167,13 @@ def test_mult_point_against_the_c_oracle_on_random_and_edge_scalars():
         kb = k.to_bytes(32, "big")
         assert mx.bn254_mult(p, kb) == common.oracle_msm(kb, p, 1), hex(k)
     assert mx.bn254_mult(bytes(64), (12345).to_bytes(32, "big")) == bytes(64)
+
+
+def test_division_step_inversion_model_stays_inside_its_registers():
+    """the finish kernels invert with 25 rounds of 30 Bernstein-Yang division steps on signed 30-bit limbs
+    (fixed_base.cuh:fe_inv_safegcd); tools/safegcd_model.py is that procedure on Python integers with every 32- / 64-bit
+    register range asserted, against pow(V, -1, p) for both base fields -- edge values and random ones"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "safegcd_model.py"), "2000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "safegcd model: ok" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]

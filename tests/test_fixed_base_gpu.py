@@ -273,11 +273,11 @@ def test_few_rows_single_launch_path_and_its_boundary(mx, srs128, n_rows):
     fb.close()
 
 
-@pytest.mark.parametrize("n_rows", [640, 1024, 1025])
-def test_host_and_device_normalisation_meet_at_1024_rows(mx, srs128, n_rows):
-    """batches of <= 1024 rows are normalised on the host (engine.hpp:HOST_FINISH_MAX_ROWS: one batched inversion in 64-bit limbs,
-    0.3 us per row, against the finish kernel's fixed 0.18 ms + output copy: equal at 1024), larger ones by k_fb_finish (reduced-radix inversion
-    chain, 4 rows per lane); rows with a zero sum on both sides; slices folded by k_fb_fold_quad in either case"""
+@pytest.mark.parametrize("n_rows", [256, 257, 1025])
+def test_host_and_device_normalisation_meet_at_256_rows(mx, srs128, n_rows):
+    """batches of <= 256 rows are normalised on the host (engine.hpp:HOST_FINISH_MAX_ROWS: one batched inversion in 64-bit limbs,
+    0.3 us per row), larger ones by k_fb_finish (4 rows per lane share one division-step inversion, fe_inv_safegcd: 0.09 ms
+    fixed) -- level at 256 rows on a fast host, earlier on a slow one; rows with a zero sum on both sides; slices folded by k_fb_fold_quad in either case"""
     rows = bytearray(rows_bytes(n_rows, 128, b"finish%d" % n_rows))
     rows[4096 * 7:4096 * 8] = bytes(4096)
     rows[4096 * (n_rows - 1):4096 * n_rows] = bytes(4096)
