@@ -17,8 +17,10 @@
 //   k_fb_multiples     wave per run of entries, lanes interleaved: (m+1)*B by double-and-add, then additions of 64*B -> XYZZ scratch
 //   k_fb_normalize     XYZZ -> affine with one inversion per 32 entries (Montgomery's trick) -> table
 //   k_fb_commit        lane = row (x slice): scalar -> reduce mod order -> signed digits -> gather + 8M+2S mixed add
-//   k_fb_fold          G lanes per row: fold the slice partials (sequential + wave-shuffle tree)
-//   k_fb_finish        lane = row: one inversion, Montgomery -> big-endian X||Y (64 zero bytes = infinity)
+//   k_fb_fold_quad     fold a row's slice partials (reduced-radix memory form): in-place pairwise tree, four lanes per addition
+//                      (k_fb_fold: the same with G lanes per row on 8 x 32-bit limbs, for a curve without the reduced-radix form)
+//   k_fb_finish        lane = 4 rows: one division-step inversion (fe_inv_safegcd), Montgomery -> big-endian X||Y (64 zero bytes = infinity)
+//   k_fb_commit_small  <= 64 host rows in ONE launch (block = row x slice), sums polled from pinned memory
 #pragma once
 #include "msm.cuh"
 #include "msm_small.cuh"

@@ -279,8 +279,8 @@ int FixedBase<C>::commit_host(const uint8_t* rows, size_t n_rows, size_t n_coeff
     if (in_bytes) PORLA_HIP(hipMemcpyAsync(io_rows, rows, in_bytes, hipMemcpyHostToDevice, stream));
     if (n_rows <= HOST_FINISH_MAX_ROWS && n_coeffs > 0) {
         // up to a few hundred rows: the projective sums come back (one strided copy) and the host normalises them with one
-        // inversion per 64 rows (h_batch_xyzz_to_affine64, ~0.15 us per row) -- the device's finish kernel is a chain of ~380
-        // dependent products on lone waves, 0.31 ms whatever the batch (33 rows: 0.52 -> 0.25 ms per call)
+        // inversion per 64 rows (h_batch_xyzz_to_affine64, ~0.3 us per row) -- the device's finish kernel costs 0.09 ms whatever
+        // the batch (one division-step inversion on lone waves) plus the output copy: level at ~256 rows
         using M = typename C::Fp;
         int rc = commit_device(io_rows, n_rows, n_coeffs, row_stride, nullptr, stream);
         if (rc) return rc;

@@ -333,3 +333,20 @@ def test_sixteen_threads_coalesce_and_a_release_in_between(mx, srs128):
     assert not errors, errors[:5]
     c, h, z, y = mx.create_proof(99, rows[:4096])           # two rows in one batch
     assert c == want[:64] and mx.verify_proof(c, h, z, y)
+
+
+@pytest.mark.parametrize("n_rows,n_coeffs", [(70, 128), (300, 37), (1100, 128)])
+def test_secp256k1_mid_size_batches_through_slice_fold_and_device_normalisation(mx, n_rows, n_coeffs):
+    """the special-form field through the kernels of a mid-size batch: slice partials in the reduced-radix memory form folded four
+    lanes per addition (k_fb_fold_quad; 37 coefficients: 32 slices), rows normalised on the host (<= 256) or by k_fb_finish's
+    division-step inversion (fe_inv_safegcd); a zero row and a base point at infinity included"""
+    base = bytearray(common.secp_bench_points(128))
+    base[64 * 5:64 * 6] = bytes(64)
+    fb = mx.FixedBase("secp256k1", bytes(base), 128, window_bits=9)
+    stride = 32 * n_coeffs
+    rows = bytearray(rows_bytes(n_rows, n_coeffs, b"secp-mid%d" % n_rows))
+    rows[stride * 3:stride * 4] = bytes(stride)
+    got = fb.commit_host(bytes(rows), n_rows, n_coeffs)
+    fb.close()
+    assert got[64 * 3:64 * 4] == bytes(64)
+    assert got == common.oracle_commit_batch("secp256k1", bytes(rows), n_rows, n_coeffs, bytes(base))
