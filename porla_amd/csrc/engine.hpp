@@ -115,6 +115,7 @@ struct Workspace {
     hipStream_t own_stream = nullptr;
     hipStream_t aux_stream = nullptr;            // second stream of the reduction tree (msm_tree_launch)
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    hipEvent_t front_fork_ev = nullptr, front_join_ev = nullptr;   // points_to_mont beside the digit / sort chain (msm_launch)
     int slot = 0;
     hipEvent_t done = nullptr;  // recorded after the last kernel + D2H copy of a launched MSM
     int pend_W = 0, pend_c = 0; // window count / width of the launched, not yet folded MSM (0 = none)

@@ -258,15 +258,30 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
     uint32_t* ctrl = (uint32_t*)ws->cursor.p;
     PORLA_HIP(hipMemsetAsync(ctrl, 0, CTRL_WORDS * 4, stream));
     const Affine<M>* pts = (const Affine<M>*)ws->pts.p;
+    // The conversion of the points is independent of the digit / sort chain and only the accumulation reads its output: for a
+    // caller that waits for this one MSM it runs on the workspace's second stream beside that chain (with another MSM in flight
+    // the other MSM already fills the gaps, as for the tree split below)
+    static const bool front_split_on = !(getenv("PORLA_FRONT_SPLIT") && getenv("PORLA_FRONT_SPLIT")[0] == '0');
+    const bool front_split = front_split_on && ws->lone && !forced && n >= ((size_t)1 << 18);
+    hipStream_t pst = stream;
+    if (front_split) {
+        if (!ws->aux_stream) PORLA_HIP(hipStreamCreateWithFlags(&ws->aux_stream, hipStreamNonBlocking));
+        if (!ws->front_fork_ev) PORLA_HIP(hipEventCreateWithFlags(&ws->front_fork_ev, hipEventDisableTiming));
+        if (!ws->front_join_ev) PORLA_HIP(hipEventCreateWithFlags(&ws->front_join_ev, hipEventDisableTiming));
+        PORLA_HIP(hipEventRecord(ws->front_fork_ev, stream));
+        PORLA_HIP(hipStreamWaitEvent(ws->aux_stream, ws->front_fork_ev, 0));
+        pst = ws->aux_stream;
+    }
     {
-        ProfScope ps("points_to_mont", stream);
+        ProfScope ps("points_to_mont", pst);
         if (glv)
-            hipLaunchKernelGGL((k_points_to_mont<C, true, C::F30_BUCKETS>), dim3((n32 + 255) / 256), dim3(256), 0, stream, d_points_be,
+            hipLaunchKernelGGL((k_points_to_mont<C, true, C::F30_BUCKETS>), dim3((n32 + 255) / 256), dim3(256), 0, pst, d_points_be,
                                (Affine<M>*)ws->pts.p, n32);
         else
-            hipLaunchKernelGGL((k_points_to_mont<C, false, C::F30_BUCKETS>), dim3((n32 + 255) / 256), dim3(256), 0, stream, d_points_be,
+            hipLaunchKernelGGL((k_points_to_mont<C, false, C::F30_BUCKETS>), dim3((n32 + 255) / 256), dim3(256), 0, pst, d_points_be,
                                (Affine<M>*)ws->pts.p, n32);
     }
+    if (front_split) PORLA_HIP(hipEventRecord(ws->front_join_ev, ws->aux_stream));
     PORLA_TRACE("to_mont");
     const int lowbits = sort_lowbits(c, n_sub, W);
     const int P = 1 << (c - 1 - lowbits);
@@ -309,6 +324,7 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
         if (!C::F30_LAZY) { set_last_error("porla: merged pair ranges need the reduced-radix bucket form"); return PORLA_ERR_STATE; }
         if (after) PORLA_HIP(hipStreamWaitEvent(stream, after, 0));
     }
+    if (front_split) PORLA_HIP(hipStreamWaitEvent(stream, ws->front_join_ev, 0));
     {
         ProfScope ps("bucket_sum", stream, true);
         if constexpr (C::F30_BUCKETS)

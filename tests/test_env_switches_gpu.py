@@ -1,7 +1,8 @@
 """GPU box: the documented off-switches still give the oracle's bytes.  Every switch is read once per process, so each case is a
 child process: PORLA_MSM_SHARED_BUCKETS=0 (one complete MSM per host range), PORLA_MSM_SMALL=0 (general path at audit sizes),
 PORLA_ICC_F30=0 (8 x 32-bit ICC kernel), PORLA_MAC_QUAD=0 (one lane per MAC butterfly), PORLA_COMMIT_SMALL=0 (batch kernels for
-single rows), PORLA_NO_ADX=1 (portable host field products), PORLA_TREE_SPLIT=1 (reduction tree on one stream)."""
+single rows), PORLA_NO_ADX=1 (portable host field products), PORLA_TREE_SPLIT=1 (reduction tree on one stream),
+PORLA_FRONT_SPLIT=0 (point conversion on the MSM's own stream)."""
 import os
 import subprocess
 import sys
@@ -20,6 +21,7 @@ CASES = {
     "PORLA_COMMIT_SMALL=0": "tests/test_fixed_base_gpu.py -k 'small or single or coalesc or row'",
     "PORLA_NO_ADX=1": "tests/test_msm_bn254_gpu.py -k 'edge or audit_like or kat or eip'",
     "PORLA_TREE_SPLIT=1": "tests/test_msm_bn254_gpu.py -k 'full or 2p20 or uniform'",
+    "PORLA_FRONT_SPLIT=0": "tests/test_msm_bn254_gpu.py -k 'full or 2p20 or uniform'",
 }
 
 
