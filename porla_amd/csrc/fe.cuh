@@ -51,7 +51,7 @@ struct Bn254Fp {
     static constexpr uint32_t RR_30[8] = {0x2e53b794u, 0x242db528u, 0x301f5ed1u, 0xa3522573u,
                                           0x9d4e3aa6u, 0x93560daau, 0x51b66a12u, 0x0d15816du};
     // 2^782 mod p = 2^(512 + 270): the plain inverse of the INTEGER a residue's Fe form holds (A 2^256), times this in the
-    // reduced-radix product, is A^-1 2^256 -- the inverse in the Fe form (fixed_base.cuh:fe_inv_safegcd)
+    // reduced-radix product, is A^-1 2^256 -- the inverse in the Fe form (inv30.cuh:fe_inv_safegcd)
     static constexpr uint32_t INV_OUT_30[8] = {0x27118959u, 0x136c05cau, 0x42d79087u, 0x7eef37ccu,
                                                0x568e8d6du, 0x5c91832eu, 0x53347fadu, 0x13616943u};
 };

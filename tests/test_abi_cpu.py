@@ -171,7 +171,7 @@ def test_mult_point_against_the_c_oracle_on_random_and_edge_scalars():
 
 def test_division_step_inversion_model_stays_inside_its_registers():
     """the finish kernels invert with 25 rounds of 30 Bernstein-Yang division steps on signed 30-bit limbs
-    (fixed_base.cuh:fe_inv_safegcd); tools/safegcd_model.py is that procedure on Python integers with every 32- / 64-bit
+    (inv30.cuh:fe_inv_safegcd); tools/safegcd_model.py is that procedure on Python integers with every 32- / 64-bit
     register range asserted, against pow(V, -1, p) for both base fields -- edge values and random ones"""
     import subprocess
     import sys

@@ -28,3 +28,5 @@ def test_reduced_radix_product_matches_portable_product():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count(" 0 mismatches") == 4, r.stdout
+    # and the division-step inversion of the finish kernels (inv30.cuh): a * a^-1 = 1 over 4096 residues per base field
+    assert r.stdout.count(" 0 wrong inverses") == 2, r.stdout

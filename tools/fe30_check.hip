@@ -5,6 +5,7 @@
 #include "host_curve.hpp"
 #include "icc.cuh"
 #include "ec30.cuh"
+#include "inv30.cuh"
 #include <cstdio>
 #include <cstring>
 #include <random>
@@ -249,8 +250,64 @@ static double time_ms(F f, int reps = 3) {
     return best;
 }
 
+// fe_inv_safegcd: a * a^-1 must be the unit of the Fe form (R mod p; 1 for the special-form modulus) for edge and random residues
+template <class M>
+__global__ void k_inv_check(const uint32_t* a8, uint32_t* out8, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe<M> a;
+    for (int k = 0; k < 8; k++) a.v[k] = a8[i * 8 + k];
+    const Fe<M> r = fe_inv_safegcd<M>(a);
+    const Fe<M> one = fe_mul_call<M>(a, r);
+    for (int k = 0; k < 8; k++) out8[i * 8 + k] = one.v[k];
+}
+template <class M>
+static int check_inv(const char* name) {
+    const int N = 4096;
+    std::vector<uint32_t> h((size_t)N * 8), o((size_t)N * 8);
+    std::mt19937_64 rng(20261004);
+    auto put = [&](int i, const uint32_t w[8]) { for (int k = 0; k < 8; k++) h[(size_t)i * 8 + k] = w[k]; };
+    for (int i = 0; i < N; i++) {
+        uint32_t w[9];
+        for (int k = 0; k < 8; k++) w[k] = (uint32_t)rng();
+        w[8] = 0;
+        Fe<M> v = mod_p<M>(w, 9);
+        bool zero = true;
+        for (int k = 0; k < 8; k++) zero = zero && v.v[k] == 0;
+        if (zero) v.v[0] = 1;
+        put(i, v.v);
+    }
+    // edge residues: 1, 2, 3, p - 1, p - 2, (p - 1) / 2, (p + 1) / 2, 2^k, 2^k - 1, all-ones low limbs
+    int e = 0;
+    uint32_t w[8];
+    auto small = [&](uint32_t x) { for (int k = 0; k < 8; k++) w[k] = 0; w[0] = x; put(e++, w); };
+    small(1); small(2); small(3); small(0xffffffffu);
+    for (uint32_t sub = 1; sub <= 2; sub++) { for (int k = 0; k < 8; k++) w[k] = M::P[k]; w[0] -= sub; put(e++, w); }   // P[0] >= 2 for both
+    { uint32_t c = 0; for (int k = 7; k >= 0; k--) { uint32_t x = M::P[k]; w[k] = (x >> 1) | (c << 31); c = x & 1u; } put(e++, w);   // (p - 1) / 2
+      w[0] += 1; put(e++, w); }                                                                                                   // (p + 1) / 2 (no carry: p = 3 mod 4 here)
+    for (int bit : {1, 29, 30, 31, 32, 59, 60, 61, 119, 120, 239, 240, 241, 252}) {
+        for (int k = 0; k < 8; k++) w[k] = 0;
+        w[bit >> 5] = 1u << (bit & 31); put(e++, w);
+        for (int k = 0; k < 8; k++) w[k] = k < (bit >> 5) ? 0xffffffffu : 0; w[bit >> 5] = (1u << (bit & 31)) - 1u; put(e++, w);
+    }
+    uint32_t *da, *dout;
+    CK(hipMalloc(&da, h.size() * 4)); CK(hipMalloc(&dout, o.size() * 4));
+    CK(hipMemcpy(da, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL((k_inv_check<M>), dim3((N + 63) / 64), dim3(64), 0, 0, da, dout, N);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(o.data(), dout, o.size() * 4, hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (int i = 0; i < N; i++)
+        for (int k = 0; k < 8; k++) if (o[(size_t)i * 8 + k] != M::R1[k]) { bad++; break; }
+    printf("%s: fe_inv_safegcd over %d residues (%d edge): %d wrong inverses\n", name, N, e, bad);
+    (void)hipFree(da); (void)hipFree(dout);
+    return bad;
+}
+
 int main(int argc, char** argv) {
     int bad = 0;
+    bad += check_inv<Bn254Fp>("bn254_p");
+    bad += check_inv<Secp256k1Fp>("secp256k1_p");
     bad += check<Bn254Fp>("bn254_p");
     bad += check<IccBn254Fr>("bn254_r");
     bad += check<IccFp>("p_icc");
