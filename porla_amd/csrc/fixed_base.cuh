@@ -134,7 +134,9 @@ k_fb_normalize(const XYZZ<typename C::Fp>* __restrict__ scratch, size_t n, Affin
         store_fe<M>(reinterpret_cast<uint32_t*>(table + e), run);
         run = fe_mul_call<M>(run, z);
     }
-    Fe<M> inv = fe_inv_dev<M>(run);
+    Fe<M> inv;
+    if constexpr (C::F30_BUCKETS) inv = fe_inv_safegcd<M>(run);
+    else inv = fe_inv_dev<M>(run);
 #pragma unroll 1
     for (int k = cnt - 1; k >= 0; k--) {
         const size_t e = base + (size_t)k * 64;
