@@ -395,10 +395,10 @@ int porla_icc_mac_scale_host(const uint8_t mac_in[64], size_t n_total, unsigned 
     h_load_be(k, wt);
     if (curve == 0) {
         fe_reduce_plain<Bn254Fr>(k, 8);                 // bn254_mult -> fr.SetBytes reduces mod r (main.go:209)
-        h_affine_to_bytes<Bn254Fp>(mac_out, h_xyzz_to_affine64<Bn254Fp>(h_scalar_mul64<Bn254Fp>(h_affine_from_bytes<Bn254Fp>(mac_in), k)));
+        h_affine_to_bytes<Bn254Fp>(mac_out, h_xyzz_to_affine64<Bn254Fp>(h_scalar_mul64_glv<Bn254Fp, GlvBn254>(h_affine_from_bytes<Bn254Fp>(mac_in), k)));
     } else {
         fe_reduce_plain<IccSecp256k1FnHost>(k, 2);
-        h_affine_to_bytes<Secp256k1Fp>(mac_out, h_xyzz_to_affine64<Secp256k1Fp>(h_scalar_mul64<Secp256k1Fp>(h_affine_from_bytes<Secp256k1Fp>(mac_in), k)));
+        h_affine_to_bytes<Secp256k1Fp>(mac_out, h_xyzz_to_affine64<Secp256k1Fp>(h_scalar_mul64_glv<Secp256k1Fp, GlvSecp256k1>(h_affine_from_bytes<Secp256k1Fp>(mac_in), k)));
     }
     return PORLA_OK;
 }

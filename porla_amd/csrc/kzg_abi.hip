@@ -487,7 +487,7 @@ void mult_point(GoSlice* point_a, GoSlice* scalar) {
     uint32_t k[8];
     h_fe_to_plain<Fr>(k, s);
     uint8_t out[64];
-    h_affine_to_bytes<Fp>(out, h_xyzz_to_affine64<Fp>(h_scalar_mul64<Fp>(a, k)));
+    h_affine_to_bytes<Fp>(out, h_xyzz_to_affine64<Fp>(h_scalar_mul64_glv<Fp, GlvBn254>(a, k)));     // k is reduced (h_fe_from_be_var)
     copy_out(point_a, out, 64);
 }
 
