@@ -269,10 +269,11 @@ void init_SRS(GoInt SRS_size, GoSlice* out, GoInt64* out_len) {
     for (long long i = 0; i < SRS_size; i++) {
         uint32_t k[8];
         h_fe_to_plain<Fr>(k, t);
-        proj[(size_t)i] = h_scalar_mul64<Fp>(G, k);
+        static HostFixedBase<Fp> fb_gen;              // every power of tau multiplies the same generator: table of its multiples
+        proj[(size_t)i] = fb_gen.mul(G, k);
         t = fe_mul<Fr>(t, g.tau);
     }
-    for (long long i = 0; i < SRS_size; i++) g.srs[(size_t)i] = h_xyzz_to_affine64<Fp>(proj[(size_t)i]);
+    h_batch_xyzz_to_affine64<Fp>(proj.data(), (size_t)SRS_size, g.srs.data());       // one inversion per 64 points
     uint32_t tau_plain[8];
     h_fe_to_plain<Fr>(tau_plain, g.tau);
     g.g2[0] = g2_generator();
