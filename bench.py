@@ -46,7 +46,7 @@ HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E peak, /opt/skills/guides/MI355X_MIC
 MSM_BYTES_PER_PAIR = 96       # 32-B scalar + 64-B affine point
 COMMIT_BYTES_PER_ROW = 4096 + 64  # 128 x 32-B coefficients in, 64-B point out (SRS table resident)
 ICC_BYTES_PER_ELEMENT = 64    # 32 B in + 32 B out
-# measured back-to-back 256-bit modular products, G/s per GPU, in the reduced-radix form of fe30.cuh the accumulation kernels
+# measured back-to-back 256-bit modular products, G/s per GPU, in the reduced-radix form of fe30.hip.h the accumulation kernels
 # compute in (profiles/r01_l_ubench_fe30.txt): BN254 180.7 G products/s and 213.6 G squares/s ->
 # 186.5 for the 8M + 2S mix of a mixed addition; secp256k1 (special-form fold) 194.2 and 226.2 -> 199.9
 FE_MUL_PEAK_G = {"bn254_msm": 186.5, "kzg_commit": 186.5, "secp256k1_msm": 199.9}

@@ -187,6 +187,9 @@ int  porla_bn254_pairing_product_is_one(const uint8_t p1[64], const uint8_t q1[1
 int  porla_kzg_set_commit_window(int window_bits);
 /* diagnostic: window bits / windows per coefficient of the SRS table currently resident (0, 0 before the first batch) */
 int  porla_kzg_commit_shape(int *window_bits, int *windows);
+/* coefficients per commitment row = the SRS size given to init_SRS / init_SRS_from_data (main.go:45-68; the reference's
+ * NUM_CHUNKS = 128, config.hpp), 0 before either ran: the row stride of every *_batch_* entry point is 32 bytes times this */
+int  porla_kzg_row_coefficients(size_t *n_out);
 
 /* ---- ICC encode (CRebuild_Cached data part + align_MAC scalar part) ----
  * rows_in : n_rows * n_cols elements, 32 bytes little-endian each (8 x uint32 LE words, utils.h:353-364; the layout

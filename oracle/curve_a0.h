@@ -11,7 +11,8 @@
  * Also: the multi-scalar multiplication both back-ends expose
  *   (main.go:118-138 -> G1Affine.MultiExp; ecmult_impl.h:814-860 secp256k1_ecmult_multi_var)
  * as (1) a naive sum of double-and-add products and (2) a bucket (Pippenger) method with
- * plain unsigned c-bit windows, range-split over threads like Client.hpp:761-787.
+ * signed c-bit windows (digits in (-2^(c-1), 2^(c-1)], see the comment at the bucket method below), range-split over threads
+ * like Client.hpp:761-787.
  */
 #ifndef PORLA_ORACLE_CURVE_A0_H
 #define PORLA_ORACLE_CURVE_A0_H

@@ -13,7 +13,7 @@
 // 64 consecutive 64-byte symbols = 4 KiB per row, fully coalesced); a second kernel adds the slice partials and reduces
 // once per column mod p_icc and mod q.  Algorithmic bytes: 8 192 B per challenged row in, 64 B per column out.
 #include "engine.hpp"
-#include "icc.cuh"
+#include "icc.hip.h"
 
 #include <vector>
 

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <string>
 #include <vector>
 
 using namespace porla;
@@ -41,13 +42,19 @@ DistState D;
 
 int load_rccl() {
     if (D.lib.handle) return PORLA_OK;
-    const char* names[] = {getenv("PORLA_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // PORLA_RCCL_LIB names THE library to bind (nothing else is tried: an explicit choice that fails is an error, not a
+    // reason to pick another build silently); without it the usual names
+    const char* forced = getenv("PORLA_RCCL_LIB");
+    const bool only_forced = forced && *forced;
+    const char* names[] = {forced, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     std::string tried;
     for (const char* nm : names) {
         if (!nm || !*nm) continue;
+        if (only_forced && nm != forced) break;
         void* h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
         if (h) { D.lib.handle = h; break; }
-        tried += std::string(nm) + ": " + (dlerror() ? dlerror() : "?") + "; ";
+        const char* e = dlerror();          // one call: it returns the message AND clears it
+        tried += std::string(nm) + ": " + (e ? e : "?") + "; ";
     }
     if (!D.lib.handle) { set_last_error("porla: RCCL not found (" + tried + ")"); return PORLA_ERR_STATE; }
     auto sym = [&](const char* n) { return dlsym(D.lib.handle, n); };
@@ -111,6 +118,14 @@ int gather_fold(const uint8_t partial[PORLA_JACOBIAN_BYTES], uint8_t out_affine[
 }
 
 }  // namespace
+
+namespace porla {
+// ranks of the in-library communicator (0 without one): msm_impl's implicit range split stays on the current device when > 1
+int dist_world_size() {
+    std::lock_guard<std::mutex> lk(D.mu);
+    return D.comm ? D.world : 0;
+}
+}  // namespace porla
 
 extern "C" {
 

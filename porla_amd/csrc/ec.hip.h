@@ -8,7 +8,7 @@
 // needs no inversion; every exceptional case (empty bucket, P + P, P + (-P), infinity operand)
 // is handled, because real audit inputs repeat points (SURVEY.md s7 "hard parts" ii).
 #pragma once
-#include "fe.cuh"
+#include "fe.hip.h"
 
 namespace porla {
 

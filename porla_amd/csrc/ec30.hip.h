@@ -1,5 +1,5 @@
-// Mixed addition of the bucket accumulation in the reduced-radix field form of fe30.cuh (30-bit limbs, radix 2^270).
-// Same group law and exceptional cases as ec.cuh:xyzz_madd (the reference: gnark-crypto's g1JacExtended.addMixed behind
+// Mixed addition of the bucket accumulation in the reduced-radix field form of fe30.hip.h (30-bit limbs, radix 2^270).
+// Same group law and exceptional cases as ec.hip.h:xyzz_madd (the reference: gnark-crypto's g1JacExtended.addMixed behind
 // G1Affine.MultiExp, porla/main.go:136) -- only the residues' representation differs, so the bucket sums are the same
 // group elements and the MSM result stays bit-exact.
 //
@@ -15,8 +15,8 @@
 //   Y3 = R D - Y1 PPP + 2p                         <= 3
 // Everything is below 8p < 2^257, so limb 8 stays below 2^18 as the products require.
 #pragma once
-#include "ec.cuh"
-#include "fe30.cuh"
+#include "ec.hip.h"
+#include "fe30.hip.h"
 
 namespace porla {
 
@@ -205,7 +205,7 @@ __device__ __forceinline__ XYZZ30<M> xyzz30_load_lazy(const XYZZ<M>* src) {
     return p;
 }
 
-// Out-of-line group operations on the lazy memory form (for the scalar-multiplication ladders of mac_fft.cuh, whose
+// Out-of-line group operations on the lazy memory form (for the scalar-multiplication ladders of mac_fft.hip.h, whose
 // working set -- a table of multiples -- lives in private memory anyway): one body of each in the instruction cache.
 //   *p += (neg ? -1 : 1) * (phi ? (beta X, Y, ZZ, ZZZ) : (X, Y, ZZ, ZZZ)) of *q;   beta30 = beta in the 2^270 form
 template <class M>
@@ -389,7 +389,7 @@ __device__ __forceinline__ void xyzz30_dbl_quad(const XYZZ<M>* p, XYZZ<M>* out, 
     else if (r == 3u) xyzz30_store_coord<M>(out, 3, M3, false);
 }
 
-// the accumulator as an ec.cuh XYZZ in the 2^256 Montgomery form (canonical residues); infinity = all zero
+// the accumulator as an ec.hip.h XYZZ in the 2^256 Montgomery form (canonical residues); infinity = all zero
 template <class M>
 __device__ __forceinline__ XYZZ<M> xyzz30_to_xyzz(const XYZZ30<M>& p) {
     XYZZ<M> r;

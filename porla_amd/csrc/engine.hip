@@ -248,12 +248,19 @@ int porla_gpu_profile_get(int slot, char* name, size_t name_cap, double* total_m
 // frees the MSM scratch of every workspace slot (it grows with the largest call seen: ~0.5 GiB per slot at 2^20 pairs);
 // refused while a two-phase MSM is still pending
 int porla_gpu_release_msm_workspaces(void) {
+    // lock order everywhere: a slot's mutex is never held while g_ws_mu is taken (msm_host_multi looks its slots up first), and
+    // here the slots are only try-locked under the registry lock: a slot a host MSM is using makes the call fail, not wait
     std::lock_guard<std::mutex> lk(g_ws_mu);
-    for (auto* w : g_ws) if (w->pend_W || w->begun) { set_last_error("porla: an MSM is still pending (call the matching _end first)"); return PORLA_ERR_STATE; }
+    std::vector<Workspace*> held;
+    auto unlock_all = [&]() { for (auto* w : held) w->mu.unlock(); };
+    for (auto* w : g_ws) {
+        if (!w->mu.try_lock()) { unlock_all(); set_last_error("porla: an MSM is running on a workspace slot"); return PORLA_ERR_STATE; }
+        held.push_back(w);
+        if (w->pend_W || w->begun) { unlock_all(); set_last_error("porla: an MSM is still pending (call the matching _end first)"); return PORLA_ERR_STATE; }
+    }
     int cur = 0;
     (void)hipGetDevice(&cur);
     for (auto* w : g_ws) {
-        std::lock_guard<std::mutex> lw(w->mu);
         (void)hipSetDevice(w->device);
         Buf* bufs[] = {&w->pts, &w->keys, &w->entries, &w->counts, &w->starts, &w->fill, &w->cursor, &w->buckets, &w->in_scalars,
                        &w->in_points, &w->order, &w->blk_hist, &w->blk_off, &w->tile_off, &w->heavy, &w->chunk_out, &w->tree_s,
@@ -261,6 +268,7 @@ int porla_gpu_release_msm_workspaces(void) {
         for (Buf* b : bufs) b->release();
     }
     (void)hipSetDevice(cur);
+    unlock_all();
     return PORLA_OK;
 }
 // unit u of n belongs to shard u * world / n: shard `rank` owns [rank n / world, (rank+1) n / world) -- the one rule every
@@ -285,7 +293,7 @@ int porla_gpu_set_msm_small(int on, int window_bits) {
 }
 int porla_gpu_set_msm_glv(int on) { g_use_glv = on < 0 ? -1 : (on != 0); return PORLA_OK; }
 
-// host execution of the very code the digit kernel runs (glv.cuh is __host__ __device__): lets the CPU tests pin the
+// host execution of the very code the digit kernel runs (glv.hip.h is __host__ __device__): lets the CPU tests pin the
 // split against the Python model of tools/gen_glv.py
 int porla_glv_split(int curve, const uint8_t scalar_be[32], uint8_t k1_mag_be[16], int* k1_neg, uint8_t k2_mag_be[16], int* k2_neg) {
     if (!scalar_be || !k1_mag_be || !k2_mag_be || !k1_neg || !k2_neg || (curve != 0 && curve != 1)) return PORLA_ERR_ARG;

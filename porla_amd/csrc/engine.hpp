@@ -7,8 +7,8 @@
 #include <string>
 #include "../../include/porla_gpu.h"
 #include "host_curve.hpp"
-#include "msm.cuh"
-#include "msm_small.cuh"
+#include "msm.hip.h"
+#include "msm_small.hip.h"
 
 namespace porla {
 
@@ -40,7 +40,7 @@ template <class C>
 int msm_device(const uint8_t* d_scalars, const uint8_t* d_points, size_t n, hipStream_t stream,
                XYZZ<typename C::Fp>* total);
 
-// two-phase form (see msm_impl.cuh)
+// two-phase form (see msm_impl.hip.h)
 template <class C>
 int msm_device_begin(int slot, const uint8_t* d_scalars, const uint8_t* d_points, size_t n, hipStream_t stream);
 template <class C>
@@ -132,7 +132,7 @@ constexpr int MSM_MULTI_SLOTS = 4;
 constexpr int MSM_POOL_SLOT0 = 8;
 constexpr size_t MSM_SCAN_MAX = 1u << 16;  // inputs up to this size are scanned for their longest scalar first
 constexpr size_t MSM_RANGE_MAX = 1u << 22; // larger inputs run as ranges of this size into one bucket array (msm_launch)
-// Batched fixed-base commitments (fixed_base.cuh): resident table of window multiples of one base.
+// Batched fixed-base commitments (fixed_base.hip.h): resident table of window multiples of one base.
 // Calls on one object are serialised by `mu`; the *_device form leaves its kernels in flight on the caller's stream, and a
 // later call on another stream waits (on the device, through `fence`) for them before it reuses the slice-partial scratch.
 template <class C>
@@ -156,7 +156,7 @@ struct FixedBase {
     uint32_t last_S = 1;                      // slices per row of the last commit_device (layout of `partial`)
     UseFence fence;                           // orders `partial` (and the table after a rebuild) between calls on different streams
     static constexpr size_t HOST_FINISH_MAX_ROWS = 256;   // batches up to this size are normalised on the host (commit_host)
-    // single-launch path for a handful of host rows (fixed_base.cuh:k_fb_commit_small): pinned staging (header, row sums,
+    // single-launch path for a handful of host rows (fixed_base.hip.h:k_fb_commit_small): pinned staging (header, row sums,
     // rows) + the blocks' partial sums and arrival counters in HBM
     void* h_small = nullptr;
     void* d_small = nullptr;

@@ -41,7 +41,7 @@ struct Bn254Fp {
     static constexpr int SPARE_BITS = 2;            // p < 2^254
     static constexpr bool PSEUDO_MERSENNE = false;
     static constexpr uint32_t FOLD = 0;
-    // reduced-radix form (fe30.cuh, Montgomery radix 2^270): 2^270 mod p, and 2^(256+270) mod p -- the factor that takes a
+    // reduced-radix form (fe30.hip.h, Montgomery radix 2^270): 2^270 mod p, and 2^(256+270) mod p -- the factor that takes a
     // plain residue into the 2^270 form through fe_mul (which divides by 2^256)
     static constexpr uint32_t R1_30[8] = {0x5accccc9u, 0xf89a7d3au, 0x9a1dcc9du, 0x50fea7bdu,
                                           0xdf1160f4u, 0x9e7d8ca3u, 0xed6d3304u, 0x279be39au};
@@ -51,7 +51,7 @@ struct Bn254Fp {
     static constexpr uint32_t RR_30[8] = {0x2e53b794u, 0x242db528u, 0x301f5ed1u, 0xa3522573u,
                                           0x9d4e3aa6u, 0x93560daau, 0x51b66a12u, 0x0d15816du};
     // 2^782 mod p = 2^(512 + 270): the plain inverse of the INTEGER a residue's Fe form holds (A 2^256), times this in the
-    // reduced-radix product, is A^-1 2^256 -- the inverse in the Fe form (inv30.cuh:fe_inv_safegcd)
+    // reduced-radix product, is A^-1 2^256 -- the inverse in the Fe form (inv30.hip.h:fe_inv_safegcd)
     static constexpr uint32_t INV_OUT_30[8] = {0x27118959u, 0x136c05cau, 0x42d79087u, 0x7eef37ccu,
                                                0x568e8d6du, 0x5c91832eu, 0x53347fadu, 0x13616943u};
 };
@@ -69,7 +69,7 @@ struct Secp256k1Fp {
     static constexpr int SPARE_BITS = 0;
     static constexpr bool PSEUDO_MERSENNE = true;   // p = 2^256 - (2^32 + FOLD)
     static constexpr uint32_t FOLD = 977;
-    // reduced-radix form (fe30.cuh): plain residues there too, so both conversion factors are 1
+    // reduced-radix form (fe30.hip.h): plain residues there too, so both conversion factors are 1
     static constexpr uint32_t R1_30[8] = {1, 0, 0, 0, 0, 0, 0, 0};
     static constexpr uint32_t R2_30[8] = {1, 0, 0, 0, 0, 0, 0, 0};
     static constexpr uint32_t RR_30[8] = {1, 0, 0, 0, 0, 0, 0, 0};

@@ -1,18 +1,18 @@
 // Reduced-radix field arithmetic for the accumulation kernels: 9 limbs of 30 bits in 32-bit registers, Montgomery radix
-// 2^270.  Same role as fe.cuh (the reference's field layer: gnark-crypto ecc/bn254/fp behind porla/main.go:130-137) -- a
+// 2^270.  Same role as fe.hip.h (the reference's field layer: gnark-crypto ecc/bn254/fp behind porla/main.go:130-137) -- a
 // second representation of the SAME residues, chosen for the gfx950 VALU:
 //   * a 30 x 30-bit product is < 2^60, so a 64-bit column accumulator takes all 16..18 products of a column WITHOUT a
-//     carry: one v_mad_u64_u32 per product and nothing else (the 8 x 32-bit form of fe.cuh needs a v_addc per product
+//     carry: one v_mad_u64_u32 per product and nothing else (the 8 x 32-bit form of fe.hip.h needs a v_addc per product
 //     for the third accumulator word: 128 + ~120 instructions against 162 + ~60 here);
 //   * the radix 2^270 exceeds p^2 / p by 2^16, so a Montgomery product of operands below 2^258 is already < p + 1:
 //     no conditional subtraction, and sums / differences of a few products may stay unreduced (value bounds in the
-//     comments of ec30.cuh);
+//     comments of ec30.hip.h);
 //   * the price: limbs must be < 2^30 when they enter a product (one carry ripple after every addition chain) and
 //     values change representation at the kernel boundary (pack / unpack, a constant product to switch the radix).
 // Overflow budget of a column accumulator (checked for every modulus by tools/check_fe30_bounds.py): operands with limbs
 // 0..7 < 2^30 and limb 8 < 2^18; the widest column holds 16 products below 2^60 plus terms with a small top limb.
 #pragma once
-#include "fe.cuh"
+#include "fe.hip.h"
 
 namespace porla {
 
@@ -108,7 +108,7 @@ __device__ __forceinline__ F30<M> f30_sqr_portable(const F30<M>& a) {
 }
 
 // ---------------------------------------------------------------- special-form modulus p = 2^256 - 2^32 - FOLD (secp256k1)
-// Plain residues (no Montgomery factor), as in fe.cuh and in the reference's field_5x52.  The 18-limb schoolbook product is
+// Plain residues (no Montgomery factor), as in fe.hip.h and in the reference's field_5x52.  The 18-limb schoolbook product is
 // folded with 2^270 = 2^14 (2^32 + FOLD) = C1 2^30 + C0 (mod p), then everything above 2^256 once more with
 // 2^256 = 2^32 + FOLD.  Operands: limbs 0..7 < 2^30, limb 8 < 2^19 (value < 2^259).  Result: limbs < 2^30, value < 2^256 + 2^49.
 template <class M>
@@ -240,7 +240,7 @@ __device__ __forceinline__ void f30_pack(uint32_t w[8], const F30<M>& a) {
 
 // ---------------------------------------------------------------- additions and subtractions
 // Products need NORMAL operands: limbs 0..7 < 2^30, limb 8 < 2^18.  Limb-wise sums are rippled back to that form before
-// they enter a product; values are tracked in multiples of p in the comments of ec30.cuh (everything stays below 8p).
+// they enter a product; values are tracked in multiples of p in the comments of ec30.hip.h (everything stays below 8p).
 template <class M>
 __device__ __forceinline__ void f30_ripple(F30<M>& a) {
 #pragma unroll

@@ -22,9 +22,9 @@
 //   k_fb_finish        lane = 4 rows: one division-step inversion (fe_inv_safegcd), Montgomery -> big-endian X||Y (64 zero bytes = infinity)
 //   k_fb_commit_small  <= 64 host rows in ONE launch (block = row x slice), sums polled from pinned memory
 #pragma once
-#include "msm.cuh"
-#include "msm_small.cuh"
-#include "inv30.cuh"
+#include "msm.hip.h"
+#include "msm_small.hip.h"
+#include "inv30.hip.h"
 #include <type_traits>
 
 namespace porla {
@@ -181,7 +181,7 @@ k_fb_commit(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_coeffs
     const uint32_t Bh = 1u << (c - 1);
     const uint32_t mask = (1u << c) - 1;
     const uint8_t* row = rows + (size_t)r * row_stride;
-    // accumulator: the reduced-radix form of ec30.cuh where the curve has it (the table is then in the 2^270 form too)
+    // accumulator: the reduced-radix form of ec30.hip.h where the curve has it (the table is then in the 2^270 form too)
     using Acc = typename std::conditional<C::F30_BUCKETS, XYZZ30<M>, XYZZ<M>>::type;
     Acc acc;
     if constexpr (C::F30_BUCKETS) acc.inf = true;
@@ -268,7 +268,7 @@ k_fb_commit(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_coeffs
 // 1077-1078, 2061-2062), and create_proof commits two rows (main.go:164,170).  Through the batch kernels above a single row
 // costs three launches, two copies and 15 dependent additions per lane (0.28 ms).  Here ONE launch does it:
 //   block (row, slice) owns a slice of the row's (coefficient, window) pairs: a lane recodes the digit of each of its <= ~2
-//   pairs (the carry into a window from one masked compare, as in msm_small.cuh), gathers the table entry and accumulates;
+//   pairs (the carry into a window from one masked compare, as in msm_small.hip.h), gathers the table entry and accumulates;
 //   the 256 lane sums are folded in LDS with four lanes per addition (8 levels); the LAST block of a row to arrive folds the
 //   slices' sums and writes the row's projective sum into pinned host memory; the last row to finish publishes the sequence
 //   number the host polls for.  The rows are read where they lie: `rows` may be device memory or mapped pinned host memory
@@ -318,7 +318,7 @@ k_fb_commit_small(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_
             for (int k = 0; k < 8; k++) t[k] = d[k];
         }
         const uint32_t wc = w * (uint32_t)c;
-        bool gt = false, eq = true;                                // carry into window w (see msm_small.cuh)
+        bool gt = false, eq = true;                                // carry into window w (see msm_small.hip.h)
 #pragma unroll
         for (int q = 7; q >= 0; q--) {
             const uint32_t below = wc > 32u * q ? wc - 32u * q : 0u;
@@ -418,7 +418,7 @@ k_fb_fold(XYZZ<typename C::Fp>* __restrict__ partial, uint32_t n_rows, uint32_t 
 }
 
 // The same fold where the partials are in the reduced-radix memory form (k_fb_commit with S > 1): a pairwise tree in place --
-// level n adds partial[q + n] to partial[q] for q < n on the four lanes of quad q (ec30.cuh:xyzz30_add_quad: ~2 us per level
+// level n adds partial[q + n] to partial[q] for q < n on the four lanes of quad q (ec30.hip.h:xyzz30_add_quad: ~2 us per level
 // against ~6 us for a one-lane addition and ~12 us for the out-of-line 8 x 32-bit one above), a barrier between levels; the
 // last level leaves the row's sum in the 2^256 form k_fb_finish and the host read.  S a power of two (2 .. 128); a row takes
 // S / 2 quads, a block of 256 lanes 128 / S rows.

@@ -1,7 +1,7 @@
-// Host-side launch logic of the batched fixed-base commitment (fixed_base.cuh); included by the per-curve TUs.
+// Host-side launch logic of the batched fixed-base commitment (fixed_base.hip.h); included by the per-curve TUs.
 #pragma once
 #include "engine.hpp"
-#include "fixed_base.cuh"
+#include "fixed_base.hip.h"
 #include "host_fold64.hpp"
 #include <cstdlib>
 #include <chrono>

@@ -9,7 +9,7 @@
 //
 // Constants and the bit-for-bit Python model of glv_split: tools/gen_glv.py (self-checked on 2*10^5 scalars per curve).
 #pragma once
-#include "fe.cuh"
+#include "fe.hip.h"
 
 namespace porla {
 
@@ -19,7 +19,7 @@ namespace porla {
 //   proven bound (|a1|+|a2|)/2, (|b1|+|b2|)/2 (+ rounding): 126 / 126 bits; worst seen over the self-check: 126 bits
 struct GlvBn254 {
     static constexpr uint32_t BETA[8] = {0x607cfd48u, 0xe4bd44e5u, 0xbb966e3du, 0xc28f069fu, 0xe0acccb0u, 0x5e6dd9e7u, 0xe131a029u, 0x30644e72u};   // plain
-    // beta in the field form the reduced-radix kernels compute in (fe30.cuh): beta * 2^270 mod p
+    // beta in the field form the reduced-radix kernels compute in (fe30.hip.h): beta * 2^270 mod p
     static constexpr uint32_t BETA_30[8] = {0x553ba9feu, 0xf084d174u, 0x425467c7u, 0x743dbd42u, 0xac1030d9u, 0x64efb88du, 0x788d0b37u, 0x24f261b7u};
     static constexpr int SHIFT = 382;
     static constexpr uint32_t G1[8] = {0xf2d2e698u, 0x058ed210u, 0xf5792573u, 0x45275503u, 0xc03fd959u, 0x94e63f40u, 0x29dcf4b4u, 0x9333bc05u};     // round(2^SHIFT |b2| / n)

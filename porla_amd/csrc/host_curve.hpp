@@ -2,10 +2,10 @@
 // projective -> affine normalisation, (un)marshalling, and the
 // single-point operations of the plug-in (add_point / mult_point / neg_point, porla/main.go:195-230),
 // which SURVEY.md s8(e) classifies as "replicas only" (one 64-byte operand: a PCIe round trip would cost
-// more than the arithmetic).  It reuses the SAME limb code as the device (fe.cuh / ec.cuh are
+// more than the arithmetic).  It reuses the SAME limb code as the device (fe.hip.h / ec.hip.h are
 // __host__ __device__), so the GPU parity tests exercise these formulas too.
 #pragma once
-#include "ec.cuh"
+#include "ec.hip.h"
 #include <cstring>
 
 namespace porla {

@@ -1,11 +1,11 @@
 // Host tail of the MSM in 4 x 64-bit limbs: the Horner fold of the tree's single-bit sums (W*c dependent doublings and additions)
 // is a purely sequential chain, so it runs on one host core -- with 64x64->128 products it costs ~60 us instead of the
-// ~270 us of the portable 8 x 32-bit code shared with the device.  Same Montgomery radix (R = 2^256) as fe.cuh, so
+// ~270 us of the portable 8 x 32-bit code shared with the device.  Same Montgomery radix (R = 2^256) as fe.hip.h, so
 // elements convert by repacking limbs.  The reference does this fold inside gnark's MultiExp / at the end of
 // secp256k1_ecmult_pippenger_wnaf (porla/Utils/secp256k1_lib/ecmult_impl.h:544-564).
 #pragma once
-#include "ec.cuh"
-#include "glv.cuh"
+#include "ec.hip.h"
+#include "glv.hip.h"
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -104,7 +104,7 @@ struct Fp64 {
     }
 #undef PORLA_MUL_ROW
 #endif
-    // special-form product for p = 2^256 - 2^32 - FOLD on plain residues (fe_mul_pseudo_mersenne in fe.cuh)
+    // special-form product for p = 2^256 - 2^32 - FOLD on plain residues (fe_mul_pseudo_mersenne in fe.hip.h)
     E mul_pseudo_mersenne(const E& a, const E& b) const {
         const uint64_t c = ((uint64_t)1 << 32) + M::FOLD;
         uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -133,7 +133,7 @@ struct Fp64 {
         return cond_sub(r, 0);
     }
 #if PORLA_FP64_ADX
-    E mul_adx(const E& a, const E& b) const {          // fe.cuh:mont_mul4_adx
+    E mul_adx(const E& a, const E& b) const {          // fe.hip.h:mont_mul4_adx
         uint64_t t[4];
         mont_mul4_adx(t, a.v, b.v, p, inv);
         return cond_sub(t, 0);
@@ -220,7 +220,7 @@ struct Fp64 {
     XYZZ<M> to(const Pt& q) const { XYZZ<M> r; r.x = to(q.x); r.y = to(q.y); r.zz = to(q.zz); r.zzz = to(q.zzz); return r; }
     Pt inf() const { Pt r; r.x = from(fe_one<M>()); r.y = r.x; r.zz = from(fe_zero<M>()); r.zzz = r.zz; return r; }
 
-    // dbl-2008-s-1 (a = 0), same formulas as xyzz_double in ec.cuh
+    // dbl-2008-s-1 (a = 0), same formulas as xyzz_double in ec.hip.h
     Pt dbl(const Pt& q) const {
         if (is_zero(q.zz) || is_zero(q.y)) return inf();
         Pt r;
@@ -232,7 +232,7 @@ struct Fp64 {
         r.zzz = mul(W, q.zzz);
         return r;
     }
-    // add-2008-s, all exceptional cases as xyzz_add in ec.cuh
+    // add-2008-s, all exceptional cases as xyzz_add in ec.hip.h
     Pt padd(const Pt& a, const Pt& b) const {
         if (is_zero(b.zz)) return a;
         if (is_zero(a.zz)) return b;
@@ -298,7 +298,7 @@ inline XYZZ<M> h_scalar_mul64(const Affine<M>& a, const uint32_t k[8]) {
     return F.to(acc);
 }
 
-// The same with the scalar split by the curve's endomorphism (glv.cuh: k = k1 + k2 lambda, |k1|, |k2| < 2^128, phi(x, y) = (beta x, y)
+// The same with the scalar split by the curve's endomorphism (glv.hip.h: k = k1 + k2 lambda, |k1|, |k2| < 2^128, phi(x, y) = (beta x, y)
 // = lambda (x, y)): 33 windows of 4 doublings with two additions each instead of 65 with one -- half the doublings (mult_point
 // 82 -> ~50 us).  k must be reduced modulo the group order (glv_split's precondition; mult_point and the MAC scaling reduce first).
 template <class M, class G>
@@ -441,7 +441,7 @@ struct HostFixedBase {
     }
 };
 
-// Tree form of the bucket reduction (msm.cuh, k_tree_level): window w arrives as fin[w][0] = S (sum of its buckets) and
+// Tree form of the bucket reduction (msm.hip.h, k_tree_level): window w arrives as fin[w][0] = S (sum of its buckets) and
 // fin[w][1 + k] = M_k (sum of the buckets whose index has bit k set), k < c - 1, and is worth S + sum_k 2^k M_k.
 // total = sum_w 2^(c*w) * that: one Horner pass over single bits -- the same W*c doublings, W*c additions.
 template <class M>

@@ -2,8 +2,8 @@
 // Patch site in the reference (no function boundary exists there): Server::CRebuild_Cached,
 // porla/Server/Server.hpp:1544-1833; see INTEGRATION.md.
 #include "engine.hpp"
-#include "icc.cuh"
-#include "icc30.cuh"
+#include "icc.hip.h"
+#include "icc30.hip.h"
 #include "icc_host.hpp"
 
 #include <cstdlib>
@@ -17,7 +17,7 @@ namespace porla {
 struct IccWs {
     int device = -1;
     Buf work, tw, tw30, wpow, in, xo, al, sc;
-    uint32_t tw_n = 0, tw30_n = 0;   // tw30: the same table in the reduced-radix form of icc30.cuh (80-byte slots)
+    uint32_t tw_n = 0, tw30_n = 0;   // tw30: the same table in the reduced-radix form of icc30.hip.h (80-byte slots)
     int tw30_curve = -1;
     int tw_curve = -1;
     UseFence fence;   // work / twiddle buffers are shared between calls that may come on different streams
@@ -137,7 +137,7 @@ static int icc_encode_core(IccWs* ws, int curve, const uint8_t* d_rows, size_t n
     if (fused) {
         // ceil(logn / 8) passes of (almost) equal stage counts, each through LDS tiles of 512 symbols; the first pass reads
         // the raw chunks, the last one writes the outputs: the residue-pair working set only travels between passes.
-        // Default: the reduced-radix kernel of icc30.cuh (72 bytes per symbol between the passes); PORLA_ICC_F30=0: icc.cuh's.
+        // Default: the reduced-radix kernel of icc30.hip.h (72 bytes per symbol between the passes); PORLA_ICC_F30=0: icc.hip.h's.
         if (f30) {
             if ((rc = ws->work.ensure(total * ICC30_PACK_WORDS * 4))) return rc;
             if (ws->tw30_n != n || ws->tw30_curve != curve) {

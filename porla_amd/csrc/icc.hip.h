@@ -15,11 +15,11 @@
 // ~1 000 vector instructions per symbol and pass.  The first pass converts the raw 32-byte chunks on the way in, the last writes
 // the CRT / alignment outputs; the N-entry twiddle table stays L2-resident; lanes run along the columns of a row, so global
 // accesses are coalesced.  Two kernels share this tiling: k_icc_fused below (8 x 32-bit limbs, Montgomery radix 2^256) and the
-// default k_icc_fused30 of icc30.cuh (9 x 30-bit limbs, radix 2^270, sparse reduction for p_icc).  The element-wise kernels of
+// default k_icc_fused30 of icc30.hip.h (9 x 30-bit limbs, radix 2^270, sparse reduction for p_icc).  The element-wise kernels of
 // this file (k_icc_load, k_icc_finish, k_icc_stages, k_icc_mix) serve the unfused fallback, Server::mix and HAdd.
 // No MFMA: there is no contraction.
 #pragma once
-#include "fe.cuh"
+#include "fe.hip.h"
 
 namespace porla {
 

@@ -1,7 +1,7 @@
 // Host helpers shared by the ICC data encode (icc.hip) and the MAC-side encode (mac_fft.hip).
 #pragma once
 #include "host_curve.hpp"
-#include "icc.cuh"
+#include "icc.hip.h"
 
 namespace porla {
 

@@ -1,9 +1,9 @@
-// Modular inversion on the device by division steps (used by the finish kernels: fixed_base.cuh:k_fb_finish,
-// mac_fft.cuh:k_mac_finish / store_affine_be).  Checked directly by tools/fe30_check.hip (a * a^-1 over edge and random residues,
+// Modular inversion on the device by division steps (used by the finish kernels: fixed_base.hip.h:k_fb_finish,
+// mac_fft.hip.h:k_mac_finish / store_affine_be).  Checked directly by tools/fe30_check.hip (a * a^-1 over edge and random residues,
 // both base fields) and modelled on Python integers, register ranges asserted, by tools/safegcd_model.py.
 #pragma once
-#include "fe.cuh"
-#include "fe30.cuh"
+#include "fe.hip.h"
+#include "fe30.hip.h"
 
 namespace porla {
 
@@ -13,7 +13,7 @@ namespace porla {
 // (Theorem 11.2: floor((49 * 256 + 57) / 17)); 25 rounds of 30 are run, every lane the same instructions.  Numbers are nine
 // signed limbs of 30 bits (limbs 0..7 in [0, 2^30), limb 8 carries the sign); all products fit 64-bit signed accumulators
 // because |u| + |v| <= 2^30 for a matrix row.  ~22 k simple instructions against the 381 dependent field products of a^(p-2)
-// (fixed_base.cuh:fe_inv_dev: 0.32 ms for a lone wave in the 8 x 32-bit form, 0.18 ms with the reduced-radix product).  tools/safegcd_model.py is the same procedure on Python integers with the 32 / 64-bit ranges asserted.
+// (fixed_base.hip.h:fe_inv_dev: 0.32 ms for a lone wave in the 8 x 32-bit form, 0.18 ms with the reduced-radix product).  tools/safegcd_model.py is the same procedure on Python integers with the 32 / 64-bit ranges asserted.
 // a: a non-zero residue in the Fe form; returns its inverse in the Fe form (see Fp::INV_OUT_30).
 template <class M>
 __device__ __noinline__ Fe<M> fe_inv_safegcd(Fe<M> a) {

@@ -3,7 +3,7 @@
 // (absent) error behaviour: failures of the GPU path print one line and abort(), as there is no error
 // channel at this boundary and silently wrong MACs would be worse.
 //
-//   MSMs (compute_multi_exp, compute_digest_from_srs, create_proof)  -> HIP kernels (engine.hip / msm.cuh)
+//   MSMs (compute_multi_exp, compute_digest_from_srs, create_proof)  -> HIP kernels (engine.hip / msm.hip.h)
 //   single-point ops, Horner evaluation, pairing check               -> host (latency-bound, 64-byte operands)
 #include "engine.hpp"
 #include "pairing_host.hpp"
@@ -65,7 +65,7 @@ struct KzgState {
         Affine<Fp>* d_srs = nullptr;  // resident Montgomery copy of the SRS
         size_t d_srs_cap = 0;
         unsigned long long srs_version = 0, g_version = 0, h_version = 0;   // what the tables below were built from
-        FixedBase<Bn254G1> fb;        // window-multiples table of the SRS (fixed_base.cuh)
+        FixedBase<Bn254G1> fb;        // window-multiples table of the SRS (fixed_base.hip.h)
         FixedBase<Bn254G1> fb_g, fb_h;   // one-point tables of G1[0] and of the MAC hiding base (client-side batches)
         void* d_eval = nullptr;       // scratch: evaluated scalars of a digest batch
         size_t d_eval_cap = 0;
@@ -589,18 +589,30 @@ int porla_kzg_complement_batch_device(const void* d_scalars, size_t n, void* d_o
     return kd->fb_h.commit_device((const uint8_t*)d_scalars, n, 1, 32, (uint8_t*)d_out, (hipStream_t)hip_stream);
 }
 
+// the SRS size as the state holds it now (g.mu: init_SRS / init_SRS_from_data may run on another thread)
+static size_t kzg_n_samples() {
+    std::lock_guard<std::mutex> lk(g.mu);
+    return (size_t)g.n_samples;
+}
+// coefficients per commitment row = SRS size (0 before init_SRS*): callers that slice a row-major batch derive the row stride
+// (32 bytes per coefficient) from it instead of assuming the reference's 128 (config.hpp NUM_CHUNKS)
+int porla_kzg_row_coefficients(size_t* n_out) {
+    if (!n_out) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    *n_out = kzg_n_samples();
+    return PORLA_OK;
+}
 // ---- batched form of compute_digest_from_srs (include/porla_gpu.h) ----
 int porla_kzg_commit_batch_device(const void* d_rows, size_t n_rows, void* d_out, void* hip_stream) {
     if (n_rows && (!d_rows || !d_out)) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
     int rc = ensure_device();
     if (rc) return rc;
-    return commit_rows((const uint8_t*)d_rows, true, n_rows, (size_t)g.n_samples, (uint8_t*)d_out, (hipStream_t)hip_stream);
+    return commit_rows((const uint8_t*)d_rows, true, n_rows, kzg_n_samples(), (uint8_t*)d_out, (hipStream_t)hip_stream);
 }
 int porla_kzg_commit_batch_host(const uint8_t* rows, size_t n_rows, uint8_t* out) {
     if (n_rows && (!rows || !out)) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
     int rc = ensure_device();
     if (rc) return rc;
-    return commit_rows(rows, false, n_rows, (size_t)g.n_samples, out, nullptr);
+    return commit_rows(rows, false, n_rows, kzg_n_samples(), out, nullptr);
 }
 // Server::HAdd for the KZG build, everything it computes before the level bookkeeping (Server.hpp:1388-1428): data_B2 = data * wt
 // aligned mod p_icc, MAC_B2 = wt * MAC, MAC_align_B2 = Commit(alignment scalars of data_B2) -- align_MAC's compute_digest_from_srs
@@ -608,7 +620,7 @@ int porla_kzg_commit_batch_host(const uint8_t* rows, size_t n_rows, uint8_t* out
 int porla_kzg_hadd_host(const uint8_t* data_in, const uint8_t mac_in[64], size_t n_total, unsigned long long write_step,
                         uint8_t* data_b2_out, uint8_t mac_b2_out[64], uint8_t mac_align_b2_out[64]) {
     if (!data_in || !mac_in || !data_b2_out || !mac_b2_out || !mac_align_b2_out) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
-    const size_t n_cols = (size_t)g.n_samples;
+    const size_t n_cols = kzg_n_samples();
     if (n_cols == 0) { set_last_error("porla: SRS not initialised"); return PORLA_ERR_STATE; }
     std::vector<uint8_t> scalars(32 * n_cols);
     uint8_t wt[32];
@@ -630,7 +642,7 @@ int porla_kzg_commit_batch_host_multi(const uint8_t* rows, size_t n_rows, uint8_
     int G = devices <= 0 ? visible : (devices < visible ? devices : visible);
     if ((size_t)G > n_rows) G = (int)n_rows;
     if (G < 1) G = 1;
-    const size_t len = (size_t)g.n_samples;
+    const size_t len = kzg_n_samples();
     std::vector<int> rcs((size_t)G, PORLA_OK);
     std::vector<std::string> errs((size_t)G);
     auto worker = [&](int d) {

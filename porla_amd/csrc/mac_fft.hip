@@ -1,17 +1,17 @@
 // MAC-side ICC encode: launch logic + C ABI (include/porla_gpu.h: porla_icc_mac_encode_device / _host).
 //
 // Two forms of the same linear map over the group (bit-exact on the affine result):
-//   ladder (N > PORLA_MAC_MATRIX_MAX, default 2048): stage by stage, one lane per butterfly (mac_fft.cuh); a stage costs
+//   ladder (N > PORLA_MAC_MATRIX_MAX, default 2048): stage by stage, one lane per butterfly (mac_fft.hip.h); a stage costs
 //          one 256-bit scalar multiplication of LATENCY (~2.9 ms for a lone wave), so small N is latency-bound;
 //   matrix (N <= 2048): out_k = sum_i F[k][i] * MAC_i with F = the butterfly network as an N x N matrix over Z_q (the
 //          data-side encode applied to the identity, cached per (N, curve, part, wt)); evaluated as N commitments
-//          against the per-call base {MAC_i} with the batched fixed-base kernels (fixed_base.cuh, 8-bit windows):
+//          against the per-call base {MAC_i} with the batched fixed-base kernels (fixed_base.hip.h, 8-bit windows):
 //          N^2 * 32 independent mixed additions instead of log2(N) dependent ladders -- throughput- not latency-bound.
 // Patch site in the reference (no function boundary exists there): the MAC halves of Server::CRebuild_Cached,
 // porla/Server/Server.hpp:1523-1536, 1590-1609, 1658-1676 and the Y-part twins; see INTEGRATION.md.
 #include "engine.hpp"
 #include <cstring>
-#include "mac_fft.cuh"
+#include "mac_fft.hip.h"
 #include "icc_host.hpp"
 
 #include <cstdlib>

@@ -1,4 +1,4 @@
-// MAC-side ICC encode ("FFT in the exponent") on gfx950: the butterfly network of icc.cuh applied to group elements.
+// MAC-side ICC encode ("FFT in the exponent") on gfx950: the butterfly network of icc.hip.h applied to group elements.
 //
 // Reference: Server::CRebuild_Cached interleaves, with every data butterfly, the same butterfly on the block MACs
 //   tm = v^j * MAC[k+m2];  MAC[k] = um + tm;  MAC[k+m2] = um - tm
@@ -13,12 +13,12 @@
 // stages (128 B per MAC), so a stage is N/2 * (256 doublings + ~64 additions) and is VALU (integer multiply) bound;
 // HBM traffic is 2 * 128 B per MAC per stage.  Stage twiddles with value 1 (j = 0) skip the ladder.
 #pragma once
-#include "fixed_base.cuh"
-#include "icc.cuh"
+#include "fixed_base.hip.h"
+#include "icc.hip.h"
 
 namespace porla {
 
-// plain little-endian limbs of (w^e mod p_icc) mod q for e in [0, n)   (cf. k_icc_twiddles in icc.cuh)
+// plain little-endian limbs of (w^e mod p_icc) mod q for e in [0, n)   (cf. k_icc_twiddles in icc.hip.h)
 template <class Q>
 __global__ void k_mac_twiddles(uint32_t* __restrict__ tws, uint32_t n, const Fe<IccFp>* __restrict__ wpow, int logn) {
     uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -90,10 +90,10 @@ __device__ __noinline__ XYZZ<M> xyzz_scalar_mul(XYZZ<M> P, const uint32_t k[8]) 
 }
 
 // ---------------------------------------------------------------- the same ladder in the reduced-radix form (C::F30_LAZY)
-// k * P with the curve's endomorphism: k = k1 + lambda k2 (glv.cuh; |k1|, |k2| < 2^128), then ONE joint ladder over both
+// k * P with the curve's endomorphism: k = k1 + lambda k2 (glv.hip.h; |k1|, |k2| < 2^128), then ONE joint ladder over both
 // halves -- 33 signed 4-bit windows, 4 doublings each, and per window at most one addition from the table of P's multiples
 // and one from the same table with X scaled by beta (= the table of phi(P)): 132 doublings + <= 66 additions instead of
-// 260 + 65, every field product in the 9 x 30-bit form of fe30.cuh.  Points are in the lazy memory form of ec30.cuh.
+// 260 + 65, every field product in the 9 x 30-bit form of fe30.hip.h.  Points are in the lazy memory form of ec30.hip.h.
 template <class C>
 __device__ __noinline__ void mac30_scalar_mul(XYZZ<typename C::Fp>* out, const XYZZ<typename C::Fp>* P, const uint32_t k[8]) {
     using M = typename C::Fp;
@@ -229,14 +229,14 @@ k_mac_stage30(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restric
 // ---------------------------------------------------------------- the butterfly stage with FOUR LANES per butterfly
 // Below N = 2^16 rows a stage is one lone wave per SIMD walking a ladder of ~200 dependent group operations: its time is the
 // latency of those operations (1.08 ms with one lane per butterfly).  Here every group operation runs on the four lanes of a
-// quad (ec30.cuh: xyzz30_add_quad 3.6 us instead of 7, xyzz30_dbl_quad 3 rounds of products instead of 9 in sequence); the
+// quad (ec30.hip.h: xyzz30_add_quad 3.6 us instead of 7, xyzz30_dbl_quad 3 rounds of products instead of 9 in sequence); the
 // ladder is the same (endomorphism split, 33 signed 4-bit windows, one table of multiples, phi(P)'s entries by scaling X with
 // beta), its state -- table, accumulator, the operand being added -- lives in LDS, and the control flow is the same for every
 // butterfly of the block (a zero digit computes its addition and does not store it), so block barriers order the LDS traffic.
 constexpr int MACQ_BF = 32;                       // butterflies per block (128 lanes): 11 slots of 128 B each = 44 KiB of LDS
 
 // signed 4-bit digit i (0 .. 32) of the 128-bit magnitude m: ((m >> 4i) & 15) + carry, minus 16 above 8.  The carry into
-// window i is 1 exactly when the bits below it exceed 0x88..8 (the recoding with digits in (-8, 8] is unique: msm_small.cuh).
+// window i is 1 exactly when the bits below it exceed 0x88..8 (the recoding with digits in (-8, 8] is unique: msm_small.hip.h).
 __device__ __forceinline__ int mac_signed_digit(const uint32_t m[4], int i) {
     bool gt = false, eq = true;
 #pragma unroll

@@ -16,7 +16,7 @@
 //                       lanes of a wave run the same trip count; a heavy bucket becomes many items (skew-proof)
 //   k_bucket_sum30      ONE THREAD PER WORK ITEM: walks its index list, gathers 64-B points (L2 / Infinity-Cache
 //                       resident: 2^20 points = 64 MiB) and accumulates with the 8M+2S mixed add in the reduced-radix
-//                       field form of fe30.cuh / ec30.cuh (k_bucket_sum: the same on 8 x 32-bit limbs, kept for curves
+//                       field form of fe30.hip.h / ec30.hip.h (k_bucket_sum: the same on 8 x 32-bit limbs, kept for curves
 //                       without that form)
 //   k_bucket_combine    wave per multi-item bucket: folds that bucket's item sums (no-op for uniform scalars)
 //   k_tree_level(_quad), k_tree_tail   per window sum_b (b+1)*B_b as a bit-sliced tree: S (plain sum) and M_k (sum of the
@@ -28,9 +28,9 @@
 // of a 64-B point (the 64 MiB point set lives in the Infinity Cache; PMC: 3.1 GB of fabric requests per 2^20-pair launch).
 // The accumulation is VALU (integer multiply) bound, see DESIGN.md s4.
 #pragma once
-#include "ec.cuh"
-#include "ec30.cuh"
-#include "glv.cuh"
+#include "ec.hip.h"
+#include "ec30.hip.h"
+#include "glv.hip.h"
 #include <type_traits>
 
 namespace porla {
@@ -46,10 +46,10 @@ struct Bn254G1 {
     // 254-bit scalars fill 16 windows of 16 bits exactly; the GLV split would halve the windows but double the entries per
     // bucket and the gathered point set (measured: 3.31 ms vs 2.85 ms at 2^20) -- off by default, on with porla_gpu_set_msm_glv(1)
     static constexpr bool GLV_DEFAULT = false;
-    static constexpr size_t GLV_BELOW = (size_t)1 << 17;   // ... but on up to this many pairs (msm_impl.cuh:msm_use_glv)
-    // bucket accumulation in the reduced-radix field form (fe30.cuh / ec30.cuh): 1.35-1.6x the field-product rate
+    static constexpr size_t GLV_BELOW = (size_t)1 << 17;   // ... but on up to this many pairs (msm_impl.hip.h:msm_use_glv)
+    // bucket accumulation in the reduced-radix field form (fe30.hip.h / ec30.hip.h): 1.35-1.6x the field-product rate
     static constexpr bool F30_BUCKETS = true;
-    // ... and the sums stay in that form ("lazy" memory form of ec30.cuh: unreduced residues, X <= 5p < 2^256) through the
+    // ... and the sums stay in that form ("lazy" memory form of ec30.hip.h: unreduced residues, X <= 5p < 2^256) through the
     // combine and tree kernels
     static constexpr bool F30_LAZY = true;
     static constexpr int BUCKET_SUM_WAVES = 4;   // waves per SIMD k_bucket_sum30 is compiled for
@@ -134,7 +134,7 @@ __device__ __forceinline__ XYZZ<M> load_xyzz(const XYZZ<M>* src) {
 // ------------------------------------------------------------------------------------------------
 // G1Affine.Unmarshal semantics for the uncompressed form (main.go:130): X, Y <- SetBytes (reduced
 // mod p); (0,0) stays (0,0) = infinity.  Output: Montgomery limbs, 64 B per point.
-// F30: the residues are stored in the 2^270 Montgomery form of fe30.cuh (still canonical 256-bit values) -- the MSM's
+// F30: the residues are stored in the 2^270 Montgomery form of fe30.hip.h (still canonical 256-bit values) -- the MSM's
 // bucket accumulation with C::F30_BUCKETS; every other consumer takes the 2^256 form.
 template <class C, bool GLV, bool F30 = false>
 __global__ void k_points_to_mont(const uint8_t* __restrict__ in, Affine<typename C::Fp>* __restrict__ out, uint32_t n) {
@@ -656,8 +656,8 @@ k_bucket_sum(const Affine<typename C::Fp>* __restrict__ pts, const uint32_t* __r
     else store_xyzz<M>(chunk_out + cb + item.y, acc);
 }
 
-// The same accumulation in the reduced-radix field form (ec30.cuh): the points arrive in the 2^270 Montgomery form
-// (k_points_to_mont<.., F30>), the item's sum leaves in the lazy memory form of ec30.cuh, which the combine and tree kernels
+// The same accumulation in the reduced-radix field form (ec30.hip.h): the points arrive in the 2^270 Montgomery form
+// (k_points_to_mont<.., F30>), the item's sum leaves in the lazy memory form of ec30.hip.h, which the combine and tree kernels
 // of this curve read; the last tree level converts to the 2^256 form for the host.
 template <class C>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C::BUCKET_SUM_WAVES, 4)))
@@ -736,8 +736,8 @@ struct TreeLevelArgs {
     uint32_t last;           // 1: write fin instead of s_out / m_out (+ one copy task per node for the aliased M_l)
 };
 
-// How the reduction kernels read, add and write bucket sums: the lazy reduced-radix form of ec30.cuh where the curve has
-// it (C::F30_LAZY), ec.cuh's XYZZ otherwise; `fin` (read by the host) is always XYZZ in the 2^256 form.
+// How the reduction kernels read, add and write bucket sums: the lazy reduced-radix form of ec30.hip.h where the curve has
+// it (C::F30_LAZY), ec.hip.h's XYZZ otherwise; `fin` (read by the host) is always XYZZ in the 2^256 form.
 template <class C>
 struct Node {
     using M = typename C::Fp;
@@ -803,7 +803,7 @@ __device__ __forceinline__ void tree_task(const TreeLevelArgs<typename C::Fp>& a
     if (o.final) N::store_final(o.out, x);
     else N::store(o.out, x);
 }
-// the same on the four lanes of a quad (ec30.cuh:xyzz30_add_quad): ALL lanes of the quad call it with the same arguments
+// the same on the four lanes of a quad (ec30.hip.h:xyzz30_add_quad): ALL lanes of the quad call it with the same arguments
 template <class C>
 __device__ __forceinline__ void tree_task_quad(const TreeLevelArgs<typename C::Fp>& a, uint32_t s, uint32_t i, uint32_t jp, uint32_t jo,
                                                bool live, uint32_t lane) {

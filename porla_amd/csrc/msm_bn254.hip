@@ -1,6 +1,6 @@
-// Bn254G1 instantiation of the bucket MSM (kernels + launch sequence); see msm.cuh / msm_impl.cuh.
-#include "msm_impl.cuh"
-#include "fixed_base_impl.cuh"
+// Bn254G1 instantiation of the bucket MSM (kernels + launch sequence); see msm.hip.h / msm_impl.hip.h.
+#include "msm_impl.hip.h"
+#include "fixed_base_impl.hip.h"
 
 namespace porla {
 template int msm_device<Bn254G1>(const uint8_t*, const uint8_t*, size_t, hipStream_t, XYZZ<Bn254Fp>*);

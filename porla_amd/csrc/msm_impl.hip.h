@@ -3,7 +3,7 @@
 #pragma once
 #include "engine.hpp"
 #include "host_fold64.hpp"
-#include "msm_small.cuh"
+#include "msm_small.hip.h"
 #include <cstdlib>
 #include <chrono>
 #include <thread>
@@ -77,7 +77,7 @@ static inline int choose_window(size_t m, int bits) {
         double t_combine = 0.0;
         if (top_load > (double)CHUNK) t_combine = 50.0 + top_load / CHUNK / 64.0 * 7.0;
         if (load > 0.6 * CHUNK) t_combine += 1e6;                      // every bucket would need the combine pass
-        // ---- bucket reduction (bit-sliced tree, msm.cuh): level l holds W (l+1) B / 2^(l+1) independent additions; a level
+        // ---- bucket reduction (bit-sliced tree, msm.hip.h): level l holds W (l+1) B / 2^(l+1) independent additions; a level
         // launch costs at least one addition's latency, the per-window tail levels run back to back in one kernel; the host
         // then folds W c single-bit terms
         double t_reduce = 0.3 * W * c;
@@ -99,7 +99,7 @@ static inline int choose_window(size_t m, int bits) {
     return best;
 }
 
-// the single-launch path of msm_small.cuh (n <= SMALL_MAX_N): one kernel, results + shape written to pinned memory
+// the single-launch path of msm_small.hip.h (n <= SMALL_MAX_N): one kernel, results + shape written to pinned memory
 template <class C>
 static int msm_small_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_points_be, size_t n, hipStream_t stream) {
     using M = typename C::Fp;
@@ -351,7 +351,7 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
     return msm_tree_launch<C>(ws, bk, c, W, glv, stream);
 }
 
-// bucket reduction of W windows of 2^(c-1) buckets each (the bit-sliced tree of msm.cuh) into the workspace's pinned buffer;
+// bucket reduction of W windows of 2^(c-1) buckets each (the bit-sliced tree of msm.hip.h) into the workspace's pinned buffer;
 // records ws->done and leaves the shape for msm_finish
 template <class C>
 static int msm_tree_launch(Workspace* ws, const XYZZ<typename C::Fp>* buckets, int c, int W, bool glv, hipStream_t stream) {
@@ -628,9 +628,16 @@ int msm_host_multi(const uint8_t* scalars, const uint8_t* points, size_t n, int 
         constexpr int PIPE = MSM_MULTI_SLOTS;
         Workspace* slot_ws[PIPE] = {nullptr, nullptr, nullptr, nullptr};
         const int used_slots = R < PIPE ? R : PIPE;
+        // every slot is looked up (registry lock) BEFORE any slot mutex is taken: porla_gpu_release_msm_workspaces holds the
+        // registry lock while it try-locks the slots, so a slot mutex is never held across get_workspace_slot
+        Workspace* found[PIPE] = {nullptr, nullptr, nullptr, nullptr};
         for (int k = 0; k < used_slots && !r; k++) {
-            int rr = get_workspace_slot(MSM_MULTI_SLOT0 + k, &slot_ws[k]);
-            if (rr) { slot_ws[k] = nullptr; fail(rr); break; }
+            int rr = get_workspace_slot(MSM_MULTI_SLOT0 + k, &found[k]);
+            if (rr) { found[k] = nullptr; fail(rr); }
+        }
+        for (int k = 0; k < used_slots && !r; k++) {
+            int rr;
+            slot_ws[k] = found[k];
             slot_ws[k]->mu.lock();
             slot_ws[k]->pend_W = 0;
             slot_ws[k]->lone = false;       // (the two-stream tree made the host-buffer call slower: 2.72 -> 2.90 ms at 2^20)
@@ -732,11 +739,24 @@ static inline size_t msm_host_split_min() {
     static const size_t v = getenv("PORLA_MSM_SPLIT_MIN") ? (size_t)atoll(getenv("PORLA_MSM_SPLIT_MIN")) : ((size_t)1 << 18);
     return v;
 }
+// Devices the IMPLICIT range split of a blocking host-buffer call (compute_multi_exp, the secp256k1 shim) may touch.  One
+// process that owns the node -- the unmodified C++ Server -- spreads a large call over every visible GPU (0 = automatic,
+// DESIGN.md s5).  A rank of a one-process-per-GPU job sees the other ranks' GPUs too and must stay on its own: the call is
+// then range-pipelined on the current device only.  PORLA_MSM_DEVICES overrides both; the explicit *_host_multi entry points
+// take the caller's count.
+int dist_world_size();   // dist.hip: ranks of the in-library RCCL communicator, 0 without one
+static inline int msm_implicit_devices() {
+    if (getenv("PORLA_MSM_DEVICES")) return 0;   // msm_host_multi reads it
+    const char* ws = getenv("WORLD_SIZE");
+    const char* lws = getenv("LOCAL_WORLD_SIZE");
+    if ((ws && atoi(ws) > 1) || (lws && atoi(lws) > 1) || dist_world_size() > 1) return 1;
+    return 0;
+}
 template <class C>
 int msm_host(const uint8_t* scalars, const uint8_t* points, size_t n, XYZZ<typename C::Fp>* total) {
     int rc = ensure_device();
     if (rc) return rc;
-    if (n >= msm_host_split_min()) return msm_host_multi<C>(scalars, points, n, 0, 0, total);
+    if (n >= msm_host_split_min()) return msm_host_multi<C>(scalars, points, n, 0, msm_implicit_devices(), total);
     Workspace* ws;
     if ((rc = lease_blocking_slot(&ws))) return rc;
     std::lock_guard<std::mutex> lk(ws->mu, std::adopt_lock);

@@ -1,6 +1,6 @@
-// Secp256k1G instantiation of the bucket MSM (kernels + launch sequence); see msm.cuh / msm_impl.cuh.
-#include "msm_impl.cuh"
-#include "fixed_base_impl.cuh"
+// Secp256k1G instantiation of the bucket MSM (kernels + launch sequence); see msm.hip.h / msm_impl.hip.h.
+#include "msm_impl.hip.h"
+#include "fixed_base_impl.hip.h"
 
 namespace porla {
 template int msm_device<Secp256k1G>(const uint8_t*, const uint8_t*, size_t, hipStream_t, XYZZ<Secp256k1Fp>*);

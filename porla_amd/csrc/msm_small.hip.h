@@ -2,21 +2,21 @@
 // porla/Server/Server.hpp:585-587, 838-848, 900-901; the client's 176- and 1 408-point calls, porla/Client/Client.hpp:664-669,
 // 756-787) on both curves.
 //
-// The general path (msm.cuh) is built for throughput: ~20 dependent launches, a sort through global memory and a 15-level
+// The general path (msm.hip.h) is built for throughput: ~20 dependent launches, a sort through global memory and a 15-level
 // tree over mostly empty buckets cost 0.3-0.5 ms whatever the input.  Here ONE kernel does everything and what is left is
 // a chain of ~15 dependent group additions:
 //
 //   grid = 256 blocks of 256 lanes (one block per CU, one wave per SIMD: dependent chains run at the lone-wave latency).
 //   Every block first ORs all n scalars (<= 128 KB, L2 resident) to learn their bit length -- no host round trip: the audit's
 //   abs(int32) coefficients (utils.h:271-275) then need 9 windows of 4 bits instead of 32 -- and derives the shape from it:
-//   scalars longer than 128 bits are split with the curve endomorphism (k = k1 + lambda k2, glv.cuh; 2n sub-scalars of
+//   scalars longer than 128 bits are split with the curve endomorphism (k = k1 + lambda k2, glv.hip.h; 2n sub-scalars of
 //   <= 128 bits), so the host fold is <= 130 doublings instead of 255.
 //   block (w, s) owns window w and slice s of the sub-scalars:
 //     1. signed c-bit digits of its slice for its window (carries walked from window 0), counting-sorted by bucket in LDS
 //     2. T = 256 / buckets lanes share a bucket: each accumulates every T-th entry with the mixed addition (points are
 //        converted from the 64-byte wire format on the fly: the 2 extra products per addition are cheaper than a launch)
-//     3. the T partial sums of a bucket are folded, then the bucket reduction runs as the bit-sliced tree of msm.cuh
-//        (S and M_k per node) -- all in LDS, four lanes per addition (ec30.cuh:xyzz30_add_quad)
+//     3. the T partial sums of a bucket are folded, then the bucket reduction runs as the bit-sliced tree of msm.hip.h
+//        (S and M_k per node) -- all in LDS, four lanes per addition (ec30.hip.h:xyzz30_add_quad)
 //     4. the block's c sums (S, M_0 .. M_(c-2)) go to global memory; the LAST block of a window to arrive (one atomic per
 //        block) folds the slices' sums and writes fin[w][*] straight into pinned host memory, next to the shape (W, c)
 //   host: the same Horner fold over single bits as the general path (host_fold64.hpp).
@@ -24,7 +24,7 @@
 // Same arithmetic as the general path (digits, endomorphism split, mixed / full additions are the very same functions), so the
 // result is the same group element and the marshalled 64 bytes are bit-exact.
 #pragma once
-#include "msm.cuh"
+#include "msm.hip.h"
 
 namespace porla {
 
@@ -33,12 +33,15 @@ constexpr int SMALL_THREADS = 256;
 constexpr int SMALL_BLOCKS = 256;
 constexpr int SMALL_MAX_C = 8;                       // <= 128 buckets per window
 constexpr int SMALL_MAX_B = 1 << (SMALL_MAX_C - 1);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "msm_small.hip.h sizes its per-block state (about 105 KB of static LDS) for gfx950's 160 KB of LDS per CU; there is no smaller-LDS variant"
+#endif
 constexpr uint32_t SMALL_MAX_SUB = 8192;             // sub-scalars ONE block (a slice of a window) can hold: LDS, 13-bit local index
 constexpr int SMALL_MAX_S = 32;                      // slices per window: S * c <= 256 sums fit the LDS fold
 constexpr int SMALL_DONE_SLOT = 255;                 // counters[0 .. W): arrivals per window; [255]: finished windows
 constexpr uint32_t SMALL_HDR_WORDS = 32;             // pinned header in front of fin: [0] = sequence, [1] = W, [2] = c, [3] = glv
 
-// the single-launch commitment of fixed_base.cuh (k_fb_commit_small): rows per launch, slices per row
+// the single-launch commitment of fixed_base.hip.h (k_fb_commit_small): rows per launch, slices per row
 constexpr int FB_SMALL_MAX_ROWS = 64;            // 64 rows x 4 slices = 256 blocks: one round on the chip (96 rows: 0.19 ms, the batch kernels 0.22)
 constexpr int FB_SMALL_MAX_SLICES = 8;
 
@@ -345,7 +348,7 @@ k_small_msm(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ poi
         __syncthreads();
     }
     SMALL_STAMP(5);
-    // ---- 3b. bucket reduction: the bit-sliced tree of msm.cuh on one window's B buckets, in LDS
+    // ---- 3b. bucket reduction: the bit-sliced tree of msm.hip.h on one window's B buckets, in LDS
     const uint32_t nlev = (uint32_t)(cw - 1);
     auto s_level = [&](uint32_t l) { return slev + (B - (B >> l)); };     // B/2 + ... + B/2^l entries before level l
     auto m_half = [&](uint32_t h) { return mlev + (h & 1u) * (SMALL_MAX_B / 4 + 1); };

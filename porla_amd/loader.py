@@ -107,6 +107,7 @@ def _declare(L):
     L.porla_bn254_pairing_product_is_one.argtypes = [u8p, u8p, u8p, u8p, ctypes.c_int]; L.porla_bn254_pairing_product_is_one.restype = ctypes.c_int
     L.porla_kzg_set_commit_window.argtypes = [ctypes.c_int]; L.porla_kzg_set_commit_window.restype = ctypes.c_int
     L.porla_kzg_commit_shape.argtypes = [ctypes.POINTER(ctypes.c_int)] * 2; L.porla_kzg_commit_shape.restype = ctypes.c_int
+    L.porla_kzg_row_coefficients.argtypes = [ctypes.POINTER(ctypes.c_size_t)]; L.porla_kzg_row_coefficients.restype = ctypes.c_int
     L.porla_kzg_release_device_memory.argtypes = []; L.porla_kzg_release_device_memory.restype = ctypes.c_int
     L.porla_gpu_release_msm_workspaces.argtypes = []; L.porla_gpu_release_msm_workspaces.restype = ctypes.c_int
     L.porla_icc_mac_encode_device.argtypes = [vp, sz, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_int, vp, vp]

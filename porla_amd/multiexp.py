@@ -306,6 +306,13 @@ def profile_enable(on=True):
     lib.porla_gpu_profile_enable(int(on))
 
 
+def kzg_row_coefficients():
+    """coefficients per commitment row = the SRS size of this process (0 before init_SRS / init_SRS_from_data)"""
+    n = ctypes.c_size_t(0)
+    _check(lib.porla_kzg_row_coefficients(ctypes.byref(n)))
+    return n.value
+
+
 def kzg_commit_shape():
     """(window bits, windows per coefficient) of the resident SRS table"""
     c, w = ctypes.c_int(0), ctypes.c_int(0)

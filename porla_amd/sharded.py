@@ -54,12 +54,19 @@ def my_range(n):
     return mx.shard_range(n, rank, world)
 
 
-def sharded_commit_rows(rows, n_rows, commit=None):
+def sharded_commit_rows(rows, n_rows, commit=None, row_coefficients=None):
     """this rank's row range of a commitment batch -> (first row, its 64-byte commitments).  `commit(rows, n)` defaults to the
-    engine (porla_kzg_commit_batch_host); the CPU tests pass the oracle in its place."""
+    engine (porla_kzg_commit_batch_host); the CPU tests pass the oracle in its place.  A row is `row_coefficients` 32-byte
+    coefficients: by default the library's SRS size (porla_kzg_row_coefficients; the reference's NUM_CHUNKS = 128), or --
+    with a stand-in `commit` and no count given -- len(rows) / n_rows."""
     lo, hi = my_range(n_rows)
     fn = commit or mx.kzg_commit_batch_host
-    return lo, fn(rows[4096 * lo:4096 * hi], hi - lo)
+    if row_coefficients is None:
+        row_coefficients = mx.kzg_row_coefficients() if commit is None else (len(rows) // (32 * n_rows) if n_rows else 0)
+    stride = 32 * row_coefficients
+    if n_rows and (stride == 0 or len(rows) != stride * n_rows):
+        raise ValueError("commitment rows: %d bytes for %d rows of %d coefficients" % (len(rows), n_rows, row_coefficients))
+    return lo, fn(rows[stride * lo:stride * hi], hi - lo)
 
 
 def gather_objects(obj):

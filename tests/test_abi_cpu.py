@@ -138,7 +138,7 @@ def test_eip196_vectors_through_the_host_side_symbols():
 
 
 def test_host_field_arithmetic_without_adx_instructions():
-    """the x86-64 host pass multiplies with mulx / adcx / adox where the CPU has them (fe.cuh:mont_mul4_adx,
+    """the x86-64 host pass multiplies with mulx / adcx / adox where the CPU has them (fe.hip.h:mont_mul4_adx,
     host_fold64.hpp:mul512_adx); PORLA_NO_ADX=1 takes the portable products instead -- the path of any other host.  The known
     answers, the tree fold and the pairing self-check must come out the same there (a child process: the switch is read once)"""
     import subprocess
@@ -171,9 +171,44 @@ def test_mult_point_against_the_c_oracle_on_random_and_edge_scalars():
 
 def test_division_step_inversion_model_stays_inside_its_registers():
     """the finish kernels invert with 25 rounds of 30 Bernstein-Yang division steps on signed 30-bit limbs
-    (inv30.cuh:fe_inv_safegcd); tools/safegcd_model.py is that procedure on Python integers with every 32- / 64-bit
+    (inv30.hip.h:fe_inv_safegcd); tools/safegcd_model.py is that procedure on Python integers with every 32- / 64-bit
     register range asserted, against pow(V, -1, p) for both base fields -- edge values and random ones"""
     import subprocess
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "safegcd_model.py"), "2000"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "safegcd model: ok" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
+
+
+def test_unloadable_rccl_is_an_error_code_not_a_crash():
+    """ADVICE r02 (dist.hip:load_rccl): a candidate that fails to dlopen must end in PORLA_ERR_STATE with the loader's message --
+    dlerror() returns its message once and clears it, a second call appended NULL to a std::string.  PORLA_RCCL_LIB names THE
+    library to bind, nothing else is tried.  A child process: the first successful bind is kept for the process's lifetime."""
+    import subprocess
+    import sys
+    code = ("import ctypes, sys\n"
+            "from porla_amd import lib\n"
+            "buf = ctypes.create_string_buffer(128)\n"
+            "rc = lib.porla_dist_unique_id(buf)\n"
+            "lib.porla_gpu_last_error.restype = ctypes.c_char_p\n"
+            "print('rc', rc, lib.porla_gpu_last_error().decode())\n"
+            "w = ctypes.c_int(-1)\n"
+            "lib.porla_dist_info(None, ctypes.byref(w))\n"
+            "print('world', w.value)\n")
+    env = dict(os.environ, PORLA_RCCL_LIB="/nonexistent/librccl-not-here.so")
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("rc ")][0]
+    assert int(line.split()[1]) != 0                      # PORLA_ERR_STATE
+    assert "librccl-not-here.so" in line and "RCCL not found" in line
+    assert "world 0" in r.stdout
+
+
+def test_sharded_commit_rows_takes_its_row_stride_from_the_caller_or_the_library():
+    """ADVICE r02 (sharded.py): the row stride is 32 bytes x the SRS size, not a hard-coded 4096"""
+    from porla_amd import sharded
+    seen = []
+    rows = bytes(range(256)) * 3                          # 6 rows of 4 coefficients (128 B each)
+    lo, out = sharded.sharded_commit_rows(rows, 6, commit=lambda r, n: seen.append((bytes(r), n)) or b"x" * n)
+    assert lo == 0 and out == b"x" * 6 and seen == [(rows, 6)]
+    with pytest.raises(ValueError):
+        sharded.sharded_commit_rows(rows, 6, commit=lambda r, n: b"", row_coefficients=128)

@@ -28,8 +28,8 @@ def struct_tables(path, struct):
 
 
 def test_field_parameter_packs():
-    for path, struct, p in ((os.path.join(CSRC, "fe.cuh"), "Bn254Fp", gc.BN_P),
-                            (os.path.join(CSRC, "fe.cuh"), "Secp256k1Fp", gc.SECP_P),
+    for path, struct, p in ((os.path.join(CSRC, "fe.hip.h"), "Bn254Fp", gc.BN_P),
+                            (os.path.join(CSRC, "fe.hip.h"), "Secp256k1Fp", gc.SECP_P),
                             (os.path.join(CSRC, "host_curve.hpp"), "Bn254Fr", gc.BN_R)):
         t = struct_tables(path, struct)
         m = gc.mont(p)
@@ -40,13 +40,13 @@ def test_field_parameter_packs():
             assert p == 2**256 - 2**32 - 977
         else:
             assert t["R1"] == m["R1"] and t["R2"] == m["R2"], struct
-        if struct == "Bn254Fp":   # reduced-radix form of fe30.cuh: Montgomery radix 2^270
+        if struct == "Bn254Fp":   # reduced-radix form of fe30.hip.h: Montgomery radix 2^270
             assert t["R1_30"] == gc.limbs(pow(2, 270, p)) and t["R2_30"] == gc.limbs(pow(2, 256 + 270, p))
 
 
 def test_group_orders():
-    assert struct_tables(os.path.join(CSRC, "msm.cuh"), "Bn254G1")["ORDER"] == gc.limbs(gc.BN_R)
-    assert struct_tables(os.path.join(CSRC, "msm.cuh"), "Secp256k1G")["ORDER"] == gc.limbs(gc.SECP_N)
+    assert struct_tables(os.path.join(CSRC, "msm.hip.h"), "Bn254G1")["ORDER"] == gc.limbs(gc.BN_R)
+    assert struct_tables(os.path.join(CSRC, "msm.hip.h"), "Secp256k1G")["ORDER"] == gc.limbs(gc.SECP_N)
 
 
 def test_final_exponent_and_ate_loop():
@@ -57,7 +57,7 @@ def test_final_exponent_and_ate_loop():
 
 
 def test_reduced_radix_column_sums_fit_64_bits():
-    """fe30.cuh accumulates the 16..18 products of a column in one 64-bit register without carries: the worst case must fit"""
+    """fe30.hip.h accumulates the 16..18 products of a column in one 64-bit register without carries: the worst case must fit"""
     import check_fe30_bounds as cb
     assert all(cb.check(name, p) for name, p in cb.MODULI.items())
     # and the generated assembly is what the generator produces

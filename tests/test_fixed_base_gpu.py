@@ -1,4 +1,4 @@
-"""Parity of the batched fixed-base commitment kernels (porla_amd/csrc/fixed_base.cuh) against the oracle, through the
+"""Parity of the batched fixed-base commitment kernels (porla_amd/csrc/fixed_base.hip.h) against the oracle, through the
 C ABI (GPU box only).
 
 What the reference does row by row: compute_digest_from_srs (porla/main.go:103-116; callers

@@ -1,4 +1,4 @@
-"""CPU: the GLV scalar split compiled into the engine (porla_amd/csrc/glv.cuh, executed on the host through the diagnostic
+"""CPU: the GLV scalar split compiled into the engine (porla_amd/csrc/glv.hip.h, executed on the host through the diagnostic
 entry porla_glv_split) against the bit-for-bit Python model of tools/gen_glv.py, and the defining identity
 k = k1 + lambda * k2 (mod n) with |k1|, |k2| below the bound the window count relies on.  The reference's secp256k1 path
 performs the same split (secp256k1_scalar_split_lambda, porla/Utils/secp256k1_lib/scalar_impl.h:123-156)."""

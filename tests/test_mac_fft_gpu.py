@@ -1,4 +1,4 @@
-"""Parity of the HIP MAC-side encode ("FFT in the exponent", porla_amd/csrc/mac_fft.cuh) against the oracle, through the
+"""Parity of the HIP MAC-side encode ("FFT in the exponent", porla_amd/csrc/mac_fft.hip.h) against the oracle, through the
 C ABI (GPU box only).  Reference: the MAC halves of Server::CRebuild_Cached, porla/Server/Server.hpp:1523-1536 (init
 scaling), :1590-1609 and :1658-1676 (butterflies); client twin porla/Client/Client.hpp:1040-1453.  Bit-exact 64-byte MACs."""
 import ctypes

@@ -18,7 +18,7 @@ LAMBDA = 0x30644e72e131a029048b6e193fd84104cc37a73fec2bc5e9b8ca0b2d36636f23  # t
 @pytest.fixture(autouse=True, params=["glv", "plain", "general"])
 def scalar_split(request):
     """every test runs with the GLV scalar split and with plain full-width windows (inputs of up to 4096 pairs then take the
-    single-launch path of msm_small.cuh), and once more with that path switched off (the general path at every size)"""
+    single-launch path of msm_small.hip.h), and once more with that path switched off (the general path at every size)"""
     from porla_amd import lib
     lib.porla_gpu_set_msm_glv(0 if request.param == "plain" else 1)
     lib.porla_gpu_set_msm_small(0 if request.param == "general" else 1, 0)

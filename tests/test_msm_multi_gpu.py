@@ -101,7 +101,7 @@ def test_2p24_config3_whole_job(mx):
     assert mx.bn254_multi_exp(pt, sc, n) == want     # compute_multi_exp, automatic split
     if G == 1:
         # the same job device-resident on one GPU: ranges of 2^22 pairs into one bucket array (17-bit windows, the sort's staged
-        # path), and as ONE pass with 20-bit windows (the sort's scattered-store fallback) -- msm_impl.cuh:msm_launch
+        # path), and as ONE pass with 20-bit windows (the sort's scattered-store fallback) -- msm_impl.hip.h:msm_launch
         import time
         import torch
         d_sc = torch.frombuffer(bytearray(sc), dtype=torch.uint8).cuda()
@@ -127,7 +127,7 @@ def test_2p24_config3_whole_job(mx):
 
 
 def test_device_resident_ranges_share_one_bucket_array(mx):
-    """above 2^22 pairs a device-resident MSM runs as ranges into one bucket array (msm_impl.cuh:msm_launch): 2^22 + 12 345 pairs =
+    """above 2^22 pairs a device-resident MSM runs as ranges into one bucket array (msm_impl.hip.h:msm_launch): 2^22 + 12 345 pairs =
     two ranges; the same scalar repeated 300 000 times across the range boundary makes one bucket per window a multi-item
     bucket in BOTH ranges (k_bucket_combine adds the earlier range's sum), and a block of zero scalars leaves buckets that
     only one range touches"""

@@ -1,4 +1,4 @@
-"""GPU box: the single-launch MSM of msm_small.cuh (n <= 4096 pairs -- every size the reference issues: the audit's n_points
+"""GPU box: the single-launch MSM of msm_small.hip.h (n <= 4096 pairs -- every size the reference issues: the audit's n_points
 <= 3200 with abs(int32) coefficients, Server.hpp:585-587, 617-621, 838-848, 900-901; the client's 16 / 176 / 1408-point calls,
 Client.hpp:374-406, 756-787) against the oracle, through compute_multi_exp and the device-pointer entries, on both curves:
 every window width, every scalar length class (the kernel derives its shape from the scalars' bit length), edge operands."""

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""MSM wall time by size with the automatic window (both curves): checks the window model of msm_impl.cuh:choose_window."""
+"""MSM wall time by size with the automatic window (both curves): checks the window model of msm_impl.hip.h:choose_window."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

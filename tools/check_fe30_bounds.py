@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Worst-case column sums of fe30.cuh:f30_mul / f30_sqr for every modulus the engine uses: all must stay below 2^64.
+"""Worst-case column sums of fe30.hip.h:f30_mul / f30_sqr for every modulus the engine uses: all must stay below 2^64.
 Operand limbs 0..7 <= 2^30 - 1, limb 8 <= TOP - 1 (value < 2^258 -> TOP = 2^18); m_i <= 2^30 - 1; the modulus limbs are exact."""
 MODULI = {
     "bn254_p": 21888242871839275222246405745257275088696311157297823662689037894645226208583,
     "bn254_r": 21888242871839275222246405745257275088548364400416034343698204186575808495617,
     "p_icc": 207 * 2**248 + 1,
 }
-# the ICC kernel of icc30.cuh multiplies an UNREDUCED butterfly output (< 2^263: limb 8 < 2^23) by a twiddle (a product's result,
+# the ICC kernel of icc30.hip.h multiplies an UNREDUCED butterfly output (< 2^263: limb 8 < 2^23) by a twiddle (a product's result,
 # < p + 2^248: limb 8 < 2^17) modulo p_icc, the BN254 group order and the secp256k1 group order
 ICC_MODULI = {
     "p_icc": 207 * 2**248 + 1,

@@ -1,11 +1,11 @@
-// Device-vs-host check and throughput of the reduced-radix field product (porla_amd/csrc/fe30.cuh) against the portable
-// Montgomery product of fe.cuh: f30_mul(x, y) = x*y / 2^270, fe_mul_generic(x, y) = x*y / 2^256, so the two agree after one
+// Device-vs-host check and throughput of the reduced-radix field product (porla_amd/csrc/fe30.hip.h) against the portable
+// Montgomery product of fe.hip.h: f30_mul(x, y) = x*y / 2^270, fe_mul_generic(x, y) = x*y / 2^256, so the two agree after one
 // factor 2^14.  Operands: random reduced values, unreduced values up to 2^258 - 1, all-ones limbs, squares.
 // Built by porla_amd/csrc/Makefile as porla_amd/fe30_check; run by tests/test_fe_gpu.py on the GPU box.  --bench: G products/s.
 #include "host_curve.hpp"
-#include "icc.cuh"
-#include "ec30.cuh"
-#include "inv30.cuh"
+#include "icc.hip.h"
+#include "ec30.hip.h"
+#include "inv30.hip.h"
 #include <cstdio>
 #include <cstring>
 #include <random>

@@ -3,7 +3,7 @@
 // division -- for every field of the engine, on random, unreduced and all-ones-limb operands.
 // Built by porla_amd/csrc/Makefile as porla_amd/fe_check; run by tests/test_fe_gpu.py on the GPU box.
 #include "host_curve.hpp"
-#include "icc.cuh"
+#include "icc.hip.h"
 #include <cstdio>
 #include <random>
 #include <vector>

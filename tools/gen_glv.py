@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Derives and self-checks the GLV constants used by porla_amd/csrc/glv.cuh, and prints them as C++ initialisers.
+"""Derives and self-checks the GLV constants used by porla_amd/csrc/glv.hip.h, and prints them as C++ initialisers.
 
 Curves y^2 = x^3 + b have the endomorphism phi(x, y) = (beta*x, y) = lambda*(x, y) with beta^3 = 1 mod p, lambda^3 = 1 mod n.
 A scalar k is split as k = k1 + lambda*k2 (mod n) with |k1|, |k2| ~ sqrt(n) using a reduced basis (a1, b1), (a2, b2) of the
@@ -93,7 +93,7 @@ M256 = (1 << 256) - 1
 
 
 def split_model(d, k):
-    """bit-for-bit model of glv_split in glv.cuh: unsigned 256-bit words, constants by magnitude + compile-time sign"""
+    """bit-for-bit model of glv_split in glv.hip.h: unsigned 256-bit words, constants by magnitude + compile-time sign"""
     sh = d["shift"]
     assert d["g1"] < 1 << 256 and d["g2"] < 1 << 256
     c1 = (k * d["g1"] + (1 << (sh - 1))) >> sh       # approximates |b2| k / n

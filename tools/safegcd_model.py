@@ -1,4 +1,4 @@
-"""Model of porla_amd/csrc/inv30.cuh:fe_inv_safegcd on Python integers: the same 25 rounds of 30 Bernstein-Yang division
+"""Model of porla_amd/csrc/inv30.hip.h:fe_inv_safegcd on Python integers: the same 25 rounds of 30 Bernstein-Yang division
 steps on nine signed 30-bit limbs, with every value the device code keeps in a 32-bit or 64-bit register asserted to fit.
 usage: safegcd_model.py [samples per modulus]"""
 import random

@@ -1,4 +1,4 @@
-// Phase timing of k_small_msm (msm_small.cuh) with wall_clock64 stamps per block: where the ~100 us of a small MSM go.
+// Phase timing of k_small_msm (msm_small.hip.h) with wall_clock64 stamps per block: where the ~100 us of a small MSM go.
 // Synthetic operands (random residues: the group-law formulas execute the same instructions as on curve points).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DPORLA_SMALL_STAMPS -Iporla_amd/csrc tools/small_stamps.hip -o tools/small_stamps
 #include <hip/hip_runtime.h>
@@ -6,7 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
-#include "msm_small.cuh"
+#include "msm_small.hip.h"
 using namespace porla;
 
 int main(int argc, char** argv) {

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Wall time of one blocking MSM for every (size, window width) around the automatic choice: the data behind the window
-model of msm_impl.cuh:choose_window.  Usage: sweep_window_sizes.py [bn254|secp256k1] [full|int32]"""
+model of msm_impl.hip.h:choose_window.  Usage: sweep_window_sizes.py [bn254|secp256k1] [full|int32]"""
 import json, os, struct, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -6,8 +6,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "fe.cuh"
-#include "ec.cuh"
+#include "fe.hip.h"
+#include "ec.hip.h"
 using namespace porla;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
