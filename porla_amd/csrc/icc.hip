@@ -4,6 +4,7 @@
 #include "engine.hpp"
 #include "icc.hip.h"
 #include "icc30.hip.h"
+#include "icc30_split.hip.h"
 #include "icc_host.hpp"
 
 #include <cstdlib>
@@ -16,9 +17,10 @@ namespace porla {
 
 struct IccWs {
     int device = -1;
-    Buf work, tw, tw30, wpow, in, xo, al, sc;
+    Buf work, tw, tw30, tw30p, tw30q, wpow, in, xo, al, sc;
     uint32_t tw_n = 0, tw30_n = 0;   // tw30: the same table in the reduced-radix form of icc30.hip.h (80-byte slots)
-    int tw30_curve = -1;
+    uint32_t tw30s_n = 0;            // tw30p / tw30q: the plane tables of icc30_split.hip.h (40-byte slots)
+    int tw30_curve = -1, tw30s_curve = -1;
     int tw_curve = -1;
     UseFence fence;   // work / twiddle buffers are shared between calls that may come on different streams
     std::mutex mu;    // one encode at a time per device (the column-range splitter runs one host thread per device)
@@ -57,6 +59,7 @@ static int ensure_twiddles(IccWs* ws, int curve, size_t n, hipStream_t stream) {
     ws->tw_n = (uint32_t)n;
     ws->tw_curve = curve;
     ws->tw30_n = 0;
+    ws->tw30s_n = 0;
     return PORLA_OK;
 }
 
@@ -138,9 +141,20 @@ static int icc_encode_core(IccWs* ws, int curve, const uint8_t* d_rows, size_t n
         // ceil(logn / 8) passes of (almost) equal stage counts, each through LDS tiles of 512 symbols; the first pass reads
         // the raw chunks, the last one writes the outputs: the residue-pair working set only travels between passes.
         // Default: the reduced-radix kernel of icc30.hip.h (72 bytes per symbol between the passes); PORLA_ICC_F30=0: icc.hip.h's.
+        // PORLA_ICC_SPLIT=0: the kernel of icc30.hip.h (both residues of a symbol side by side in 80-byte LDS slots, one stage per
+        // round trip); default: icc30_split.hip.h (one plane at a time, two stages per round trip)
+        static const int split = !(getenv("PORLA_ICC_SPLIT") && getenv("PORLA_ICC_SPLIT")[0] == '0');
         if (f30) {
             if ((rc = ws->work.ensure(total * ICC30_PACK_WORDS * 4))) return rc;
-            if (ws->tw30_n != n || ws->tw30_curve != curve) {
+            if (split) {
+                if (ws->tw30s_n != n || ws->tw30s_curve != curve) {
+                    if ((rc = ws->tw30p.ensure(n * ICC30_PSLOT_WORDS * 4)) || (rc = ws->tw30q.ensure(n * ICC30_PSLOT_WORDS * 4))) return rc;
+                    hipLaunchKernelGGL((k_icc_twiddles30_planes<Q>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                                       (const IccElem<Q>*)ws->tw.p, (uint32_t)n, (uint32_t*)ws->tw30p.p, (uint32_t*)ws->tw30q.p);
+                    ws->tw30s_n = (uint32_t)n;
+                    ws->tw30s_curve = curve;
+                }
+            } else if (ws->tw30_n != n || ws->tw30_curve != curve) {
                 if ((rc = ws->tw30.ensure(n * ICC30_SLOT_WORDS * 4))) return rc;
                 hipLaunchKernelGGL((k_icc_twiddles30<Q>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                                    (const IccElem<Q>*)ws->tw.p, (uint32_t)n, (uint32_t*)ws->tw30.p);
@@ -160,7 +174,11 @@ static int icc_encode_core(IccWs* ws, int curve, const uint8_t* d_rows, size_t n
             ProfScope ps("icc_fused", stream, true);
 #define PORLA_ICC_LAUNCH(F, L)                                                                                              \
     do {                                                                                                                    \
-        if (f30)                                                                                                            \
+        if (f30 && split)                                                                                                   \
+            hipLaunchKernelGGL((k_icc_split30<Q, F, L>), grid, dim3(ICC30_SPLIT_THREADS), 0, stream, (uint32_t*)ws->work.p, \
+                               (uint32_t*)ws->work.p + total * ICC30_PLANE_WORDS, (const uint32_t*)ws->tw30p.p,            \
+                               (const uint32_t*)ws->tw30q.p, (uint32_t)n, (uint32_t)ncols, s, ns, cc_log, d_rows, wt, use_wt, out); \
+        else if (f30)                                                                                                       \
             hipLaunchKernelGGL((k_icc_fused30<Q, F, L>), grid, dim3(256), 0, stream, (uint32_t*)ws->work.p,                 \
                                (const uint32_t*)ws->tw30.p, (uint32_t)n, (uint32_t)ncols, s, ns, cc_log, d_rows, wt, use_wt, out); \
         else                                                                                                                \
