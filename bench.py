@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the MI355X commitment engine on BASELINE.json's metric, one rank per GPU.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bn254_msm|kzg_commit|secp256k1_msm|icc]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bn254_msm|kzg_commit|secp256k1_msm|icc|config3|crebuild]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 Default workload (the headline metric): a "step" is ONE 2^20-pair BN254 G1 MSM per GPU (BASELINE.json config 2, "KZG
@@ -9,31 +9,35 @@ scheme, single 2^20-point BN254 G1 MSM on 1 MI355X"), inputs resident in HBM in 
 big-endian scalars + 64-B X||Y points, porla/main.go:118-138) when the timed region starts.  With N > 1 every rank owns
 its own 2^20 pairs (input-range sharding, weak scaling), produces one partial Jacobian sum, the 96-byte partials are
 exchanged with ONE ncclAllGather issued from C++ inside libmultiexp.so (porla_dist_*; RCCL over xGMI) and folded with N-1 group
-additions on every host: the whole job is one N*2^20-pair MSM per step.  Steps are independent MSMs; `--in-flight 2` (default) keeps two of them in flight on two streams through the
-two-phase API (porla_bn254_msm_device_begin/_end) -- the audit issues its MSMs in pairs (Server.hpp:900-901) -- so the
-latency-bound tail of one MSM (bucket reduction, host fold) overlaps the bucket accumulation of the next; every step is
-still one complete MSM whose result is produced and checked, and K steps = K results inside the timed region
-(`--in-flight 1` = blocking calls).  The same JSON line carries `kzg_commits`: the second half of BASELINE.json's metric ("KZG commits/s"),
-2^17 rows x 128 coefficients per GPU against the resident SRS (compute_digest_from_srs hoisted over rows), timed
-separately after the MSM region, with the per-call figures of the real symbol next to it (one row per call from 1 and 8
-threads of a plain-C caller).  Also on the line, never as `value`: `blocking_ms_per_step` (the same MSM with one in flight),
-`audit_size_msm` (128 / 1 408 / 3 200 pairs: the sizes the reference issues) and
-`host_boundary` (compute_multi_exp on caller-owned pageable host buffers, PCIe included).
+additions on every host (SURVEY.md s8e): the whole job is one N*2^20-pair MSM per step.  Steps are independent MSMs;
+`--in-flight 2` (default) keeps two of them in flight on two streams through the two-phase API
+(porla_bn254_msm_device_begin/_end) -- the audit issues its MSMs in pairs (Server.hpp:900-901) -- so the latency-bound tail of
+one MSM (bucket reduction, host fold) overlaps the bucket accumulation of the next; every step is still one complete MSM whose
+result is produced and checked, and K steps = K results inside the timed region (`--in-flight 1` = blocking calls).
 
-Other workloads (parity-test configurations of BASELINE.json, selectable for profiling; never the default line):
-  kzg_commit      2^17 rows x 128 coefficients per GPU, commits/s                     (SURVEY.md s8(f)-1, config 3 variant)
-  secp256k1_msm   2^20-point secp256k1 MSM per GPU, bench_ecmult.c inputs            (config 4)
-  icc             2^15 rows x 128 columns ICC encode (X part + alignment) per GPU    (config 5)
+The same JSON line carries every other BASELINE.json configuration as a LEG -- an object with its own value, roofline,
+cpu_baseline and bit_exact_vs_oracle, timed separately after the headline region, never as `value`:
+  kzg_commits     2^17 rows x 128 coefficients per GPU against the resident SRS (the second half of the metric, "KZG commits/s";
+                  compute_digest_from_srs hoisted over rows), with the per-call figures of the real symbol from a plain-C caller
+  secp256k1_msm   2^20-point secp256k1 ecmult_multi per GPU, bench_ecmult.c's inputs                        (config 4)
+  icc             2^15 rows x 128 columns ICC encode (X part + alignment scalars) per GPU = 2^22 elements      (config 5)
+  config3         ONE 2^24-pair BN254 MSM over all ranks: 2^24 / N pairs per rank (strong scaling), partials exchanged and
+                  folded as above, the whole job checked against the oracle                                   (config 3)
+and, for the headline MSM: `blocking_ms_per_step` + `blocking_kernels_ms` (one MSM in flight: what a caller that waits for
+every result sees, with its own per-kernel breakdown), `audit_size_msm` (128 / 1 408 / 3 200 pairs: the sizes the reference
+issues), `host_boundary` (compute_multi_exp on caller-owned pageable host buffers, PCIe included).
+`--workload X` prints leg X alone as the line (`crebuild`: the device-resident last encode stage, tools/bench_crebuild.py).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel of the workload, timed with HIP events on the
 launch stream inside the library over the timed region; `traffic` comes from the committed rocprofv3 PMC passes
-(profiles/pmc_latest.json: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, KiB -> bytes, per launch);
-`cpu_baseline` is the oracle (CPU restatement -- NOT gnark / libsecp256k1 / NTL) timed on this box's host cores.
+(profiles/pmc_latest*.json: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, KiB -> bytes, per launch);
+`int_multiplier.peak` is measured in this run on this box (porla_amd/fe30_check --peak: back-to-back products of the field
+form the kernels use); `cpu_baseline` is the oracle (CPU restatement -- NOT gnark / libsecp256k1 / NTL) timed on this box's
+host cores.
 """
 import argparse
 import ctypes
 import subprocess
-import hashlib
 import json
 import os
 import sys
@@ -46,21 +50,23 @@ HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E peak, /opt/skills/guides/MI355X_MIC
 MSM_BYTES_PER_PAIR = 96       # 32-B scalar + 64-B affine point
 COMMIT_BYTES_PER_ROW = 4096 + 64  # 128 x 32-B coefficients in, 64-B point out (SRS table resident)
 ICC_BYTES_PER_ELEMENT = 64    # 32 B in + 32 B out
-# measured back-to-back 256-bit modular products, G/s per GPU, in the reduced-radix form of fe30.hip.h the accumulation kernels
-# compute in (profiles/r01_l_ubench_fe30.txt): BN254 180.7 G products/s and 213.6 G squares/s ->
-# 186.5 for the 8M + 2S mix of a mixed addition; secp256k1 (special-form fold) 194.2 and 226.2 -> 199.9
-FE_MUL_PEAK_G = {"bn254_msm": 186.5, "kzg_commit": 186.5, "secp256k1_msm": 199.9}
+# fallback when the in-run measurement is unavailable: back-to-back 256-bit modular products, G/s per GPU, in the reduced-radix
+# form of fe30.hip.h (profiles/r01_l_ubench_fe30.txt): BN254 180.7 G products/s and 213.6 G squares/s -> 186.5 for the 8M + 2S
+# mix of a mixed addition; secp256k1 (special-form fold) 194.2 and 226.2 -> 199.9
+FE_MUL_PEAK_FALLBACK = {"bn254": 186.5, "secp256k1": 199.9}
+WORKLOAD_FIELD = {"bn254_msm": "bn254", "kzg_commit": "bn254", "secp256k1_msm": "secp256k1", "config3": "bn254"}
+PMC_FILE = {"bn254_msm": "pmc_latest.json", "config3": "pmc_latest.json"}
 
 KERNEL_SYMBOL = {  # profile slot -> substring of the kernel symbol in the rocprofv3 output
     "bucket_sum": "k_bucket_sum30", "tree_levels": "k_tree_level", "tree_tail": "k_tree_tail", "partition_sort": "k_partition_sort",
     "fb_commit": "k_fb_commit", "digits_partition": "k_digits_partition", "points_to_mont": "k_points_to_mont",
-    "icc_fused": "k_icc_fused30", "icc_stages_r4": "k_icc_stages", "icc_stages_r2": "k_icc_stages", "icc_load": "k_icc_load", "icc_finish": "k_icc_finish",
+    "icc_fused": "k_icc_split30", "icc_stages_r4": "k_icc_stages", "icc_stages_r2": "k_icc_stages", "icc_load": "k_icc_load", "icc_finish": "k_icc_finish",
 }
 
 
 def pmc_traffic(slot, workload):
     """HBM-side bytes per launch of `slot`'s kernel from the committed PMC summary of this workload, or None"""
-    path = os.path.join(ROOT, "profiles", "pmc_latest.json" if workload == "bn254_msm" else "pmc_latest_%s.json" % workload)
+    path = os.path.join(ROOT, "profiles", PMC_FILE.get(workload, "pmc_latest_%s.json" % workload))
     sym = KERNEL_SYMBOL.get(slot, slot)
     try:
         d = json.load(open(path))
@@ -82,8 +88,22 @@ def child_env():
     return {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCPROF", "ROCPROFILER", "ROCP_"))}
 
 
-def sha_rows(seed, count):
-    return b"".join(hashlib.sha256(seed + i.to_bytes(4, "little")).digest() for i in range(count))
+def measure_fe_mul_peak():
+    """back-to-back product / square rates of both base fields on THIS box, now (a child process, ~0.1 s of GPU time), as the
+    8M + 2S mix of a mixed addition: G fe_mul/s per field, or the committed round-1 figures when the tool is missing"""
+    exe = os.path.join(ROOT, "porla_amd", "fe30_check")
+    try:
+        r = subprocess.run([exe, "--peak"], capture_output=True, text=True, timeout=120, env=child_env())
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        out = {}
+        for field in ("bn254", "secp256k1"):
+            m, s = d[field]["mul_G_s"], d[field]["sqr_G_s"]
+            out[field] = {"mix_8M_2S": round(10.0 / (8.0 / m + 2.0 / s), 2), "mul_G_s": m, "sqr_G_s": s,
+                          "source": "porla_amd/fe30_check --peak in this run (%d waves per SIMD)" % d["waves_per_simd"]}
+        return out
+    except Exception as e:  # noqa: BLE001
+        return {f: {"mix_8M_2S": v, "source": "profiles/r01_l_ubench_fe30.txt (in-run measurement failed: %r)" % (e,)}
+                for f, v in FE_MUL_PEAK_FALLBACK.items()}
 
 
 def main():
@@ -91,22 +111,36 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="bn254_msm", choices=["bn254_msm", "kzg_commit", "secp256k1_msm", "icc"])
+    ap.add_argument("--workload", default="bn254_msm",
+                    choices=["bn254_msm", "kzg_commit", "secp256k1_msm", "icc", "config3", "crebuild"])
     ap.add_argument("--log2n", type=int, default=20, help="MSM pairs per GPU = 2^log2n (default: the 2^20 of BASELINE.json)")
     ap.add_argument("--log2rows", type=int, default=17, help="kzg_commit rows per GPU = 2^log2rows; icc rows = 2^(log2rows-2)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / bit-exact check leg")
+    ap.add_argument("--log2job", type=int, default=24, help="config3: pairs of the whole job = 2^log2job, split over the ranks")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / bit-exact check legs")
     ap.add_argument("--no-commits", action="store_true", help="bn254_msm: skip the kzg_commits leg")
+    ap.add_argument("--no-legs", action="store_true", help="bn254_msm: skip the secp256k1_msm / icc / config3 legs")
+    ap.add_argument("--no-config3", action="store_true", help="bn254_msm: skip the config3 leg")
     ap.add_argument("--no-host-boundary", action="store_true", help="bn254_msm: skip the compute_multi_exp-on-host-buffers leg")
     ap.add_argument("--in-flight", type=int, default=2, help="bn254_msm: independent MSMs in flight (1 = blocking calls; 2 = the "
                     "audit's pair of MSMs, Server.hpp:900-901, overlapped on two streams)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
+    if args.workload == "crebuild":
+        # the device-resident last encode stage has its own driver (same JSON contract), run as a child: nothing here has touched
+        # the GPU yet
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_crebuild.py"), "--steps", str(args.steps),
+                            "--warmup", str(args.warmup)] + (["--no-cpu"] if args.no_cpu else []))
+        sys.exit(r.returncode)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # the multiplier's rate on this box, before this process has any work on the GPU (rank 0 measures, one device)
+    fe_peak = measure_fe_mul_peak() if rank == 0 else None
+
+    import torch
+    import torch.distributed as dist
+
     # PORLA_DIST_BACKEND=gloo: exercise the multi-rank path on a box with fewer GPUs than ranks (ranks share devices, the
     # 96-byte partials travel over gloo on the host); the driver's runs use nccl = RCCL over xGMI, one rank per GPU
     backend = os.environ.get("PORLA_DIST_BACKEND", "nccl")
@@ -219,6 +253,18 @@ def main():
         timed.dominant = [name for name, ms, cnt in prof]
         return el, kern, res
 
+    def breakdown(step, reps=3):
+        """per-kernel HIP-event times (ms per launch, ms per step) of `reps` untimed steps issued one at a time"""
+        sync()
+        mx.profile_enable(True)
+        for _ in range(reps):
+            step()
+            torch.cuda.synchronize()
+        prof = mx.profile_get()
+        mx.profile_enable(False)
+        return ({name: round(ms / max(cnt, 1), 4) for name, ms, cnt in prof},
+                {name: round(ms / reps, 4) for name, ms, cnt in prof})
+
     def roofline(kern, algo_bytes_per_launch, workload, fe_mults_per_launch=None):
         if not kern:
             return None
@@ -227,17 +273,17 @@ def main():
         r = {"bound": "hbm", "kernel": KERNEL_SYMBOL.get(dom, dom), "achieved": round(ach, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
              "frac": round(ach / HBM_PEAK_GBPS, 6), "traffic": pmc_traffic(dom, workload),
              "traffic_source": "committed rocprofv3 --pmc passes (profiles/%s), not collected in this run"
-                               % ("pmc_latest.json" if workload == "bn254_msm" else "pmc_latest_%s.json" % workload),
+                               % PMC_FILE.get(workload, "pmc_latest_%s.json" % workload),
              "kernel_ms": round(kern[dom], 4), "all_kernels_ms": {k: round(v, 4) for k, v in kern.items()}}
-        if fe_mults_per_launch:
-            # the elliptic-curve kernels are bound by the 32x32->64 multiplier issue rate, which neither "hbm" nor "mfma"
+        if fe_mults_per_launch and fe_peak:
+            # the elliptic-curve kernels are bound by the VALU's 32x32->64 multiply-add issue rate, which neither "hbm" nor "mfma"
             # names: the supplement prices the dominant kernel's 256-bit modular multiplications against the rate the
-            # multiply microbenchmark sustains on this chip (tools/fe30_check.hip --bench, tools/ubench.hip; profiles/r01_l_ubench_fe30.txt)
+            # multiply microbenchmark sustains on this chip in this run (tools/fe30_check.hip --peak)
             g = fe_mults_per_launch / (kern[dom] * 1e-3) / 1e9
-            peak = FE_MUL_PEAK_G[workload]
-            r["int_multiplier"] = {"achieved": round(g, 2), "peak": peak, "unit": "G fe_mul/s (256-bit modular)",
-                                   "frac": round(g / peak, 4),
-                                   "note": "mixed addition = 8M + 2S = 10 fe_mul; peak = measured back-to-back product rate "
+            pk = fe_peak[WORKLOAD_FIELD[workload]]
+            r["int_multiplier"] = {"achieved": round(g, 2), "peak": pk["mix_8M_2S"], "unit": "G fe_mul/s (256-bit modular)",
+                                   "frac": round(g / pk["mix_8M_2S"], 4), "peak_source": pk["source"],
+                                   "note": "mixed addition = 8M + 2S = 10 fe_mul; peak = back-to-back product rate "
                                            "of the field form the kernel uses (8M + 2S mix)"}
         return r
 
@@ -246,7 +292,15 @@ def main():
         c, windows, glv = mx.last_msm_shape()
         return 10.0 * n * (2 if glv else 1) * windows
 
-    # ---------------------------------------------------------------- KZG batched commitments (shared by two workloads)
+    def line(metric, value, unit, el, scaling, dtype, config, rl, cpu, verified, **extra):
+        d = {"metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+             "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+             "dtype": dtype, "data": "synthetic", "config": config, "roofline": rl, "cpu_baseline": cpu,
+             "bit_exact_vs_oracle": verified}
+        d.update(extra)
+        return d
+
+    # ---------------------------------------------------------------- KZG batched commitments
     def kzg_setup():
         tau = bytes.fromhex("ffeeddccbbaa99887766554433221100")     # TAU_KEY, config.hpp:39
         alpha = bytes.fromhex("00112233445566778899aabbccddeeff")   # SECRET_KEY, config.hpp:38
@@ -260,7 +314,8 @@ def main():
         o.oracle_kzg_srs_g1_raw(raw)
         return raw.raw
 
-    def kzg_commit_leg(rows_n):
+    def leg_kzg_commit():
+        rows_n = 1 << args.log2rows
         srs_raw = kzg_setup()
         g = torch.Generator(device=dev).manual_seed(1234 + rank)
         d_rows = torch.randint(0, 256, (rows_n * 4096,), dtype=torch.uint8, device=dev, generator=g)
@@ -284,22 +339,13 @@ def main():
             for threads in (1, 8):
                 try:
                     r = subprocess.run([harness, "bench", str(threads), "1500"], capture_output=True, text=True, timeout=180, env=child_env())
-                    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-                    d = json.loads(line)
+                    ln = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+                    d = json.loads(ln)
                     per_call["threads_%d" % threads] = {"commits_per_s": d["commits_per_s"], "latency_ms_per_call": d["latency_ms_per_call"],
                                                         "consistent": d["consistent"]}
                 except Exception as e:  # noqa: BLE001
                     per_call["threads_%d" % threads] = {"error": repr(e)}
         cshape = mx.kzg_commit_shape()
-        out = {"value": round(world * rows_n * args.steps / el, 1), "unit": "commits/s", "rows_per_gpu": rows_n,
-               "table": {"window_bits": cshape[0], "windows_per_coefficient": cshape[1],
-                         "GiB": round(128 * cshape[1] * (1 << (cshape[0] - 1)) * 64 / 2**30, 2) if cshape[0] else None,
-                         "budget": "PORLA_COMMIT_TABLE_GB (default 16 GiB)"},
-               "per_call_compute_digest_from_srs": per_call,
-               "coefficients_per_row": 128, "equiv_Mmul_per_s": round(world * rows_n * 128 * args.steps / el / 1e6, 1),
-               "ms_per_step": round(el / args.steps * 1e3, 4), "table_build_s": round(build_s, 3),
-               "roofline": roofline(kern, COMMIT_BYTES_PER_ROW * rows_n, "kzg_commit",
-                                    10.0 * rows_n * 128 * mx.kzg_commit_shape()[1])}
         cpu = None
         ok = None
         if not args.no_cpu and rank == 0:
@@ -313,13 +359,21 @@ def main():
             cpu = {"value": round(sample / cpu_s, 1), "unit": "commits/s", "cores": cores, "kind": "port",
                    "sample": "the first %d rows, one 128-point bucket MSM per row (oracle/bn254_ref.c, CPU restatement of "
                              "compute_digest_from_srs, not gnark) over %d threads; %.2f s wall" % (sample, cores, cpu_s)}
-        out["cpu_baseline"] = cpu
-        out["bit_exact_vs_oracle"] = ok
-        return out
+        return line("KZG commits/s (128-coefficient rows against the resident SRS)", round(world * rows_n * args.steps / el, 1),
+                    "commits/s", el, "weak", "u32x8 (256-bit modular integer)",
+                    {"workload": "2^%d rows x 128 coefficients per GPU, compute_digest_from_srs hoisted over rows "
+                                 "(fixed-base window table resident in HBM)" % args.log2rows,
+                     "rows_per_gpu": rows_n, "sharding": "row range per rank, no collective" if world > 1 else "single GPU",
+                     "table_build_s": round(build_s, 3)},
+                    roofline(kern, COMMIT_BYTES_PER_ROW * rows_n, "kzg_commit", 10.0 * rows_n * 128 * cshape[1]), cpu, ok,
+                    rows_per_gpu=rows_n, coefficients_per_row=128, per_call_compute_digest_from_srs=per_call,
+                    table={"window_bits": cshape[0], "windows_per_coefficient": cshape[1],
+                           "GiB": round(128 * cshape[1] * (1 << (cshape[0] - 1)) * 64 / 2**30, 2) if cshape[0] else None,
+                           "budget": "PORLA_COMMIT_TABLE_GB (default 16 GiB)"},
+                    equiv_Mmul_per_s=round(world * rows_n * 128 * args.steps / el / 1e6, 1), table_build_s=round(build_s, 3))
 
-    out = None
-    failed = False
-    if args.workload == "bn254_msm":
+    # ---------------------------------------------------------------- BN254 MSM (headline)
+    def leg_bn254_msm():
         n = 1 << args.log2n
         # ---- synthetic inputs (SURVEY.md s8d cfg 2): points k_i*G, scalars SHA-256 stream (81 % of them >= r)
         t0 = time.time()
@@ -368,19 +422,27 @@ def main():
 
         el, kern, result = timed(step, drain)
         fe_mults = msm_fe_mults(n)        # read now: the audit-size MSMs below run with another (window, GLV) shape
-        # the same MSM as blocking calls (one in flight): what a caller that waits for every result sees
+        # the same MSM as blocking calls (one in flight): what a caller that waits for every result sees, and ITS per-kernel
+        # breakdown (the one above is taken with `depth` MSMs contending for the chip)
         blocking_ms = None
+        blocking_kern = None
         if depth > 1:
+            def blocking_step():
+                return mx.msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n, stream, partial=world > 1)
             reps = max(3, args.steps // 4)
             for _ in range(2):
-                mx.msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n, stream, partial=world > 1)
+                blocking_step()
             sync()
             t_b = time.perf_counter()
             for _ in range(reps):
-                mx.msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n, stream, partial=world > 1)
+                blocking_step()
             torch.cuda.synchronize()
             blocking_ms = (time.perf_counter() - t_b) / reps * 1e3
-        # the reference's own boundary: compute_multi_exp on caller-owned pageable HOST buffers (PCIe included; never `value`)
+            per_launch, per_step = breakdown(blocking_step)
+            blocking_kern = {"ms_per_launch": per_launch, "ms_per_step": per_step,
+                             "sum_ms_per_step": round(sum(per_step.values()), 4),
+                             "note": "HIP events around every kernel of 3 blocking calls (each event pair adds ~10 us of idle "
+                                     "GPU around its kernel; the call's wall time is blocking_ms_per_step)"}
         # ---- the sizes the reference really issues (n_points <= 3 200, Server.hpp:585-587; coefficients abs(int32), utils.h:271-275):
         # latency of one blocking call on device-resident inputs, each checked against the oracle
         audit = None
@@ -402,6 +464,7 @@ def main():
                         audit[label][str(m)] = {"ms": round(ms, 4), "bit_exact_vs_oracle": r == common.oracle_msm(host_sc, pt, m)}
             except Exception as e:  # noqa: BLE001
                 audit = {"error": repr(e)}
+        # the reference's own boundary: compute_multi_exp on caller-owned pageable HOST buffers (PCIe included; never `value`)
         host_boundary = None
         if world == 1 and rank == 0 and not args.no_host_boundary:
             # in a child process (its launches at other sizes stay out of this process's kernel statistics; a profiler
@@ -413,10 +476,9 @@ def main():
                 host_boundary["same_result"] = host_boundary.pop("result") == result.hex()
             except Exception as e:  # noqa: BLE001
                 host_boundary = {"error": repr(e)}
-        commits = None if args.no_commits else kzg_commit_leg(1 << args.log2rows)
+        cpu = None
+        verified = None
         if rank == 0:
-            cpu = None
-            verified = None
             if not args.no_cpu and world == 1:
                 cores = common.ncpu()
                 t1 = time.perf_counter()
@@ -436,39 +498,94 @@ def main():
                 # scalars (rank g: SHA-256 stream starting at g * 2^20) against the oracle
                 all_sc = sc + b"".join(common.synth_scalars(n, start=g * n) for g in range(1, world))
                 verified = common.oracle_msm(all_sc, pt * world, world * n, threads=common.ncpu()) == result
-            failed = verified is False or (commits is not None and commits.get("bit_exact_vs_oracle") is False)
-            out = {
-                "metric": "BN254 G1 MSM Mscalar-mul/s at 2^20 pts", "value": round(world * n * args.steps / el / 1e6, 3),
-                "unit": "Mmul/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "u32x8 (256-bit modular integer)", "data": "synthetic",
-                "config": {"workload": "KZG scheme, single 2^%d-point BN254 G1 MSM per GPU, inputs resident in HBM, "
-                                       "output 64-B affine point" % args.log2n,
-                           "pairs_per_gpu": n, "msm_in_flight": depth,
-                           "sharding": "input-pair range per rank + all-gather of 96-B Jacobian partials, folded on every host"
-                           if world > 1 else "single GPU", "collective": collective, "input_gen_s": round(gen_s, 1)},
-                "roofline": roofline(kern, MSM_BYTES_PER_PAIR * n, "bn254_msm", fe_mults), "cpu_baseline": cpu,
-                "bit_exact_vs_oracle": verified, "result": result.hex() if result else None,
-                "blocking_ms_per_step": round(blocking_ms, 4) if blocking_ms else None,
-                "blocking_Mmul_s": round(world * n / blocking_ms / 1e3, 1) if blocking_ms else None,
-                "host_boundary": host_boundary, "audit_size_msm": audit, "kzg_commits": commits,
-            }
-    elif args.workload == "kzg_commit":
-        rows_n = 1 << args.log2rows
-        c = kzg_commit_leg(rows_n)
+        return line("BN254 G1 MSM Mscalar-mul/s at 2^20 pts", round(world * n * args.steps / el / 1e6, 3), "Mmul/s", el, "weak",
+                    "u32x8 (256-bit modular integer)",
+                    {"workload": "KZG scheme, single 2^%d-point BN254 G1 MSM per GPU, inputs resident in HBM, "
+                                 "output 64-B affine point" % args.log2n,
+                     "pairs_per_gpu": n, "msm_in_flight": depth,
+                     "sharding": "input-pair range per rank + all-gather of 96-B Jacobian partials, folded on every host"
+                     if world > 1 else "single GPU", "collective": collective, "input_gen_s": round(gen_s, 1)},
+                    roofline(kern, MSM_BYTES_PER_PAIR * n, "bn254_msm", fe_mults), cpu, verified,
+                    result=result.hex() if result else None,
+                    blocking_ms_per_step=round(blocking_ms, 4) if blocking_ms else None,
+                    blocking_Mmul_s=round(world * n / blocking_ms / 1e3, 1) if blocking_ms else None,
+                    blocking_kernels_ms=blocking_kern, host_boundary=host_boundary, audit_size_msm=audit)
+
+    # ---------------------------------------------------------------- config 3: ONE 2^24-pair MSM over all ranks
+    def leg_config3():
+        import numpy as np
+        total = 1 << args.log2job
+        blk = 1 << 20
+        base_n = min(total, blk)
+        lo, hi = mx.shard_range(total, rank, world)         # this rank's pair range of the job (porla_shard_range)
+        n_local = hi - lo
+        t0 = time.time()
         if rank == 0:
-            failed = c.get("bit_exact_vs_oracle") is False
-            out = {"metric": "KZG commits/s (128-coefficient rows against the resident SRS)", "value": c["value"],
-                   "unit": "commits/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                   "ms_per_step": c["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                   "dtype": "u32x8 (256-bit modular integer)", "data": "synthetic",
-                   "config": {"workload": "2^%d rows x 128 coefficients per GPU, compute_digest_from_srs hoisted over rows "
-                                          "(fixed-base window table resident in HBM)" % args.log2rows,
-                              "rows_per_gpu": rows_n, "sharding": "row range per rank, no collective" if world > 1 else "single GPU",
-                              "table_build_s": c["table_build_s"]},
-                   "roofline": c["roofline"], "cpu_baseline": c["cpu_baseline"], "bit_exact_vs_oracle": c["bit_exact_vs_oracle"],
-                   "equiv_Mmul_per_s": c["equiv_Mmul_per_s"]}
-    elif args.workload == "secp256k1_msm":
+            common.cached_inputs(base_n)
+        if world > 1:
+            dist.barrier()
+        _, pt = common.cached_inputs(base_n)                # the job's points: the 2^20 base points, repeated
+
+        def job_scalars(a, b):
+            # pair i of the job: 32 bytes of PCG64(seed 3 + i // 2^20) -- one generator per 2^20-pair block, so any range of
+            # the job can be produced without the rest (16 M SHA-256 calls from Python would take longer than the benchmark)
+            out = []
+            for k in range(a // blk, (b + blk - 1) // blk):
+                raw = np.random.Generator(np.random.PCG64(3 + k)).bytes(32 * blk)
+                s, e = max(a, k * blk) - k * blk, min(b, (k + 1) * blk) - k * blk
+                out.append(raw[32 * s:32 * e])
+            return b"".join(out)
+
+        def job_points(a, b):
+            out = []
+            i = a
+            while i < b:
+                s = i % base_n
+                take = min(base_n - s, b - i)
+                out.append(pt[64 * s:64 * (s + take)])
+                i += take
+            return b"".join(out)
+
+        sc = job_scalars(lo, hi)
+        pts = job_points(lo, hi)
+        gen_s = time.time() - t0
+        d_sc, d_pt = to_dev(sc), to_dev(pts)
+        del sc, pts
+
+        def step():
+            if world == 1:
+                return mx.msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n_local, stream)
+            return fold_across_ranks("bn254", mx.msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n_local, stream, partial=True))
+
+        el, kern, result = timed(step)
+        launches = max(1, (n_local + (1 << 22) - 1) >> 22)    # an input above 2^22 pairs runs as ranges of 2^22 into one bucket set
+        fe_mults = msm_fe_mults(n_local)
+        cpu = None
+        verified = None
+        if rank == 0 and not args.no_cpu:
+            cores = common.ncpu()
+            all_sc = job_scalars(0, total)
+            all_pt = job_points(0, total)
+            t1 = time.perf_counter()
+            want = common.oracle_msm(all_sc, all_pt, total, threads=cores)
+            cpu_s = time.perf_counter() - t1
+            del all_sc, all_pt
+            verified = want == result
+            cpu = {"value": round(total / cpu_s / 1e6, 4), "unit": "Mmul/s", "cores": cores, "kind": "port",
+                   "sample": "the whole 2^%d-pair job, oracle/bn254_ref.c bucket MSM range-split over %d threads (CPU restatement, "
+                             "not gnark); %.1f s wall" % (args.log2job, cores, cpu_s)}
+        return line("BN254 G1 MSM Mscalar-mul/s, one 2^%d-pair job over all GPUs" % args.log2job,
+                    round(total * args.steps / el / 1e6, 3), "Mmul/s", el, "strong", "u32x8 (256-bit modular integer)",
+                    {"workload": "KZG audit over 2^%d blocks: ONE 2^%d-pair BN254 G1 MSM, pair range [g 2^%d / N, (g+1) 2^%d / N) on "
+                                 "GPU g, inputs resident in HBM, 96-B Jacobian partials all-gathered and folded on every host"
+                                 % (args.log2job, args.log2job, args.log2job, args.log2job),
+                     "pairs_total": total, "pairs_per_gpu": n_local, "collective": collective, "input_gen_s": round(gen_s, 1),
+                     "accumulation_launches_per_step": launches},
+                    roofline(kern, MSM_BYTES_PER_PAIR * n_local / launches, "config3", fe_mults / launches), cpu, verified,
+                    result=result.hex() if result else None)
+
+    # ---------------------------------------------------------------- secp256k1 MSM (config 4)
+    def leg_secp256k1_msm():
         n = 1 << args.log2n
         t0 = time.time()
         path = os.path.join(os.environ.get("PORLA_CACHE", "/tmp"), "porla_secp_points_%d.bin" % n)
@@ -490,30 +607,28 @@ def main():
 
         el, kern, result = timed(step)
         fe_mults = msm_fe_mults(n)
-        if rank == 0:
-            cpu = None
-            verified = None
-            if not args.no_cpu and world == 1:
-                cores = common.ncpu()
-                t1 = time.perf_counter()
-                want = common.oracle_secp_msm(sc, pt, n, threads=cores)
-                cpu_s = time.perf_counter() - t1
-                closed = common.secp_bench_expected(sc, n)  # (sum s_i 2^i) * G, bench teardown (bench_ecmult.c:258-270)
-                verified = (want == result) and (closed == result)
-                cpu = {"value": round(n / cpu_s / 1e6, 4), "unit": "Mmul/s", "cores": cores, "kind": "port",
-                       "sample": "the same 2^%d pairs, oracle/secp256k1_ref.c bucket MSM over %d threads (CPU restatement, "
-                                 "not libsecp256k1); %.1f s wall" % (args.log2n, cores, cpu_s)}
-            failed = verified is False
-            out = {"metric": "secp256k1 MSM Mscalar-mul/s at 2^20 pts", "value": round(world * n * args.steps / el / 1e6, 3),
-                   "unit": "Mmul/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                   "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-                   "vs_baseline": None, "dtype": "u32x8 (256-bit modular integer)", "data": "synthetic",
-                   "config": {"workload": "IPA scheme, 2^%d-point secp256k1 ecmult_multi per GPU (points 2^i*G, scalars "
-                                          "SHA-256(\"ecmult\"||i) as bench_ecmult.c), inputs resident in HBM" % args.log2n,
-                              "pairs_per_gpu": n, "input_gen_s": round(gen_s, 1)},
-                   "roofline": roofline(kern, MSM_BYTES_PER_PAIR * n, "secp256k1_msm", fe_mults), "cpu_baseline": cpu,
-                   "bit_exact_vs_oracle": verified, "result": result.hex() if result else None}
-    else:  # icc
+        cpu = None
+        verified = None
+        if rank == 0 and not args.no_cpu and world == 1:
+            cores = common.ncpu()
+            t1 = time.perf_counter()
+            want = common.oracle_secp_msm(sc, pt, n, threads=cores)
+            cpu_s = time.perf_counter() - t1
+            closed = common.secp_bench_expected(sc, n)  # (sum s_i 2^i) * G, bench teardown (bench_ecmult.c:258-270)
+            verified = (want == result) and (closed == result)
+            cpu = {"value": round(n / cpu_s / 1e6, 4), "unit": "Mmul/s", "cores": cores, "kind": "port",
+                   "sample": "the same 2^%d pairs, oracle/secp256k1_ref.c bucket MSM over %d threads (CPU restatement, "
+                             "not libsecp256k1); %.1f s wall" % (args.log2n, cores, cpu_s)}
+        return line("secp256k1 MSM Mscalar-mul/s at 2^20 pts", round(world * n * args.steps / el / 1e6, 3), "Mmul/s", el, "weak",
+                    "u32x8 (256-bit modular integer)",
+                    {"workload": "IPA scheme, 2^%d-point secp256k1 ecmult_multi per GPU (points 2^i*G, scalars "
+                                 "SHA-256(\"ecmult\"||i) as bench_ecmult.c), blocking calls, inputs resident in HBM" % args.log2n,
+                     "pairs_per_gpu": n, "input_gen_s": round(gen_s, 1)},
+                    roofline(kern, MSM_BYTES_PER_PAIR * n, "secp256k1_msm", fe_mults), cpu, verified,
+                    result=result.hex() if result else None)
+
+    # ---------------------------------------------------------------- ICC encode (config 5)
+    def leg_icc():
         from porla_amd import icc
         n_rows, n_cols = 1 << (args.log2rows - 2), 128
         g = torch.Generator(device=dev).manual_seed(99 + rank)
@@ -526,50 +641,76 @@ def main():
             return None
 
         el, kern, _ = timed(step)
-        if rank == 0:
-            total_ms = sum(timed.totals.values())
-            cpu = None
-            verified = None
-            if not args.no_cpu and world == 1:
-                sample_rows = min(n_rows, 1 << 11)
-                rows = bytes(d_in[:sample_rows * n_cols * 32].cpu().numpy())
-                d_s_al = torch.empty(32 * sample_rows * n_cols, dtype=torch.uint8, device=dev)
-                d_s_sc = torch.empty(32 * sample_rows * n_cols, dtype=torch.uint8, device=dev)
-                icc.crebuild_device(d_in.data_ptr(), sample_rows, n_cols, "bn254", 0, 0, 0, d_s_al.data_ptr(), d_s_sc.data_ptr(),
-                                    stream=stream)
-                torch.cuda.synchronize()
-                L = common.oracle()
-                x = ctypes.create_string_buffer(64 * sample_rows * n_cols)
-                al = ctypes.create_string_buffer(32 * sample_rows * n_cols)
-                scb = ctypes.create_string_buffer(32 * sample_rows * n_cols)
-                cores = common.ncpu()
-                t1 = time.perf_counter()
-                L.oracle_icc_crebuild(rows, ctypes.c_size_t(sample_rows), ctypes.c_size_t(n_cols), 0, 0, ctypes.c_uint64(0),
-                                      x, al, scb, cores)
-                cpu_s = time.perf_counter() - t1
-                verified = al.raw == bytes(d_s_al.cpu().numpy()) and scb.raw == bytes(d_s_sc.cpu().numpy())
-                cpu = {"value": round(sample_rows * n_cols / cpu_s / 1e6, 4), "unit": "Melements/s", "cores": cores,
-                       "kind": "port", "sample": "a %d-row x 128-column encode (oracle/icc_ref.c, CPU restatement of "
-                       "CRebuild_Cached + align_MAC scalars in Z/LCM, not NTL) over %d threads; %.2f s wall"
-                       % (sample_rows, cores, cpu_s)}
-            failed = verified is False
-            passes = max(1, ((n_rows.bit_length() - 1) + 7) // 8)      # LDS-fused passes per encode = launches of the dominant kernel
-            rl = roofline(kern, ICC_BYTES_PER_ELEMENT * n_rows * n_cols / passes, "icc")
-            if rl:
-                rl["note"] = ("an encode is %d launches of the dominant kernel; `achieved` prices the encode's algorithmic bytes / %d "
-                              "per launch, `traffic` is the per-launch average of the counters" % (passes, passes))
-                rl["launches_per_encode"] = {k: round(timed.totals[k] / v) for k, v in kern.items() if v > 0}
-                rl["whole_encode_kernels_ms"] = round(total_ms, 4)
-                rl["whole_encode_achieved_GBps"] = round(ICC_BYTES_PER_ELEMENT * n_rows * n_cols / (total_ms * 1e-3) / 1e9, 2)
-            out = {"metric": "ICC encode Melements/s (2^22 Fp elements)", "value": round(world * n_rows * n_cols * args.steps / el / 1e6, 3),
-                   "unit": "Melements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                   "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-                   "vs_baseline": None, "dtype": "u32x8 residue pair (mod p_icc, mod q)", "data": "synthetic",
-                   "config": {"workload": "ICC encode (CRebuild_Cached X part + align_MAC scalars), %d rows x 128 columns per GPU, "
-                                          "rows resident in HBM" % n_rows, "rows_per_gpu": n_rows, "columns": n_cols},
-                   "roofline": rl, "cpu_baseline": cpu, "bit_exact_vs_oracle": verified}
+        total_ms = sum(timed.totals.values())
+        cpu = None
+        verified = None
+        if rank == 0 and not args.no_cpu and world == 1:
+            sample_rows = min(n_rows, 1 << 11)
+            rows = bytes(d_in[:sample_rows * n_cols * 32].cpu().numpy())
+            d_s_al = torch.empty(32 * sample_rows * n_cols, dtype=torch.uint8, device=dev)
+            d_s_sc = torch.empty(32 * sample_rows * n_cols, dtype=torch.uint8, device=dev)
+            icc.crebuild_device(d_in.data_ptr(), sample_rows, n_cols, "bn254", 0, 0, 0, d_s_al.data_ptr(), d_s_sc.data_ptr(),
+                                stream=stream)
+            torch.cuda.synchronize()
+            L = common.oracle()
+            x = ctypes.create_string_buffer(64 * sample_rows * n_cols)
+            al = ctypes.create_string_buffer(32 * sample_rows * n_cols)
+            scb = ctypes.create_string_buffer(32 * sample_rows * n_cols)
+            cores = common.ncpu()
+            t1 = time.perf_counter()
+            L.oracle_icc_crebuild(rows, ctypes.c_size_t(sample_rows), ctypes.c_size_t(n_cols), 0, 0, ctypes.c_uint64(0),
+                                  x, al, scb, cores)
+            cpu_s = time.perf_counter() - t1
+            verified = al.raw == bytes(d_s_al.cpu().numpy()) and scb.raw == bytes(d_s_sc.cpu().numpy())
+            cpu = {"value": round(sample_rows * n_cols / cpu_s / 1e6, 4), "unit": "Melements/s", "cores": cores,
+                   "kind": "port", "sample": "a %d-row x 128-column encode (oracle/icc_ref.c, CPU restatement of "
+                   "CRebuild_Cached + align_MAC scalars in Z/LCM, not NTL) over %d threads; %.2f s wall"
+                   % (sample_rows, cores, cpu_s)}
+        passes = max(1, ((n_rows.bit_length() - 1) + 7) // 8)      # LDS-fused passes per encode = launches of the dominant kernel
+        rl = roofline(kern, ICC_BYTES_PER_ELEMENT * n_rows * n_cols / passes, "icc")
+        if rl:
+            rl["note"] = ("an encode is %d launches of the dominant kernel; `achieved` prices the encode's algorithmic bytes / %d "
+                          "per launch, `traffic` is the per-launch average of the counters; the kernel is bound by VALU issue "
+                          "(profiles/r03_b_icc_stall_counters.txt)" % (passes, passes))
+            rl["launches_per_encode"] = {k: round(timed.totals[k] / v) for k, v in kern.items() if v > 0}
+            rl["whole_encode_kernels_ms"] = round(total_ms, 4)
+            rl["whole_encode_achieved_GBps"] = round(ICC_BYTES_PER_ELEMENT * n_rows * n_cols / (total_ms * 1e-3) / 1e9, 2)
+        return line("ICC encode Melements/s (2^22 Fp elements)", round(world * n_rows * n_cols * args.steps / el / 1e6, 3),
+                    "Melements/s", el, "weak", "u32x9 residue pair (mod p_icc, mod q), 30-bit limbs",
+                    {"workload": "ICC encode (CRebuild_Cached X part + align_MAC scalars), %d rows x 128 columns per GPU, "
+                                 "rows resident in HBM" % n_rows, "rows_per_gpu": n_rows, "columns": n_cols},
+                    rl, cpu, verified)
 
-    if rank == 0 and out is not None:
+    # ---------------------------------------------------------------- the line
+    legs = {"bn254_msm": leg_bn254_msm, "kzg_commit": leg_kzg_commit, "secp256k1_msm": leg_secp256k1_msm, "icc": leg_icc,
+            "config3": leg_config3}
+    out = legs[args.workload]()
+    if args.workload == "bn254_msm":
+        # every other BASELINE.json configuration rides on the default line
+        extra = []
+        if not args.no_commits:
+            extra.append(("kzg_commits", leg_kzg_commit))
+        if not args.no_legs:
+            extra += [("secp256k1_msm", leg_secp256k1_msm), ("icc", leg_icc)]
+            if not args.no_config3:
+                extra.append(("config3", leg_config3))
+        for name, fn in extra:
+            torch.cuda.empty_cache()
+            try:
+                leg = fn()
+            except Exception as e:  # noqa: BLE001  (a leg must not take the headline down with it: it is reported as failed)
+                if world > 1:
+                    raise                      # ... except where the ranks would fall out of step
+                leg = {"error": repr(e), "bit_exact_vs_oracle": False}
+            for k in ("n_gpus", "steps", "warmup", "higher_is_better", "vs_baseline", "data"):
+                leg.pop(k, None)               # the leg shares the line's
+            out[name] = leg
+    failed = False
+    if rank == 0:
+        failed = out.get("bit_exact_vs_oracle") is False or any(
+            isinstance(v, dict) and v.get("bit_exact_vs_oracle") is False for v in out.values())
+        if fe_peak:
+            out["fe_mul_peak"] = fe_peak
         print(json.dumps(out))
         if failed:
             print("ERROR: GPU result differs from the oracle", file=sys.stderr)

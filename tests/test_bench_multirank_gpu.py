@@ -21,7 +21,7 @@ def test_two_rank_bench_line_is_bit_exact():
     env = dict(os.environ, PORLA_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(common.ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--no-commits"]
+           "--no-commits", "--log2job", "21"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=common.ROOT)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
@@ -31,13 +31,18 @@ def test_two_rank_bench_line_is_bit_exact():
     assert d["cpu_baseline"] is None                 # reported at N = 1 only
     assert d["roofline"]["kernel"] and d["value"] > 0
     assert 0 < d["roofline"]["int_multiplier"]["frac"] <= 1.0
+    # BASELINE config 3 in small: ONE 2^21-pair job, half of it per rank (strong scaling), the whole job against the oracle
+    c3 = d["config3"]
+    assert c3["scaling"] == "strong" and c3["config"]["pairs_total"] == 1 << 21 and c3["config"]["pairs_per_gpu"] == 1 << 20
+    assert c3["bit_exact_vs_oracle"] is True and c3["value"] > 0
+    assert d["secp256k1_msm"]["value"] > 0 and d["icc"]["value"] > 0
 
 
 def test_single_rank_bench_line_prices_the_kernel_it_timed():
     """N = 1, the default workload with its audit-size and host-boundary legs: one JSON line, the roofline's two fractions in
     (0, 1] -- the multiplication count must be the timed 2^20-pair MSM's, not that of an audit-size MSM run after it --
     and every leg bit-exact"""
-    r = subprocess.run([sys.executable, os.path.join(common.ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-commits"],
+    r = subprocess.run([sys.executable, os.path.join(common.ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-commits", "--log2job", "22"],
                        capture_output=True, text=True, timeout=600, cwd=common.ROOT)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
@@ -48,6 +53,16 @@ def test_single_rank_bench_line_prices_the_kernel_it_timed():
     assert abs(rf["achieved"] - 96 * (1 << 20) / (rf["kernel_ms"] * 1e-3) / 1e9) < 0.01 * rf["achieved"]
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
     assert d["host_boundary"]["same_result"] is True
+    assert "in this run" in rf["int_multiplier"]["peak_source"] and d["fe_mul_peak"]["bn254"]["mul_G_s"] > 50
+    # the blocking call's own per-kernel breakdown next to the pipelined one
+    bk = d["blocking_kernels_ms"]
+    assert bk["ms_per_step"]["bucket_sum"] > 0 and bk["sum_ms_per_step"] < 2 * d["blocking_ms_per_step"]
+    # every other BASELINE configuration as a leg with its own roofline / cpu_baseline / oracle check
+    for leg, kernel in (("secp256k1_msm", "k_bucket_sum30"), ("icc", "k_icc_split30"), ("config3", "k_bucket_sum30")):
+        assert d[leg]["bit_exact_vs_oracle"] is True, leg
+        assert d[leg]["roofline"]["kernel"] == kernel and 0 < d[leg]["roofline"]["frac"] <= 1.0
+        assert d[leg]["cpu_baseline"]["kind"] == "port" and d[leg]["cpu_baseline"]["value"] > 0
+    assert d["config3"]["scaling"] == "strong" and d["config3"]["config"]["pairs_total"] == 1 << 22
     for group in d["audit_size_msm"].values():
         if isinstance(group, dict):
             assert all(v["bit_exact_vs_oracle"] for v in group.values())

@@ -99,3 +99,189 @@ def test_wrapper_compiles_against_the_vendored_headers(tmp_path, lang):
     libc = {"free", "malloc", "memset", "memcpy", "memcmp", "getenv", "strtol", "atol", "abort", "fprintf", "stderr", "__stack_chk_fail",
             "_GLOBAL_OFFSET_TABLE_", "__gxx_personality_v0", "_Unwind_Resume"}
     assert undefined <= allowed | libc, undefined - allowed - libc
+
+
+# ---- the wrapper EXECUTED on the vendored internals (build container only) -----------------------------------------------------
+# What this is: a marshalling probe.  The translation unit below is PROBE (the shim's rename + wrapper around the vendored
+# INTERNAL headers, read where they lie under /root/reference) plus a driver; it is written to pytest's tmp_path, compiled there
+# and run there -- nothing of it enters the repository, travels to the GPU box, is timed, or serves as an oracle.  The engine is
+# a counting stub over the CPU oracle (as in harness_stub_*), so what is pinned is the wrapper's use of the REAL
+# secp256k1_fe / secp256k1_scalar / secp256k1_ge / scratch semantics -- fe_normalize_var + fe_get_b32 on 5x52 limbs,
+# scalar_get_b32, ge infinity, the checkpoint hand-back, fe_set_b32 + ge_set_xy + gej_set_ge on the way out -- which
+# integration/ipa_harness only exercises on its hand-written model of those types.
+# What this is NOT: a build of the reference library.  libsecp256k1's unity file and its generator tables
+# (precomputed_ecmult.c) need the installed public header, absent from this image; the two table symbols the internal headers
+# declare `extern` are defined here as ZERO-FILLED arrays so that the unit links.  They are never read: Porla passes g_sc = 0 at
+# every call site (Client.hpp:395,778; Server.hpp:842,848), the Strauss body skips the generator table when every wNAF digit of
+# g_sc is zero (ecmult_impl.h:321), and the driver passes &szero like the reference.  Parity of the vendored CPU body is not
+# claimed from this test.
+RUNNER = PROBE + r"""
+#include <dlfcn.h>
+#include <stdio.h>
+const secp256k1_ge_storage secp256k1_pre_g[ECMULT_TABLE_SIZE(WINDOW_G)] = {{{{0}}}};        /* never read: g_sc = 0 */
+const secp256k1_ge_storage secp256k1_pre_g_128[ECMULT_TABLE_SIZE(WINDOW_G)] = {{{{0}}}};
+
+typedef void (*oracle_multi_fn)(const unsigned char*, const unsigned char*, size_t, unsigned char*, int, int);
+typedef void (*oracle_chain_fn)(size_t, unsigned char*);
+static oracle_multi_fn oracle_multi;
+static long engine_calls = 0;
+int porla_secp256k1_msm_host(const unsigned char *scalars, const unsigned char *points, size_t n, unsigned char out_affine[64]) {
+    engine_calls++;
+    oracle_multi(scalars, points, n, out_affine, 1, 0);
+    return 0;
+}
+const char *porla_gpu_last_error(void) { return "stub"; }
+
+typedef struct { secp256k1_scalar *sc; secp256k1_ge *pt; } ecmult_multi_data;                 /* utils.h:166-171 */
+static int ecmult_multi_callback(secp256k1_scalar *sc, secp256k1_ge *pt, size_t idx, void *cbdata) {
+    ecmult_multi_data *data = (ecmult_multi_data*)cbdata;
+    *sc = data->sc[idx];
+    *pt = data->pt[idx];
+    return 1;
+}
+static int failures = 0;
+static void on_error(const char *text, void *data) { (void)data; printf("error callback: %s\n", text); failures++; }
+static const secp256k1_callback error_callback = { on_error, NULL };
+#define CHECK(cond, what) do { if (cond) printf("ok: %s\n", what); else { printf("FAIL: %s\n", what); failures++; } } while (0)
+
+/* the returned Jacobian point normalised with the vendored group / field code -> 64 bytes (infinity: zeros) */
+static void gej_bytes(unsigned char out[64], const secp256k1_gej *r) {
+    secp256k1_gej t = *r;
+    secp256k1_ge a;
+    if (secp256k1_gej_is_infinity(&t)) { memset(out, 0, 64); return; }
+    secp256k1_ge_set_gej(&a, &t);
+    secp256k1_fe_normalize_var(&a.x); secp256k1_fe_normalize_var(&a.y);
+    secp256k1_fe_get_b32(out, &a.x); secp256k1_fe_get_b32(out + 32, &a.y);
+}
+/* what the oracle says for the very operands the callback hands out */
+static void expect(const secp256k1_scalar *sc, const secp256k1_ge *pt, size_t n, unsigned char out[64]) {
+    unsigned char *s = (unsigned char*)malloc(32 * n + 1), *p = (unsigned char*)malloc(64 * n + 1);
+    size_t i;
+    for (i = 0; i < n; i++) {
+        secp256k1_ge g = pt[i];
+        secp256k1_scalar_get_b32(s + 32 * i, &sc[i]);
+        if (secp256k1_ge_is_infinity(&g)) memset(p + 64 * i, 0, 64);
+        else {
+            secp256k1_fe_normalize_var(&g.x); secp256k1_fe_normalize_var(&g.y);
+            secp256k1_fe_get_b32(p + 64 * i, &g.x); secp256k1_fe_get_b32(p + 64 * i + 32, &g.y);
+        }
+    }
+    oracle_multi(s, p, n, out, 1, 0);
+    free(s); free(p);
+}
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static uint64_t rng(void) { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return rng_state; }
+
+int main(int argc, char **argv) {
+    enum { NPTS = 1408 };
+    void *lib = dlopen(argv[1], RTLD_NOW);
+    oracle_chain_fn chain;
+    unsigned char *raw, got[64], want[64], b32[32];
+    secp256k1_ge *pt;
+    secp256k1_scalar *sc_full, *sc_audit, szero;
+    secp256k1_gej r;
+    secp256k1_scratch *scratch, *tiny;
+    ecmult_multi_data data;
+    size_t i;
+    int rc, overflow, w;
+    long e0;
+    (void)argc;
+    if (!lib) { fprintf(stderr, "%s\n", dlerror()); return 2; }
+    oracle_multi = (oracle_multi_fn)dlsym(lib, "oracle_secp256k1_multi");
+    chain = (oracle_chain_fn)dlsym(lib, "oracle_secp256k1_doubling_chain");
+    if (!oracle_multi || !chain) return 2;
+    secp256k1_scalar_set_int(&szero, 0);
+    raw = (unsigned char*)malloc(64 * NPTS);
+    chain(NPTS, raw);                                                      /* P_i = 2^i G, bench_ecmult.c:328-337 */
+    pt = (secp256k1_ge*)malloc(sizeof(secp256k1_ge) * NPTS);
+    sc_full = (secp256k1_scalar*)malloc(sizeof(secp256k1_scalar) * NPTS);
+    sc_audit = (secp256k1_scalar*)malloc(sizeof(secp256k1_scalar) * NPTS);
+    for (i = 0; i < NPTS; i++) {
+        secp256k1_fe x, y;
+        int k;
+        if (!secp256k1_fe_set_b32(&x, raw + 64 * i) || !secp256k1_fe_set_b32(&y, raw + 64 * i + 32)) return 2;
+        secp256k1_ge_set_xy(&pt[i], &x, &y);
+        for (k = 0; k < 32; k++) b32[k] = (unsigned char)rng();
+        secp256k1_scalar_set_b32(&sc_full[i], b32, &overflow);             /* any 256-bit value, reduced as the reference reduces it */
+        secp256k1_scalar_set_int(&sc_audit[i], (unsigned int)(rng() & 0x7fffffffu));     /* abs(int32), prg.h:84-97 */
+    }
+    w = secp256k1_pippenger_bucket_window(NPTS);
+    scratch = secp256k1_scratch_create(&error_callback, secp256k1_pippenger_scratch_size(NPTS, w) + PIPPENGER_SCRATCH_OBJECTS * ALIGNMENT);
+
+    /* 1. the server audit's call (Server.hpp:838-848): 1408 points, abs(int32) coefficients, then full-width scalars, one scratch */
+    data.sc = sc_audit; data.pt = pt;
+    e0 = engine_calls;
+    rc = secp256k1_ecmult_multi_var(&error_callback, scratch, &r, &szero, ecmult_multi_callback, &data, NPTS);
+    gej_bytes(got, &r); expect(sc_audit, pt, NPTS, want);
+    CHECK(rc == 1 && engine_calls - e0 == 1 && memcmp(got, want, 64) == 0, "1408-point audit call: one engine call, result normalises to the oracle's point");
+    data.sc = sc_full;
+    rc = secp256k1_ecmult_multi_var(&error_callback, scratch, &r, &szero, ecmult_multi_callback, &data, NPTS);
+    gej_bytes(got, &r); expect(sc_full, pt, NPTS, want);
+    CHECK(rc == 1 && memcmp(got, want, 64) == 0 && secp256k1_scratch_checkpoint(&error_callback, scratch) == 0,
+          "full-width scalars on the same scratch, scratch handed back");
+
+    /* 2. operands whose field elements are NOT normalised when the callback hands them out (magnitude > 1: a negated y, a
+     *    doubled-and-halved x): the wrapper must normalise before fe_get_b32 */
+    {
+        secp256k1_ge *q = (secp256k1_ge*)malloc(sizeof(secp256k1_ge) * 200);
+        for (i = 0; i < 200; i++) {
+            secp256k1_ge_neg(&q[i], &pt[i]);                                /* y has magnitude 2, not normalised */
+            if (i & 1) secp256k1_ge_neg(&q[i], &q[i]);                      /* back to +P with magnitude 3 */
+        }
+        data.sc = sc_audit; data.pt = q;
+        rc = secp256k1_ecmult_multi_var(&error_callback, scratch, &r, &szero, ecmult_multi_callback, &data, 200);
+        gej_bytes(got, &r); expect(sc_audit, q, 200, want);
+        CHECK(rc == 1 && memcmp(got, want, 64) == 0, "un-normalised field elements from the callback");
+        free(q);
+    }
+    /* 3. infinity among the inputs; inputs that cancel pairwise (P, -P with equal scalars) except one; all cancelling */
+    {
+        secp256k1_ge *q = (secp256k1_ge*)malloc(sizeof(secp256k1_ge) * 200);
+        secp256k1_scalar *s = (secp256k1_scalar*)malloc(sizeof(secp256k1_scalar) * 200);
+        for (i = 0; i < 200; i += 2) {
+            q[i] = pt[i]; secp256k1_ge_neg(&q[i + 1], &pt[i]);
+            s[i] = sc_full[i]; s[i + 1] = sc_full[i];
+        }
+        data.sc = s; data.pt = q;
+        rc = secp256k1_ecmult_multi_var(&error_callback, scratch, &r, &szero, ecmult_multi_callback, &data, 200);
+        CHECK(rc == 1 && secp256k1_gej_is_infinity(&r), "pairwise cancelling inputs through the engine -> infinity");
+        s[199] = sc_audit[7];                                               /* one pair no longer cancels */
+        secp256k1_ge_set_infinity(&q[40]);                                  /* and one operand is the point at infinity */
+        rc = secp256k1_ecmult_multi_var(&error_callback, scratch, &r, &szero, ecmult_multi_callback, &data, 200);
+        gej_bytes(got, &r); expect(s, q, 200, want);
+        CHECK(rc == 1 && !secp256k1_gej_is_infinity(&r) && memcmp(got, want, 64) == 0, "an infinity operand and a surviving pair");
+        free(q); free(s);
+    }
+    /* 4. dispatch edges on the real scratch implementation: too small for the staging buffers -> the vendored CPU body (its
+     *    simple algorithm, ecmult_impl.h:740-770) with the scratch untouched; below the threshold -> the CPU body */
+    tiny = secp256k1_scratch_create(&error_callback, 1024);
+    data.sc = sc_audit; data.pt = pt;
+    e0 = engine_calls;
+    rc = secp256k1_ecmult_multi_var(&error_callback, tiny, &r, &szero, ecmult_multi_callback, &data, 200);
+    gej_bytes(got, &r); expect(sc_audit, pt, 200, want);
+    CHECK(rc == 1 && engine_calls == e0 && memcmp(got, want, 64) == 0 && secp256k1_scratch_checkpoint(&error_callback, tiny) == 0,
+          "scratch too small -> CPU body, same point, scratch untouched");
+    rc = secp256k1_ecmult_multi_var(&error_callback, scratch, &r, &szero, ecmult_multi_callback, &data, 2);
+    gej_bytes(got, &r); expect(sc_audit, pt, 2, want);
+    CHECK(rc == 1 && engine_calls == e0 && memcmp(got, want, 64) == 0, "2-point call -> CPU body");
+    secp256k1_scratch_destroy(&error_callback, tiny);
+    secp256k1_scratch_destroy(&error_callback, scratch);
+    printf(failures ? "RUNNER FAILED (%d)\n" : "RUNNER OK\n", failures);
+    return failures ? 1 : 0;
+}
+"""
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="build container only: needs the reference tree")
+def test_wrapper_runs_on_the_vendored_internal_types(tmp_path):
+    common.oracle()
+    src = tmp_path / "runner.c"
+    src.write_text(RUNNER)
+    exe = tmp_path / "runner"
+    cmd = ["gcc", "-O2", "-Wall", "-Wno-unused-function", str(src), "-o", str(exe), "-I" + SHIM_DIR, "-I" + REF, "-I" + REF + "/Utils",
+           "-I" + REF + "/Utils/secp256k1_lib", "-I/usr/local/include", "-DSECP256K1_GNUC_PREREQ(a,b)=1", "-DSECP256K1_INLINE=inline", "-ldl"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([str(exe), common.ORACLE_SO], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RUNNER OK" in r.stdout and "FAIL" not in r.stdout, r.stdout + r.stderr
+    assert r.stdout.count("ok:") == 7

@@ -304,7 +304,32 @@ static int check_inv(const char* name) {
     return bad;
 }
 
+// --peak: ONE JSON line with the back-to-back product / square rates (G per second, whole chip) of both base fields at 4
+// waves per SIMD -- the occupancy the accumulation kernels run at -- and nothing else: bench.py prices `int_multiplier` with it
+// in the same run, on the same box (boxes of the pool differ by a few per cent)
+static int peak_line() {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, 0) != hipSuccess) { printf("{\"error\": \"no device\"}\n"); return 1; }
+    const int CUS = prop.multiProcessorCount, w = 4, it = 512;
+    const int blocks = CUS * w;
+    uint32_t* buf;
+    if (hipMalloc(&buf, (size_t)blocks * 256 * 9 * 4) != hipSuccess) { printf("{\"error\": \"hipMalloc\"}\n"); return 1; }
+    std::vector<uint32_t> h((size_t)blocks * 256 * 9);
+    for (size_t i = 0; i < h.size(); i++) h[i] = (uint32_t)(i * 2654435761u + 12345);
+    (void)hipMemcpy(buf, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    auto rate = [&](double ms) { return (double)blocks * 256 * it * 2 / ms / 1e6; };
+    const double bm = rate(time_ms([&] { hipLaunchKernelGGL((k_bench<Bn254Fp, 0>), dim3(blocks), dim3(256), 0, 0, buf, it); }, 5));
+    const double bs = rate(time_ms([&] { hipLaunchKernelGGL((k_bench<Bn254Fp, 1>), dim3(blocks), dim3(256), 0, 0, buf, it); }, 5));
+    const double sm = rate(time_ms([&] { hipLaunchKernelGGL((k_bench<Secp256k1Fp, 0>), dim3(blocks), dim3(256), 0, 0, buf, it); }, 5));
+    const double ss = rate(time_ms([&] { hipLaunchKernelGGL((k_bench<Secp256k1Fp, 1>), dim3(blocks), dim3(256), 0, 0, buf, it); }, 5));
+    printf("{\"waves_per_simd\": %d, \"compute_units\": %d, \"bn254\": {\"mul_G_s\": %.2f, \"sqr_G_s\": %.2f}, "
+           "\"secp256k1\": {\"mul_G_s\": %.2f, \"sqr_G_s\": %.2f}}\n", w, CUS, bm, bs, sm, ss);
+    (void)hipFree(buf);
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "--peak")) return peak_line();
     int bad = 0;
     bad += check_inv<Bn254Fp>("bn254_p");
     bad += check_inv<Secp256k1Fp>("secp256k1_p");
