@@ -14,9 +14,11 @@ namespace porla {
 // signed limbs of 30 bits (limbs 0..7 in [0, 2^30), limb 8 carries the sign); all products fit 64-bit signed accumulators
 // because |u| + |v| <= 2^30 for a matrix row.  ~22 k simple instructions against the 381 dependent field products of a^(p-2)
 // (fixed_base.hip.h:fe_inv_dev: 0.32 ms for a lone wave in the 8 x 32-bit form, 0.18 ms with the reduced-radix product).  tools/safegcd_model.py is the same procedure on Python integers with the 32 / 64-bit ranges asserted.
-// a: a non-zero residue in the Fe form; returns its inverse in the Fe form (see Fp::INV_OUT_30).
+// f30_inv_safegcd_raw: a = any non-zero 256-bit value V; returns the integer V^-1 mod p plus a multiple of p, non-negative and
+// below 4 p, in normal 30-bit limbs -- the caller's product with a constant puts it into the form it needs
+// (fe_inv_safegcd below: the Fe form, constant Fp::INV_OUT_30).
 template <class M>
-__device__ __noinline__ Fe<M> fe_inv_safegcd(Fe<M> a) {
+__device__ __noinline__ F30<M> f30_inv_safegcd_raw(Fe<M> a) {
     constexpr int32_t M30 = (int32_t)F30_MASK;
     int32_t f[9], g[9], d[9], e[9];
     {
@@ -105,7 +107,12 @@ __device__ __noinline__ Fe<M> fe_inv_safegcd(Fe<M> a) {
             else x.v[i] = (uint32_t)t;
         }
     }
-    return f30_to_fe_canonical<M>(f30_mul<M>(x, f30_const<M>(M::INV_OUT_30)));
+    return x;
+}
+// a: a non-zero residue in the Fe form; returns its inverse in the Fe form (see Fp::INV_OUT_30).
+template <class M>
+__device__ __forceinline__ Fe<M> fe_inv_safegcd(Fe<M> a) {
+    return f30_to_fe_canonical<M>(f30_mul<M>(f30_inv_safegcd_raw<M>(a), f30_const<M>(M::INV_OUT_30)));
 }
 
 }  // namespace porla
