@@ -226,6 +226,14 @@ int porla_icc_encode_host_multi(const uint8_t *rows_in, size_t n_rows, size_t n_
  * curve, write_step, part : as for porla_icc_encode_* (part 1 = Y: inputs pre-multiplied by wt) */
 int porla_icc_mac_encode_device(const void *d_macs_in, size_t n_rows, int curve, unsigned long long write_step, int part,
                                 void *d_macs_out, void *hip_stream);
+/* BOTH parts from one butterfly network (what CRebuild_Cached needs: Server.hpp:1548-1687 X part, :1691-1830 Y part): the network
+ * is linear over Z_q and the Y part's inputs are wt * MAC_U (:1528-1536), so Y_k = wt * X_k -- one scalar multiplication per
+ * row instead of a second run of log2(n_rows) dependent stages; the 64 output bytes per point are those of the two single-part
+ * calls */
+int porla_icc_mac_encode_xy_device(const void *d_macs_in, size_t n_rows, int curve, unsigned long long write_step,
+                                   void *d_macs_x_out, void *d_macs_y_out, void *hip_stream);
+int porla_icc_mac_encode_xy_host(const uint8_t *macs_in, size_t n_rows, int curve, unsigned long long write_step,
+                                 uint8_t *macs_x_out, uint8_t *macs_y_out);
 int porla_icc_mac_encode_host(const uint8_t *macs_in, size_t n_rows, int curve, unsigned long long write_step, int part,
                               uint8_t *macs_out);
 /* tuning: row counts <= n_rows use the matrix form (N commitments against the per-call base, throughput-bound), larger

@@ -21,7 +21,7 @@ namespace porla {
 
 struct MacWs {
     int device = -1;
-    Buf work, tws, wpow, wt, in, out;
+    Buf work, work_y, tws, wpow, in, out, out_y;
     uint32_t tw_n = 0;
     int tw_curve = -1;
     // matrix form
@@ -93,9 +93,13 @@ static int mac_mix_core(MacWs* ws, int curve, const uint8_t* d_a0, const uint8_t
     return PORLA_OK;
 }
 
+// d_out_y != nullptr (with part == 0): BOTH parts from one butterfly network.  The network is linear over Z_q and the Y part is
+// the X part's network applied to inputs scaled by wt (Server.hpp:1494-1536: Y = wt * MAC_U, then the same stages, :1691-1830),
+// so Y_k = wt * X_k as group elements: one scalar multiplication per row on the X part's work array instead of a second run of
+// log2(N) dependent ladders -- the affine points, hence the 64 output bytes, are the same
 template <class C, class Q>
 static int mac_encode_core(MacWs* ws, int curve, const uint8_t* d_in, size_t n, unsigned long long write_step, int part,
-                           uint8_t* d_out, hipStream_t stream) {
+                           uint8_t* d_out, hipStream_t stream, uint8_t* d_out_y = nullptr) {
     using M = typename C::Fp;
     const int logn = ilog2u(n);
     if (n < 2 || ((size_t)1 << logn) != n || n > (1u << 30)) {
@@ -103,6 +107,11 @@ static int mac_encode_core(MacWs* ws, int curve, const uint8_t* d_in, size_t n, 
         return PORLA_ERR_ARG;
     }
     int rc;
+    if (n <= g_matrix_max && d_out_y) {
+        // the matrix form evaluates one cached N x N matrix per part: both parts = two runs
+        if ((rc = mac_encode_core<C, Q>(ws, curve, d_in, n, write_step, 0, d_out, stream))) return rc;
+        return mac_encode_core<C, Q>(ws, curve, d_in, n, write_step, 1, d_out_y, stream);
+    }
     if (n <= g_matrix_max) {
         // ---- matrix form
         const unsigned long long wt_exp = part == 1 ? rev_bits(write_step % n, logn) : 0;
@@ -122,18 +131,16 @@ static int mac_encode_core(MacWs* ws, int curve, const uint8_t* d_in, size_t n, 
         return fb.commit_device((const uint8_t*)ws->F.p, n, n, n * 32, d_out, stream);
     }
     if ((rc = ws->work.ensure(n * sizeof(XYZZ<M>)))) return rc;
-    if ((rc = ws->wt.ensure(64))) return rc;
     if ((rc = ensure_mac_twiddles<Q>(ws, curve, n, stream))) return rc;
     int use_wt = 0;
-    if (part == 1) {
-        // wt as the group sees it: the integer (wt mod p_icc) reduced mod the group order (Server.hpp:1494-1503)
+    MacScalar wt{};
+    if (part == 1 || d_out_y) {
+        // wt as the group sees it: the integer (wt mod p_icc) reduced mod the group order (Server.hpp:1494-1503); a kernel
+        // argument, so the call stays asynchronous
         Fe<IccFp> plain = fe_from_mont<IccFp>(icc_wt(n, write_step));
-        uint32_t k[8];
-        for (int i = 0; i < 8; i++) k[i] = plain.v[i];
-        fe_reduce_plain<Q>(k, 8);
-        PORLA_HIP(hipMemcpyAsync(ws->wt.p, k, 32, hipMemcpyHostToDevice, stream));
-        PORLA_HIP(hipStreamSynchronize(stream));
-        use_wt = 1;
+        for (int i = 0; i < 8; i++) wt.v[i] = plain.v[i];
+        fe_reduce_plain<Q>(wt.v, 8);
+        use_wt = part == 1;
     }
     {
         ProfScope ps("mac_load", stream);
@@ -141,13 +148,13 @@ static int mac_encode_core(MacWs* ws, int curve, const uint8_t* d_in, size_t n, 
             static const bool quad = !(getenv("PORLA_MAC_QUAD") && getenv("PORLA_MAC_QUAD")[0] == '0');
             if (use_wt && quad && n <= ((size_t)1 << 14))
                 hipLaunchKernelGGL((k_mac_load30_quad<C>), dim3((unsigned)((n + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), 0, stream, d_in,
-                                   (uint32_t)n, (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->wt.p);
+                                   (uint32_t)n, (XYZZ<M>*)ws->work.p, wt);
             else
                 hipLaunchKernelGGL((k_mac_load30<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_in, (uint32_t)n,
-                                   (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->wt.p, use_wt);
+                                   (XYZZ<M>*)ws->work.p, wt, use_wt);
         } else
             hipLaunchKernelGGL((k_mac_load<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_in, (uint32_t)n,
-                               (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->wt.p, use_wt);
+                               (XYZZ<M>*)ws->work.p, wt, use_wt);
     }
     for (int s = 1; s <= logn; s++) {
         ProfScope ps("mac_stage", stream);
@@ -170,20 +177,41 @@ static int mac_encode_core(MacWs* ws, int curve, const uint8_t* d_in, size_t n, 
         hipLaunchKernelGGL((k_mac_finish<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, (const XYZZ<M>*)ws->work.p,
                            (uint32_t)n, d_out);
     }
+    if (d_out_y) {
+        if constexpr (C::F30_LAZY) {
+            if ((rc = ws->work_y.ensure(n * sizeof(XYZZ<M>)))) return rc;
+            {
+                ProfScope ps("mac_scale", stream);
+                static const bool quad = !(getenv("PORLA_MAC_QUAD") && getenv("PORLA_MAC_QUAD")[0] == '0');
+                if (quad && n <= ((size_t)1 << 14))
+                    hipLaunchKernelGGL((k_mac_load30_quad<C, true>), dim3((unsigned)((n + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), 0, stream,
+                                       (const uint8_t*)ws->work.p, (uint32_t)n, (XYZZ<M>*)ws->work_y.p, wt);
+                else
+                    hipLaunchKernelGGL((k_mac_scale30<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, (const XYZZ<M>*)ws->work.p,
+                                       (uint32_t)n, (XYZZ<M>*)ws->work_y.p, wt);
+            }
+            ProfScope ps("mac_finish", stream);
+            hipLaunchKernelGGL((k_mac_finish<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, (const XYZZ<M>*)ws->work_y.p,
+                               (uint32_t)n, d_out_y);
+        } else {
+            set_last_error("porla: the two-part MAC encode needs the reduced-radix ladder");
+            return PORLA_ERR_STATE;
+        }
+    }
     PORLA_HIP(hipGetLastError());
     return PORLA_OK;
 }
 
 static int mac_dispatch(MacWs* ws, int curve, const uint8_t* d_in, size_t n, unsigned long long write_step, int part,
-                        uint8_t* d_out, hipStream_t stream) {
+                        uint8_t* d_out, hipStream_t stream, uint8_t* d_out_y = nullptr) {
     if (curve != 0 && curve != 1) {
         set_last_error("porla: curve must be 0 (BN254) or 1 (secp256k1)");
         return PORLA_ERR_ARG;
     }
     int rc = ws->fence.enter(stream);
     if (rc) return rc;
-    rc = curve == 0 ? mac_encode_core<Bn254G1, IccBn254Fr>(ws, 0, d_in, n, write_step, part, d_out, stream)
-                    : mac_encode_core<Secp256k1G, IccSecp256k1Fn>(ws, 1, d_in, n, write_step, part, d_out, stream);
+    rc = curve == 0 ? mac_encode_core<Bn254G1, IccBn254Fr>(ws, 0, d_in, n, write_step, part, d_out, stream, d_out_y)
+                    : mac_encode_core<Secp256k1G, IccSecp256k1Fn>(ws, 1, d_in, n, write_step, part, d_out, stream, d_out_y);
     if (rc) return rc;
     return ws->fence.leave(stream);
 }
@@ -209,6 +237,36 @@ int porla_icc_mac_encode_device(const void* d_macs_in, size_t n_rows, int curve,
     MacWs* ws;
     if ((rc = get_mac_ws(&ws))) return rc;
     return mac_dispatch(ws, curve, (const uint8_t*)d_macs_in, n_rows, write_step, part, (uint8_t*)d_macs_out, (hipStream_t)hip_stream);
+}
+
+int porla_icc_mac_encode_xy_device(const void* d_macs_in, size_t n_rows, int curve, unsigned long long write_step, void* d_macs_x_out,
+                                   void* d_macs_y_out, void* hip_stream) {
+    if (!d_macs_in || !d_macs_x_out || !d_macs_y_out) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mac_mu);
+    MacWs* ws;
+    if ((rc = get_mac_ws(&ws))) return rc;
+    return mac_dispatch(ws, curve, (const uint8_t*)d_macs_in, n_rows, write_step, 0, (uint8_t*)d_macs_x_out, (hipStream_t)hip_stream,
+                        (uint8_t*)d_macs_y_out);
+}
+int porla_icc_mac_encode_xy_host(const uint8_t* macs_in, size_t n_rows, int curve, unsigned long long write_step, uint8_t* macs_x_out,
+                                 uint8_t* macs_y_out) {
+    if (!macs_in || !macs_x_out || !macs_y_out) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mac_mu);
+    MacWs* ws;
+    if ((rc = get_mac_ws(&ws))) return rc;
+    if ((rc = ws->in.ensure(n_rows * 64)) || (rc = ws->out.ensure(n_rows * 64)) || (rc = ws->out_y.ensure(n_rows * 64))) return rc;
+    hipStream_t s = engine_stream();
+    PORLA_HIP(hipMemcpyAsync(ws->in.p, macs_in, n_rows * 64, hipMemcpyHostToDevice, s));
+    rc = mac_dispatch(ws, curve, (const uint8_t*)ws->in.p, n_rows, write_step, 0, (uint8_t*)ws->out.p, s, (uint8_t*)ws->out_y.p);
+    if (rc) return rc;
+    PORLA_HIP(hipMemcpyAsync(macs_x_out, ws->out.p, n_rows * 64, hipMemcpyDeviceToHost, s));
+    PORLA_HIP(hipMemcpyAsync(macs_y_out, ws->out_y.p, n_rows * 64, hipMemcpyDeviceToHost, s));
+    PORLA_HIP(hipStreamSynchronize(s));
+    return PORLA_OK;
 }
 
 int porla_icc_mac_mix_device(const void* d_a0, const void* d_a1, size_t len, size_t n_total, int curve, void* d_out, void* hip_stream) {

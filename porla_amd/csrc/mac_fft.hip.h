@@ -18,6 +18,11 @@
 
 namespace porla {
 
+// a 256-bit scalar handed to a kernel BY VALUE (the init scaling wt of the Y part): no device buffer to fill, so no copy the
+// host would have to wait for before it may reuse its temporary
+struct MacScalar { uint32_t v[8]; };
+
+
 // plain little-endian limbs of (w^e mod p_icc) mod q for e in [0, n)   (cf. k_icc_twiddles in icc.hip.h)
 template <class Q>
 __global__ void k_mac_twiddles(uint32_t* __restrict__ tws, uint32_t n, const Fe<IccFp>* __restrict__ wpow, int logn) {
@@ -184,8 +189,7 @@ __device__ __forceinline__ XYZZ<M> load_affine_be_lazy(const uint8_t* src) {
 // 64-byte big-endian affine MACs -> work array in the lazy memory form; part 1 (Y): times wt
 template <class C>
 __global__ void __launch_bounds__(64)
-k_mac_load30(const uint8_t* __restrict__ in, uint32_t n, XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restrict__ wt,
-             int use_wt) {
+k_mac_load30(const uint8_t* __restrict__ in, uint32_t n, XYZZ<typename C::Fp>* __restrict__ work, MacScalar wt, int use_wt) {
     using M = typename C::Fp;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -193,12 +197,28 @@ k_mac_load30(const uint8_t* __restrict__ in, uint32_t n, XYZZ<typename C::Fp>* _
     if (use_wt) {
         uint32_t k[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) k[j] = wt[j];
+        for (int j = 0; j < 8; j++) k[j] = wt.v[j];
         XYZZ<M> r;
         mac30_scalar_mul<C>(&r, &p, k);
         p = r;
     }
     store_xyzz<M>(work + i, p);
+}
+
+// out[i] = wt * in[i] on the work array's own form (the Y part from the X part, see mac_fft.hip:mac_encode_core): one lane per MAC
+template <class C>
+__global__ void __launch_bounds__(64)
+k_mac_scale30(const XYZZ<typename C::Fp>* __restrict__ in, uint32_t n, XYZZ<typename C::Fp>* __restrict__ out, MacScalar wt) {
+    using M = typename C::Fp;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    XYZZ<M> p = load_xyzz<M>(in + i);
+    uint32_t k[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) k[j] = wt.v[j];
+    XYZZ<M> r;
+    mac30_scalar_mul<C>(&r, &p, k);
+    store_xyzz<M>(out + i, r);
 }
 
 template <class C>
@@ -332,6 +352,10 @@ __global__ void __launch_bounds__(4 * MACQ_BF)
 k_mac_stage30_quad(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restrict__ tws, uint32_t n, int s) {
     using M = typename C::Fp;
     __shared__ MacQuadLds<M> L;
+    // a stage is one wave per SIMD walking ~200 dependent group operations: when another kernel shares the chip (the
+    // commitments of the same CRebuild on a second stream) this wave must win the SIMD's issue arbitration every time it is
+    // ready -- the wide kernel's waves fill the cycles in between (beside k_fb_commit a stage took 1.45 ms without this, 0.9 alone)
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t q = threadIdx.x >> 2, r = threadIdx.x & 3u, lane = threadIdx.x & 63u;
     uint32_t t = blockIdx.x * MACQ_BF + q;
     const bool valid = t < n / 2;
@@ -358,9 +382,10 @@ k_mac_stage30_quad(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __re
 }
 
 // init scaling of the Y part (k_mac_load30 with use_wt) with four lanes per MAC: work[i] = wt * MAC[i]
-template <class C>
+// FROM_WORK: `in` is a work array (n points in the lazy memory form) instead of 64-byte big-endian affine MACs
+template <class C, bool FROM_WORK = false>
 __global__ void __launch_bounds__(4 * MACQ_BF)
-k_mac_load30_quad(const uint8_t* __restrict__ in, uint32_t n, XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restrict__ wt) {
+k_mac_load30_quad(const uint8_t* __restrict__ in, uint32_t n, XYZZ<typename C::Fp>* __restrict__ work, MacScalar wt) {
     using M = typename C::Fp;
     __shared__ MacQuadLds<M> L;
     const uint32_t q = threadIdx.x >> 2, r = threadIdx.x & 3u, lane = threadIdx.x & 63u;
@@ -369,8 +394,9 @@ k_mac_load30_quad(const uint8_t* __restrict__ in, uint32_t n, XYZZ<typename C::F
     if (!valid) i = 0;
     uint32_t sc[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) sc[j] = wt[j];
-    if (r == 0u) store_xyzz<M>(&L.tbl[q][0], load_affine_be_lazy<M>(in + (size_t)i * 64));
+    for (int j = 0; j < 8; j++) sc[j] = wt.v[j];
+    if (FROM_WORK) macq_copy_coord<M>(&L.tbl[q][0], reinterpret_cast<const XYZZ<M>*>(in) + i, r);
+    else if (r == 0u) store_xyzz<M>(&L.tbl[q][0], load_affine_be_lazy<M>(in + (size_t)i * 64));
     __syncthreads();
     macq_ladder<C>(L, q, r, lane, sc);
     if (valid) macq_copy_coord<M>(work + i, &L.acc[q], r);
@@ -412,8 +438,7 @@ k_mac_mix_quad(const uint8_t* __restrict__ a0, const uint8_t* __restrict__ a1, u
 // 64-byte big-endian affine MACs -> XYZZ work array; part 1 (Y): times wt (Server.hpp:1528-1536)
 template <class C>
 __global__ void __launch_bounds__(64)
-k_mac_load(const uint8_t* __restrict__ in, uint32_t n, XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restrict__ wt,
-           int use_wt) {
+k_mac_load(const uint8_t* __restrict__ in, uint32_t n, XYZZ<typename C::Fp>* __restrict__ work, MacScalar wt, int use_wt) {
     using M = typename C::Fp;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -428,7 +453,7 @@ k_mac_load(const uint8_t* __restrict__ in, uint32_t n, XYZZ<typename C::Fp>* __r
     if (use_wt) {
         uint32_t k[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) k[j] = wt[j];
+        for (int j = 0; j < 8; j++) k[j] = wt.v[j];
         p = xyzz_scalar_mul<M>(p, k);
     }
     store_xyzz<M>(work + i, p);

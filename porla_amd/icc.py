@@ -64,6 +64,18 @@ def mac_crebuild_host(macs, n_rows, curve="bn254", write_step=0, part=0):
     return out.raw
 
 
+def mac_crebuild_xy_host(macs, n_rows, curve="bn254", write_step=0):
+    """both MAC halves of CRebuild_Cached from one butterfly network (Y_k = wt * X_k): (X part, Y part)"""
+    ox, oy = ctypes.create_string_buffer(64 * n_rows), ctypes.create_string_buffer(64 * n_rows)
+    _check(lib.porla_icc_mac_encode_xy_host(bytes(macs), n_rows, CURVE[curve], write_step, ox, oy))
+    return ox.raw, oy.raw
+
+
+def mac_crebuild_xy_device(d_macs, n_rows, curve, write_step, d_out_x, d_out_y, stream=0):
+    _check(lib.porla_icc_mac_encode_xy_device(ctypes.c_void_p(d_macs), n_rows, CURVE[curve], write_step, ctypes.c_void_p(d_out_x),
+                                              ctypes.c_void_p(d_out_y), ctypes.c_void_p(stream)))
+
+
 def mac_crebuild_device(d_macs, n_rows, curve, write_step, part, d_out, stream=0):
     _check(lib.porla_icc_mac_encode_device(ctypes.c_void_p(d_macs), n_rows, CURVE[curve], write_step, part,
                                            ctypes.c_void_p(d_out), ctypes.c_void_p(stream)))

@@ -112,6 +112,10 @@ def _declare(L):
     L.porla_gpu_release_msm_workspaces.argtypes = []; L.porla_gpu_release_msm_workspaces.restype = ctypes.c_int
     L.porla_icc_mac_encode_device.argtypes = [vp, sz, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_int, vp, vp]
     L.porla_icc_mac_encode_device.restype = ctypes.c_int
+    L.porla_icc_mac_encode_xy_device.argtypes = [vp, sz, ctypes.c_int, ctypes.c_ulonglong, vp, vp, vp]
+    L.porla_icc_mac_encode_xy_device.restype = ctypes.c_int
+    L.porla_icc_mac_encode_xy_host.argtypes = [u8p, sz, ctypes.c_int, ctypes.c_ulonglong, u8p, u8p]
+    L.porla_icc_mac_encode_xy_host.restype = ctypes.c_int
     L.porla_icc_mac_encode_host.argtypes = [u8p, sz, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_int, u8p]
     L.porla_icc_mac_encode_host.restype = ctypes.c_int
     L.porla_icc_mac_set_matrix_max.argtypes = [sz]; L.porla_icc_mac_set_matrix_max.restype = ctypes.c_int

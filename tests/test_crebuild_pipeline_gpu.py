@@ -34,7 +34,11 @@ def test_chain_matches_the_oracle_chain(log2rows, write_step):
     d_macs = torch.empty(64 * n, dtype=torch.uint8, device=dev)
     mx.kzg_commit_batch_device(d_rows.data_ptr(), n, d_macs.data_ptr(), stream)
     bufs = bc.alloc(torch, n, dev)
-    bc.run_chain(torch, icc, mx, d_rows, d_macs, n, write_step, bufs, stream)       # nothing between the calls but the stream
+    side = torch.cuda.Stream(device=dev)
+    if log2rows == 8:       # the calls in the reference's order, one MAC encode per part, one stream
+        bc.run_chain(torch, icc, mx, d_rows, d_macs, n, write_step, bufs, stream, reference_order=True)
+    else:                   # both MAC halves from one network, on a second stream beside the data side
+        bc.run_chain(torch, icc, mx, d_rows, d_macs, n, write_step, bufs, stream, side.cuda_stream)
     torch.cuda.synchronize()
     rows, macs = bytes(d_rows.cpu().numpy()), bytes(d_macs.cpu().numpy())
     L = common.oracle()

@@ -100,3 +100,37 @@ def test_device_pointer_api_4096():
     icc.mac_crebuild_device(d_in.data_ptr(), n, "bn254", 0, 0, d_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert bytes(d_out.cpu().numpy()) == oracle_mac(macs, n, "bn254", 0, 0)
+
+
+@pytest.mark.parametrize("curve", ["bn254", "secp256k1"])
+@pytest.mark.parametrize("n,ws", [(2, 1), (16, 6), (256, 77), (1024, 5), (4096, 123457)])
+def test_both_parts_from_one_network_match_the_two_single_part_encodes(curve, n, ws, form):
+    """porla_icc_mac_encode_xy_*: the network is linear over Z_q and the Y part is the X part's network on inputs scaled by wt
+    (Server.hpp:1494-1536, :1691-1830), so Y_k = wt * X_k -- one scalar multiplication per row instead of a second run of the
+    stages.  Both outputs against the oracle's two separate encodes; infinity MACs and repeated MACs among the inputs."""
+    from porla_amd import icc
+    macs = bytearray(macs_for(curve, n))
+    if n >= 16:
+        macs[64 * 3:64 * 4] = bytes(64)
+        macs[64 * 8:64 * 9] = macs[0:64]
+        macs[64 * 9:64 * 10] = bytes(64)
+    macs = bytes(macs)
+    x, y = icc.mac_crebuild_xy_host(macs, n, curve, ws)
+    assert x == oracle_mac(macs, n, curve, 0, ws)
+    assert y == oracle_mac(macs, n, curve, 1, ws)
+    assert icc.mac_crebuild_xy_host(bytes(64 * n), n, curve, ws) == (bytes(64 * n), bytes(64 * n))
+
+
+def test_both_parts_device_form_at_2_15_rows():
+    """the size of a large CRebuild (one lane per row for the scaling above 2^14 rows), device pointers, against the oracle"""
+    import torch
+    from porla_amd import icc
+    n = 1 << 15
+    macs = macs_for("bn254", n)
+    d_in = torch.frombuffer(bytearray(macs), dtype=torch.uint8).cuda()
+    d_x = torch.empty(64 * n, dtype=torch.uint8, device="cuda")
+    d_y = torch.empty(64 * n, dtype=torch.uint8, device="cuda")
+    icc.mac_crebuild_xy_device(d_in.data_ptr(), n, "bn254", 1000003, d_x.data_ptr(), d_y.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert bytes(d_x.cpu().numpy()) == oracle_mac(macs, n, "bn254", 0, 1000003)
+    assert bytes(d_y.cpu().numpy()) == oracle_mac(macs, n, "bn254", 1, 1000003)
