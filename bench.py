@@ -232,8 +232,16 @@ def main():
         t_w = time.perf_counter()
         for _ in range(args.warmup):
             res = step()
-        while min_warm_s and time.perf_counter() - t_w < min_warm_s:
-            res = step()
+        if min_warm_s and args.warmup:
+            # the SAME number of extra steps on every rank (a step may contain a collective): from this rank's pace, MAX over ranks
+            per = max((time.perf_counter() - t_w) / args.warmup, 1e-5)
+            extra = max(0, min(2000, int((min_warm_s - (time.perf_counter() - t_w)) / per) + 1))
+            if world > 1:
+                t = torch.tensor([extra], dtype=torch.int64, device=coll_dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                extra = int(t.item())
+            for _ in range(extra):
+                res = step()
         if drain:
             res = drain() or res
         sync()
