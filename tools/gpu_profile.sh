@@ -8,7 +8,7 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 WORKLOAD=${WORKLOAD:-bn254_msm}
-BENCH="python3 $PWD/bench.py --workload $WORKLOAD"
+BENCH="python3 $PWD/bench.py --workload $WORKLOAD ${BENCH_EXTRA:-}"
 SHORT="--steps 10 --warmup 2"
 if [ "${SKIP_TESTS:-0}" != 1 ]; then (timeout 900 python3 -m pytest tests -m gpu -x -q 2>&1 | tail -5) > "$OUT/pytest.txt"; fi
 (timeout 600 $BENCH 2>/dev/null | grep '^{') > "$OUT/bench_n1.json"
