@@ -81,21 +81,32 @@ __device__ __forceinline__ void icc30_bfly(F30<M>& a, F30<M>& b, const F30<M>& w
     b = icc30_sub<M, 2>(a, t);
     a = icc30_add<M>(a, t);
 }
-// stage 1 of the first pass: every twiddle is w^0 and both operands are fresh products of the load step
-template <class M>
+// a butterfly whose twiddle is w^0 and whose lower operand is known to be small: (a, b) <- (a + b, a - b + K p), b <= (K - 1) p
+// + 2^240.  Stage 1 of the first pass: operands straight from the load step -- products of it (K = 2: b < p + 2^248) or RAW 256-bit
+// chunks (K = 7: b < 2^256 < 6 p + 2^240 for all three moduli, the smallest being the BN254 group order at 0.189 x 2^256)
+template <class M, int K>
 __device__ __forceinline__ void icc30_bfly_plain(F30<M>& a, F30<M>& b) {
+    static_assert(K <= 4 || (unsigned __int128)(K - 1) * ((((unsigned __int128)M::P[7]) << 32) | M::P[6]) >= ((unsigned __int128)1 << 64),
+                  "K = 7 is for raw 256-bit operands: (K - 1) p must exceed 2^256 (K <= 4: the caller bounds b by (K - 1) p itself)");
     const F30<M> t = b;
-    b = icc30_sub<M, 2>(a, t);
+    b = icc30_sub<M, K>(a, t);
     a = icc30_add<M>(a, t);
 }
 
 struct IccTile {           // what a block knows about its tile (the same for both planes)
     uint32_t n, ncols, elems, cc_log, lo_bits, lo, row_base, c0;
     int s0, ns;
+    int raw;               // first pass without an init scaling: the chunks enter the network as they are (see icc30_fetch)
 };
 
-// a tile symbol from where the pass finds it: the raw 32-byte chunk times the load step's constant K of this plane (FIRST:
-// x * K / 2^270 -- the plain residue x, or x wt, below p + 2^248; the chunk is not reduced first), or the plane's work array
+// a tile symbol from where the pass finds it.  FIRST: the raw 32-byte chunk x.  The stream is made of PLAIN residues and nothing
+// in the network needs them reduced -- a product with a twiddle brings any operand below 2^263 under p + 2^248, sums and
+// differences stay unreduced anyway -- so without an init scaling (the X part: T.raw) the 256-bit chunk enters as it is: nine
+// normal limbs, value below 2^256 (the first stage's difference then adds 7 p instead of 2 p, and a symbol is bounded by
+// 8.3 p + 2 p per later stage: 66.3 p < 2^263 after 30 stages -- limb 8 below 2^23, the column bound tools/check_fe30_bounds.py proves -- like the
+// 63 p of the scaled form).  With an init scaling (the Y part) the load step is the product x * (wt 2^270) / 2^270 = x wt.
+// (icc30.hip.h:icc30_load_raw multiplies by the Montgomery unit in the unscaled case: two products per symbol that only reduce.)
+// Not FIRST: the plane's work array.
 template <class M, bool FIRST>
 __device__ __forceinline__ F30<M> icc30_fetch(const IccTile& T, uint32_t e, const uint8_t* __restrict__ raw, const F30<M>& K,
                                               const uint32_t* __restrict__ work) {
@@ -103,7 +114,8 @@ __device__ __forceinline__ F30<M> icc30_fetch(const IccTile& T, uint32_t e, cons
     const size_t gi = (size_t)(T.row_base + (mid << T.lo_bits)) * T.ncols + T.c0 + col;
     if (FIRST) {
         const Fe<IccFp> x = ld_fe<IccFp>(reinterpret_cast<const uint32_t*>(raw + 32 * gi));
-        return icc30_mul<M>(f30_unpack<M>(x.v), K);
+        const F30<M> u = f30_unpack<M>(x.v);
+        return T.raw ? u : icc30_mul<M>(u, K);
     }
     return icc30_ld_work<M>(work + gi * ICC30_PLANE_WORDS);
 }
@@ -133,9 +145,9 @@ __device__ __forceinline__ void icc30_round(uint32_t* lds, const IccTile& T, int
             }
             const uint32_t j = (low << T.lo_bits) + T.lo;                        // row index mod m2 of stage s
             if (FIRST && GLOBAL_IN) {
-                // stage 1 of the encode: every twiddle is w^0 and both operands are fresh products of the load step
-                icc30_bfly_plain<M>(a[0], a[1]);
-                icc30_bfly_plain<M>(a[2], a[3]);
+                // stage 1 of the encode: every twiddle is w^0 and both operands come straight from the load step
+                if (T.raw) { icc30_bfly_plain<M, 7>(a[0], a[1]); icc30_bfly_plain<M, 7>(a[2], a[3]); }
+                else { icc30_bfly_plain<M, 2>(a[0], a[1]); icc30_bfly_plain<M, 2>(a[2], a[3]); }
             } else {
                 const F30<M> w1 = icc30_ld_pslot<M>(tw + (size_t)j * (T.n >> (s - 1)) * ICC30_PSLOT_WORDS);
                 icc30_bfly<M>(a[0], a[1], w1);
@@ -143,7 +155,14 @@ __device__ __forceinline__ void icc30_round(uint32_t* lds, const IccTile& T, int
             }
             // stage s + 1: m2' = 2^s; pair (0, 2): j' = j; pair (1, 3): j' = j + 2^(s-1) -> table entry + N / 2
             const size_t i2 = (size_t)j * (T.n >> s);
-            {
+            if (FIRST && GLOBAL_IN) {
+                // the encode's first round: j = 0 for EVERY unit, the twiddle of pair (0, 2) is w^0 -- a product with the
+                // Montgomery unit would only reduce a[2].  Whole waves skip it: a[2] = a2 + a3 is below 2^257 (raw chunks; a short
+                // reduction brings it under 2 p, K = 3) or below 2 (p + 2^248) (scaled chunks, K = 4); the outputs stay under
+                // 2^257 + 3 p, inside the bound icc30_fetch states
+                if (T.raw) { a[2] = icc30_reduce_top<M>(a[2]); icc30_bfly_plain<M, 3>(a[0], a[2]); }
+                else icc30_bfly_plain<M, 4>(a[0], a[2]);
+            } else {
                 const F30<M> w2 = icc30_ld_pslot<M>(tw + i2 * ICC30_PSLOT_WORDS);
                 icc30_bfly<M>(a[0], a[2], w2);
             }
@@ -171,7 +190,8 @@ __device__ __forceinline__ void icc30_round(uint32_t* lds, const IccTile& T, int
                 F30<M> a = GLOBAL_IN ? icc30_fetch<M, FIRST>(T, e0, raw, K, work) : icc30_ld_pslot<M>(lds + (size_t)e0 * ICC30_PSLOT_WORDS);
                 F30<M> b = GLOBAL_IN ? icc30_fetch<M, FIRST>(T, e1, raw, K, work) : icc30_ld_pslot<M>(lds + (size_t)e1 * ICC30_PSLOT_WORDS);
                 if (FIRST && GLOBAL_IN) {
-                    icc30_bfly_plain<M>(a, b);
+                    if (T.raw) icc30_bfly_plain<M, 7>(a, b);
+                    else icc30_bfly_plain<M, 2>(a, b);
                 } else {
                     const uint32_t j = (low << T.lo_bits) + T.lo;
                     const F30<M> w = icc30_ld_pslot<M>(tw + (size_t)j * (T.n >> (s - 1)) * ICC30_PSLOT_WORDS);
@@ -226,6 +246,7 @@ k_icc_split30(uint32_t* __restrict__ work_p, uint32_t* __restrict__ work_q, cons
     IccTile T;
     T.n = n; T.ncols = ncols; T.s0 = s0; T.ns = ns; T.cc_log = (uint32_t)cc_log;
     T.elems = (1u << ns) << cc_log;
+    T.raw = FIRST && !use_wt;
     T.lo_bits = (uint32_t)(s0 - 1);
     const uint32_t Cc = 1u << cc_log;
     const uint32_t col_tiles = (ncols + Cc - 1) >> cc_log;
@@ -247,8 +268,8 @@ k_icc_split30(uint32_t* __restrict__ work_p, uint32_t* __restrict__ work_q, cons
     if (need_p) {
         F30<IccFp> rp[4];
         F30<IccFp> K;
-        if (FIRST) K = use_wt ? icc30_mul<IccFp>(f30_unpack<IccFp>(wt256.p.v), f30_const<IccFp>(Icc30Const<IccFp>::C284))
-                              : icc30_ld_pslot<IccFp>(twp);
+        if (FIRST && use_wt) K = icc30_mul<IccFp>(f30_unpack<IccFp>(wt256.p.v), f30_const<IccFp>(Icc30Const<IccFp>::C284));
+        else K = F30<IccFp>{};
         icc30_plane<IccFp, FIRST>(lds, T, raw, K, work_p, twp, rp, slot);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -275,7 +296,8 @@ k_icc_split30(uint32_t* __restrict__ work_p, uint32_t* __restrict__ work_q, cons
     if (need_q) {
         F30<Q> rq[4];
         F30<Q> K;
-        if (FIRST) K = use_wt ? icc30_mul<Q>(f30_unpack<Q>(wt256.q.v), f30_const<Q>(Icc30Const<Q>::C284)) : icc30_ld_pslot<Q>(twq);
+        if (FIRST && use_wt) K = icc30_mul<Q>(f30_unpack<Q>(wt256.q.v), f30_const<Q>(Icc30Const<Q>::C284));
+        else K = F30<Q>{};
         icc30_plane<Q, FIRST>(lds, T, raw, K, work_q, twq, rq, slot);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
