@@ -96,11 +96,27 @@ while time.time() < t_end:
         n = 1 << rnd.choice([1, 2, 3, 4, 5, 6, 7, 8])
         part, ws = rnd.choice([0, 1]), rnd.choice([0, 1, n - 1, rnd.randrange(1 << 40)])
         m = macs(n, curve)
-        got = icc.mac_crebuild_host(m, n, curve, ws, part)
         want = ctypes.create_string_buffer(64 * n)
-        L.oracle_icc_mac_crebuild(m, ctypes.c_size_t(n), cid, part, ctypes.c_uint64(ws), want, NCPU)
-        ok = got == want.raw
-        desc = "n=%d part=%d ws=%d" % (n, part, ws)
+        if rnd.random() < 0.4:
+            # both halves from one network (porla_icc_mac_encode_xy_host: Y_k = wt * X_k) against the oracle's two encodes; the
+            # ladder form too at these small sizes every fourth time (the matrix form is the default up to 512 rows)
+            from porla_amd import lib
+            ladder = rnd.random() < 0.25
+            if ladder:
+                lib.porla_icc_mac_set_matrix_max(0)
+            gx, gy = icc.mac_crebuild_xy_host(m, n, curve, ws)
+            if ladder:
+                lib.porla_icc_mac_set_matrix_max(512)
+            ok = True
+            for p_, g_ in ((0, gx), (1, gy)):
+                L.oracle_icc_mac_crebuild(m, ctypes.c_size_t(n), cid, p_, ctypes.c_uint64(ws), want, NCPU)
+                ok = ok and g_ == want.raw
+            desc = "xy n=%d ws=%d ladder=%s" % (n, ws, ladder)
+        else:
+            got = icc.mac_crebuild_host(m, n, curve, ws, part)
+            L.oracle_icc_mac_crebuild(m, ctypes.c_size_t(n), cid, part, ctypes.c_uint64(ws), want, NCPU)
+            ok = got == want.raw
+            desc = "n=%d part=%d ws=%d" % (n, part, ws)
     else:
         length = 1 << rnd.choice([0, 1, 2, 4, 6, 8])
         n_total = (2 * length) << rnd.choice([0, 0, 1, 4])
