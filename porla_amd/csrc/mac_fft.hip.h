@@ -237,7 +237,8 @@ k_mac_stage30(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restric
     sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
     XYZZ<M> hi = load_xyzz<M>(work + k + m2);
     XYZZ<M> tm;
-    mac30_scalar_mul<C>(&tm, &hi, sc);
+    if (s == 1) tm = hi;                            // stage 1: every twiddle is w^0 = 1 (uniform over the launch): no ladder
+    else mac30_scalar_mul<C>(&tm, &hi, sc);
     XYZZ<M> sum = load_xyzz<M>(work + k);
     XYZZ<M> dif = sum;
     xyzz30_add_mem<M>(&sum, &tm, 0, 0, nullptr);
@@ -379,6 +380,25 @@ k_mac_stage30_quad(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __re
     macq_prepare<M>(&L.tmp[q], &L.acc[q], true, false, F30<M>{}, r, lane);
     __syncthreads();
     xyzz30_add_quad<M>(&L.um[q], &L.tmp[q], work + k + m2, false, valid, lane);
+}
+
+// Stage 1 of the network with four lanes per butterfly: every twiddle is w^0 = 1 (tm = MAC[k+1]), so the stage is its two
+// additions and nothing else -- the 0.86 ms ladder of a general stage would multiply by one.  256 lanes = 64 butterflies per block.
+template <class C>
+__global__ void __launch_bounds__(256)
+k_mac_stage1_quad(XYZZ<typename C::Fp>* __restrict__ work, uint32_t n) {
+    using M = typename C::Fp;
+    __shared__ XYZZ<M> tp[64], tn[64];                                     // tm and -tm
+    const uint32_t q = threadIdx.x >> 2, r = threadIdx.x & 3u, lane = threadIdx.x & 63u;
+    uint32_t t = blockIdx.x * 64 + q;
+    const bool valid = t < n / 2;
+    if (!valid) t = 0;
+    const uint32_t k = 2 * t;
+    macq_copy_coord<M>(&tp[q], work + k + 1, r);
+    macq_prepare<M>(&tn[q], work + k + 1, true, false, F30<M>{}, r, lane);
+    __syncthreads();
+    xyzz30_add_quad<M>(work + k, &tn[q], work + k + 1, false, valid, lane);    // um - tm (tm's copies are in LDS)
+    xyzz30_add_quad<M>(work + k, &tp[q], work + k, false, valid, lane);        // um + tm, in place: a quad loads before it stores
 }
 
 // init scaling of the Y part (k_mac_load30 with use_wt) with four lanes per MAC: work[i] = wt * MAC[i]
