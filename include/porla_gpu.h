@@ -212,6 +212,12 @@ int porla_icc_encode_host(const uint8_t *rows_in, size_t n_rows, size_t n_cols, 
  * encoded and written back into the same columns of the full-width outputs.  One process per GPU: rank g passes
  * porla_shard_range(n_cols, g, G) -- 16 columns each on 8 GPUs; or let _host_multi run `devices` GPUs of this process
  * (0 = every visible one) from one host thread each.  No collective. */
+/* BOTH parts from one run of the network (device pointers; any output may be NULL): the network is linear over Z/LCM and the Y
+ * part's chunks are the X part's times wt (Server.hpp:1494, :1512-1522), so Y_k = wt X_k mod LCM -- one product per residue and
+ * symbol in the last pass instead of a second encode; the bytes are those of the part = 0 and part = 1 calls */
+int porla_icc_encode_xy_device(const void *d_rows_in, size_t n_rows, size_t n_cols, int curve, unsigned long long write_step,
+                               void *d_x_out, void *d_aligned_out, void *d_scalars_out, void *d_y_x_out, void *d_y_aligned_out,
+                               void *d_y_scalars_out, int scalar_le, void *hip_stream);
 int porla_icc_encode_cols_host(const uint8_t *rows_in, size_t n_rows, size_t n_cols, size_t col_begin, size_t col_end, int curve,
                                unsigned long long write_step, int part, uint8_t *x_out, uint8_t *aligned_out,
                                uint8_t *scalars_out, int scalar_le);

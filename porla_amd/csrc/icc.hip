@@ -17,7 +17,7 @@ namespace porla {
 
 struct IccWs {
     int device = -1;
-    Buf work, tw, tw30, tw30p, tw30q, wpow, in, xo, al, sc;
+    Buf work, tw, tw30, tw30p, tw30q, wpow, in, xo, al, sc, park_y;
     uint32_t tw_n = 0, tw30_n = 0;   // tw30: the same table in the reduced-radix form of icc30.hip.h (80-byte slots)
     uint32_t tw30s_n = 0;            // tw30p / tw30q: the plane tables of icc30_split.hip.h (40-byte slots)
     int tw30_curve = -1, tw30s_curve = -1;
@@ -115,10 +115,11 @@ static int icc_scale_align_core(IccWs* ws, const uint8_t* d_in, size_t total, si
     return PORLA_OK;
 }
 
+// out_y != nullptr (part must be 0): the Y part's outputs from the SAME network -- Y_k = wt X_k mod LCM (icc30_split.hip.h, XY)
 template <class Q>
 static int icc_encode_core(IccWs* ws, int curve, const uint8_t* d_rows, size_t n, size_t ncols, unsigned long long write_step,
                            int part, uint8_t* d_x, uint8_t* d_al, uint8_t* d_sc, int scalar_le, hipStream_t stream,
-                           uint8_t* d_qres = nullptr) {
+                           uint8_t* d_qres = nullptr, const IccOut* out_y = nullptr) {
     const int logn = ilog2u(n);
     if (n < 2 || ((size_t)1 << logn) != n || n > (1u << 30) || ncols == 0) {
         set_last_error("porla: ICC encode needs a power-of-two row count >= 2");
@@ -136,14 +137,27 @@ static int icc_encode_core(IccWs* ws, int curve, const uint8_t* d_rows, size_t n
     if (part == 1) { wt = icc_wt<Q>(n, write_step, nullptr); use_wt = 1; }
     static const int fused = !(getenv("PORLA_ICC_FUSED") && getenv("PORLA_ICC_FUSED")[0] == '0');
     static const int f30 = !(getenv("PORLA_ICC_F30") && getenv("PORLA_ICC_F30")[0] == '0');
+    static const int split_on = !(getenv("PORLA_ICC_SPLIT") && getenv("PORLA_ICC_SPLIT")[0] == '0');
     IccOut out{d_x, d_al, d_sc, d_qres, scalar_le};
+    if (out_y) {
+        if (part != 0) { set_last_error("porla: the two-part encode takes part = 0"); return PORLA_ERR_ARG; }
+        if (!(fused && f30 && split_on)) {
+            // the other kernels have no two-part form: the Y part as its own encode
+            if ((rc = icc_encode_core<Q>(ws, curve, d_rows, n, ncols, write_step, 0, d_x, d_al, d_sc, scalar_le, stream, d_qres))) return rc;
+            return icc_encode_core<Q>(ws, curve, d_rows, n, ncols, write_step, 1, out_y->x, out_y->al, out_y->sc, out_y->scalar_le, stream,
+                                      out_y->qres);
+        }
+        wt = icc_wt<Q>(n, write_step, nullptr);        // handed to the last pass; the network itself runs unscaled (use_wt = 0)
+        if (!out_y->al && (out_y->x || out_y->sc) && (rc = ws->park_y.ensure(total * 32))) return rc;
+    }
+    const IccOut oy = out_y ? *out_y : IccOut{nullptr, nullptr, nullptr, nullptr, 0};
     if (fused) {
         // ceil(logn / 8) passes of (almost) equal stage counts, each through LDS tiles of 512 symbols; the first pass reads
         // the raw chunks, the last one writes the outputs: the residue-pair working set only travels between passes.
         // Default: the reduced-radix kernel of icc30.hip.h (72 bytes per symbol between the passes); PORLA_ICC_F30=0: icc.hip.h's.
         // PORLA_ICC_SPLIT=0: the kernel of icc30.hip.h (both residues of a symbol side by side in 80-byte LDS slots, one stage per
         // round trip); default: icc30_split.hip.h (one plane at a time, two stages per round trip)
-        static const int split = !(getenv("PORLA_ICC_SPLIT") && getenv("PORLA_ICC_SPLIT")[0] == '0');
+        const int split = split_on;
         if (f30) {
             if ((rc = ws->work.ensure(total * ICC30_PACK_WORDS * 4))) return rc;
             if (split) {
@@ -174,10 +188,16 @@ static int icc_encode_core(IccWs* ws, int curve, const uint8_t* d_rows, size_t n
             ProfScope ps("icc_fused", stream, true);
 #define PORLA_ICC_LAUNCH(F, L)                                                                                              \
     do {                                                                                                                    \
-        if (f30 && split)                                                                                                   \
+        if (f30 && split && L && out_y)                                                                                     \
+            hipLaunchKernelGGL((k_icc_split30<Q, F, L, L>), grid, dim3(ICC30_SPLIT_THREADS), 0, stream, (uint32_t*)ws->work.p, \
+                               (uint32_t*)ws->work.p + total * ICC30_PLANE_WORDS, (const uint32_t*)ws->tw30p.p,            \
+                               (const uint32_t*)ws->tw30q.p, (uint32_t)n, (uint32_t)ncols, s, ns, cc_log, d_rows, wt, use_wt, out, oy, \
+                               (uint32_t*)ws->park_y.p);                                                                    \
+        else if (f30 && split)                                                                                              \
             hipLaunchKernelGGL((k_icc_split30<Q, F, L>), grid, dim3(ICC30_SPLIT_THREADS), 0, stream, (uint32_t*)ws->work.p, \
                                (uint32_t*)ws->work.p + total * ICC30_PLANE_WORDS, (const uint32_t*)ws->tw30p.p,            \
-                               (const uint32_t*)ws->tw30q.p, (uint32_t)n, (uint32_t)ncols, s, ns, cc_log, d_rows, wt, use_wt, out); \
+                               (const uint32_t*)ws->tw30q.p, (uint32_t)n, (uint32_t)ncols, s, ns, cc_log, d_rows, wt, use_wt, out, oy, \
+                               (uint32_t*)nullptr);                                                                         \
         else if (f30)                                                                                                       \
             hipLaunchKernelGGL((k_icc_fused30<Q, F, L>), grid, dim3(256), 0, stream, (uint32_t*)ws->work.p,                 \
                                (const uint32_t*)ws->tw30.p, (uint32_t)n, (uint32_t)ncols, s, ns, cc_log, d_rows, wt, use_wt, out); \
@@ -224,15 +244,15 @@ static int icc_encode_core(IccWs* ws, int curve, const uint8_t* d_rows, size_t n
 
 static int icc_encode_dispatch(IccWs* ws, int curve, const uint8_t* d_rows, size_t n, size_t ncols, unsigned long long ws_step,
                                int part, uint8_t* d_x, uint8_t* d_al, uint8_t* d_sc, int scalar_le, hipStream_t stream,
-                               uint8_t* d_qres = nullptr) {
+                               uint8_t* d_qres = nullptr, const IccOut* out_y = nullptr) {
     if (curve != 0 && curve != 1) {
         set_last_error("porla: curve must be 0 (BN254 / KZG) or 1 (secp256k1 / IPA)");
         return PORLA_ERR_ARG;
     }
     int rc = ws->fence.enter(stream);      // an earlier encode on another stream may still use work / the twiddles
     if (rc) return rc;
-    rc = curve == 0 ? icc_encode_core<IccBn254Fr>(ws, 0, d_rows, n, ncols, ws_step, part, d_x, d_al, d_sc, scalar_le, stream, d_qres)
-                    : icc_encode_core<IccSecp256k1Fn>(ws, 1, d_rows, n, ncols, ws_step, part, d_x, d_al, d_sc, scalar_le, stream, d_qres);
+    rc = curve == 0 ? icc_encode_core<IccBn254Fr>(ws, 0, d_rows, n, ncols, ws_step, part, d_x, d_al, d_sc, scalar_le, stream, d_qres, out_y)
+                    : icc_encode_core<IccSecp256k1Fn>(ws, 1, d_rows, n, ncols, ws_step, part, d_x, d_al, d_sc, scalar_le, stream, d_qres, out_y);
     if (rc) return rc;
     return ws->fence.leave(stream);
 }
@@ -277,6 +297,20 @@ int porla_icc_encode_device(const void* d_rows_in, size_t n_rows, size_t n_cols,
     std::lock_guard<std::mutex> lk(ws->mu);
     return icc_encode_dispatch(ws, curve, (const uint8_t*)d_rows_in, n_rows, n_cols, write_step, part, (uint8_t*)d_x_out,
                                (uint8_t*)d_aligned_out, (uint8_t*)d_scalars_out, scalar_le, (hipStream_t)stream);
+}
+
+int porla_icc_encode_xy_device(const void* d_rows_in, size_t n_rows, size_t n_cols, int curve, unsigned long long write_step,
+                               void* d_x_out, void* d_aligned_out, void* d_scalars_out, void* d_y_x_out, void* d_y_aligned_out,
+                               void* d_y_scalars_out, int scalar_le, void* stream) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!d_rows_in) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    IccWs* ws;
+    if ((rc = get_icc_ws(&ws))) return rc;
+    std::lock_guard<std::mutex> lk(ws->mu);
+    const IccOut oy{(uint8_t*)d_y_x_out, (uint8_t*)d_y_aligned_out, (uint8_t*)d_y_scalars_out, nullptr, scalar_le};
+    return icc_encode_dispatch(ws, curve, (const uint8_t*)d_rows_in, n_rows, n_cols, write_step, 0, (uint8_t*)d_x_out,
+                               (uint8_t*)d_aligned_out, (uint8_t*)d_scalars_out, scalar_le, (hipStream_t)stream, nullptr, &oy);
 }
 
 // columns [c0, c1) of row-major host rows: strided upload into a compact n_rows x (c1 - c0) image, encode, strided download into

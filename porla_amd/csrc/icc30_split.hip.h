@@ -236,11 +236,17 @@ __device__ __forceinline__ void icc30_plane(uint32_t* lds, const IccTile& T, con
 }
 
 // LDS-fused stages s0 .. s0+ns-1 of a tile of 2^ns rows x 2^cc_log columns (<= 512 symbols), both planes; grid = tiles
-template <class Q, bool FIRST, bool LAST>
+// XY (last pass only): the outputs of BOTH parts from this one network.  The network is linear over Z/LCM and the Y part is the X
+// part's network on chunks scaled by wt (Server.hpp:1494, :1512-1522, then the same stages :1691-1830), so Y_k = wt X_k mod LCM,
+// residue by residue: one product per plane and symbol on the last round's registers, then the same finish step with `out_y`'s
+// pointers -- instead of a second run of every pass.  use_wt must be 0 (the network is the X part's); wt256 is the scaling.
+// A mod p_icc of the Y part waits for the q plane in out_y.al or, when the caller does not want it, in park_y (32 B per symbol).
+template <class Q, bool FIRST, bool LAST, bool XY = false>
 __global__ void __launch_bounds__(ICC30_SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_icc_split30(uint32_t* __restrict__ work_p, uint32_t* __restrict__ work_q, const uint32_t* __restrict__ twp,
               const uint32_t* __restrict__ twq, uint32_t n, uint32_t ncols, int s0, int ns, int cc_log,
-              const uint8_t* __restrict__ raw, IccElem<Q> wt256, int use_wt, IccOut out) {
+              const uint8_t* __restrict__ raw, IccElem<Q> wt256, int use_wt, IccOut out, IccOut out_y, uint32_t* __restrict__ park_y) {
+    static_assert(LAST || !XY, "the second part's outputs are derived in the last pass");
     __shared__ uint2 lds2[ICC_TILE_ELEMS * ICC30_PSLOT_WORDS / 2];
     uint32_t* lds = reinterpret_cast<uint32_t*>(lds2);
     IccTile T;
@@ -262,8 +268,10 @@ k_icc_split30(uint32_t* __restrict__ work_p, uint32_t* __restrict__ work_q, cons
 
     // planes the requested outputs need: the values mod p_icc (al) only the p_icc plane, the values mod q (qres: the MAC side's
     // network matrix) only the q plane; the alignment scalars and the values mod LCM both
-    const bool need_p = !LAST || out.x || out.al || out.sc;
-    const bool need_q = !LAST || out.x || out.sc || out.qres;
+    const bool y_p = XY && (out_y.x || out_y.al || out_y.sc), y_q = XY && (out_y.x || out_y.sc || out_y.qres);
+    const bool x_q = out.x || out.sc || out.qres;
+    const bool need_p = !LAST || out.x || out.al || out.sc || y_p;
+    const bool need_q = !LAST || x_q || y_q;
     uint32_t slot[4];
     if (need_p) {
         F30<IccFp> rp[4];
@@ -271,6 +279,8 @@ k_icc_split30(uint32_t* __restrict__ work_p, uint32_t* __restrict__ work_q, cons
         if (FIRST && use_wt) K = icc30_mul<IccFp>(f30_unpack<IccFp>(wt256.p.v), f30_const<IccFp>(Icc30Const<IccFp>::C284));
         else K = F30<IccFp>{};
         icc30_plane<IccFp, FIRST>(lds, T, raw, K, work_p, twp, rp, slot);
+        F30<IccFp> Ky = F30<IccFp>{};
+        if (XY) Ky = icc30_mul<IccFp>(f30_unpack<IccFp>(wt256.p.v), f30_const<IccFp>(Icc30Const<IccFp>::C284));   // wt in the 2^270 form
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             if (slot[i] != 0xffffffffu) {
@@ -279,12 +289,19 @@ k_icc_split30(uint32_t* __restrict__ work_p, uint32_t* __restrict__ work_q, cons
                 if (LAST) {
                     // A mod p_icc leaves the registers here: to `aligned` when the caller wants it, and -- for the q plane's finish
                     // step, by the same lane -- to the symbol's own place in the p_icc work plane, which this block has finished reading
-                    const Fe<IccFp> P = icc30_finish_p(rp[i]);
-                    if (out.al) st_fe<IccFp>(reinterpret_cast<uint32_t*>(out.al + 32 * gi), P);
-                    if (need_q && !out.al) {
-                        uint32_t* d = work_p + gi * ICC30_PLANE_WORDS;
+                    if (out.x || out.al || out.sc) {
+                        const Fe<IccFp> P = icc30_finish_p(rp[i]);
+                        if (out.al) st_fe<IccFp>(reinterpret_cast<uint32_t*>(out.al + 32 * gi), P);
+                        if ((out.x || out.sc) && !out.al) {
+                            uint32_t* d = work_p + gi * ICC30_PLANE_WORDS;
 #pragma unroll
-                        for (int k = 0; k < 8; k++) d[k] = P.v[k];
+                            for (int k = 0; k < 8; k++) d[k] = P.v[k];
+                        }
+                    }
+                    if (y_p) {
+                        const Fe<IccFp> P = icc30_finish_p(icc30_mul<IccFp>(rp[i], Ky));      // (wt X) mod p_icc
+                        if (out_y.al) st_fe<IccFp>(reinterpret_cast<uint32_t*>(out_y.al + 32 * gi), P);
+                        if ((out_y.x || out_y.sc) && !out_y.al) st_fe<IccFp>(park_y + gi * 8, P);
                     }
                 } else {
                     icc30_st_work<IccFp>(work_p + gi * ICC30_PLANE_WORDS, rp[i]);
@@ -299,19 +316,32 @@ k_icc_split30(uint32_t* __restrict__ work_p, uint32_t* __restrict__ work_q, cons
         if (FIRST && use_wt) K = icc30_mul<Q>(f30_unpack<Q>(wt256.q.v), f30_const<Q>(Icc30Const<Q>::C284));
         else K = F30<Q>{};
         icc30_plane<Q, FIRST>(lds, T, raw, K, work_q, twq, rq, slot);
+        F30<Q> Ky = F30<Q>{};
+        if (XY) Ky = icc30_mul<Q>(f30_unpack<Q>(wt256.q.v), f30_const<Q>(Icc30Const<Q>::C284));
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             if (slot[i] != 0xffffffffu) {
                 const uint32_t mid = slot[i] >> cc_log, col = slot[i] & (Cc - 1);
                 const size_t gi = (size_t)(T.row_base + (mid << T.lo_bits)) * ncols + T.c0 + col;
                 if (LAST) {
-                    Fe<IccFp> P = fe_zero<IccFp>();
-                    if (out.x || out.sc) {               // what this lane stored after the p_icc plane
-                        const uint32_t* src = out.al ? reinterpret_cast<const uint32_t*>(out.al + 32 * gi) : work_p + gi * ICC30_PLANE_WORDS;
+                    if (x_q) {
+                        Fe<IccFp> P = fe_zero<IccFp>();
+                        if (out.x || out.sc) {               // what this lane stored after the p_icc plane
+                            const uint32_t* src = out.al ? reinterpret_cast<const uint32_t*>(out.al + 32 * gi) : work_p + gi * ICC30_PLANE_WORDS;
 #pragma unroll
-                        for (int k = 0; k < 8; k++) P.v[k] = src[k];
+                            for (int k = 0; k < 8; k++) P.v[k] = src[k];
+                        }
+                        icc30_finish_q<Q>(P, rq[i], gi, out);
                     }
-                    icc30_finish_q<Q>(P, rq[i], gi, out);
+                    if (y_q) {
+                        Fe<IccFp> P = fe_zero<IccFp>();
+                        if (out_y.x || out_y.sc) {
+                            const uint32_t* src = out_y.al ? reinterpret_cast<const uint32_t*>(out_y.al + 32 * gi) : park_y + gi * 8;
+#pragma unroll
+                            for (int k = 0; k < 8; k++) P.v[k] = src[k];
+                        }
+                        icc30_finish_q<Q>(P, icc30_mul<Q>(rq[i], Ky), gi, out_y);               // (wt X) mod q
+                    }
                 } else {
                     icc30_st_work<Q>(work_q + gi * ICC30_PLANE_WORDS, rq[i]);
                 }

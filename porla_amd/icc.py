@@ -57,6 +57,15 @@ def crebuild_device(d_rows, n_rows, n_cols, curve, write_step, part, d_x=0, d_al
                                        ctypes.c_void_p(d_scalars or None), 1 if scalar_le else 0, ctypes.c_void_p(stream)))
 
 
+def crebuild_xy_device(d_rows, n_rows, n_cols, curve, write_step, d_x=0, d_aligned=0, d_scalars=0, d_y_x=0, d_y_aligned=0,
+                       d_y_scalars=0, scalar_le=False, stream=0):
+    """X and Y parts from one run of the network (Y_k = wt X_k mod LCM); device pointers, any output may be 0"""
+    vp = ctypes.c_void_p
+    _check(lib.porla_icc_encode_xy_device(vp(d_rows), n_rows, n_cols, CURVE[curve], write_step, vp(d_x or None), vp(d_aligned or None),
+                                          vp(d_scalars or None), vp(d_y_x or None), vp(d_y_aligned or None), vp(d_y_scalars or None),
+                                          1 if scalar_le else 0, vp(stream)))
+
+
 def mac_crebuild_host(macs, n_rows, curve="bn254", write_step=0, part=0):
     """MAC halves of CRebuild_Cached (Server.hpp:1523-1536, 1590-1609, 1658-1676): n_rows 64-byte affine MACs in/out."""
     out = ctypes.create_string_buffer(64 * n_rows)

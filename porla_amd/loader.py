@@ -112,6 +112,8 @@ def _declare(L):
     L.porla_gpu_release_msm_workspaces.argtypes = []; L.porla_gpu_release_msm_workspaces.restype = ctypes.c_int
     L.porla_icc_mac_encode_device.argtypes = [vp, sz, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_int, vp, vp]
     L.porla_icc_mac_encode_device.restype = ctypes.c_int
+    L.porla_icc_encode_xy_device.argtypes = [vp, sz, sz, ctypes.c_int, ctypes.c_ulonglong, vp, vp, vp, vp, vp, vp, ctypes.c_int, vp]
+    L.porla_icc_encode_xy_device.restype = ctypes.c_int
     L.porla_icc_mac_encode_xy_device.argtypes = [vp, sz, ctypes.c_int, ctypes.c_ulonglong, vp, vp, vp]
     L.porla_icc_mac_encode_xy_device.restype = ctypes.c_int
     L.porla_icc_mac_encode_xy_host.argtypes = [u8p, sz, ctypes.c_int, ctypes.c_ulonglong, u8p, u8p]

@@ -125,3 +125,39 @@ def test_both_field_forms_agree(monkeypatch):
                          env=dict(os.environ, PORLA_ICC_F30="0"))
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().splitlines()[-1] == hashlib.sha256(a[0] + a[1] + a[2]).hexdigest()
+
+
+@pytest.mark.parametrize("curve", ["bn254", "secp256k1"])
+@pytest.mark.parametrize("n,ncols,ws", [(2, 128, 1), (16, 3, 5), (256, 128, 77), (2048, 16, 1234567), (1 << 17, 3, 99991)])
+def test_both_parts_from_one_network(curve, n, ncols, ws):
+    """porla_icc_encode_xy_device: the network is linear over Z/LCM and the Y part is the X part's network on chunks scaled by wt
+    (Server.hpp:1494, :1512-1522, :1691-1830), so Y_k = wt X_k mod LCM -- one product per residue and symbol in the last pass
+    instead of a second encode.  All six outputs against the oracle's two separate encodes (1, 2 and 3 passes; edge-valued chunks
+    among the rows), then every output on its own (each subset takes its own way through the finish step)."""
+    import torch
+    from porla_amd import icc
+    import icc_py
+    rows = bytearray(rows_bytes(n, ncols, seed=n + ws))
+    edge = [0, 2**256 - 1, icc_py.P_ICC, icc_py.P_ICC - 1, icc_py.Q[curve], icc_py.Q[curve] - 1]
+    for k, v in enumerate(edge):
+        if k < n * ncols:
+            rows[32 * k:32 * k + 32] = v.to_bytes(32, "little")
+    rows = bytes(rows)
+    want = [oracle_crebuild(rows, n, ncols, icc.CURVE[curve], part, ws) for part in (0, 1)]
+    d_in = torch.frombuffer(bytearray(rows), dtype=torch.uint8).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    widths = (64, 32, 32)
+    outs = [[torch.empty(w * n * ncols, dtype=torch.uint8, device="cuda") for w in widths] for _ in (0, 1)]
+    icc.crebuild_xy_device(d_in.data_ptr(), n, ncols, curve, ws, *[t.data_ptr() for t in outs[0]], *[t.data_ptr() for t in outs[1]],
+                           stream=stream)
+    torch.cuda.synchronize()
+    for part in (0, 1):
+        for k, name in enumerate(("values mod LCM", "values mod p_icc", "alignment scalars")):
+            assert bytes(outs[part][k].cpu().numpy()) == want[part][k], "%s, part %d" % (name, part)
+    if n <= 2048:
+        names = ("d_x", "d_aligned", "d_scalars", "d_y_x", "d_y_aligned", "d_y_scalars")
+        for k, name in enumerate(names):
+            t = torch.zeros(widths[k % 3] * n * ncols, dtype=torch.uint8, device="cuda")
+            icc.crebuild_xy_device(d_in.data_ptr(), n, ncols, curve, ws, stream=stream, **{name: t.data_ptr()})
+            torch.cuda.synchronize()
+            assert bytes(t.cpu().numpy()) == want[k // 3][k % 3], name

@@ -35,16 +35,21 @@ NCOLS = 128
 def run_chain(torch, icc, mx, d_rows, d_macs, n, write_step, bufs, stream, mac_stream=None, reference_order=False):
     """both parts of the last encode stage for n rows; everything asynchronous, nothing waits on the host.
     reference_order: the calls as the reference orders its work (per part: encode, align_MAC commitments, MAC encode), one stream,
-    one MAC encode per part.  Default: the MAC halves of both parts from ONE butterfly network (porla_icc_mac_encode_xy_device:
-    Y_k = wt * X_k), on `mac_stream` when given -- their stages are chains of dependent group operations on one wave per SIMD,
+    one encode and one MAC encode per part.  Default: the data side AND the MAC halves of both parts each from ONE run of their
+    network (porla_icc_encode_xy_device, porla_icc_mac_encode_xy_device: Y_k = wt * X_k), the MAC encode on `mac_stream` when given -- their stages are chains of dependent group operations on one wave per SIMD,
     the data side (encode + commitments) is bound by VALU issue: side by side they share the chip instead of queueing."""
-    for part in (0, 1):
-        al, sc, am, mh = bufs[part]
-        icc.crebuild_device(d_rows.data_ptr(), n, NCOLS, "bn254", write_step, part, 0, al.data_ptr(), sc.data_ptr(), stream=stream)
-        mx.kzg_commit_batch_device(sc.data_ptr(), n, am.data_ptr(), stream)
-        if reference_order:
+    if reference_order:
+        for part in (0, 1):
+            al, sc, am, mh = bufs[part]
+            icc.crebuild_device(d_rows.data_ptr(), n, NCOLS, "bn254", write_step, part, 0, al.data_ptr(), sc.data_ptr(), stream=stream)
+            mx.kzg_commit_batch_device(sc.data_ptr(), n, am.data_ptr(), stream)
             icc.mac_crebuild_device(d_macs.data_ptr(), n, "bn254", write_step, part, mh.data_ptr(), stream)
-    if not reference_order:
+    else:
+        # the data side of both parts from one run of the network too (porla_icc_encode_xy_device: Y_k = wt X_k mod LCM)
+        icc.crebuild_xy_device(d_rows.data_ptr(), n, NCOLS, "bn254", write_step, 0, bufs[0][0].data_ptr(), bufs[0][1].data_ptr(),
+                               0, bufs[1][0].data_ptr(), bufs[1][1].data_ptr(), stream=stream)
+        for part in (0, 1):
+            mx.kzg_commit_batch_device(bufs[part][1].data_ptr(), n, bufs[part][2].data_ptr(), stream)
         icc.mac_crebuild_xy_device(d_macs.data_ptr(), n, "bn254", write_step, bufs[0][3].data_ptr(), bufs[1][3].data_ptr(),
                                    mac_stream if mac_stream is not None else stream)
 
