@@ -473,7 +473,7 @@ def main():
                 rnd = random.Random(5)
                 a_sc = b"".join(mx.bn254_scalar_set_int(rnd.getrandbits(31)) for _ in range(3200))
                 d_a = to_dev(a_sc)
-                audit = {"what": "one blocking MSM on device-resident inputs, ms per call", "abs_int32_coefficients": {}, "256_bit_scalars": {}}
+                audit = {"what": "ms per blocking call on device-resident inputs: one MSM (ms) and the audit's pair of MSMs over one scalar array (pair_ms)", "abs_int32_coefficients": {}, "256_bit_scalars": {}}
                 for label, host_sc, dev_sc in (("abs_int32_coefficients", a_sc, d_a), ("256_bit_scalars", sc, d_sc)):
                     for m in (128, 1408, 3200):
                         for _ in range(3):
@@ -483,6 +483,17 @@ def main():
                             r = mx.msm_device("bn254", dev_sc.data_ptr(), d_pt.data_ptr(), m, stream)
                         ms = (time.perf_counter() - t1) / 20 * 1e3
                         audit[label][str(m)] = {"ms": round(ms, 4), "bit_exact_vs_oracle": r == common.oracle_msm(host_sc, pt, m)}
+                        # the audit's PAIR (same coefficients over the commitments and over the alignment points, Server.hpp:900-901)
+                        # as one call / one launch; the second point set: the same points, 64 further on
+                        pb = d_pt.data_ptr() + 64 * 64
+                        for _ in range(3):
+                            r2 = mx.msm_pair_device("bn254", dev_sc.data_ptr(), d_pt.data_ptr(), pb, m, stream)
+                        t1 = time.perf_counter()
+                        for _ in range(20):
+                            r2 = mx.msm_pair_device("bn254", dev_sc.data_ptr(), d_pt.data_ptr(), pb, m, stream)
+                        ms2 = (time.perf_counter() - t1) / 20 * 1e3
+                        audit[label][str(m)].update(pair_ms=round(ms2, 4), pair_bit_exact_vs_oracle=(
+                            r2 == (r, common.oracle_msm(host_sc, pt[64 * 64:], m))))
             except Exception as e:  # noqa: BLE001
                 audit = {"error": repr(e)}
         # the reference's own boundary: compute_multi_exp on caller-owned pageable HOST buffers (PCIe included; never `value`)

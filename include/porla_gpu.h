@@ -87,6 +87,15 @@ int porla_bn254_msm_device(const void *d_scalars, const void *d_points, size_t n
                            void *hip_stream);
 int porla_bn254_msm_device_partial(const void *d_scalars, const void *d_points, size_t n, uint8_t out_jacobian[96],
                                    void *hip_stream);
+/* The audit's pair: ONE scalar array over TWO point arrays -- replaces the two back-to-back calls
+ *   bn254_multi_exp(combined_MAC, ptc, sc, n); bn254_multi_exp(combined_align, pta, sc, n);    (porla/Server/Server.hpp:900-901,
+ *   and the secp256k1 twins secp256k1_ecmult_multi_var x2 at :842-848)
+ * For n <= 32 768 both run in ONE kernel launch (half the chip each); above that they run one after the other.
+ * out_a = sum scalars[i] * points_a[i], out_b = sum scalars[i] * points_b[i]; encodings as porla_bn254_msm_device. */
+int porla_bn254_msm_pair_device(const void *d_scalars, const void *d_points_a, const void *d_points_b, size_t n,
+                                uint8_t out_a[64], uint8_t out_b[64], void *hip_stream);
+int porla_bn254_msm_pair_host(const uint8_t *scalars, const uint8_t *points_a, const uint8_t *points_b, size_t n,
+                              uint8_t out_a[64], uint8_t out_b[64]);
 /* Two-phase form for independent MSMs in flight at once (e.g. the audit's two MSMs, Server.hpp:900-901): begin enqueues
  * every kernel of one MSM on hip_stream and returns; end waits for that slot, folds the reduction tree's sums on the host and writes
  * 64 bytes affine (jacobian = 0) or 96 bytes Jacobian (jacobian = 1).  slot in 1..3 (0 is used by the blocking calls);
@@ -116,6 +125,10 @@ int porla_bn254_tree_fold(const uint8_t *sums_affine, int windows, int window_bi
 /* ---- secp256k1 MSM (canonical encodings: 32-byte BE scalar, 64-byte x||y BE affine, zeros = infinity) ---- */
 int porla_secp256k1_msm_device(const void *d_scalars, const void *d_points, size_t n, uint8_t out_affine[64],
                                void *hip_stream);
+int porla_secp256k1_msm_pair_device(const void *d_scalars, const void *d_points_a, const void *d_points_b, size_t n,
+                                    uint8_t out_a[64], uint8_t out_b[64], void *hip_stream);
+int porla_secp256k1_msm_pair_host(const uint8_t *scalars, const uint8_t *points_a, const uint8_t *points_b, size_t n,
+                                  uint8_t out_a[64], uint8_t out_b[64]);
 int porla_secp256k1_msm_device_partial(const void *d_scalars, const void *d_points, size_t n,
                                        uint8_t out_jacobian[96], void *hip_stream);
 int porla_secp256k1_msm_device_begin(int slot, const void *d_scalars, const void *d_points, size_t n, void *hip_stream);

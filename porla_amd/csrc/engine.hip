@@ -163,6 +163,19 @@ static int abi_msm_host(const uint8_t* scalars, const uint8_t* points, size_t n,
     return PORLA_OK;
 }
 template <class C>
+static int abi_msm_pair(const void* scalars, const void* points_a, const void* points_b, size_t n, uint8_t* out_a, uint8_t* out_b, void* stream,
+                        bool device) {
+    using M = typename C::Fp;
+    if (!out_a || !out_b || (n && (!scalars || !points_a || !points_b))) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    XYZZ<M> ta, tb;
+    int rc = device ? msm_pair_device<C>((const uint8_t*)scalars, (const uint8_t*)points_a, (const uint8_t*)points_b, n, (hipStream_t)stream, &ta, &tb)
+                    : msm_pair_host<C>((const uint8_t*)scalars, (const uint8_t*)points_a, (const uint8_t*)points_b, n, &ta, &tb);
+    if (rc) return rc;
+    h_affine_to_bytes<M>(out_a, h_xyzz_to_affine64<M>(ta));
+    h_affine_to_bytes<M>(out_b, h_xyzz_to_affine64<M>(tb));
+    return PORLA_OK;
+}
+template <class C>
 static int abi_msm_host_multi(const uint8_t* scalars, const uint8_t* points, size_t n, int shards, int devices, uint8_t* out) {
     using M = typename C::Fp;
     if (n && (!scalars || !points || !out)) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
@@ -321,8 +334,24 @@ int porla_bn254_msm_device_partial(const void* d_scalars, const void* d_points, 
 int porla_bn254_msm_host(const uint8_t* scalars, const uint8_t* points, size_t n, uint8_t out_affine[64]) {
     return abi_msm_host<Bn254G1>(scalars, points, n, out_affine);
 }
+int porla_bn254_msm_pair_device(const void* d_scalars, const void* d_points_a, const void* d_points_b, size_t n, uint8_t out_a[64],
+                                uint8_t out_b[64], void* s) {
+    return abi_msm_pair<Bn254G1>(d_scalars, d_points_a, d_points_b, n, out_a, out_b, s, true);
+}
+int porla_bn254_msm_pair_host(const uint8_t* scalars, const uint8_t* points_a, const uint8_t* points_b, size_t n, uint8_t out_a[64],
+                              uint8_t out_b[64]) {
+    return abi_msm_pair<Bn254G1>(scalars, points_a, points_b, n, out_a, out_b, nullptr, false);
+}
 int porla_bn254_msm_host_multi(const uint8_t* scalars, const uint8_t* points, size_t n, int shards, int devices, uint8_t out_affine[64]) {
     return abi_msm_host_multi<Bn254G1>(scalars, points, n, shards, devices, out_affine);
+}
+int porla_secp256k1_msm_pair_device(const void* d_scalars, const void* d_points_a, const void* d_points_b, size_t n, uint8_t out_a[64],
+                                    uint8_t out_b[64], void* s) {
+    return abi_msm_pair<Secp256k1G>(d_scalars, d_points_a, d_points_b, n, out_a, out_b, s, true);
+}
+int porla_secp256k1_msm_pair_host(const uint8_t* scalars, const uint8_t* points_a, const uint8_t* points_b, size_t n, uint8_t out_a[64],
+                                  uint8_t out_b[64]) {
+    return abi_msm_pair<Secp256k1G>(scalars, points_a, points_b, n, out_a, out_b, nullptr, false);
 }
 int porla_secp256k1_msm_host_multi(const uint8_t* scalars, const uint8_t* points, size_t n, int shards, int devices, uint8_t out_affine[64]) {
     return abi_msm_host_multi<Secp256k1G>(scalars, points, n, shards, devices, out_affine);

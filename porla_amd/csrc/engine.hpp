@@ -42,6 +42,12 @@ int msm_device(const uint8_t* d_scalars, const uint8_t* d_points, size_t n, hipS
 
 // two-phase form (see msm_impl.hip.h)
 template <class C>
+int msm_pair_device(const uint8_t* d_scalars, const uint8_t* d_points_a, const uint8_t* d_points_b, size_t n, hipStream_t stream,
+                    XYZZ<typename C::Fp>* total_a, XYZZ<typename C::Fp>* total_b);
+template <class C>
+int msm_pair_host(const uint8_t* scalars, const uint8_t* points_a, const uint8_t* points_b, size_t n, XYZZ<typename C::Fp>* total_a,
+                  XYZZ<typename C::Fp>* total_b);
+template <class C>
 int msm_device_begin(int slot, const uint8_t* d_scalars, const uint8_t* d_points, size_t n, hipStream_t stream);
 template <class C>
 int msm_device_end(int slot, XYZZ<typename C::Fp>* total);

@@ -110,9 +110,9 @@ static int msm_small_launch(Workspace* ws, const uint8_t* d_scalars, const uint8
         PORLA_HIP(hipHostMalloc(&ws->h_windows, ws->h_windows_cap, hipHostMallocMapped | hipHostMallocCoherent));
     }
     const size_t part_bytes = (size_t)SMALL_BLOCKS * SMALL_MAX_C * sizeof(XYZZ<M>);
-    if (ws->small_part.cap < part_bytes + 1024) {
-        if ((rc = ws->small_part.ensure(part_bytes + 1024))) return rc;
-        PORLA_HIP(hipMemsetAsync(ws->small_part.p, 0, part_bytes + 1024, stream));    // the per-window arrival counters start at zero
+    if (ws->small_part.cap < part_bytes + 2048) {    // 2 x 256 arrival counters (the pair form uses both halves)
+        if ((rc = ws->small_part.ensure(part_bytes + 2048))) return rc;
+        PORLA_HIP(hipMemsetAsync(ws->small_part.p, 0, part_bytes + 2048, stream));    // the per-window arrival counters start at zero
     }
     void* h_dev = nullptr;
     PORLA_HIP(hipHostGetDevicePointer(&h_dev, ws->h_windows, 0));
@@ -124,13 +124,75 @@ static int msm_small_launch(Workspace* ws, const uint8_t* d_scalars, const uint8
         ProfScope ps("small_msm", stream, true);
         hipLaunchKernelGGL((k_small_msm<C>), dim3(SMALL_BLOCKS), dim3(SMALL_THREADS), 0, stream, d_scalars, d_points_be, (uint32_t)n,
                            g_small_c | (g_use_glv == 0 ? 0x100 : 0), (XYZZ<M>*)ws->small_part.p, counters, (uint32_t*)h_dev,
-                           (XYZZ<M>*)((uint8_t*)h_dev + SMALL_HDR_WORDS * 4), ws->small_seq);
+                           (XYZZ<M>*)((uint8_t*)h_dev + SMALL_HDR_WORDS * 4), ws->small_seq, (const uint8_t*)nullptr, 0u);
     }
     PORLA_HIP(hipGetLastError());
     if (!ws->done) PORLA_HIP(hipEventCreateWithFlags(&ws->done, hipEventDisableTiming));
     PORLA_HIP(hipEventRecord(ws->done, stream));
     ws->pend_W = -1;            // shape known to the device only: read from the pinned header by msm_finish
     ws->pend_c = 0;
+    return PORLA_OK;
+}
+
+// The audit's pair of MSMs -- ONE scalar array over TWO point arrays (bn254_multi_exp(combined_MAC, ptc, sc, n) and
+// bn254_multi_exp(combined_align, pta, sc, n), porla/Server/Server.hpp:900-901; the IPA twins :842-848) -- as one launch of the
+// single-launch kernel: half of the chip's blocks per point set.  Both are chains of ~15 dependent additions, so side by side
+// they take little longer than one alone.  Results: two regions of the slot's pinned area, PAIR_STRIDE bytes apart.
+constexpr uint32_t SMALL_PAIR_STRIDE = 64 * 1024;
+template <class C>
+static int msm_small_pair_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_points_a, const uint8_t* d_points_b, size_t n,
+                                 hipStream_t stream) {
+    using M = typename C::Fp;
+    int rc;
+    if (ws->h_windows_cap < 2 * SMALL_PAIR_STRIDE) {
+        if (ws->h_windows) PORLA_HIP(hipHostFree(ws->h_windows));
+        ws->h_windows_cap = 2 * SMALL_PAIR_STRIDE;
+        PORLA_HIP(hipHostMalloc(&ws->h_windows, ws->h_windows_cap, hipHostMallocMapped | hipHostMallocCoherent));
+    }
+    const size_t part_bytes = (size_t)SMALL_BLOCKS * SMALL_MAX_C * sizeof(XYZZ<M>);
+    if (ws->small_part.cap < part_bytes + 2048) {
+        if ((rc = ws->small_part.ensure(part_bytes + 2048))) return rc;
+        PORLA_HIP(hipMemsetAsync(ws->small_part.p, 0, part_bytes + 2048, stream));    // arrival counters of both sets start at zero
+    }
+    void* h_dev = nullptr;
+    PORLA_HIP(hipHostGetDevicePointer(&h_dev, ws->h_windows, 0));
+    uint32_t* counters = (uint32_t*)((uint8_t*)ws->small_part.p + part_bytes);
+    ws->small_seq++;
+    if (ws->small_seq == 0) ws->small_seq = 1;
+    ((volatile uint32_t*)ws->h_windows)[0] = 0;
+    ((volatile uint32_t*)((uint8_t*)ws->h_windows + SMALL_PAIR_STRIDE))[0] = 0;
+    {
+        ProfScope ps("small_msm", stream, true);
+        hipLaunchKernelGGL((k_small_msm<C>), dim3(SMALL_BLOCKS / 2, 2), dim3(SMALL_THREADS), 0, stream, d_scalars, d_points_a, (uint32_t)n,
+                           g_small_c | (g_use_glv == 0 ? 0x100 : 0), (XYZZ<M>*)ws->small_part.p, counters, (uint32_t*)h_dev,
+                           (XYZZ<M>*)((uint8_t*)h_dev + SMALL_HDR_WORDS * 4), ws->small_seq, d_points_b, SMALL_PAIR_STRIDE);
+    }
+    PORLA_HIP(hipGetLastError());
+    if (!ws->done) PORLA_HIP(hipEventCreateWithFlags(&ws->done, hipEventDisableTiming));
+    PORLA_HIP(hipEventRecord(ws->done, stream));
+    return PORLA_OK;
+}
+// waits for set `which` (0, 1) of a pair launch and folds its window sums on the host
+template <class C>
+static int msm_small_pair_finish(Workspace* ws, int which, XYZZ<typename C::Fp>* total) {
+    using M = typename C::Fp;
+    const uint8_t* region = (const uint8_t*)ws->h_windows + (size_t)which * SMALL_PAIR_STRIDE;
+    const volatile uint32_t* hdr = (const volatile uint32_t*)region;
+    const auto t_spin = std::chrono::steady_clock::now();
+    bool seen = false;
+    for (uint32_t it = 0;; it++) {
+        if (__atomic_load_n((const uint32_t*)&hdr[0], __ATOMIC_ACQUIRE) == ws->small_seq) { seen = true; break; }
+        __builtin_ia32_pause();
+        if ((it & 1023u) == 1023u && std::chrono::steady_clock::now() - t_spin > std::chrono::milliseconds(2)) break;
+    }
+    if (!seen) PORLA_HIP(hipEventSynchronize(ws->done));
+    const int W = (int)hdr[1], c = (int)hdr[2];
+    if (hdr[0] != ws->small_seq || W < 1 || c < 1 || c > SMALL_MAX_C || (size_t)W * c * sizeof(XYZZ<M>) + SMALL_HDR_WORDS * 4 > SMALL_PAIR_STRIDE) {
+        set_last_error("porla: the single-launch MSM pair left no valid result header");
+        return PORLA_ERR_HIP;
+    }
+    g_last_shape[0] = c; g_last_shape[1] = W; g_last_shape[2] = (int)hdr[3];
+    *total = h_fold_tree64<M>((const XYZZ<M>*)(region + SMALL_HDR_WORDS * 4), W, c);
     return PORLA_OK;
 }
 
@@ -518,6 +580,34 @@ int msm_device(const uint8_t* d_scalars, const uint8_t* d_points, size_t n, hipS
     ws->lone = true;
     return msm_core<C>(ws, d_scalars, d_points, n, stream, total);
 }
+// ONE scalar array over TWO point arrays (device pointers).  Up to SMALL_MAX_N pairs: one launch for both (msm_small_pair_launch);
+// above: the two MSMs through the general path, one after the other on this slot (callers that want them overlapped use the
+// two-phase form on two streams).
+template <class C>
+static int msm_pair_locked(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_points_a, const uint8_t* d_points_b, size_t n,
+                           hipStream_t stream, XYZZ<typename C::Fp>* total_a, XYZZ<typename C::Fp>* total_b) {
+    int rc;
+    ws->lone = true;
+    if (n <= SMALL_MAX_N && g_small_mode != 0 && g_window_override == 0) {
+        ws->pend_W = 0;
+        if ((rc = msm_small_pair_launch<C>(ws, d_scalars, d_points_a, d_points_b, n, stream))) return rc;
+        if ((rc = msm_small_pair_finish<C>(ws, 0, total_a))) return rc;
+        return msm_small_pair_finish<C>(ws, 1, total_b);
+    }
+    if ((rc = msm_core<C>(ws, d_scalars, d_points_a, n, stream, total_a))) return rc;
+    return msm_core<C>(ws, d_scalars, d_points_b, n, stream, total_b);
+}
+template <class C>
+int msm_pair_device(const uint8_t* d_scalars, const uint8_t* d_points_a, const uint8_t* d_points_b, size_t n, hipStream_t stream,
+                    XYZZ<typename C::Fp>* total_a, XYZZ<typename C::Fp>* total_b) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n == 0) { *total_a = xyzz_inf<typename C::Fp>(); *total_b = *total_a; return PORLA_OK; }
+    Workspace* ws;
+    if ((rc = lease_blocking_slot(&ws))) return rc;
+    std::lock_guard<std::mutex> lk(ws->mu, std::adopt_lock);
+    return msm_pair_locked<C>(ws, d_scalars, d_points_a, d_points_b, n, stream, total_a, total_b);
+}
 // Two-phase form: several MSMs in flight on different streams, each in its own workspace slot (1 .. MSM_USER_SLOTS-1; slot 0
 // belongs to the blocking calls).  begin enqueues all kernels and returns; end waits for that slot and folds on the host.
 // A slot belongs to the device that was current at begin: end must be called with the same current device.
@@ -766,5 +856,28 @@ int msm_host(const uint8_t* scalars, const uint8_t* points, size_t n, XYZZ<typen
     return msm_finish<C>(ws, total);
 }
 
+// host-pointer form of the pair: one upload of the scalars, both point arrays side by side in the slot's staging buffer
+template <class C>
+int msm_pair_host(const uint8_t* scalars, const uint8_t* points_a, const uint8_t* points_b, size_t n, XYZZ<typename C::Fp>* total_a,
+                  XYZZ<typename C::Fp>* total_b) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n == 0) { *total_a = xyzz_inf<typename C::Fp>(); *total_b = *total_a; return PORLA_OK; }
+    if (n >= msm_host_split_min()) {
+        if ((rc = msm_host<C>(scalars, points_a, n, total_a))) return rc;
+        return msm_host<C>(scalars, points_b, n, total_b);
+    }
+    Workspace* ws;
+    if ((rc = lease_blocking_slot(&ws))) return rc;
+    std::lock_guard<std::mutex> lk(ws->mu, std::adopt_lock);
+    if ((rc = ws->in_scalars.ensure(n * 32))) return rc;
+    if ((rc = ws->in_points.ensure(n * 128))) return rc;
+    hipStream_t s = ws->own_stream;
+    uint8_t* d_pts = (uint8_t*)ws->in_points.p;
+    PORLA_HIP(hipMemcpyAsync(ws->in_scalars.p, scalars, n * 32, hipMemcpyHostToDevice, s));
+    PORLA_HIP(hipMemcpyAsync(d_pts, points_a, n * 64, hipMemcpyHostToDevice, s));
+    PORLA_HIP(hipMemcpyAsync(d_pts + n * 64, points_b, n * 64, hipMemcpyHostToDevice, s));
+    return msm_pair_locked<C>(ws, (const uint8_t*)ws->in_scalars.p, d_pts, d_pts + n * 64, n, s, total_a, total_b);
+}
 
 }  // namespace porla

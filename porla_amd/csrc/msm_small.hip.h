@@ -131,8 +131,19 @@ template <class C>
 __global__ void __launch_bounds__(SMALL_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_small_msm(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ points, uint32_t n, int c_override,
             XYZZ<typename C::Fp>* __restrict__ part, uint32_t* __restrict__ counters, uint32_t* __restrict__ hdr,
-            XYZZ<typename C::Fp>* __restrict__ fin, uint32_t seq SMALL_STAMP_ARG) {
+            XYZZ<typename C::Fp>* __restrict__ fin, uint32_t seq, const uint8_t* __restrict__ points_b,
+            uint32_t pair_stride_bytes SMALL_STAMP_ARG) {
     using M = typename C::Fp;
+    // gridDim.y == 2: the audit's PAIR of MSMs -- the same scalars over two point sets (combined_MAC and combined_align,
+    // porla/Server/Server.hpp:842-848 / :900-901) -- in one launch: set blockIdx.y takes its own points, partial sums, arrival
+    // counters and pinned result region (header + window sums at pair_stride_bytes); each set shapes itself for gridDim.x blocks
+    if (blockIdx.y) {
+        points = points_b;
+        part += (size_t)gridDim.x * SMALL_MAX_C;
+        counters += 256;
+        hdr = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(hdr) + pair_stride_bytes);
+        fin = reinterpret_cast<XYZZ<M>*>(reinterpret_cast<uint8_t*>(fin) + pair_stride_bytes);
+    }
     __shared__ uint32_t ent[SMALL_MAX_SUB];                    // sorted entries: sub-scalar index | sign << 31
     __shared__ XYZZ<M> pts[SMALL_THREADS];                     // first the unsorted digits (uint32 view), then the lane sums
     __shared__ XYZZ<M> bk[SMALL_MAX_B];                        // bucket sums

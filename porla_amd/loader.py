@@ -69,6 +69,8 @@ def _declare(L):
         f = getattr(L, "porla_%s_msm_device" % curve); f.argtypes = [vp, vp, sz, u8p, vp]; f.restype = ctypes.c_int
         f = getattr(L, "porla_%s_msm_device_partial" % curve); f.argtypes = [vp, vp, sz, u8p, vp]; f.restype = ctypes.c_int
         f = getattr(L, "porla_%s_msm_host" % curve); f.argtypes = [u8p, u8p, sz, u8p]; f.restype = ctypes.c_int
+        f = getattr(L, "porla_%s_msm_pair_device" % curve); f.argtypes = [vp, vp, vp, sz, u8p, u8p, vp]; f.restype = ctypes.c_int
+        f = getattr(L, "porla_%s_msm_pair_host" % curve); f.argtypes = [u8p, u8p, u8p, sz, u8p, u8p]; f.restype = ctypes.c_int
         f = getattr(L, "porla_%s_msm_host_multi" % curve); f.argtypes = [u8p, u8p, sz, ctypes.c_int, ctypes.c_int, u8p]; f.restype = ctypes.c_int
         f = getattr(L, "porla_%s_dist_fold" % curve); f.argtypes = [u8p, u8p]; f.restype = ctypes.c_int
         f = getattr(L, "porla_%s_msm_device_dist" % curve); f.argtypes = [vp, vp, sz, u8p, vp]; f.restype = ctypes.c_int

@@ -167,6 +167,20 @@ def msm_host(curve, scalars, points, n):
     return out.raw
 
 
+def msm_pair_device(curve, d_scalars, d_points_a, d_points_b, n, stream=0):
+    """the audit's two MSMs over one scalar array (Server.hpp:900-901 / :842-848) in one call: (sum s_i A_i, sum s_i B_i)"""
+    oa, ob = ctypes.create_string_buffer(64), ctypes.create_string_buffer(64)
+    _check(getattr(lib, "porla_%s_msm_pair_device" % curve)(ctypes.c_void_p(d_scalars), ctypes.c_void_p(d_points_a), ctypes.c_void_p(d_points_b),
+                                                            n, oa, ob, ctypes.c_void_p(stream)))
+    return oa.raw, ob.raw
+
+
+def msm_pair_host(curve, scalars, points_a, points_b, n):
+    oa, ob = ctypes.create_string_buffer(64), ctypes.create_string_buffer(64)
+    _check(getattr(lib, "porla_%s_msm_pair_host" % curve)(bytes(scalars), bytes(points_a), bytes(points_b), n, oa, ob))
+    return oa.raw, ob.raw
+
+
 def msm_host_multi(curve, scalars, points, n, shards=0, devices=0):
     """range-sharded over `shards` pair ranges and `devices` GPUs of this process (0 = automatic), behind the C ABI"""
     out = ctypes.create_string_buffer(64)

@@ -160,3 +160,48 @@ def test_two_msms_in_flight_do_not_block_each_other(mx, inputs):
         assert mx.msm_end(1) == want[0]
         assert mx.msm_end(2) == want[1]
     assert t_enqueue < 2e-3
+
+
+@pytest.mark.parametrize("c", [0, 1, 4, 8])
+def test_audit_pair_one_launch(mx, inputs, c):
+    """Server::audit ends in TWO MSMs over the same coefficients (combined_MAC over the commitments, combined_align over the
+    alignment points; Server.hpp:900-901): porla_bn254_msm_pair_* runs both in one launch -- each must equal its own MSM"""
+    import torch
+    from porla_amd import lib
+    sc, pt = inputs
+    lib.porla_gpu_set_msm_small(1, c)
+    rnd = random.Random(17)
+    for n in (1, 2, 128, 1408, 3200, 4096):
+        for kind in ("int32", "full"):
+            s = b"".join(mx.bn254_scalar_set_int(rnd.getrandbits(31)) for _ in range(n)) if kind == "int32" else sc[:32 * n]
+            pa = pt[:64 * n]
+            pb = b"".join(pt[64 * ((7 * i + 3) % 4096):64 * ((7 * i + 3) % 4096) + 64] for i in range(n))
+            want = (common.oracle_msm(s, pa, n), common.oracle_msm(s, pb, n))
+            assert mx.msm_pair_host("bn254", s, pa, pb, n) == want, (n, kind)
+            if n in (128, 3200):
+                d = [torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda() for b in (s, pa, pb)]
+                torch.cuda.synchronize()
+                for _ in range(3):       # repeated launches on one workspace: the arrival counters of both halves reset themselves
+                    assert mx.msm_pair_device("bn254", d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), n) == want
+                assert mx.msm_device("bn254", d[0].data_ptr(), d[2].data_ptr(), n) == want[1]   # and the lone form still works after a pair
+    # one set sums to infinity, the other does not; and n = 0
+    import bn254_py as o
+    P0 = pt[:64]
+    s = (5).to_bytes(32, "big") * 2
+    assert mx.msm_pair_host("bn254", s, P0 + o.neg_point(P0), P0 + P0, 2) == (bytes(64), common.oracle_msm(s, P0 + P0, 2, naive=True))
+    assert mx.msm_pair_host("bn254", b"", b"", b"", 0) == (bytes(64), bytes(64))
+
+
+def test_audit_pair_secp256k1_and_large(mx, inputs):
+    """the IPA twin (Server.hpp:842-848) and the fall-through above 32 768 pairs (two MSMs, one after the other)"""
+    rnd = random.Random(23)
+    for n in (16, 1408):
+        s = b"".join(rnd.getrandbits(31).to_bytes(32, "big") for _ in range(n))
+        pa = common.secp_bench_points(n)
+        pb = pa[64:] + pa[:64]
+        assert mx.msm_pair_host("secp256k1", s, pa, pb, n) == (common.oracle_secp_msm(s, pa, n), common.oracle_secp_msm(s, pb, n))
+    sc, pt = common.synth_inputs(8192)
+    for n in (8192, 40000):               # one launch up to 32 768 pairs; above: the general path twice (points repeated to get there)
+        s, pa = (sc * 5)[:32 * n], (pt * 5)[:64 * n]
+        pb = pa[64 * 100:] + pa[:64 * 100]
+        assert mx.msm_pair_host("bn254", s, pa, pb, n) == (common.oracle_msm(s, pa, n), common.oracle_msm(s, pb, n))

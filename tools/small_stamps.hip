@@ -35,7 +35,7 @@ int main(int argc, char** argv) {
         hipMemset(d_st, 0, SMALL_BLOCKS * 16 * 8);
         hipEventRecord(e0, 0);
         hipLaunchKernelGGL((k_small_msm<C>), dim3(SMALL_BLOCKS), dim3(SMALL_THREADS), 0, 0, d_sc, d_pt, n, c, (XYZZ<M>*)d_part,
-                           (uint32_t*)(d_part + part_bytes), (uint32_t*)hd, (XYZZ<M>*)((uint8_t*)hd + SMALL_HDR_WORDS * 4), (uint32_t)(rep + 1), d_st);
+                           (uint32_t*)(d_part + part_bytes), (uint32_t*)hd, (XYZZ<M>*)((uint8_t*)hd + SMALL_HDR_WORDS * 4), (uint32_t)(rep + 1), (const uint8_t*)nullptr, 0u, d_st);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
