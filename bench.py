@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the MI355X commitment engine on BASELINE.json's metric, one rank per GPU.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bn254_msm|kzg_commit|secp256k1_msm|icc|config3|crebuild]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bn254_msm|kzg_commit|secp256k1_msm|icc|config3|crebuild|audit_combine]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 Default workload (the headline metric): a "step" is ONE 2^20-pair BN254 G1 MSM per GPU (BASELINE.json config 2, "KZG
@@ -23,6 +23,8 @@ cpu_baseline and bit_exact_vs_oracle, timed separately after the headline region
   icc             2^15 rows x 128 columns ICC encode (X part + alignment scalars) per GPU = 2^22 elements      (config 5)
   config3         ONE 2^24-pair BN254 MSM over all ranks: 2^24 / N pairs per rank (strong scaling), partials exchanged and
                   folded as above, the whole job checked against the oracle                                   (config 3)
+  audit_combine   Server::audit's row combine + align_MAC scalars on an 8 GiB level store: 2^18 challenged rows (the path's one
+                  HBM-bound kernel: GB/s against the 8 TB/s peak) and the audit's own 3 200 rows (ms per call); N = 1 only  (s8 f-4)
 and, for the headline MSM: `blocking_ms_per_step` + `blocking_kernels_ms` (one MSM in flight: what a caller that waits for
 every result sees, with its own per-kernel breakdown), `audit_size_msm` (128 / 1 408 / 3 200 pairs: the sizes the reference
 issues), `host_boundary` (compute_multi_exp on caller-owned pageable host buffers, PCIe included).
@@ -61,6 +63,7 @@ KERNEL_SYMBOL = {  # profile slot -> substring of the kernel symbol in the rocpr
     "bucket_sum": "k_bucket_sum30", "tree_levels": "k_tree_level", "tree_tail": "k_tree_tail", "partition_sort": "k_partition_sort",
     "fb_commit": "k_fb_commit", "digits_partition": "k_digits_partition", "points_to_mont": "k_points_to_mont",
     "icc_fused": "k_icc_split30", "icc_stages_r4": "k_icc_stages", "icc_stages_r2": "k_icc_stages", "icc_load": "k_icc_load", "icc_finish": "k_icc_finish",
+    "audit_accumulate": "k_audit_accumulate",
 }
 
 
@@ -117,7 +120,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="bn254_msm",
-                    choices=["bn254_msm", "kzg_commit", "secp256k1_msm", "icc", "config3", "crebuild"])
+                    choices=["bn254_msm", "kzg_commit", "secp256k1_msm", "icc", "config3", "crebuild", "audit_combine"])
     ap.add_argument("--log2n", type=int, default=20, help="MSM pairs per GPU = 2^log2n (default: the 2^20 of BASELINE.json)")
     ap.add_argument("--log2rows", type=int, default=17, help="kzg_commit rows per GPU = 2^log2rows; icc rows = 2^(log2rows-2)")
     ap.add_argument("--log2job", type=int, default=24, help="config3: pairs of the whole job = 2^log2job, split over the ranks")
@@ -713,9 +716,40 @@ def main():
                                  "rows resident in HBM" % n_rows, "rows_per_gpu": n_rows, "columns": n_cols},
                     rl, cpu, verified)
 
+    # ---------------------------------------------------------------- audit row combine: the path's HBM-bound kernel
+    def leg_audit_combine():
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("bench_audit", os.path.join(ROOT, "tools", "bench_audit.py"))
+        ba = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ba)
+        # an 8 GiB level store (2^20 rows of 128 x 64-byte symbols: no row is read twice from a cache), challenges of the audit's
+        # own size (3 200 rows) and of 2^18 rows (2 GiB gathered: the bandwidth regime)
+        res, cpu = ba.measure(20, [3200, 1 << 18], mixed=False, reps_small=100)
+        small, big = res
+        rl = dict(big["roofline"])
+        # the committed PMC passes ran this very leg: its launches of the kernel are 1 parity call + per size 5 warm-up + 100 or 20
+        # timed + 10 profiled calls -- 116 launches of 3 200 (+ 1 of 1 024) rows and 35 of 2^18 rows; the counters' per-launch average
+        # is scaled to the 2^18-row launch by the algorithmic bytes of that mix
+        avg = pmc_traffic("audit_accumulate", "audit_combine")
+        if avg:
+            mix = (1 * 1024 + 115 * 3200 + 35 * (1 << 18)) / 151.0
+            rl["traffic"] = int(avg * (1 << 18) / mix)
+            rl["traffic_note"] = "profiles/pmc_latest_audit_combine.json: average over the leg's 151 launches, scaled to a 2^18-row launch"
+        rl["note"] = ("algorithmic bytes = 8 192 per challenged row (+ indices, coefficients, 64 B per column out) / the accumulation "
+                      "kernel's HIP-event time; random 8-KiB rows of an 8 GiB store")
+        return {"metric": "audit row combine GB/s (2^18 challenged rows x 128 symbols of 64 B)", "value": rl["achieved"], "unit": "GB/s",
+                "n_gpus": world, "steps": 20, "warmup": 5, "ms_per_step": big["ms_per_call_back_to_back"], "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs, exact 608-bit integer accumulation", "data": "synthetic",
+                "config": {"workload": "Server::audit row combine + align_MAC scalar part (Server.hpp:790-828, 531-541), level store "
+                                       "resident in HBM", "store_rows": 1 << 20, "challenged_rows": 1 << 18},
+                "kernels_ms": big["kernels_ms"], "roofline": rl, "cpu_baseline": cpu,
+                "audit_size": {"challenged_rows": 3200, "ms_per_call": small["ms_per_call_back_to_back"], "kernels_ms": small["kernels_ms"],
+                               "achieved_GBps": small["roofline"]["achieved"]},
+                "bit_exact_vs_oracle": bool(big["bit_exact_vs_oracle_1024_row_challenge"])}
+
     # ---------------------------------------------------------------- the line
     legs = {"bn254_msm": leg_bn254_msm, "kzg_commit": leg_kzg_commit, "secp256k1_msm": leg_secp256k1_msm, "icc": leg_icc,
-            "config3": leg_config3}
+            "config3": leg_config3, "audit_combine": leg_audit_combine}
     out = legs[args.workload]()
     if args.workload == "bn254_msm":
         # every other BASELINE.json configuration rides on the default line
@@ -724,6 +758,8 @@ def main():
             extra.append(("kzg_commits", leg_kzg_commit))
         if not args.no_legs:
             extra += [("secp256k1_msm", leg_secp256k1_msm), ("icc", leg_icc)]
+            if world == 1:
+                extra.append(("audit_combine", leg_audit_combine))
             if not args.no_config3:
                 extra.append(("config3", leg_config3))
         for name, fn in extra:

@@ -10,8 +10,9 @@
 // MI355X: the encoded levels are resident in HBM (2^24 blocks x 8 KiB = 137 GB fits the 288 GB part), so an audit is a
 // gather of <= 3 200 rows of 8 KiB: HBM-bound, ~26 MB.  One lane owns one of the 128 columns of a slice of the challenged
 // rows and accumulates the EXACT integer (512-bit value x 32-bit coefficient, 576-bit accumulator; lanes of a wave read
-// 64 consecutive 64-byte symbols = 4 KiB per row, fully coalesced); a second kernel adds the slice partials and reduces
-// once per column mod p_icc and mod q.  Algorithmic bytes: 8 192 B per challenged row in, 64 B per column out.
+// 64 consecutive 64-byte symbols = 4 KiB per row, fully coalesced); the eight slices of a block meet in LDS; a second kernel
+// adds the blocks' partials and reduces once per column mod p_icc and mod q.  Algorithmic bytes: 8 192 B per challenged row
+// in (4 096 for a 256-bit row), 64 B per column out.
 #include "engine.hpp"
 #include "icc.hip.h"
 
@@ -21,71 +22,135 @@ namespace porla {
 
 constexpr int ACC_LIMBS = 19;  // 512 + 32 + 32 bits of head-room for up to 2^32 rows
 
-// partial[(b * ACC_LIMBS + limb) * n_cols + col]
-static __global__ void __launch_bounds__(128)
-k_audit_accumulate(const uint8_t* __restrict__ rows64, const uint64_t* __restrict__ idx64, const uint32_t* __restrict__ coef64,
-                   uint32_t n64, const uint8_t* __restrict__ rows32, const uint64_t* __restrict__ idx32,
-                   const uint32_t* __restrict__ coef32, uint32_t n32, uint32_t n_cols, uint32_t per_block,
-                   uint32_t* __restrict__ partial) {
-    const uint32_t col = blockIdx.y * blockDim.x + threadIdx.x;
-    if (col >= n_cols) return;
-    const uint32_t lo = blockIdx.x * per_block;
-    const uint32_t total = n64 + n32;
-    uint32_t hi = lo + per_block < total ? lo + per_block : total;
-    uint32_t acc[ACC_LIMBS];
+// The accumulation: a block is AUD_SLICES row slices x 128 columns (one wave pair per slice; a wave reads 64 consecutive symbols of
+// a row = 4 KiB); a lane adds coeff * symbol of its slice's rows into an exact 19-limb integer, two rows' loads in flight.  The
+// slices' sums meet in LDS and leave as ONE carry-save partial per block: partial[(b * ACC_LIMBS + limb) * n_cols + col], 64-bit
+// limb sums (no carry chain here; k_audit_finish runs it once per column).
+constexpr int AUD_SLICES = 8;
+constexpr int AUD_COLS = 128;
+
+// acc += cf * v, v = WORDS little-endian 32-bit words
+template <int WORDS>
+__device__ __forceinline__ void audit_mac(uint32_t (&acc)[ACC_LIMBS], const uint32_t (&v)[WORDS], uint32_t cf) {
+    uint64_t carry = 0;
 #pragma unroll
-    for (int k = 0; k < ACC_LIMBS; k++) acc[k] = 0;
-    for (uint32_t i = lo; i < hi; i++) {
-        uint32_t v[16];
-        uint32_t cf;
-        if (i < n64) {
-            const uint4* src = reinterpret_cast<const uint4*>(rows64 + (idx64[i] * n_cols + col) * 64);
-            uint4 a = src[0], b = src[1], c = src[2], d = src[3];
-            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-            v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w; v[12] = d.x; v[13] = d.y; v[14] = d.z; v[15] = d.w;
-            cf = coef64[i];
-        } else {
-            const uint32_t k = i - n64;
-            const uint4* src = reinterpret_cast<const uint4*>(rows32 + (idx32[k] * n_cols + col) * 32);
-            uint4 a = src[0], b = src[1];
-            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-#pragma unroll
-            for (int t = 8; t < 16; t++) v[t] = 0;
-            cf = coef32[k];
-        }
-        // acc += cf * v
-        uint64_t carry = 0;
-#pragma unroll
-        for (int t = 0; t < 16; t++) {
-            uint64_t x = (uint64_t)v[t] * cf + acc[t] + carry;
-            acc[t] = (uint32_t)x;
-            carry = x >> 32;
-        }
-#pragma unroll
-        for (int t = 16; t < ACC_LIMBS; t++) {
-            uint64_t x = (uint64_t)acc[t] + carry;
-            acc[t] = (uint32_t)x;
-            carry = x >> 32;
-        }
+    for (int t = 0; t < WORDS; t++) {
+        uint64_t x = (uint64_t)v[t] * cf + acc[t] + carry;
+        acc[t] = (uint32_t)x;
+        carry = x >> 32;
     }
 #pragma unroll
-    for (int k = 0; k < ACC_LIMBS; k++) partial[((size_t)blockIdx.x * ACC_LIMBS + k) * n_cols + col] = acc[k];
+    for (int t = WORDS; t < ACC_LIMBS; t++) {
+        uint64_t x = (uint64_t)acc[t] + carry;
+        acc[t] = (uint32_t)x;
+        carry = x >> 32;
+    }
+}
+template <int WORDS>
+__device__ __forceinline__ void audit_load(uint32_t (&v)[WORDS], const uint8_t* rows, uint64_t row, uint32_t n_cols, uint32_t col) {
+    const uint4* src = reinterpret_cast<const uint4*>(rows + (row * n_cols + col) * (4 * WORDS));
+#pragma unroll
+    for (int t = 0; t < WORDS / 4; t++) {
+        const uint4 q = src[t];
+        v[4 * t] = q.x; v[4 * t + 1] = q.y; v[4 * t + 2] = q.z; v[4 * t + 3] = q.w;
+    }
+}
+// rows [a, b) of one row format (WORDS = 16: 64-byte symbols, 8: 32-byte symbols), two rows' loads in flight
+template <int WORDS>
+__device__ __forceinline__ void audit_span(uint32_t (&acc)[ACC_LIMBS], const uint8_t* __restrict__ rows, const uint64_t* __restrict__ idx,
+                                           const uint32_t* __restrict__ coef, uint32_t a, uint32_t b, uint32_t n_cols, uint32_t col) {
+    uint32_t i = a;
+    for (; i + 2 <= b; i += 2) {
+        uint32_t v0[WORDS], v1[WORDS];
+        const uint64_t r0 = idx[i], r1 = idx[i + 1];
+        const uint32_t c0 = coef[i], c1 = coef[i + 1];
+        audit_load<WORDS>(v0, rows, r0, n_cols, col);
+        audit_load<WORDS>(v1, rows, r1, n_cols, col);
+        audit_mac<WORDS>(acc, v0, c0);
+        audit_mac<WORDS>(acc, v1, c1);
+    }
+    if (i < b) {
+        uint32_t v0[WORDS];
+        audit_load<WORDS>(v0, rows, idx[i], n_cols, col);
+        audit_mac<WORDS>(acc, v0, coef[i]);
+    }
 }
 
-template <class Q>
-static __global__ void __launch_bounds__(128)
-k_audit_finish(const uint32_t* __restrict__ partial, uint32_t n_blocks, uint32_t n_cols, uint8_t* __restrict__ exact_out,
-               uint8_t* __restrict__ al_out, uint8_t* __restrict__ al_be_out, uint8_t* __restrict__ sc_out) {
-    const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= n_cols) return;
+static __global__ void __launch_bounds__(AUD_SLICES * AUD_COLS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_audit_accumulate(const uint8_t* __restrict__ rows64, const uint64_t* __restrict__ idx64, const uint32_t* __restrict__ coef64,
+                   uint32_t n64, const uint8_t* __restrict__ rows32, const uint64_t* __restrict__ idx32,
+                   const uint32_t* __restrict__ coef32, uint32_t n32, uint32_t n_cols, uint32_t per_slice,
+                   unsigned long long* __restrict__ partial) {
+    __shared__ uint32_t sums[AUD_SLICES][ACC_LIMBS][AUD_COLS];
+    const uint32_t lane_col = threadIdx.x % AUD_COLS;
+    const uint32_t slice = __builtin_amdgcn_readfirstlane(threadIdx.x / AUD_COLS);
+    const uint32_t col0 = blockIdx.y * AUD_COLS;
+    const bool live = col0 + lane_col < n_cols;
+    const uint32_t col = live ? col0 + lane_col : n_cols - 1;       // idle lanes re-read the last column and drop the result
+    const uint32_t total = n64 + n32;
+    const uint64_t first = ((uint64_t)blockIdx.x * AUD_SLICES + slice) * per_slice;
+    const uint32_t lo = first < total ? (uint32_t)first : total;
+    const uint32_t hi = first + per_slice < total ? (uint32_t)(first + per_slice) : total;
     uint32_t acc[ACC_LIMBS];
 #pragma unroll
     for (int k = 0; k < ACC_LIMBS; k++) acc[k] = 0;
-    for (uint32_t b = 0; b < n_blocks; b++) {
-        uint64_t carry = 0;
+    // the slice's rows: first those among the 64-byte-symbol rows [0, n64), then those among the 32-byte-symbol rows
+    if (lo < n64) audit_span<16>(acc, rows64, idx64, coef64, lo, hi < n64 ? hi : n64, n_cols, col);
+    if (hi > n64) audit_span<8>(acc, rows32, idx32, coef32, (lo > n64 ? lo : n64) - n64, hi - n64, n_cols, col);
+#pragma unroll
+    for (int k = 0; k < ACC_LIMBS; k++) sums[slice][k][lane_col] = acc[k];
+    __syncthreads();
+    for (uint32_t item = threadIdx.x; item < ACC_LIMBS * AUD_COLS; item += AUD_SLICES * AUD_COLS) {
+        const uint32_t k = item / AUD_COLS, c = item % AUD_COLS;
+        unsigned long long t = 0;
+#pragma unroll
+        for (int sl = 0; sl < AUD_SLICES; sl++) t += sums[sl][k][c];
+        if (col0 + c < n_cols) partial[((size_t)blockIdx.x * ACC_LIMBS + k) * n_cols + col0 + c] = t;
+    }
+}
+
+// One block per AUD_FIN_COLS columns, a lane per (quarter of the partials, limb, column): the blocks' carry-save limb sums are added
+// up (64-bit: < 2^35 per partial; eight loads in flight per lane -- the loop is L2 latency, not bandwidth), then one lane per column
+// runs the carry chain and reduces the exact integer once mod p_icc and once mod q.
+constexpr int AUD_FIN_COLS = 8;
+constexpr int AUD_FIN_SPLIT = 4;
+template <class Q>
+static __global__ void __launch_bounds__(AUD_FIN_SPLIT * ACC_LIMBS * AUD_FIN_COLS)
+k_audit_finish(const unsigned long long* __restrict__ partial, uint32_t n_blocks, uint32_t n_cols, uint8_t* __restrict__ exact_out,
+               uint8_t* __restrict__ al_out, uint8_t* __restrict__ al_be_out, uint8_t* __restrict__ sc_out) {
+    __shared__ unsigned long long limb_sum[AUD_FIN_SPLIT][ACC_LIMBS][AUD_FIN_COLS];
+    {
+        const uint32_t c = threadIdx.x % AUD_FIN_COLS, k = (threadIdx.x / AUD_FIN_COLS) % ACC_LIMBS;
+        const uint32_t part = threadIdx.x / (AUD_FIN_COLS * ACC_LIMBS);
+        const uint32_t gc = blockIdx.x * AUD_FIN_COLS + c;
+        unsigned long long t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) t[u] = 0;
+        if (gc < n_cols) {
+            const unsigned long long* src = partial + (size_t)k * n_cols + gc;
+            const size_t stride = (size_t)ACC_LIMBS * n_cols;
+            const uint32_t b_lo = (uint32_t)((uint64_t)n_blocks * part / AUD_FIN_SPLIT), b_hi = (uint32_t)((uint64_t)n_blocks * (part + 1) / AUD_FIN_SPLIT);
+            uint32_t b = b_lo;
+            for (; b + 8 <= b_hi; b += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) t[u] += src[(size_t)(b + u) * stride];
+            }
+            for (; b < b_hi; b++) t[0] += src[(size_t)b * stride];
+        }
+        limb_sum[part][k][c] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    }
+    __syncthreads();
+    const uint32_t col = blockIdx.x * AUD_FIN_COLS + threadIdx.x;
+    if (threadIdx.x >= AUD_FIN_COLS || col >= n_cols) return;
+    uint32_t acc[ACC_LIMBS];
+    {
+        unsigned long long carry = 0;
 #pragma unroll
         for (int k = 0; k < ACC_LIMBS; k++) {
-            uint64_t x = (uint64_t)acc[k] + partial[((size_t)b * ACC_LIMBS + k) * n_cols + col] + carry;
+            // limb sums < 2^32 * (8 slices * n_blocks) and the carry < 2^32 likewise: no overflow below 2^29 blocks
+            unsigned long long x = carry;
+#pragma unroll
+            for (int part = 0; part < AUD_FIN_SPLIT; part++) x += limb_sum[part][k][threadIdx.x];
             acc[k] = (uint32_t)x;
             carry = x >> 32;
         }
@@ -142,27 +207,31 @@ extern "C" int porla_audit_combine_device(const void* d_rows64, const uint64_t* 
     if (!ws) { ws = new AuditWs(); ws->device = dev; g_audit_ws.push_back(ws); }
     hipStream_t stream = (hipStream_t)hip_stream;
     const uint32_t total = (uint32_t)(n64 + n32);
-    uint32_t per_block = (total + 255) / 256;
-    if (per_block < 4) per_block = 4;
+    // rows per slice: enough blocks for two per compute unit on a large challenge, never fewer than 4 rows per slice (the audit's
+    // 3 200 rows: 100 blocks of 32 rows)
+    uint32_t per_slice = (total + AUD_SLICES * 512 - 1) / (AUD_SLICES * 512);
+    if (per_slice < 4) per_slice = 4;
+    const uint32_t per_block = per_slice * AUD_SLICES;
     const uint32_t n_blocks = total ? (total + per_block - 1) / per_block : 1;
-    if ((rc = ws->partial.ensure((size_t)n_blocks * ACC_LIMBS * n_cols * 4))) return rc;
+    if ((rc = ws->partial.ensure((size_t)n_blocks * ACC_LIMBS * n_cols * 8))) return rc;
     if ((rc = ws->fence.enter(stream))) return rc;      // `partial` is shared with an earlier combine on another stream
     {
         ProfScope ps("audit_accumulate", stream);
-        hipLaunchKernelGGL(k_audit_accumulate, dim3(n_blocks, (unsigned)((n_cols + 127) / 128)), dim3(128), 0, stream,
-                           (const uint8_t*)d_rows64, d_idx64, d_coef64, (uint32_t)n64, (const uint8_t*)d_rows32, d_idx32, d_coef32,
-                           (uint32_t)n32, (uint32_t)n_cols, per_block, (uint32_t*)ws->partial.p);
+        hipLaunchKernelGGL(k_audit_accumulate, dim3(n_blocks, (unsigned)((n_cols + AUD_COLS - 1) / AUD_COLS)), dim3(AUD_SLICES * AUD_COLS), 0,
+                           stream, (const uint8_t*)d_rows64, d_idx64, d_coef64, (uint32_t)n64, (const uint8_t*)d_rows32, d_idx32, d_coef32,
+                           (uint32_t)n32, (uint32_t)n_cols, per_slice, (unsigned long long*)ws->partial.p);
     }
     {
         ProfScope ps("audit_finish", stream);
+        const dim3 fgrid((unsigned)((n_cols + AUD_FIN_COLS - 1) / AUD_FIN_COLS)), fblock(AUD_FIN_SPLIT * ACC_LIMBS * AUD_FIN_COLS);
         if (curve == 0)
-            hipLaunchKernelGGL((k_audit_finish<IccBn254Fr>), dim3((unsigned)((n_cols + 127) / 128)), dim3(128), 0, stream,
-                               (const uint32_t*)ws->partial.p, n_blocks, (uint32_t)n_cols, (uint8_t*)d_exact_out,
-                               (uint8_t*)d_aligned_out, (uint8_t*)d_aligned_be_out, (uint8_t*)d_scalars_out);
+            hipLaunchKernelGGL((k_audit_finish<IccBn254Fr>), fgrid, fblock, 0, stream, (const unsigned long long*)ws->partial.p, n_blocks,
+                               (uint32_t)n_cols, (uint8_t*)d_exact_out, (uint8_t*)d_aligned_out, (uint8_t*)d_aligned_be_out,
+                               (uint8_t*)d_scalars_out);
         else
-            hipLaunchKernelGGL((k_audit_finish<IccSecp256k1Fn>), dim3((unsigned)((n_cols + 127) / 128)), dim3(128), 0, stream,
-                               (const uint32_t*)ws->partial.p, n_blocks, (uint32_t)n_cols, (uint8_t*)d_exact_out,
-                               (uint8_t*)d_aligned_out, (uint8_t*)d_aligned_be_out, (uint8_t*)d_scalars_out);
+            hipLaunchKernelGGL((k_audit_finish<IccSecp256k1Fn>), fgrid, fblock, 0, stream, (const unsigned long long*)ws->partial.p, n_blocks,
+                               (uint32_t)n_cols, (uint8_t*)d_exact_out, (uint8_t*)d_aligned_out, (uint8_t*)d_aligned_be_out,
+                               (uint8_t*)d_scalars_out);
     }
     PORLA_HIP(hipGetLastError());
     return ws->fence.leave(stream);
