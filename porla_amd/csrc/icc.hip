@@ -70,10 +70,23 @@ static int icc_mix_core(IccWs* ws, int curve, const uint8_t* d_a0, const uint8_t
     if ((rc = ws->fence.enter(stream))) return rc;
     if ((rc = ensure_twiddles<Q>(ws, curve, n_total, stream))) return rc;
     const size_t total = len * ncols;
+    // default: the reduced-radix kernel (icc30.hip.h:k_icc_mix30, a third of the field products); PORLA_ICC_MIX30=0: the 2^256-form one
+    static const bool mix30 = !(getenv("PORLA_ICC_MIX30") && getenv("PORLA_ICC_MIX30")[0] == '0');
+    if (mix30 && (ws->tw30_n != n_total || ws->tw30_curve != curve)) {
+        if ((rc = ws->tw30.ensure(n_total * ICC30_SLOT_WORDS * 4))) return rc;
+        hipLaunchKernelGGL((k_icc_twiddles30<Q>), dim3((unsigned)((n_total + 255) / 256)), dim3(256), 0, stream,
+                           (const IccElem<Q>*)ws->tw.p, (uint32_t)n_total, (uint32_t*)ws->tw30.p);
+        ws->tw30_n = (uint32_t)n_total;
+        ws->tw30_curve = curve;
+    }
     {
         ProfScope ps("icc_mix", stream);
-        hipLaunchKernelGGL((k_icc_mix<Q>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, d_a0, d_a1, (uint32_t)len,
-                           (uint32_t)ncols, (const IccElem<Q>*)ws->tw.p, (uint32_t)(n_total / len), d_out);
+        if (mix30)
+            hipLaunchKernelGGL((k_icc_mix30<Q>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, d_a0, d_a1, (uint32_t)len,
+                               (uint32_t)ncols, (const uint32_t*)ws->tw30.p, (uint32_t)(n_total / len), d_out);
+        else
+            hipLaunchKernelGGL((k_icc_mix<Q>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, d_a0, d_a1, (uint32_t)len,
+                               (uint32_t)ncols, (const IccElem<Q>*)ws->tw.p, (uint32_t)(n_total / len), d_out);
     }
     PORLA_HIP(hipGetLastError());
     return ws->fence.leave(stream);
