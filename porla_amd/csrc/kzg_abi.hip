@@ -8,6 +8,7 @@
 #include "engine.hpp"
 #include "pairing_host.hpp"
 #include "host_fold64.hpp"
+#include "icc30.hip.h"
 #include "../../include/libmultiexp.h"
 #include "../../include/porla_gpu.h"
 
@@ -47,6 +48,58 @@ k_kzg_eval_rows(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_co
     }
     acc = fe_from_mont<F>(fe_mul<F>(acc, alpha));
     store_be256(out + (size_t)r * 32, acc.v);
+}
+
+// The same evaluation with EIGHT lanes per row in the reduced-radix plain stream of icc30.hip.h (modulus r = IccBn254Fr's q):
+//   f(tau) = sum_{j<8} tau^j g_j(tau^8),   g_j(x) = sum_k c_{8k+j} x^k
+// lane j runs Horner over its 16 coefficients with tau^8 in the 2^270 form -- acc * (tau^8 2^270) / 2^270 + c: the stream stays plain,
+// a raw 256-bit coefficient is added unreduced (SetBytes' reduction happens in the last step), ONE product per coefficient where
+// k_kzg_eval_rows spends two and a reduction -- then times tau^j, a butterfly sum over the eight lanes, and lane 0 multiplies by
+// alpha and reduces once.  The 8 lanes of a row read 8 consecutive coefficients (256 B) per step, a wave 8 such runs; a row is 16
+// dependent products deep instead of 128.  Bounds: acc < p + 2^248 + 2^256 < 2^258 at every step, the lane sum < 2^261.
+struct KzgEvalConsts {
+    uint32_t tj[8][8];   // tau^j * 2^270 mod r, canonical words, j < 8
+    uint32_t t8[8];      // tau^8 * 2^270 mod r
+    uint32_t alpha[8];   // alpha * 2^270 mod r
+};
+__global__ void __launch_bounds__(256)
+k_kzg_eval_rows30(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_coeffs, KzgEvalConsts K, uint8_t* __restrict__ out) {
+    using Q = IccBn254Fr;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t j = t & 7u;
+    const bool live = (t >> 3) < n_rows;
+    const uint32_t r = live ? (t >> 3) : n_rows - 1;          // idle lanes redo the last row (the lane sum below is wave-wide)
+    const uint8_t* row = rows + (size_t)r * n_coeffs * 32;
+    const F30<Q> T8 = f30_unpack<Q>(K.t8);
+    F30<Q> acc;
+#pragma unroll
+    for (int l = 0; l < 9; l++) acc.v[l] = 0;
+    for (uint32_t k = (n_coeffs + 7) / 8; k-- > 0;) {
+        const uint32_t i = 8 * k + j;
+        uint32_t c[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) c[w] = 0;
+        if (i < n_coeffs) load_be256(c, row + (size_t)i * 32);
+        acc = icc30_add<Q>(icc30_mul<Q>(acc, T8), f30_unpack<Q>(c));
+    }
+    uint32_t tj[8];
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+        tj[w] = K.tj[0][w];
+#pragma unroll
+        for (int jj = 1; jj < 8; jj++) tj[w] = j == (uint32_t)jj ? K.tj[jj][w] : tj[w];
+    }
+    acc = icc30_mul<Q>(acc, f30_unpack<Q>(tj));
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+        F30<Q> o;
+#pragma unroll
+        for (int l = 0; l < 9; l++) o.v[l] = (uint32_t)__shfl_xor((int)acc.v[l], m);
+        acc = icc30_add<Q>(acc, o);
+    }
+    if (j != 0 || !live) return;
+    const Fe<Q> res = icc30_canonical<Q>(icc30_reduce_top<Q>(icc30_mul<Q>(acc, f30_unpack<Q>(K.alpha))));
+    store_be256(out + (size_t)r * 32, res.v);
 }
 
 struct KzgState {
@@ -567,10 +620,30 @@ int porla_kzg_digest_batch_device(const void* d_rows, size_t n_rows, void* d_out
     // d_eval is read by the commit below: a previous batch on another stream must have finished with it (the table's fence
     // is recorded after that commit's last kernel)
     if ((rc = kd->fb_g.fence.enter(stream))) return rc;
+    static const bool eval30 = !(getenv("PORLA_KZG_EVAL30") && getenv("PORLA_KZG_EVAL30")[0] == '0');
     {
         ProfScope ps("kzg_eval_rows", stream);
-        hipLaunchKernelGGL(k_kzg_eval_rows, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, (const uint8_t*)d_rows,
-                           (uint32_t)n_rows, (uint32_t)g.n_samples, g.tau, g.alpha, (uint8_t*)kd->d_eval);
+        if (eval30) {
+            // tau^j, tau^8 and alpha in the 2^270 form: x 2^270 mod r = from_mont(x R * (2^270 R) / R)
+            static constexpr uint32_t C270[8] = {0x0ffead6fu, 0x36c69455u, 0x37577218u, 0xb1e9be3cu, 0xdf11f427u, 0x9e7d8ca3u, 0xed6d3304u, 0x279be39au};   // 2^270 mod r
+            Fe<Fr> c270;
+            for (int w = 0; w < 8; w++) c270.v[w] = C270[w];
+            c270 = fe_to_mont<Fr>(c270);
+            auto to270 = [&](const Fe<Fr>& xm, uint32_t* dst) {
+                const Fe<Fr> v = fe_from_mont<Fr>(fe_mul<Fr>(xm, c270));
+                for (int w = 0; w < 8; w++) dst[w] = v.v[w];
+            };
+            KzgEvalConsts K;
+            Fe<Fr> pw = fe_one<Fr>();
+            for (int jj = 0; jj < 8; jj++) { to270(pw, K.tj[jj]); pw = fe_mul<Fr>(pw, g.tau); }
+            to270(pw, K.t8);
+            to270(g.alpha, K.alpha);
+            hipLaunchKernelGGL(k_kzg_eval_rows30, dim3((unsigned)((8 * n_rows + 255) / 256)), dim3(256), 0, stream, (const uint8_t*)d_rows,
+                               (uint32_t)n_rows, (uint32_t)g.n_samples, K, (uint8_t*)kd->d_eval);
+        } else {
+            hipLaunchKernelGGL(k_kzg_eval_rows, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, (const uint8_t*)d_rows,
+                               (uint32_t)n_rows, (uint32_t)g.n_samples, g.tau, g.alpha, (uint8_t*)kd->d_eval);
+        }
     }
     return kd->fb_g.commit_device((const uint8_t*)kd->d_eval, n_rows, 1, 32, (uint8_t*)d_out, stream);
 }
