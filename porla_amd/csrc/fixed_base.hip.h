@@ -166,8 +166,15 @@ k_fb_normalize(const XYZZ<typename C::Fp>* __restrict__ scratch, size_t n, Affin
 // rows: row r, coefficient i at rows + r*row_stride + 32*i, 32 bytes big-endian (bn254_scalar, utils.h:307-318;
 //       fr.SetBytes semantics: reduced mod the group order, porla/main.go:110).
 // grid.x covers rows (lane = row), grid.y = slice s of the coefficient range; partial[r*S + s] = slice sum.
+// (-DPORLA_FB_COMMIT_4WAVES: 128 registers + 272 B of scratch for four waves per SIMD instead of 145 + 192 B for three -- measured
+// SLOWER, 19.7-20.0 against 18.95-19.1 ms for 2^17 rows on one box, profiles/r03_q_fb_commit_4waves_ab.txt)
+#ifdef PORLA_FB_COMMIT_4WAVES
+#define PORLA_FB_COMMIT_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
+#define PORLA_FB_COMMIT_ATTR
+#endif
 template <class C>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) PORLA_FB_COMMIT_ATTR
 k_fb_commit(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_coeffs, size_t row_stride,
             const Affine<typename C::Fp>* __restrict__ table, int c, int W, uint32_t S,
             XYZZ<typename C::Fp>* __restrict__ partial) {
