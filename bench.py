@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the MI355X commitment engine on BASELINE.json's metric, one rank per GPU.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bn254_msm|kzg_commit|secp256k1_msm|icc|config3|crebuild|audit_combine]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bn254_msm|kzg_commit|secp256k1_msm|icc|config3|crebuild|audit_combine|kzg_audit]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 Default workload (the headline metric): a "step" is ONE 2^20-pair BN254 G1 MSM per GPU (BASELINE.json config 2, "KZG
@@ -25,6 +25,9 @@ cpu_baseline and bit_exact_vs_oracle, timed separately after the headline region
                   folded as above, the whole job checked against the oracle                                   (config 3)
   audit_combine   Server::audit's row combine + align_MAC scalars on an 8 GiB level store: 2^18 challenged rows (the path's one
                   HBM-bound kernel: GB/s against the 8 TB/s peak) and the audit's own 3 200 rows (ms per call); N = 1 only  (s8 f-4)
+  kzg_audit       ONE server-side KZG audit at the reference's size (3 200 challenged rows of a 2^15-block level resident in HBM):
+                  row combine, the two MSMs over the challenged MACs, align_MAC's commitment and create_proof behind
+                  porla_kzg_audit_device; audits/s, checked against what the client verifies; N = 1 only            
 and, for the headline MSM: `blocking_ms_per_step` + `blocking_kernels_ms` (one MSM in flight: what a caller that waits for
 every result sees, with its own per-kernel breakdown), `audit_size_msm` (128 / 1 408 / 3 200 pairs: the sizes the reference
 issues), `host_boundary` (compute_multi_exp on caller-owned pageable host buffers, PCIe included).
@@ -120,7 +123,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="bn254_msm",
-                    choices=["bn254_msm", "kzg_commit", "secp256k1_msm", "icc", "config3", "crebuild", "audit_combine"])
+                    choices=["bn254_msm", "kzg_commit", "secp256k1_msm", "icc", "config3", "crebuild", "audit_combine", "kzg_audit"])
     ap.add_argument("--log2n", type=int, default=20, help="MSM pairs per GPU = 2^log2n (default: the 2^20 of BASELINE.json)")
     ap.add_argument("--log2rows", type=int, default=17, help="kzg_commit rows per GPU = 2^log2rows; icc rows = 2^(log2rows-2)")
     ap.add_argument("--log2job", type=int, default=24, help="config3: pairs of the whole job = 2^log2job, split over the ranks")
@@ -133,6 +136,10 @@ def main():
                     "audit's pair of MSMs, Server.hpp:900-901, overlapped on two streams)")
     args = ap.parse_args()
 
+    if args.workload == "kzg_audit":
+        # one whole server-side audit at the reference's size has its own driver too (tools/bench_audit_flow.py, same JSON contract)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_audit_flow.py")] + (["--no-cpu"] if args.no_cpu else []))
+        sys.exit(r.returncode)
     if args.workload == "crebuild":
         # the device-resident last encode stage has its own driver (same JSON contract), run as a child: nothing here has touched
         # the GPU yet
@@ -747,6 +754,15 @@ def main():
                                "achieved_GBps": small["roofline"]["achieved"]},
                 "bit_exact_vs_oracle": bool(big["bit_exact_vs_oracle_1024_row_challenge"])}
 
+    # ---------------------------------------------------------------- one whole audit (child process: tools/bench_audit_flow.py)
+    def leg_kzg_audit():
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_audit_flow.py")] + (["--no-cpu"] if args.no_cpu else [])
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=child_env())
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            raise RuntimeError("bench_audit_flow.py failed: rc=%d %s" % (r.returncode, r.stderr[-400:]))
+        return json.loads(lines[-1])
+
     # ---------------------------------------------------------------- the line
     legs = {"bn254_msm": leg_bn254_msm, "kzg_commit": leg_kzg_commit, "secp256k1_msm": leg_secp256k1_msm, "icc": leg_icc,
             "config3": leg_config3, "audit_combine": leg_audit_combine}
@@ -760,6 +776,7 @@ def main():
             extra += [("secp256k1_msm", leg_secp256k1_msm), ("icc", leg_icc)]
             if world == 1:
                 extra.append(("audit_combine", leg_audit_combine))
+                extra.append(("kzg_audit", leg_kzg_audit))
             if not args.no_config3:
                 extra.append(("config3", leg_config3))
         for name, fn in extra:

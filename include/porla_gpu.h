@@ -96,6 +96,17 @@ int porla_bn254_msm_pair_device(const void *d_scalars, const void *d_points_a, c
                                 uint8_t out_a[64], uint8_t out_b[64], void *hip_stream);
 int porla_bn254_msm_pair_host(const uint8_t *scalars, const uint8_t *points_a, const uint8_t *points_b, size_t n,
                               uint8_t out_a[64], uint8_t out_b[64]);
+/* ... and straight from the server's resident MAC arrays: per challenged row i the points store_a[idx[i]], store_b[idx[i]] (64-byte
+ * affine each) and the scalar coef[i] (abs(int32), bn254_scalar_set_int, utils.h:271-275) -- the gather Server::audit does on the
+ * host into ptc / pta / sc (Server.hpp:838-848, 893-899) runs on the device; idx / coef are the arrays porla_audit_combine_device
+ * takes.  All pointers device pointers; outputs host. */
+int porla_bn254_audit_msm_pair_device(const void *d_store_a, const void *d_store_b, const uint64_t *d_idx, const uint32_t *d_coef,
+                                      size_t n, uint8_t out_a[64], uint8_t out_b[64], void *hip_stream);
+/* two-phase form (slots 1..3 as porla_bn254_msm_device_begin): begin gathers and launches on hip_stream and returns, end waits and
+ * folds -- the audit's other chain (row combine -> alignment commitment -> proof) runs in between; 1 .. 32 768 challenged rows */
+int porla_bn254_audit_msm_pair_begin(int slot, const void *d_store_a, const void *d_store_b, const uint64_t *d_idx,
+                                     const uint32_t *d_coef, size_t n, void *hip_stream);
+int porla_bn254_audit_msm_pair_end(int slot, uint8_t out_a[64], uint8_t out_b[64]);
 /* Two-phase form for independent MSMs in flight at once (e.g. the audit's two MSMs, Server.hpp:900-901): begin enqueues
  * every kernel of one MSM on hip_stream and returns; end waits for that slot, folds the reduction tree's sums on the host and writes
  * 64 bytes affine (jacobian = 0) or 96 bytes Jacobian (jacobian = 1).  slot in 1..3 (0 is used by the blocking calls);
@@ -129,6 +140,11 @@ int porla_secp256k1_msm_pair_device(const void *d_scalars, const void *d_points_
                                     uint8_t out_a[64], uint8_t out_b[64], void *hip_stream);
 int porla_secp256k1_msm_pair_host(const uint8_t *scalars, const uint8_t *points_a, const uint8_t *points_b, size_t n,
                                   uint8_t out_a[64], uint8_t out_b[64]);
+int porla_secp256k1_audit_msm_pair_device(const void *d_store_a, const void *d_store_b, const uint64_t *d_idx,
+                                          const uint32_t *d_coef, size_t n, uint8_t out_a[64], uint8_t out_b[64], void *hip_stream);
+int porla_secp256k1_audit_msm_pair_begin(int slot, const void *d_store_a, const void *d_store_b, const uint64_t *d_idx,
+                                         const uint32_t *d_coef, size_t n, void *hip_stream);
+int porla_secp256k1_audit_msm_pair_end(int slot, uint8_t out_a[64], uint8_t out_b[64]);
 int porla_secp256k1_msm_device_partial(const void *d_scalars, const void *d_points, size_t n,
                                        uint8_t out_jacobian[96], void *hip_stream);
 int porla_secp256k1_msm_device_begin(int slot, const void *d_scalars, const void *d_points, size_t n, void *hip_stream);
@@ -178,6 +194,23 @@ void porla_fixed_base_destroy(porla_fixed_base *fb);
 /* KZG: rows of n_samples coefficients (4096 bytes per row for NUM_CHUNKS = 128) against the resident SRS */
 int  porla_kzg_commit_batch_device(const void *d_rows, size_t n_rows, void *d_out, void *hip_stream);
 int  porla_kzg_commit_batch_host(const uint8_t *rows, size_t n_rows, uint8_t *out);
+/* Server::audit (KZG build) after the challenge has been drawn, in ONE call (porla/Server/Server.hpp:564-931): the row combine and
+ * alignment scalars (arguments as porla_audit_combine_device, n_cols = the SRS size), the two MSMs over the challenged MACs
+ * (arguments as porla_bn254_audit_msm_pair_device; they run on a stream of their own beside the rest), align_MAC's commitment and
+ * create_proof(random_point, B) -- the three commitments as one launch.  Outputs on the host: combined_MAC, combined_align,
+ * align_value = Commit(c), and the proof (commitment = Commit(B), H, point, claim; main.go:153-175); b_out (may be NULL): B mod
+ * p_icc as n_cols 32-byte big-endian values.  Everything else device pointers; blocking; one audit at a time per process. */
+int  porla_kzg_audit_device(const void *d_rows64, const uint64_t *d_idx64, const uint32_t *d_coef64, size_t n64,
+                            const void *d_rows32, const uint64_t *d_idx32, const uint32_t *d_coef32, size_t n32,
+                            const void *d_mac_store, const void *d_align_store, const uint64_t *d_mac_idx,
+                            const uint32_t *d_mac_coef, size_t n_macs, unsigned long long random_point,
+                            uint8_t combined_mac[64], uint8_t combined_align[64], uint8_t align_value[64],
+                            uint8_t commitment[64], uint8_t proof_h[64], uint8_t proof_point[32], uint8_t proof_claim[32],
+                            uint8_t *b_out, void *hip_stream);
+/* rows resident on the device, results wanted on the host at once (the audit's align_MAC commitment on the scalars
+ * porla_audit_combine_device left in HBM, Server.hpp:903 -> :550-560): up to 64 rows run as ONE launch on hip_stream, behind whatever
+ * produced the rows there, and the call returns when the pinned result has arrived; blocking */
+int  porla_kzg_commit_batch_device_to_host(const void *d_rows, size_t n_rows, uint8_t *out /* n_rows * 64 */, void *hip_stream);
 /* the same with the row range split over `devices` GPUs of this process (0 = every visible one), one host thread and one
  * resident copy of the SRS table per device; rows are independent, nothing is exchanged (Server.hpp:1077-1078, 2061-2062) */
 int  porla_kzg_commit_batch_host_multi(const uint8_t *rows, size_t n_rows, uint8_t *out, int devices);

@@ -26,7 +26,8 @@ constexpr int ACC_LIMBS = 19;  // 512 + 32 + 32 bits of head-room for up to 2^32
 // a row = 4 KiB); a lane adds coeff * symbol of its slice's rows into an exact 19-limb integer, two rows' loads in flight.  The
 // slices' sums meet in LDS and leave as ONE carry-save partial per block: partial[(b * ACC_LIMBS + limb) * n_cols + col], 64-bit
 // limb sums (no carry chain here; k_audit_finish runs it once per column).
-constexpr int AUD_SLICES = 8;
+constexpr int AUD_SLICES = 8;         // large challenges; AUD_SLICES_SMALL for the audit's own size: 39 KB of LDS per block, so that
+constexpr int AUD_SLICES_SMALL = 4;   // its blocks fit beside the single-launch MSM pair's (105 KB per CU) instead of waiting for them
 constexpr int AUD_COLS = 128;
 
 // acc += cf * v, v = WORDS little-endian 32-bit words
@@ -81,19 +82,20 @@ __device__ __forceinline__ void audit_span(uint32_t (&acc)[ACC_LIMBS], const uin
     }
 }
 
-static __global__ void __launch_bounds__(AUD_SLICES * AUD_COLS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+template <int SLICES>
+static __global__ void __launch_bounds__(SLICES * AUD_COLS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_audit_accumulate(const uint8_t* __restrict__ rows64, const uint64_t* __restrict__ idx64, const uint32_t* __restrict__ coef64,
                    uint32_t n64, const uint8_t* __restrict__ rows32, const uint64_t* __restrict__ idx32,
                    const uint32_t* __restrict__ coef32, uint32_t n32, uint32_t n_cols, uint32_t per_slice,
                    unsigned long long* __restrict__ partial) {
-    __shared__ uint32_t sums[AUD_SLICES][ACC_LIMBS][AUD_COLS];
+    __shared__ uint32_t sums[SLICES][ACC_LIMBS][AUD_COLS];
     const uint32_t lane_col = threadIdx.x % AUD_COLS;
     const uint32_t slice = __builtin_amdgcn_readfirstlane(threadIdx.x / AUD_COLS);
     const uint32_t col0 = blockIdx.y * AUD_COLS;
     const bool live = col0 + lane_col < n_cols;
     const uint32_t col = live ? col0 + lane_col : n_cols - 1;       // idle lanes re-read the last column and drop the result
     const uint32_t total = n64 + n32;
-    const uint64_t first = ((uint64_t)blockIdx.x * AUD_SLICES + slice) * per_slice;
+    const uint64_t first = ((uint64_t)blockIdx.x * SLICES + slice) * per_slice;
     const uint32_t lo = first < total ? (uint32_t)first : total;
     const uint32_t hi = first + per_slice < total ? (uint32_t)(first + per_slice) : total;
     uint32_t acc[ACC_LIMBS];
@@ -105,11 +107,11 @@ k_audit_accumulate(const uint8_t* __restrict__ rows64, const uint64_t* __restric
 #pragma unroll
     for (int k = 0; k < ACC_LIMBS; k++) sums[slice][k][lane_col] = acc[k];
     __syncthreads();
-    for (uint32_t item = threadIdx.x; item < ACC_LIMBS * AUD_COLS; item += AUD_SLICES * AUD_COLS) {
+    for (uint32_t item = threadIdx.x; item < ACC_LIMBS * AUD_COLS; item += SLICES * AUD_COLS) {
         const uint32_t k = item / AUD_COLS, c = item % AUD_COLS;
         unsigned long long t = 0;
 #pragma unroll
-        for (int sl = 0; sl < AUD_SLICES; sl++) t += sums[sl][k][c];
+        for (int sl = 0; sl < SLICES; sl++) t += sums[sl][k][c];
         if (col0 + c < n_cols) partial[((size_t)blockIdx.x * ACC_LIMBS + k) * n_cols + col0 + c] = t;
     }
 }
@@ -152,7 +154,7 @@ k_audit_finish(const unsigned long long* __restrict__ partial, uint32_t n_blocks
         unsigned long long carry = 0;
 #pragma unroll
         for (int k = 0; k < ACC_LIMBS; k++) {
-            // limb sums < 2^32 * (8 slices * n_blocks) and the carry < 2^32 likewise: no overflow below 2^29 blocks
+            // limb sums < 2^32 * (<= 8 slices * n_blocks) and the carry < 2^32 likewise: no overflow below 2^29 blocks
             unsigned long long x = carry;
 #pragma unroll
             for (int part = 0; part < AUD_FIN_SPLIT; part++) x += limb_sum[part][k][threadIdx.x];
@@ -214,17 +216,25 @@ extern "C" int porla_audit_combine_device(const void* d_rows64, const uint64_t* 
     const uint32_t total = (uint32_t)(n64 + n32);
     // rows per slice: enough blocks for two per compute unit on a large challenge, never fewer than 4 rows per slice (the audit's
     // 3 200 rows: 100 blocks of 32 rows)
-    uint32_t per_slice = (total + AUD_SLICES * 512 - 1) / (AUD_SLICES * 512);
+    const bool small = total <= 16384;
+    const uint32_t slices = small ? AUD_SLICES_SMALL : AUD_SLICES;
+    uint32_t per_slice = (total + slices * 512 - 1) / (slices * 512);
     if (per_slice < 4) per_slice = 4;
-    const uint32_t per_block = per_slice * AUD_SLICES;
+    const uint32_t per_block = per_slice * slices;
     const uint32_t n_blocks = total ? (total + per_block - 1) / per_block : 1;
     if ((rc = ws->partial.ensure((size_t)n_blocks * ACC_LIMBS * n_cols * 8))) return rc;
     if ((rc = ws->fence.enter(stream))) return rc;      // `partial` is shared with an earlier combine on another stream
     {
         ProfScope ps("audit_accumulate", stream);
-        hipLaunchKernelGGL(k_audit_accumulate, dim3(n_blocks, (unsigned)((n_cols + AUD_COLS - 1) / AUD_COLS)), dim3(AUD_SLICES * AUD_COLS), 0,
-                           stream, (const uint8_t*)d_rows64, d_idx64, d_coef64, (uint32_t)n64, (const uint8_t*)d_rows32, d_idx32, d_coef32,
-                           (uint32_t)n32, (uint32_t)n_cols, per_slice, (unsigned long long*)ws->partial.p);
+        const dim3 grid(n_blocks, (unsigned)((n_cols + AUD_COLS - 1) / AUD_COLS));
+        if (small)
+            hipLaunchKernelGGL((k_audit_accumulate<AUD_SLICES_SMALL>), grid, dim3(AUD_SLICES_SMALL * AUD_COLS), 0, stream,
+                               (const uint8_t*)d_rows64, d_idx64, d_coef64, (uint32_t)n64, (const uint8_t*)d_rows32, d_idx32, d_coef32,
+                               (uint32_t)n32, (uint32_t)n_cols, per_slice, (unsigned long long*)ws->partial.p);
+        else
+            hipLaunchKernelGGL((k_audit_accumulate<AUD_SLICES>), grid, dim3(AUD_SLICES * AUD_COLS), 0, stream,
+                               (const uint8_t*)d_rows64, d_idx64, d_coef64, (uint32_t)n64, (const uint8_t*)d_rows32, d_idx32, d_coef32,
+                               (uint32_t)n32, (uint32_t)n_cols, per_slice, (unsigned long long*)ws->partial.p);
     }
     {
         ProfScope ps("audit_finish", stream);

@@ -130,7 +130,7 @@ int lease_blocking_slot(Workspace** out) {
     int rc = get_workspace_slot(0, &w0);
     if (rc) return rc;
     if (w0->mu.try_lock()) { *out = w0; return PORLA_OK; }
-    for (int k = MSM_POOL_SLOT0; k < MSM_SLOTS; k++) {
+    for (int k = MSM_POOL_SLOT0; k < MSM_POOL_SLOT0 + MSM_POOL_SLOTS; k++) {
         Workspace* w = nullptr;
         if ((rc = get_workspace_slot(k, &w))) return rc;
         if (w->mu.try_lock()) { *out = w; return PORLA_OK; }
@@ -170,6 +170,18 @@ static int abi_msm_pair(const void* scalars, const void* points_a, const void* p
     XYZZ<M> ta, tb;
     int rc = device ? msm_pair_device<C>((const uint8_t*)scalars, (const uint8_t*)points_a, (const uint8_t*)points_b, n, (hipStream_t)stream, &ta, &tb)
                     : msm_pair_host<C>((const uint8_t*)scalars, (const uint8_t*)points_a, (const uint8_t*)points_b, n, &ta, &tb);
+    if (rc) return rc;
+    h_affine_to_bytes<M>(out_a, h_xyzz_to_affine64<M>(ta));
+    h_affine_to_bytes<M>(out_b, h_xyzz_to_affine64<M>(tb));
+    return PORLA_OK;
+}
+template <class C>
+static int abi_audit_msm_pair(const void* d_store_a, const void* d_store_b, const uint64_t* d_idx, const uint32_t* d_coef, size_t n,
+                              uint8_t* out_a, uint8_t* out_b, void* stream) {
+    using M = typename C::Fp;
+    if (!out_a || !out_b || (n && (!d_store_a || !d_store_b || !d_idx || !d_coef))) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    XYZZ<M> ta, tb;
+    int rc = msm_pair_gather_device<C>((const uint8_t*)d_store_a, (const uint8_t*)d_store_b, d_idx, d_coef, n, (hipStream_t)stream, &ta, &tb);
     if (rc) return rc;
     h_affine_to_bytes<M>(out_a, h_xyzz_to_affine64<M>(ta));
     h_affine_to_bytes<M>(out_b, h_xyzz_to_affine64<M>(tb));
@@ -342,6 +354,26 @@ int porla_bn254_msm_pair_host(const uint8_t* scalars, const uint8_t* points_a, c
                               uint8_t out_b[64]) {
     return abi_msm_pair<Bn254G1>(scalars, points_a, points_b, n, out_a, out_b, nullptr, false);
 }
+int porla_bn254_audit_msm_pair_device(const void* d_store_a, const void* d_store_b, const uint64_t* d_idx, const uint32_t* d_coef, size_t n,
+                                      uint8_t out_a[64], uint8_t out_b[64], void* s) {
+    return abi_audit_msm_pair<Bn254G1>(d_store_a, d_store_b, d_idx, d_coef, n, out_a, out_b, s);
+}
+int porla_bn254_audit_msm_pair_begin(int slot, const void* d_store_a, const void* d_store_b, const uint64_t* d_idx, const uint32_t* d_coef,
+                                     size_t n, void* s) {
+    if (!d_store_a || !d_store_b || !d_idx || !d_coef) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    if (slot < 1 || slot >= MSM_USER_SLOTS) { set_last_error("porla: MSM slot out of range (1 .. 3; 0 belongs to the blocking calls)"); return PORLA_ERR_ARG; }
+    return msm_pair_gather_begin<Bn254G1>(slot, (const uint8_t*)d_store_a, (const uint8_t*)d_store_b, d_idx, d_coef, n, (hipStream_t)s);
+}
+int porla_bn254_audit_msm_pair_end(int slot, uint8_t out_a[64], uint8_t out_b[64]) {
+    if (!out_a || !out_b) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    if (slot < 1 || slot >= MSM_USER_SLOTS) { set_last_error("porla: MSM slot out of range (1 .. 3; 0 belongs to the blocking calls)"); return PORLA_ERR_ARG; }
+    XYZZ<Bn254Fp> ta, tb;
+    int rc = msm_pair_end<Bn254G1>(slot, &ta, &tb);
+    if (rc) return rc;
+    h_affine_to_bytes<Bn254Fp>(out_a, h_xyzz_to_affine64<Bn254Fp>(ta));
+    h_affine_to_bytes<Bn254Fp>(out_b, h_xyzz_to_affine64<Bn254Fp>(tb));
+    return PORLA_OK;
+}
 int porla_bn254_msm_host_multi(const uint8_t* scalars, const uint8_t* points, size_t n, int shards, int devices, uint8_t out_affine[64]) {
     return abi_msm_host_multi<Bn254G1>(scalars, points, n, shards, devices, out_affine);
 }
@@ -352,6 +384,26 @@ int porla_secp256k1_msm_pair_device(const void* d_scalars, const void* d_points_
 int porla_secp256k1_msm_pair_host(const uint8_t* scalars, const uint8_t* points_a, const uint8_t* points_b, size_t n, uint8_t out_a[64],
                                   uint8_t out_b[64]) {
     return abi_msm_pair<Secp256k1G>(scalars, points_a, points_b, n, out_a, out_b, nullptr, false);
+}
+int porla_secp256k1_audit_msm_pair_device(const void* d_store_a, const void* d_store_b, const uint64_t* d_idx, const uint32_t* d_coef,
+                                          size_t n, uint8_t out_a[64], uint8_t out_b[64], void* s) {
+    return abi_audit_msm_pair<Secp256k1G>(d_store_a, d_store_b, d_idx, d_coef, n, out_a, out_b, s);
+}
+int porla_secp256k1_audit_msm_pair_begin(int slot, const void* d_store_a, const void* d_store_b, const uint64_t* d_idx, const uint32_t* d_coef,
+                                         size_t n, void* s) {
+    if (!d_store_a || !d_store_b || !d_idx || !d_coef) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    if (slot < 1 || slot >= MSM_USER_SLOTS) { set_last_error("porla: MSM slot out of range (1 .. 3; 0 belongs to the blocking calls)"); return PORLA_ERR_ARG; }
+    return msm_pair_gather_begin<Secp256k1G>(slot, (const uint8_t*)d_store_a, (const uint8_t*)d_store_b, d_idx, d_coef, n, (hipStream_t)s);
+}
+int porla_secp256k1_audit_msm_pair_end(int slot, uint8_t out_a[64], uint8_t out_b[64]) {
+    if (!out_a || !out_b) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    if (slot < 1 || slot >= MSM_USER_SLOTS) { set_last_error("porla: MSM slot out of range (1 .. 3; 0 belongs to the blocking calls)"); return PORLA_ERR_ARG; }
+    XYZZ<Secp256k1Fp> ta, tb;
+    int rc = msm_pair_end<Secp256k1G>(slot, &ta, &tb);
+    if (rc) return rc;
+    h_affine_to_bytes<Secp256k1Fp>(out_a, h_xyzz_to_affine64<Secp256k1Fp>(ta));
+    h_affine_to_bytes<Secp256k1Fp>(out_b, h_xyzz_to_affine64<Secp256k1Fp>(tb));
+    return PORLA_OK;
 }
 int porla_secp256k1_msm_host_multi(const uint8_t* scalars, const uint8_t* points, size_t n, int shards, int devices, uint8_t out_affine[64]) {
     return abi_msm_host_multi<Secp256k1G>(scalars, points, n, shards, devices, out_affine);

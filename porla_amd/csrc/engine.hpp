@@ -45,6 +45,14 @@ template <class C>
 int msm_pair_device(const uint8_t* d_scalars, const uint8_t* d_points_a, const uint8_t* d_points_b, size_t n, hipStream_t stream,
                     XYZZ<typename C::Fp>* total_a, XYZZ<typename C::Fp>* total_b);
 template <class C>
+int msm_pair_gather_device(const uint8_t* d_store_a, const uint8_t* d_store_b, const uint64_t* d_idx, const uint32_t* d_coef, size_t n,
+                           hipStream_t stream, XYZZ<typename C::Fp>* total_a, XYZZ<typename C::Fp>* total_b);
+template <class C>
+int msm_pair_gather_begin(int slot, const uint8_t* d_store_a, const uint8_t* d_store_b, const uint64_t* d_idx, const uint32_t* d_coef, size_t n,
+                          hipStream_t stream);
+template <class C>
+int msm_pair_end(int slot, XYZZ<typename C::Fp>* total_a, XYZZ<typename C::Fp>* total_b);
+template <class C>
 int msm_pair_host(const uint8_t* scalars, const uint8_t* points_a, const uint8_t* points_b, size_t n, XYZZ<typename C::Fp>* total_a,
                   XYZZ<typename C::Fp>* total_b);
 template <class C>
@@ -126,12 +134,16 @@ struct Workspace {
     hipEvent_t done = nullptr;  // recorded after the last kernel + D2H copy of a launched MSM
     int pend_W = 0, pend_c = 0; // window count / width of the launched, not yet folded MSM (0 = none)
     bool lone = false;          // the caller waits for this MSM (blocking entry points): the reduction tree may use two streams
+    bool pair_pending = false;  // the begun launch is a pair (msm_pair_gather_begin): two result regions, msm_pair_end collects them
     bool begun = false;         // two-phase API: a begin without its end (also set for n == 0, where pend_W stays 0)
 };
 // workspace slots per device -- 0: blocking calls, 1..3: the two-phase C ABI, 4..7: msm_host_multi's pipeline,
 // 8..15: taken by blocking calls that find slot 0 busy (the reference issues its IPA MSMs from 8 pool threads at once,
-// Client.hpp:395,778: they run side by side, each on its own slot and stream, instead of queueing on one mutex)
-constexpr int MSM_SLOTS = 16;
+// Client.hpp:395,778: they run side by side, each on its own slot and stream, instead of queueing on one mutex),
+// 16: the pair of MSMs inside porla_kzg_audit_device
+constexpr int MSM_SLOTS = 17;
+constexpr int MSM_POOL_SLOTS = 8;
+constexpr int MSM_AUDIT_SLOT = 16;
 constexpr int MSM_USER_SLOTS = 4;
 constexpr int MSM_MULTI_SLOT0 = 4;
 constexpr int MSM_MULTI_SLOTS = 4;
@@ -179,7 +191,9 @@ struct FixedBase {
                     hipStream_t stream);
     // <= FB_SMALL_MAX_ROWS rows given by pointer (they need not be contiguous: the coalescing front of compute_digest_from_srs
     // hands over the callers' own buffers), one launch, results polled from pinned memory and normalised on the host
-    int commit_small(const uint8_t* const* row_ptrs, size_t n_rows, size_t n_coeffs, uint8_t* const* outs, hipStream_t stream);
+    // d_rows != nullptr: the rows are resident on the device (contiguous, 32 * n_coeffs bytes each) and row_ptrs is ignored
+    int commit_small(const uint8_t* const* row_ptrs, size_t n_rows, size_t n_coeffs, uint8_t* const* outs, hipStream_t stream,
+                     const uint8_t* d_rows = nullptr);
     static bool small_ok(size_t n_rows, size_t n_coeffs);
 };
 

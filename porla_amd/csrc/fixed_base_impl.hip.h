@@ -197,7 +197,7 @@ bool FixedBase<C>::small_ok(size_t n_rows, size_t n_coeffs) {
 }
 template <class C>
 int FixedBase<C>::commit_small(const uint8_t* const* row_ptrs, size_t n_rows, size_t n_coeffs, uint8_t* const* outs,
-                               hipStream_t stream) {
+                               hipStream_t stream, const uint8_t* d_rows) {
     using M = typename C::Fp;
     if (!table || n_coeffs > n_points) { set_last_error("porla: fixed base not built / too few base points"); return PORLA_ERR_STATE; }
     int cur = -1;
@@ -213,7 +213,8 @@ int FixedBase<C>::commit_small(const uint8_t* const* row_ptrs, size_t n_rows, si
     }
     uint8_t* hs = (uint8_t*)h_small;
     const size_t stride = n_coeffs * 32;
-    for (size_t r = 0; r < n_rows; r++) memcpy(hs + FB_SMALL_ROWS + r * stride, row_ptrs[r], stride);
+    if (!d_rows)
+        for (size_t r = 0; r < n_rows; r++) memcpy(hs + FB_SMALL_ROWS + r * stride, row_ptrs[r], stride);
     void* h_dev = nullptr;
     PORLA_HIP(hipHostGetDevicePointer(&h_dev, h_small, 0));
     if (++small_seq == 0) small_seq = 1;
@@ -228,7 +229,8 @@ int FixedBase<C>::commit_small(const uint8_t* const* row_ptrs, size_t n_rows, si
     {
         ProfScope ps("fb_commit_small", stream, true);
         hipLaunchKernelGGL((k_fb_commit_small<C>), dim3((unsigned)(n_rows * SL)), dim3(SMALL_THREADS), 0, stream,
-                           (const uint8_t*)h_dev + FB_SMALL_ROWS, (uint32_t)n_rows, (uint32_t)n_coeffs, stride, (const Affine<M>*)table, c, W, SL,
+                           d_rows ? d_rows : (const uint8_t*)h_dev + FB_SMALL_ROWS, (uint32_t)n_rows, (uint32_t)n_coeffs, stride,
+                           (const Affine<M>*)table, c, W, SL,
                            (XYZZ<M>*)d_small, (uint32_t*)((uint8_t*)d_small + part_bytes), (uint32_t*)h_dev,
                            (XYZZ<M>*)((uint8_t*)h_dev + FB_SMALL_SUMS), small_seq);
     }

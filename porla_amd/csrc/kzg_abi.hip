@@ -433,11 +433,9 @@ GoUint8 compare_commitment(GoSlice* commitment_a, GoSlice* commitment_b) {
     return 1;
 }
 
-// main.go:153-175: commitment = Commit(f); y = f(z); h = (f - y)/(X - z); H = Commit(h)
-void create_proof(GoUint64 random_point, GoSlice* data_in, GoSlice* commitment_out, GoSlice* proof_H,
-                  GoSlice* proof_point, GoSlice* proof_claim) {
-    const uint8_t* d = (const uint8_t*)data_in->data;
-    size_t n = (size_t)g.n_samples;
+// main.go:153-175 without the commitments: y = f(z) and the quotient h = (f - y)/(X - z) of the polynomial whose n coefficients are
+// given as 32-byte big-endian values (fr.SetBytes: reduced mod r); h_row receives n coefficients (the top one zero)
+static void kzg_open_rows(const uint8_t* d, size_t n, unsigned long long random_point, uint8_t* h_row, uint8_t point[32], uint8_t claim[32]) {
     uint8_t zb[32] = {0};
     for (int i = 0; i < 8; i++) zb[31 - i] = (uint8_t)(random_point >> (8 * i));
     // Horner and the synthetic division in 4 x 64-bit limbs (host_fold64.hpp): the coefficients and the running values stay
@@ -469,26 +467,37 @@ void create_proof(GoUint64 random_point, GoSlice* data_in, GoSlice* commitment_o
     E64 y;
     for (int i = 0; i < 4; i++) y.v[i] = 0;
     for (size_t i = n; i-- > 0;) y = F.add(F.mul(y, zM), f[i]);
-    // synthetic division: h[n-2] = f[n-1]; h[i-1] = f[i] + z*h[i].  Both commitments go out as ONE batch of two rows of n
-    // coefficients (h padded with a zero top coefficient: the same commitment), one launch instead of two.
-    std::vector<uint8_t> two(2 * 32 * n, 0);
-    memcpy(two.data(), d, 32 * n);
-    uint8_t* hb = two.data() + 32 * n;
+    // synthetic division: h[n-2] = f[n-1]; h[i-1] = f[i] + z*h[i]
+    memset(h_row, 0, 32 * n);
     E64 carry;
     for (int i = 0; i < 4; i++) carry.v[i] = 0;
     for (size_t i = n; i-- > 1;) {
         carry = F.add(F.mul(carry, zM), f[i]);
-        to_be(&hb[32 * (i - 1)], carry);
+        to_be(&h_row[32 * (i - 1)], carry);
     }
+    to_be(point, z);
+    to_be(claim, y);
+}
+
+// main.go:153-175: commitment = Commit(f); y = f(z); h = (f - y)/(X - z); H = Commit(h)
+void create_proof(GoUint64 random_point, GoSlice* data_in, GoSlice* commitment_out, GoSlice* proof_H,
+                  GoSlice* proof_point, GoSlice* proof_claim) {
+    const uint8_t* d = (const uint8_t*)data_in->data;
+    size_t n = (size_t)g.n_samples;
+    // Both commitments go out as ONE batch of two rows of n coefficients (h padded with a zero top coefficient: the same
+    // commitment), one launch instead of two.
+    std::vector<uint8_t> two(2 * 32 * n, 0);
+    memcpy(two.data(), d, 32 * n);
+    uint8_t zt[32], yt[32];
+    kzg_open_rows(d, n, random_point, two.data() + 32 * n, zt, yt);
     uint8_t both[128];
     int rc = n ? commit_rows(two.data(), false, 2, n, both, nullptr) : PORLA_OK;
     if (n == 0) memset(both, 0, sizeof both);
     if (rc) die("create_proof", rc);
     copy_out(commitment_out, both, 64);
     copy_out(proof_H, both + 64, 64);
-    uint8_t t[32];
-    to_be(t, z); copy_out(proof_point, t, 32);
-    to_be(t, y); copy_out(proof_claim, t, 32);
+    copy_out(proof_point, zt, 32);
+    copy_out(proof_claim, yt, 32);
 }
 
 // main.go:177-193: kzg.Verify -- e(C - y*G1, G2) == e(H, tau*G2 - z*G2), as one product of two pairings (rearranged, below)
@@ -680,6 +689,147 @@ int porla_kzg_commit_batch_device(const void* d_rows, size_t n_rows, void* d_out
     int rc = ensure_device();
     if (rc) return rc;
     return commit_rows((const uint8_t*)d_rows, true, n_rows, kzg_n_samples(), (uint8_t*)d_out, (hipStream_t)hip_stream);
+}
+// rows resident on the device, results wanted on the host NOW (the audit's align_MAC commitment, Server.hpp:903 -> :550-560, on the
+// scalars porla_audit_combine_device left in HBM): up to 64 rows go through the single-launch kernel on `hip_stream` -- behind
+// whatever produced the rows there -- and the host polls the pinned result; more rows: the batch kernels and one copy back
+int porla_kzg_commit_batch_device_to_host(const void* d_rows, size_t n_rows, uint8_t* out, void* hip_stream) {
+    if (n_rows && (!d_rows || !out)) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n_rows == 0) return PORLA_OK;
+    const size_t len = kzg_n_samples();
+    hipStream_t stream = (hipStream_t)hip_stream;
+    if (FixedBase<Bn254G1>::small_ok(n_rows, len)) {
+        std::unique_lock<std::mutex> lk(g.mu);
+        KzgState::Dev* kd = nullptr;
+        if ((rc = refresh_srs_locked(&kd))) {
+            if (rc == PORLA_ERR_STATE) set_last_error("porla: SRS not initialised (call init_SRS / init_SRS_from_data first)");
+            return rc;
+        }
+        std::unique_lock<std::mutex> lkfb(kd->fb.mu);
+        lk.unlock();
+        uint8_t* op[FB_SMALL_MAX_ROWS];
+        for (size_t r = 0; r < n_rows; r++) op[r] = out + 64 * r;
+        return kd->fb.commit_small(nullptr, n_rows, len, op, stream, (const uint8_t*)d_rows);
+    }
+    void* d_out = nullptr;
+    PORLA_HIP(hipMalloc(&d_out, n_rows * 64));
+    rc = commit_rows((const uint8_t*)d_rows, true, n_rows, len, (uint8_t*)d_out, stream);
+    hipError_t e = rc ? hipSuccess : hipMemcpyAsync(out, d_out, n_rows * 64, hipMemcpyDeviceToHost, stream);
+    hipError_t e2 = hipStreamSynchronize(stream);
+    (void)hipFree(d_out);
+    if (rc) return rc;
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync", __FILE__, __LINE__);
+    if (e2 != hipSuccess) return hip_fail(e2, "hipStreamSynchronize", __FILE__, __LINE__);
+    return PORLA_OK;
+}
+// Server::audit for the KZG build in ONE call (Server.hpp:564-931 after the challenge has been drawn), everything resident in HBM:
+//   the two MSMs over the challenged MACs start first, on the audit slot's own stream (msm_pair_gather_begin);
+//   meanwhile: row combine + alignment scalars (audit.hip) -> B and c land in pinned host memory; y = B(z) and the quotient h on
+//   the host; ONE three-row launch commits c (align_MAC, :903 -> :550-560), B and h (create_proof, :907 -> main.go:153-175);
+//   then the MSM pair is collected.
+namespace {
+struct AuditPinned { int device = -1; uint8_t* h = nullptr; size_t cap = 0; };
+std::mutex g_audit_call_mu;           // one audit at a time per process (the pinned staging and the audit slot are its own)
+std::vector<AuditPinned> g_audit_pinned;
+}  // namespace
+int porla_kzg_audit_device(const void* d_rows64, const uint64_t* d_idx64, const uint32_t* d_coef64, size_t n64, const void* d_rows32,
+                           const uint64_t* d_idx32, const uint32_t* d_coef32, size_t n32, const void* d_mac_store,
+                           const void* d_align_store, const uint64_t* d_mac_idx, const uint32_t* d_mac_coef, size_t n_macs,
+                           unsigned long long random_point, uint8_t combined_mac[64], uint8_t combined_align[64],
+                           uint8_t align_value[64], uint8_t commitment[64], uint8_t proof_h[64], uint8_t proof_point[32],
+                           uint8_t proof_claim[32], uint8_t* b_out, void* hip_stream) {
+    if (!combined_mac || !combined_align || !align_value || !commitment || !proof_h || !proof_point || !proof_claim ||
+        (n_macs && (!d_mac_store || !d_align_store || !d_mac_idx || !d_mac_coef))) {
+        set_last_error("porla: null argument");
+        return PORLA_ERR_ARG;
+    }
+    int rc = ensure_device();
+    if (rc) return rc;
+    const size_t n = kzg_n_samples();
+    if (n == 0) { set_last_error("porla: SRS not initialised (call init_SRS / init_SRS_from_data first)"); return PORLA_ERR_STATE; }
+    std::lock_guard<std::mutex> lk(g_audit_call_mu);
+    // PORLA_AUDIT_TRACE=1: host-side time of each step of the call, printed to stderr
+    static const bool trace = getenv("PORLA_AUDIT_TRACE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[audit] %-28s %7.1f us\n", what, std::chrono::duration<double, std::micro>(now - t_last).count());
+        t_last = now;
+    };
+    int dev = 0;
+    PORLA_HIP(hipGetDevice(&dev));
+    AuditPinned* pin = nullptr;
+    for (auto& p : g_audit_pinned) if (p.device == dev) pin = &p;
+    if (!pin) { g_audit_pinned.push_back(AuditPinned()); pin = &g_audit_pinned.back(); pin->device = dev; }
+    if (pin->cap < 64 * n) {
+        if (pin->h) PORLA_HIP(hipHostFree(pin->h));
+        pin->h = nullptr; pin->cap = 0;
+        PORLA_HIP(hipHostMalloc((void**)&pin->h, 64 * n, hipHostMallocMapped | hipHostMallocCoherent));
+        pin->cap = 64 * n;
+    }
+    void* pin_dev = nullptr;
+    PORLA_HIP(hipHostGetDevicePointer(&pin_dev, pin->h, 0));
+    uint8_t* h_b = pin->h;                  // B mod p_icc, n 32-byte big-endian values
+    uint8_t* h_c = pin->h + 32 * n;         // the alignment scalars
+    hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : engine_stream();
+    const bool pair = n_macs >= 1 && n_macs <= 32768;
+    bool pair_begun = false;
+    auto collect_pair = [&]() -> int {
+        if (!pair_begun) return PORLA_OK;
+        XYZZ<Fp> ta, tb;
+        int r2 = msm_pair_end<Bn254G1>(MSM_AUDIT_SLOT, &ta, &tb);
+        if (r2) return r2;
+        const XYZZ<Fp> both[2] = {ta, tb};
+        Affine<Fp> aff[2];
+        h_batch_xyzz_to_affine64<Fp>(both, 2, aff);          // one inversion for the two sums
+        h_affine_to_bytes<Fp>(combined_mac, aff[0]);
+        h_affine_to_bytes<Fp>(combined_align, aff[1]);
+        return PORLA_OK;
+    };
+    // the combine is enqueued FIRST: its two short kernels take their compute units before the pair's 256 long-lived blocks do (begun
+    // the other way round the combine was seen to wait ~85 us behind them), then the pair starts on the audit slot's own stream
+    rc = porla_audit_combine_device(d_rows64, d_idx64, d_coef64, n64, d_rows32, d_idx32, d_coef32, n32, n, 0, nullptr, nullptr,
+                                    pin_dev, (uint8_t*)pin_dev + 32 * n, stream);
+    lap("combine enqueued");
+    if (rc == PORLA_OK && pair) {
+        Workspace* aw = nullptr;
+        if ((rc = get_workspace_slot(MSM_AUDIT_SLOT, &aw)) == PORLA_OK)
+            rc = msm_pair_gather_begin<Bn254G1>(MSM_AUDIT_SLOT, (const uint8_t*)d_mac_store, (const uint8_t*)d_align_store, d_mac_idx,
+                                                d_mac_coef, n_macs, aw->own_stream);
+        pair_begun = rc == PORLA_OK;
+        lap("pair begun");
+    }
+    if (rc == PORLA_OK && hipStreamSynchronize(stream) != hipSuccess) {
+        set_last_error("porla: hipStreamSynchronize failed in the audit");
+        rc = PORLA_ERR_HIP;
+    }
+    if (rc) { (void)collect_pair(); return rc; }
+    lap("combine + wait");
+    std::vector<uint8_t> three(3 * 32 * n);
+    memcpy(three.data(), h_c, 32 * n);
+    memcpy(three.data() + 32 * n, h_b, 32 * n);
+    kzg_open_rows(h_b, n, random_point, three.data() + 64 * n, proof_point, proof_claim);
+    if (b_out) memcpy(b_out, h_b, 32 * n);
+    uint8_t outs[192];
+    lap("opening on the host");
+    rc = commit_rows(three.data(), false, 3, n, outs, nullptr);
+    lap("three commitments");
+    int rc2 = collect_pair();
+    lap("pair collected");
+    if (rc) return rc;
+    if (rc2) return rc2;
+    if (!pair) {
+        // more challenged rows than the single-launch pair takes (or none): the blocking pair form
+        if ((rc = porla_bn254_audit_msm_pair_device(d_mac_store, d_align_store, d_mac_idx, d_mac_coef, n_macs, combined_mac, combined_align, stream)))
+            return rc;
+    }
+    memcpy(align_value, outs, 64);
+    memcpy(commitment, outs + 64, 64);
+    memcpy(proof_h, outs + 128, 64);
+    return PORLA_OK;
 }
 int porla_kzg_commit_batch_host(const uint8_t* rows, size_t n_rows, uint8_t* out) {
     if (n_rows && (!rows || !out)) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }

@@ -630,8 +630,9 @@ int msm_device_end(int slot, XYZZ<typename C::Fp>* total) {
     int rc = get_workspace_slot(slot, &ws);
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(ws->mu);
-    if (!ws->begun) {
-        set_last_error("porla: no MSM was begun on this slot of the current device (end must run with the device of its begin)");
+    if (!ws->begun || ws->pair_pending) {
+        set_last_error("porla: no MSM was begun on this slot of the current device (end must run with the device of its begin; a pair "
+                       "is collected with *_audit_msm_pair_end)");
         return PORLA_ERR_STATE;
     }
     ws->begun = false;
@@ -854,6 +855,89 @@ int msm_host(const uint8_t* scalars, const uint8_t* points, size_t n, XYZZ<typen
     ws->lone = true;
     if ((rc = msm_host_launch<C>(ws, scalars, points, n))) return rc;
     return msm_finish<C>(ws, total);
+}
+
+// The audit's pair straight from the server's resident MAC arrays (Server.hpp:838-848 / :893-901 collect, per challenged index, the
+// MAC commitment, the alignment MAC and the abs(int32) coefficient into ptc / pta / sc before the two MSMs): the gather runs on the
+// device -- scalar i = coef[i] as a 32-byte big-endian integer, points a_i = store_a[idx[i]], b_i = store_b[idx[i]] -- into the slot's
+// staging buffers, then the pair MSM on the same stream.
+static __global__ void __launch_bounds__(256)
+k_audit_gather(const uint8_t* __restrict__ store_a, const uint8_t* __restrict__ store_b, const uint64_t* __restrict__ idx,
+               const uint32_t* __restrict__ coef, uint32_t n, uint8_t* __restrict__ scalars, uint8_t* __restrict__ pts_a,
+               uint8_t* __restrict__ pts_b) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = t >> 2, q = t & 3u;           // four lanes per pair: 16 bytes of each point
+    if (i >= n) return;
+    const uint64_t src = idx[i];
+    reinterpret_cast<uint4*>(pts_a + 64 * (size_t)i)[q] = reinterpret_cast<const uint4*>(store_a + 64 * src)[q];
+    reinterpret_cast<uint4*>(pts_b + 64 * (size_t)i)[q] = reinterpret_cast<const uint4*>(store_b + 64 * src)[q];
+    if (q < 2) {
+        uint4 z = make_uint4(0, 0, 0, 0);
+        if (q == 1) z.w = __builtin_bswap32(coef[i]);     // bytes 28..31 of the big-endian scalar
+        reinterpret_cast<uint4*>(scalars + 32 * (size_t)i)[q] = z;
+    }
+}
+template <class C>
+int msm_pair_gather_device(const uint8_t* d_store_a, const uint8_t* d_store_b, const uint64_t* d_idx, const uint32_t* d_coef, size_t n,
+                           hipStream_t stream, XYZZ<typename C::Fp>* total_a, XYZZ<typename C::Fp>* total_b) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n == 0) { *total_a = xyzz_inf<typename C::Fp>(); *total_b = *total_a; return PORLA_OK; }
+    if (n >= (1ull << 30)) { set_last_error("porla: too many challenged rows for one call"); return PORLA_ERR_ARG; }
+    Workspace* ws;
+    if ((rc = lease_blocking_slot(&ws))) return rc;
+    std::lock_guard<std::mutex> lk(ws->mu, std::adopt_lock);
+    if ((rc = ws->in_scalars.ensure(n * 32))) return rc;
+    if ((rc = ws->in_points.ensure(n * 128))) return rc;
+    uint8_t* d_pts = (uint8_t*)ws->in_points.p;
+    hipLaunchKernelGGL(k_audit_gather, dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, stream, d_store_a, d_store_b, d_idx, d_coef,
+                       (uint32_t)n, (uint8_t*)ws->in_scalars.p, d_pts, d_pts + n * 64);
+    PORLA_HIP(hipGetLastError());
+    return msm_pair_locked<C>(ws, (const uint8_t*)ws->in_scalars.p, d_pts, d_pts + n * 64, n, stream, total_a, total_b);
+}
+
+// Two-phase form of the same (slots as msm_device_begin): begin gathers and launches on `stream` and returns, end polls both result
+// regions and folds -- the audit's other chain (row combine -> alignment commitment -> proof) runs in between.  Up to SMALL_MAX_N rows.
+template <class C>
+int msm_pair_gather_begin(int slot, const uint8_t* d_store_a, const uint8_t* d_store_b, const uint64_t* d_idx, const uint32_t* d_coef, size_t n,
+                          hipStream_t stream) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n == 0 || n > SMALL_MAX_N || g_small_mode == 0 || g_window_override != 0) {
+        set_last_error("porla: the two-phase audit pair takes 1 .. 32768 challenged rows (single-launch path on)");
+        return PORLA_ERR_ARG;
+    }
+    Workspace* ws;
+    if ((rc = get_workspace_slot(slot, &ws))) return rc;
+    std::lock_guard<std::mutex> lk(ws->mu);
+    if (ws->begun) { set_last_error("porla: MSM slot still has a pending result (call the matching _end first)"); return PORLA_ERR_STATE; }
+    ws->lone = false;
+    if ((rc = ws->in_scalars.ensure(n * 32))) return rc;
+    if ((rc = ws->in_points.ensure(n * 128))) return rc;
+    uint8_t* d_pts = (uint8_t*)ws->in_points.p;
+    hipLaunchKernelGGL(k_audit_gather, dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, stream, d_store_a, d_store_b, d_idx, d_coef,
+                       (uint32_t)n, (uint8_t*)ws->in_scalars.p, d_pts, d_pts + n * 64);
+    PORLA_HIP(hipGetLastError());
+    ws->pend_W = 0;
+    if ((rc = msm_small_pair_launch<C>(ws, (const uint8_t*)ws->in_scalars.p, d_pts, d_pts + n * 64, n, stream))) return rc;
+    ws->begun = true;
+    ws->pair_pending = true;
+    return PORLA_OK;
+}
+template <class C>
+int msm_pair_end(int slot, XYZZ<typename C::Fp>* total_a, XYZZ<typename C::Fp>* total_b) {
+    Workspace* ws;
+    int rc = get_workspace_slot(slot, &ws);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(ws->mu);
+    if (!ws->begun || !ws->pair_pending) {
+        set_last_error("porla: no MSM pair was begun on this slot of the current device");
+        return PORLA_ERR_STATE;
+    }
+    ws->begun = false;
+    ws->pair_pending = false;
+    if ((rc = msm_small_pair_finish<C>(ws, 0, total_a))) return rc;
+    return msm_small_pair_finish<C>(ws, 1, total_b);
 }
 
 // host-pointer form of the pair: one upload of the scalars, both point arrays side by side in the slot's staging buffer

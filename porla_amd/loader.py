@@ -70,6 +70,9 @@ def _declare(L):
         f = getattr(L, "porla_%s_msm_device_partial" % curve); f.argtypes = [vp, vp, sz, u8p, vp]; f.restype = ctypes.c_int
         f = getattr(L, "porla_%s_msm_host" % curve); f.argtypes = [u8p, u8p, sz, u8p]; f.restype = ctypes.c_int
         f = getattr(L, "porla_%s_msm_pair_device" % curve); f.argtypes = [vp, vp, vp, sz, u8p, u8p, vp]; f.restype = ctypes.c_int
+        f = getattr(L, "porla_%s_audit_msm_pair_device" % curve); f.argtypes = [vp, vp, vp, vp, sz, u8p, u8p, vp]; f.restype = ctypes.c_int
+        f = getattr(L, "porla_%s_audit_msm_pair_begin" % curve); f.argtypes = [ctypes.c_int, vp, vp, vp, vp, sz, vp]; f.restype = ctypes.c_int
+        f = getattr(L, "porla_%s_audit_msm_pair_end" % curve); f.argtypes = [ctypes.c_int, u8p, u8p]; f.restype = ctypes.c_int
         f = getattr(L, "porla_%s_msm_pair_host" % curve); f.argtypes = [u8p, u8p, u8p, sz, u8p, u8p]; f.restype = ctypes.c_int
         f = getattr(L, "porla_%s_msm_host_multi" % curve); f.argtypes = [u8p, u8p, sz, ctypes.c_int, ctypes.c_int, u8p]; f.restype = ctypes.c_int
         f = getattr(L, "porla_%s_dist_fold" % curve); f.argtypes = [u8p, u8p]; f.restype = ctypes.c_int
@@ -103,6 +106,9 @@ def _declare(L):
     L.porla_fixed_base_destroy.argtypes = [vp]; L.porla_fixed_base_destroy.restype = None
     L.porla_kzg_commit_batch_device.argtypes = [vp, sz, vp, vp]; L.porla_kzg_commit_batch_device.restype = ctypes.c_int
     L.porla_kzg_commit_batch_host.argtypes = [u8p, sz, u8p]; L.porla_kzg_commit_batch_host.restype = ctypes.c_int
+    L.porla_kzg_commit_batch_device_to_host.argtypes = [vp, sz, u8p, vp]; L.porla_kzg_commit_batch_device_to_host.restype = ctypes.c_int
+    L.porla_kzg_audit_device.argtypes = [vp, vp, vp, sz, vp, vp, vp, sz, vp, vp, vp, vp, sz, ctypes.c_ulonglong] + [u8p] * 8 + [vp]
+    L.porla_kzg_audit_device.restype = ctypes.c_int
     L.porla_kzg_digest_batch_device.argtypes = [vp, sz, vp, vp]; L.porla_kzg_digest_batch_device.restype = ctypes.c_int
     L.porla_kzg_complement_batch_device.argtypes = [vp, sz, vp, vp]; L.porla_kzg_complement_batch_device.restype = ctypes.c_int
     L.porla_bn254_g2_mul_generator.argtypes = [u8p, u8p]; L.porla_bn254_g2_mul_generator.restype = ctypes.c_int

@@ -175,6 +175,25 @@ def msm_pair_device(curve, d_scalars, d_points_a, d_points_b, n, stream=0):
     return oa.raw, ob.raw
 
 
+def audit_msm_pair_device(curve, d_store_a, d_store_b, d_idx, d_coef, n, stream=0):
+    """the audit's two MSMs from resident MAC arrays: (sum coef_i store_a[idx_i], sum coef_i store_b[idx_i]); idx int64, coef abs(int32)"""
+    oa, ob = ctypes.create_string_buffer(64), ctypes.create_string_buffer(64)
+    vp = ctypes.c_void_p
+    _check(getattr(lib, "porla_%s_audit_msm_pair_device" % curve)(vp(d_store_a), vp(d_store_b), vp(d_idx), vp(d_coef), n, oa, ob, vp(stream)))
+    return oa.raw, ob.raw
+
+
+def audit_msm_pair_begin(slot, curve, d_store_a, d_store_b, d_idx, d_coef, n, stream=0):
+    vp = ctypes.c_void_p
+    _check(getattr(lib, "porla_%s_audit_msm_pair_begin" % curve)(slot, vp(d_store_a), vp(d_store_b), vp(d_idx), vp(d_coef), n, vp(stream)))
+
+
+def audit_msm_pair_end(slot, curve):
+    oa, ob = ctypes.create_string_buffer(64), ctypes.create_string_buffer(64)
+    _check(getattr(lib, "porla_%s_audit_msm_pair_end" % curve)(slot, oa, ob))
+    return oa.raw, ob.raw
+
+
 def msm_pair_host(curve, scalars, points_a, points_b, n):
     oa, ob = ctypes.create_string_buffer(64), ctypes.create_string_buffer(64)
     _check(getattr(lib, "porla_%s_msm_pair_host" % curve)(bytes(scalars), bytes(points_a), bytes(points_b), n, oa, ob))
@@ -303,6 +322,24 @@ def shard_range(n, rank, world):
 
 def kzg_commit_batch_device(d_rows, n_rows, d_out, stream=0):
     _check(lib.porla_kzg_commit_batch_device(ctypes.c_void_p(d_rows), n_rows, ctypes.c_void_p(d_out), ctypes.c_void_p(stream)))
+
+
+def kzg_commit_batch_device_to_host(d_rows, n_rows, stream=0):
+    """commitments of rows resident on the device, results on the host (blocking; <= 64 rows: one launch)"""
+    out = ctypes.create_string_buffer(64 * n_rows)
+    _check(lib.porla_kzg_commit_batch_device_to_host(ctypes.c_void_p(d_rows), n_rows, out, ctypes.c_void_p(stream)))
+    return out.raw
+
+
+def kzg_audit_device(d_rows64, d_idx64, d_coef64, n64, d_rows32, d_idx32, d_coef32, n32, d_mac_store, d_align_store, d_mac_idx,
+                     d_mac_coef, n_macs, z, n_cols=128, stream=0):
+    """Server::audit (KZG) in one call -> dict(combined_mac, combined_align, align_value, commitment, proof_h, point, claim, b)"""
+    vp = ctypes.c_void_p
+    o = [ctypes.create_string_buffer(k) for k in (64, 64, 64, 64, 64, 32, 32, 32 * n_cols)]
+    _check(lib.porla_kzg_audit_device(vp(d_rows64 or None), vp(d_idx64 or None), vp(d_coef64 or None), n64, vp(d_rows32 or None),
+                                      vp(d_idx32 or None), vp(d_coef32 or None), n32, vp(d_mac_store), vp(d_align_store), vp(d_mac_idx),
+                                      vp(d_mac_coef), n_macs, z, *o, vp(stream)))
+    return dict(zip(("combined_mac", "combined_align", "align_value", "commitment", "proof_h", "point", "claim", "b"), (x.raw for x in o)))
 
 
 def kzg_digest_batch_device(d_rows, n_rows, d_out, stream=0):

@@ -74,6 +74,14 @@ def test_kzg_audit_is_consistent_end_to_end(n_blocks, write_step, part):
     commitment, proof_h, point, claim = mx.create_proof(z, b_be)
     assert commitment == mx.bn254_add(combined_mac, align_value)
     assert mx.verify_proof(commitment, proof_h, point, claim)
+    # the same audit as ONE call (porla_kzg_audit_device): every output equal to the step-by-step ones
+    d_macs = torch.frombuffer(bytearray(macs_h), dtype=torch.uint8).cuda()
+    d_align = torch.zeros(64 * n_blocks, dtype=torch.uint8, device="cuda")      # a fresh level: alignment MACs at infinity
+    torch.cuda.synchronize()
+    one = mx.kzg_audit_device(d_rows.data_ptr(), d_idx.data_ptr(), d_coef.data_ptr(), n_points, 0, 0, 0, 0, d_macs.data_ptr(),
+                              d_align.data_ptr(), d_idx.data_ptr(), d_coef.data_ptr(), n_points, z)
+    assert one["combined_mac"] == combined_mac and one["combined_align"] == bytes(64) and one["align_value"] == align_value
+    assert (one["commitment"], one["proof_h"], one["point"], one["claim"]) == (commitment, proof_h, point, claim) and one["b"] == b_be
     # a tampered row breaks it
     bad = bytearray(b_be)
     bad[31] ^= 1

@@ -205,3 +205,79 @@ def test_audit_pair_secp256k1_and_large(mx, inputs):
         s, pa = (sc * 5)[:32 * n], (pt * 5)[:64 * n]
         pb = pa[64 * 100:] + pa[:64 * 100]
         assert mx.msm_pair_host("bn254", s, pa, pb, n) == (common.oracle_msm(s, pa, n), common.oracle_msm(s, pb, n))
+
+
+@pytest.mark.parametrize("curve", ["bn254", "secp256k1"])
+def test_audit_pair_from_resident_stores(mx, inputs, curve):
+    """porla_*_audit_msm_pair_device: the gather Server::audit does on the host (ptc / pta / sc from the challenged indices,
+    Server.hpp:838-848, 893-899) on the device, then the pair MSM -- against the oracle on the host-gathered arrays"""
+    import numpy as np
+    import torch
+    store = 512
+    if curve == "bn254":
+        pts = inputs[1][:64 * store]
+        oracle = common.oracle_msm
+    else:
+        pts = common.secp_bench_points(store)
+        oracle = common.oracle_secp_msm
+    a = bytearray(pts)
+    a[64 * 7:64 * 8] = bytes(64)                                  # an infinity entry in store a
+    a = bytes(a)
+    b = pts[64 * 100:] + pts[:64 * 100]
+    d_a = torch.frombuffer(bytearray(a), dtype=torch.uint8).cuda()
+    d_b = torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda()
+    rnd = random.Random(31)
+    for n in (1, 128, 1408, 3200):
+        idx = [rnd.randrange(store) for _ in range(n)]
+        coef = [rnd.getrandbits(31) for _ in range(n)]
+        if n > 2:
+            idx[0], idx[1], coef[0], coef[1] = 7, 7, 0x7fffffff, 0x80000000        # abs(INT_MIN) read back as unsigned
+        d_idx = torch.tensor(idx, dtype=torch.int64).cuda()
+        d_coef = torch.tensor(np.array(coef, dtype=np.uint32).view(np.int32)).cuda()
+        torch.cuda.synchronize()
+        sc = b"".join(c.to_bytes(32, "big") for c in coef)
+        pa = b"".join(a[64 * i:64 * i + 64] for i in idx)
+        pb = b"".join(b[64 * i:64 * i + 64] for i in idx)
+        got = mx.audit_msm_pair_device(curve, d_a.data_ptr(), d_b.data_ptr(), d_idx.data_ptr(), d_coef.data_ptr(), n)
+        assert got == (oracle(sc, pa, n), oracle(sc, pb, n)), (curve, n)
+
+
+def test_audit_pair_two_phase_and_commit_to_host(mx, inputs):
+    """begin / end of the audit pair with other work in between; a begun pair is not collected by the single-MSM end; and
+    porla_kzg_commit_batch_device_to_host == compute_digest_from_srs row by row (1 row: one launch; 100 rows: batch kernels)"""
+    import numpy as np
+    import torch
+    from porla_amd import lib
+    store = 256
+    pts = inputs[1][:64 * store]
+    b = pts[64 * 9:] + pts[:64 * 9]
+    d_a = torch.frombuffer(bytearray(pts), dtype=torch.uint8).cuda()
+    d_b = torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda()
+    rnd = random.Random(41)
+    n = 1408
+    idx = [rnd.randrange(store) for _ in range(n)]
+    coef = [rnd.getrandbits(31) for _ in range(n)]
+    d_idx = torch.tensor(idx, dtype=torch.int64).cuda()
+    d_coef = torch.tensor(np.array(coef, dtype=np.uint32).view(np.int32)).cuda()
+    torch.cuda.synchronize()
+    sc = b"".join(c.to_bytes(32, "big") for c in coef)
+    want = (common.oracle_msm(sc, b"".join(pts[64 * i:64 * i + 64] for i in idx), n),
+            common.oracle_msm(sc, b"".join(b[64 * i:64 * i + 64] for i in idx), n))
+    s2 = torch.cuda.Stream()
+    for _ in range(2):
+        mx.audit_msm_pair_begin(2, "bn254", d_a.data_ptr(), d_b.data_ptr(), d_idx.data_ptr(), d_coef.data_ptr(), n, s2.cuda_stream)
+        assert mx.bn254_multi_exp(pts[:64 * 200], inputs[0][:32 * 200], 200) == common.oracle_msm(inputs[0], pts, 200)   # slot 0 meanwhile
+        out = ctypes.create_string_buffer(64)
+        assert lib.porla_bn254_msm_device_end(2, out, 0) != 0                  # a pair is pending there, not a single MSM
+        assert mx.audit_msm_pair_end(2, "bn254") == want
+    with pytest.raises(RuntimeError):
+        mx.audit_msm_pair_end(2, "bn254")                                      # nothing begun
+    mx.init_key(bytes(range(16)), bytes(range(16, 32)))
+    mx.init_SRS(128)
+    for rows in (1, 3, 100):
+        data = bytes(rnd.getrandbits(8) for _ in range(4096 * rows))
+        d_rows = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+        torch.cuda.synchronize()
+        got = mx.kzg_commit_batch_device_to_host(d_rows.data_ptr(), rows, torch.cuda.current_stream().cuda_stream)
+        for r in (0, rows - 1):
+            assert got[64 * r:64 * r + 64] == mx.compute_digest_from_srs(data[4096 * r:4096 * r + 4096])

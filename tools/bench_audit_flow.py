@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench_audit_flow.py -- ONE KZG audit, server side, as the reference executes it (porla/Server/Server.hpp:564-931),
+every arithmetic step on the engine, the encoded level and its MAC arrays resident in HBM:
+
+  challenge (idx_i, coef_i = abs(int32)), i < n_points                                     Server.hpp:604-732 (PRG; given here)
+  B = sum coef_i * row[idx_i], then align_MAC's scalar part on B      porla_audit_combine_device              :790-828, :531-541
+  combined_MAC = sum coef_i MAC[idx_i], combined_align = sum coef_i MAC_align[idx_i]
+                                                                      porla_bn254_audit_msm_pair_device       :893-901
+  align_value = compute_digest_from_srs(c)                            porla_kzg_commit_batch_device (1 row)   :903 -> :550-560
+  proof = create_proof(z, B)                                          create_proof (the cgo symbol)           :907 -> main.go:153-175
+
+Setup = the protocol's own pipeline on the GPU: 2^15 random blocks -> per-block commitments -> data encode (64-byte code symbols)
+and MAC encode (porla_icc_encode_device / porla_icc_mac_encode_device), so the audit's outputs satisfy what the client checks
+(Client::audit, Client.hpp:849-876, without the client's secret parts): proof.commitment == combined_MAC + align_value and
+verify_proof(proof) == 1 -- checked in the run (a fresh level's alignment MACs are infinity; the TIMED runs use a rotated copy of
+the MAC array as the alignment store so that both MSMs do real work).
+
+Prints ONE JSON line in bench.py's format: value = audits/s through porla_kzg_audit_device (the whole audit behind one C entry: the
+pair of MSMs on its own stream beside combine -> host opening -> ONE three-row commitment launch), one audit at a time;
+`separate_calls_pair_two_phase_ms` = the same from separate calls (pair begun on a second stream, collected after combine ->
+commitment -> create_proof), `separate_calls_each_waited_for_ms` = every call waited for before the next; `steps_ms` = each alone.  cpu_baseline: the oracle's
+pieces of the same audit (oracle/bn254_ref.c MSMs over 16 threads, oracle/icc_py.py combine in Python integers)."""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+TAU = bytes.fromhex("ffeeddccbbaa99887766554433221100")     # TAU_KEY, config.hpp:39
+ALPHA = bytes.fromhex("00112233445566778899aabbccddeeff")   # SECRET_KEY, config.hpp:38
+NCOLS = 128
+HBM_PEAK_GBPS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--log2blocks", type=int, default=15)
+    ap.add_argument("--points", type=int, default=3200, help="challenged rows: NUM_CHECK_AUDIT * height (3 200 at 2^24 blocks, 1 408 at 2^10)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from porla_amd import icc, multiexp as mx
+    from tests import common
+
+    assert torch.cuda.is_available(), "bench_audit_flow.py needs a GPU (the engine has no CPU path)"
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    stream = torch.cuda.current_stream().cuda_stream
+    n, m = 1 << args.log2blocks, args.points
+    mx.init_key(TAU, ALPHA)
+    blob = mx.init_SRS(NCOLS)
+    mx.init_SRS_from_data(NCOLS, blob)
+
+    # ---- the level: blocks -> commitments -> encoded rows (64-byte symbols) + encoded MACs
+    g = torch.Generator(device=dev).manual_seed(77)
+    d_blocks = torch.randint(0, 256, (n * NCOLS, 32), dtype=torch.uint8, device=dev, generator=g)      # 32-byte little-endian chunks
+    d_coeffs_be = d_blocks.flip(1).contiguous()                                                         # the same as big-endian scalars
+    d_macs_u = torch.empty(64 * n, dtype=torch.uint8, device=dev)
+    mx.kzg_commit_batch_device(d_coeffs_be.data_ptr(), n, d_macs_u.data_ptr(), stream)
+    d_x = torch.empty(64 * n * NCOLS, dtype=torch.uint8, device=dev)
+    icc.crebuild_device(d_blocks.data_ptr(), n, NCOLS, "bn254", 0, 0, d_x.data_ptr(), 0, 0, stream=stream)
+    d_macs = torch.empty(64 * n, dtype=torch.uint8, device=dev)
+    icc.mac_crebuild_device(d_macs_u.data_ptr(), n, "bn254", 0, 0, d_macs.data_ptr(), stream)
+    torch.cuda.synchronize()
+    del d_coeffs_be, d_blocks
+    d_align_inf = torch.zeros(64 * n, dtype=torch.uint8, device=dev)                  # a fresh level: every alignment MAC is infinity
+    d_align_busy = torch.roll(d_macs.view(n, 64), 1, 0).contiguous().view(-1)         # timing: valid points, so the second MSM works
+
+    rng = np.random.Generator(np.random.PCG64(9))
+    idx = rng.integers(0, n, m, dtype=np.int64)
+    coef = rng.integers(0, 1 << 31, m, dtype=np.int64).astype(np.uint32)
+    d_idx = torch.from_numpy(idx).cuda()
+    d_coef = torch.from_numpy(coef.view(np.int32)).cuda()
+    # B lands in PINNED host memory straight from the combine's finish kernel (the address is valid on the device): by the time the
+    # commitment that follows it on the stream has been polled in, the proof's input is already on the host -- no copy, no extra wait
+    h_b_be = torch.empty(32 * NCOLS, dtype=torch.uint8).pin_memory()
+    d_c = torch.empty(32 * NCOLS, dtype=torch.uint8, device=dev)
+    z = 0x0123456789abcdef
+    side = torch.cuda.Stream(device=dev)
+
+    def data_side():
+        icc.audit_combine_device(d_x.data_ptr(), d_idx.data_ptr(), d_coef.data_ptr(), m, 0, 0, 0, 0, NCOLS, "bn254",
+                                 d_aligned_be=h_b_be.data_ptr(), d_scalars=d_c.data_ptr(), stream=stream)
+        align_value = mx.kzg_commit_batch_device_to_host(d_c.data_ptr(), 1, stream)     # one launch behind the combine; polled
+        return align_value, mx.create_proof(z, h_b_be.numpy().tobytes())
+
+    def mac_side(d_align, s):
+        return mx.audit_msm_pair_device("bn254", d_macs.data_ptr(), d_align.data_ptr(), d_idx.data_ptr(), d_coef.data_ptr(), m, s)
+
+    def audit(d_align):
+        """every call waited for before the next"""
+        combined_mac, combined_align = mac_side(d_align, stream)
+        align_value, proof = data_side()
+        return combined_mac, combined_align, align_value, proof
+
+    def audit_overlapped(d_align):
+        """the pair of MSMs begun on a second stream, collected after the data chain (one host thread)"""
+        mx.audit_msm_pair_begin(1, "bn254", d_macs.data_ptr(), d_align.data_ptr(), d_idx.data_ptr(), d_coef.data_ptr(), m, side.cuda_stream)
+        align_value, proof = data_side()
+        combined_mac, combined_align = mx.audit_msm_pair_end(1, "bn254")
+        return combined_mac, combined_align, align_value, proof
+
+    def audit_one_call(d_align):
+        """porla_kzg_audit_device: the whole audit behind one C entry point"""
+        o = mx.kzg_audit_device(d_x.data_ptr(), d_idx.data_ptr(), d_coef.data_ptr(), m, 0, 0, 0, 0, d_macs.data_ptr(), d_align.data_ptr(),
+                                d_idx.data_ptr(), d_coef.data_ptr(), m, z, stream=stream)
+        return o["combined_mac"], o["combined_align"], o["align_value"], (o["commitment"], o["proof_h"], o["point"], o["claim"])
+
+    # ---- what the client checks, on the consistent level
+    cm, ca, av, (commitment, proof_h, point, claim) = audit(d_align_inf)
+    consistent = (ca == bytes(64) and commitment == mx.bn254_add(cm, av) and bool(mx.verify_proof(commitment, proof_h, point, claim)))
+    cm2, ca2, av2, pr2 = audit_overlapped(d_align_inf)
+    consistent = consistent and (cm2, ca2, av2, pr2[0]) == (cm, ca, av, commitment)
+    consistent = consistent and audit_one_call(d_align_inf) == (cm, ca, av, (commitment, proof_h, point, claim))
+    # ... and the pair of MSMs against the oracle on the host-gathered arrays
+    macs_h = bytes(d_macs.cpu().numpy())
+    busy_h = bytes(d_align_busy.cpu().numpy())
+    sc = b"".join(int(c).to_bytes(32, "big") for c in coef)
+    pa = b"".join(macs_h[64 * int(i):64 * int(i) + 64] for i in idx)
+    pb = b"".join(busy_h[64 * int(i):64 * int(i) + 64] for i in idx)
+    t0 = time.perf_counter()
+    want = (common.oracle_msm(sc, pa, m), common.oracle_msm(sc, pb, m))
+    cpu_msm_s = time.perf_counter() - t0
+    got = mac_side(d_align_busy, stream)
+    verified = consistent and got == want and cm == want[0]
+
+    def region(fn):
+        for _ in range(args.warmup):
+            fn(d_align_busy)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fn(d_align_busy)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / args.steps * 1e3
+
+    ms_seq = region(audit)
+    ms_ovl = region(audit_overlapped)
+    ms_one = region(audit_one_call)
+
+    def alone(fn, reps=100):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return round((time.perf_counter() - t0) / reps * 1e3, 4)
+
+    b_host = h_b_be.numpy().tobytes()
+    steps_ms = {
+        "audit_combine (row combine + alignment scalars)": alone(lambda: icc.audit_combine_device(
+            d_x.data_ptr(), d_idx.data_ptr(), d_coef.data_ptr(), m, 0, 0, 0, 0, NCOLS, "bn254", d_aligned_be=h_b_be.data_ptr(),
+            d_scalars=d_c.data_ptr(), stream=stream)),
+        "audit_msm_pair (gather + both MSMs, one launch)": alone(lambda: mac_side(d_align_busy, stream)),
+        "align commitment (1 row on the device -> host)": alone(lambda: mx.kzg_commit_batch_device_to_host(d_c.data_ptr(), 1, stream)),
+        "create_proof (cgo symbol, host B)": alone(lambda: mx.create_proof(z, b_host)),
+    }
+    mx.profile_enable(True)
+    for _ in range(5):
+        audit(d_align_busy)
+    torch.cuda.synchronize()
+    kern = {k: round(ms / 5, 4) for k, ms, cnt in mx.profile_get()}
+    mx.profile_enable(False)
+
+    cpu = None
+    if not args.no_cpu:
+        import icc_py
+        rows_h = d_x.view(n, NCOLS, 64)[torch.from_numpy(idx[:256]).cuda()].cpu().numpy()
+        rows_int = [[int.from_bytes(bytes(r[j].tolist()), "little") for j in range(NCOLS)] for r in rows_h]
+        t0 = time.perf_counter()
+        icc_py.audit_combine(rows_int, [int(c) for c in coef[:256]], "bn254")
+        cpu_comb_s = (time.perf_counter() - t0) * m / 256
+        cpu = {"value": round(1.0 / (cpu_msm_s + cpu_comb_s), 2), "unit": "audits/s", "cores": common.ncpu(), "kind": "port",
+               "sample": "one audit's two %d-point MSMs through oracle/bn254_ref.c (%d threads, %.1f ms) + its row combine through "
+                         "oracle/icc_py.py (Python integers, 1 thread, 256 of the rows scaled: %.0f ms); the commitment and the proof "
+                         "are not included; restatements, not gnark / NTL" % (m, common.ncpu(), cpu_msm_s * 1e3, cpu_comb_s * 1e3)}
+    alg = 8192 * m + 2 * (64 + 4) * m + 8 * m
+    k_ms = kern.get("audit_accumulate", 0.0)
+    out = {
+        "metric": "KZG audits/s, server side (%d challenged rows of a 2^%d-block level, device-resident)" % (m, args.log2blocks),
+        "value": round(1e3 / ms_one, 1), "unit": "audits/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_one, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32 limbs: exact 608-bit row sums, 256-bit modular integers (BN254 Fp / Fr)", "data": "synthetic",
+        "config": {"workload": "Server::audit (KZG), Server.hpp:564-931: row combine + alignment scalars, the two MSMs over the challenged "
+                               "MACs, align_MAC's commitment, create_proof; level store and MAC arrays resident in HBM",
+                   "blocks": n, "challenged_rows": m, "columns": NCOLS},
+        "separate_calls_pair_two_phase_ms": round(ms_ovl, 4), "separate_calls_each_waited_for_ms": round(ms_seq, 4),
+        "steps_ms": steps_ms, "kernels_ms_per_audit": kern,
+        "roofline": {"bound": "hbm", "kernel": "k_audit_accumulate", "achieved": round(8192 * m / k_ms / 1e6, 1) if k_ms else None,
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(8192 * m / k_ms / 1e6 / HBM_PEAK_GBPS, 4) if k_ms else None,
+                     "traffic": None, "algorithmic_bytes_per_audit": alg,
+                     "note": "an audit at the reference's size is a chain of short launches: every step is latency (a 26 MB gather, two "
+                             "chains of ~15 dependent additions, 128-point commitments), none is bound by bandwidth or issue; the HBM-bound "
+                             "regime of the row combine is the audit_combine leg"},
+        "cpu_baseline": cpu, "bit_exact_vs_oracle": bool(verified),
+        "client_checks": "proof.commitment == combined_MAC + align_value and verify_proof == 1 on the consistent level: %s" % consistent,
+    }
+    print(json.dumps(out))
+    if not verified:
+        print("ERROR: the audit's outputs are not what the client / the oracle expect", file=sys.stderr)
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()
