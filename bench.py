@@ -66,7 +66,7 @@ KERNEL_SYMBOL = {  # profile slot -> substring of the kernel symbol in the rocpr
     "bucket_sum": "k_bucket_sum30", "tree_levels": "k_tree_level", "tree_tail": "k_tree_tail", "partition_sort": "k_partition_sort",
     "fb_commit": "k_fb_commit", "digits_partition": "k_digits_partition", "points_to_mont": "k_points_to_mont",
     "icc_fused": "k_icc_split30", "icc_stages_r4": "k_icc_stages", "icc_stages_r2": "k_icc_stages", "icc_load": "k_icc_load", "icc_finish": "k_icc_finish",
-    "audit_accumulate": "k_audit_accumulate",
+    "audit_accumulate": "k_audit_accumulate<8>",     # the large-challenge instantiation (8 row slices per block)
 }
 
 
@@ -734,14 +734,8 @@ def main():
         res, cpu = ba.measure(20, [3200, 1 << 18], mixed=False, reps_small=100)
         small, big = res
         rl = dict(big["roofline"])
-        # the committed PMC passes ran this very leg: its launches of the kernel are 1 parity call + per size 5 warm-up + 100 or 20
-        # timed + 10 profiled calls -- 116 launches of 3 200 (+ 1 of 1 024) rows and 35 of 2^18 rows; the counters' per-launch average
-        # is scaled to the 2^18-row launch by the algorithmic bytes of that mix
-        avg = pmc_traffic("audit_accumulate", "audit_combine")
-        if avg:
-            mix = (1 * 1024 + 115 * 3200 + 35 * (1 << 18)) / 151.0
-            rl["traffic"] = int(avg * (1 << 18) / mix)
-            rl["traffic_note"] = "profiles/pmc_latest_audit_combine.json: average over the leg's 151 launches, scaled to a 2^18-row launch"
+        # the committed PMC passes ran this very leg; the 2^18-row launches are the only ones of the 8-slice instantiation
+        rl["traffic"] = pmc_traffic("audit_accumulate", "audit_combine")
         rl["note"] = ("algorithmic bytes = 8 192 per challenged row (+ indices, coefficients, 64 B per column out) / the accumulation "
                       "kernel's HIP-event time; random 8-KiB rows of an 8 GiB store")
         return {"metric": "audit row combine GB/s (2^18 challenged rows x 128 symbols of 64 B)", "value": rl["achieved"], "unit": "GB/s",

@@ -141,7 +141,7 @@ static int msm_small_launch(Workspace* ws, const uint8_t* d_scalars, const uint8
 constexpr uint32_t SMALL_PAIR_STRIDE = 64 * 1024;
 template <class C>
 static int msm_small_pair_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_points_a, const uint8_t* d_points_b, size_t n,
-                                 hipStream_t stream) {
+                                 hipStream_t stream, int bits_hint = 0) {
     using M = typename C::Fp;
     int rc;
     if (ws->h_windows_cap < 2 * SMALL_PAIR_STRIDE) {
@@ -164,8 +164,8 @@ static int msm_small_pair_launch(Workspace* ws, const uint8_t* d_scalars, const 
     {
         ProfScope ps("small_msm", stream, true);
         hipLaunchKernelGGL((k_small_msm<C>), dim3(SMALL_BLOCKS / 2, 2), dim3(SMALL_THREADS), 0, stream, d_scalars, d_points_a, (uint32_t)n,
-                           g_small_c | (g_use_glv == 0 ? 0x100 : 0), (XYZZ<M>*)ws->small_part.p, counters, (uint32_t*)h_dev,
-                           (XYZZ<M>*)((uint8_t*)h_dev + SMALL_HDR_WORDS * 4), ws->small_seq, d_points_b, SMALL_PAIR_STRIDE);
+                           g_small_c | (g_use_glv == 0 ? 0x100 : 0) | (bits_hint << 16), (XYZZ<M>*)ws->small_part.p, counters,
+                           (uint32_t*)h_dev, (XYZZ<M>*)((uint8_t*)h_dev + SMALL_HDR_WORDS * 4), ws->small_seq, d_points_b, SMALL_PAIR_STRIDE);
     }
     PORLA_HIP(hipGetLastError());
     if (!ws->done) PORLA_HIP(hipEventCreateWithFlags(&ws->done, hipEventDisableTiming));
@@ -585,12 +585,12 @@ int msm_device(const uint8_t* d_scalars, const uint8_t* d_points, size_t n, hipS
 // two-phase form on two streams).
 template <class C>
 static int msm_pair_locked(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_points_a, const uint8_t* d_points_b, size_t n,
-                           hipStream_t stream, XYZZ<typename C::Fp>* total_a, XYZZ<typename C::Fp>* total_b) {
+                           hipStream_t stream, XYZZ<typename C::Fp>* total_a, XYZZ<typename C::Fp>* total_b, int bits_hint = 0) {
     int rc;
     ws->lone = true;
     if (n <= SMALL_MAX_N && g_small_mode != 0 && g_window_override == 0) {
         ws->pend_W = 0;
-        if ((rc = msm_small_pair_launch<C>(ws, d_scalars, d_points_a, d_points_b, n, stream))) return rc;
+        if ((rc = msm_small_pair_launch<C>(ws, d_scalars, d_points_a, d_points_b, n, stream, bits_hint))) return rc;
         if ((rc = msm_small_pair_finish<C>(ws, 0, total_a))) return rc;
         return msm_small_pair_finish<C>(ws, 1, total_b);
     }
@@ -893,7 +893,7 @@ int msm_pair_gather_device(const uint8_t* d_store_a, const uint8_t* d_store_b, c
     hipLaunchKernelGGL(k_audit_gather, dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, stream, d_store_a, d_store_b, d_idx, d_coef,
                        (uint32_t)n, (uint8_t*)ws->in_scalars.p, d_pts, d_pts + n * 64);
     PORLA_HIP(hipGetLastError());
-    return msm_pair_locked<C>(ws, (const uint8_t*)ws->in_scalars.p, d_pts, d_pts + n * 64, n, stream, total_a, total_b);
+    return msm_pair_locked<C>(ws, (const uint8_t*)ws->in_scalars.p, d_pts, d_pts + n * 64, n, stream, total_a, total_b, 32);
 }
 
 // Two-phase form of the same (slots as msm_device_begin): begin gathers and launches on `stream` and returns, end polls both result
@@ -919,7 +919,7 @@ int msm_pair_gather_begin(int slot, const uint8_t* d_store_a, const uint8_t* d_s
                        (uint32_t)n, (uint8_t*)ws->in_scalars.p, d_pts, d_pts + n * 64);
     PORLA_HIP(hipGetLastError());
     ws->pend_W = 0;
-    if ((rc = msm_small_pair_launch<C>(ws, (const uint8_t*)ws->in_scalars.p, d_pts, d_pts + n * 64, n, stream))) return rc;
+    if ((rc = msm_small_pair_launch<C>(ws, (const uint8_t*)ws->in_scalars.p, d_pts, d_pts + n * 64, n, stream, 32))) return rc;
     ws->begun = true;
     ws->pair_pending = true;
     return PORLA_OK;
