@@ -63,3 +63,9 @@ def test_edge_values_and_ragged_columns():
     run("bn254", 40, 9, 128, seed=1, edge=True)
     run("secp256k1", 40, 9, 5, seed=2, edge=True)       # fewer columns than a wave
     run("bn254", 300, 0, 200, seed=3)                    # more than 128 columns: second column block
+
+
+def test_large_challenge_takes_the_eight_slice_kernel():
+    """more than 16 384 challenged rows: k_audit_accumulate<8> (the bandwidth-regime instantiation), both row formats, ragged split"""
+    run("bn254", 12001, 6007, 128, seed=99, edge=True)
+    run("secp256k1", 17000, 0, 128, seed=100)
