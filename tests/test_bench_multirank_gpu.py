@@ -66,3 +66,10 @@ def test_single_rank_bench_line_prices_the_kernel_it_timed():
     for group in d["audit_size_msm"].values():
         if isinstance(group, dict):
             assert all(v["bit_exact_vs_oracle"] for v in group.values())
+            assert all(v["pair_bit_exact_vs_oracle"] for v in group.values())     # the audit's pair of MSMs in one launch
+    # the audit side: the HBM-bound row combine and one whole audit behind porla_kzg_audit_device
+    ac = d["audit_combine"]
+    assert ac["bit_exact_vs_oracle"] is True and ac["roofline"]["bound"] == "hbm" and 0.3 < ac["roofline"]["frac"] <= 1.0
+    assert abs(ac["roofline"]["achieved"] - ac["roofline"]["algorithmic_bytes"] / ac["kernels_ms"]["audit_accumulate"] / 1e6) < 0.02 * ac["roofline"]["achieved"]
+    ka = d["kzg_audit"]
+    assert ka["bit_exact_vs_oracle"] is True and ka["unit"] == "audits/s" and ka["value"] > 100 and "True" in ka["client_checks"]
