@@ -199,7 +199,7 @@ struct FixedBase {
 
 extern std::mutex g_ws_mu;   // the workspace registry (lookup / creation / release); a slot's use is under Workspace::mu
 extern int g_window_override;
-extern int g_small_mode;      // single-launch path for n <= 4096: 1 on (default), 0 off
+extern int g_small_mode;      // single-launch path for n <= SMALL_MAX_N (32 768): 1 on (default), 0 off
 extern int g_small_c;         // its window bits, 0 = automatic
 extern int g_last_multi[2];   // ranges, devices of the most recent msm_host_multi (diagnostic)
 extern int g_last_shape[3];   // window bits, window count, GLV flag of the most recently launched MSM (diagnostic)
