@@ -87,3 +87,69 @@ def test_kzg_audit_is_consistent_end_to_end(n_blocks, write_step, part):
     bad[31] ^= 1
     c2, h2, p2, y2 = mx.create_proof(z, bytes(bad))
     assert c2 != mx.bn254_add(combined_mac, align_value)
+
+
+def test_one_call_audit_edges_and_two_threads():
+    """porla_kzg_audit_device: an empty challenge (B = 0: every commitment is infinity, the claim 0), a challenge without MACs, and
+    two threads calling at once (the call serialises itself: both get the single-threaded answer); the two-phase pair's error paths"""
+    import threading
+    import numpy as np
+    import torch
+    from porla_amd import icc, lib, multiexp as mx
+    ncols, n_rows, n_points = 128, 64, 40
+    mx.init_key(TAU, ALPHA)
+    mx.init_SRS_from_data(ncols, mx.init_SRS(ncols))
+    rnd = random.Random(77)
+    lcm = R * (207 * 2 ** 248 + 1)
+    store = b"".join(rnd.randrange(lcm).to_bytes(64, "little") for _ in range(n_rows * ncols))
+    macs = common.synth_points(n_rows, start=500)
+    d_rows = torch.frombuffer(bytearray(store), dtype=torch.uint8).cuda()
+    d_macs = torch.frombuffer(bytearray(macs), dtype=torch.uint8).cuda()
+    d_align = torch.frombuffer(bytearray(macs[64:] + macs[:64]), dtype=torch.uint8).cuda()
+    idx = [rnd.randrange(n_rows) for _ in range(n_points)]
+    coef = [rnd.getrandbits(31) for _ in range(n_points)]
+    d_idx = torch.tensor(idx, dtype=torch.int64).cuda()
+    d_coef = torch.tensor(np.array(coef, dtype=np.uint32).view(np.int32)).cuda()
+    torch.cuda.synchronize()
+    z = 99
+    # empty challenge
+    e = mx.kzg_audit_device(0, 0, 0, 0, 0, 0, 0, 0, d_macs.data_ptr(), d_align.data_ptr(), d_idx.data_ptr(), d_coef.data_ptr(), 0, z)
+    assert e["combined_mac"] == e["combined_align"] == e["align_value"] == e["commitment"] == e["proof_h"] == bytes(64)
+    assert e["claim"] == bytes(32) and e["b"] == bytes(32 * ncols) and int.from_bytes(e["point"], "big") == z
+    # the reference result of a real challenge, from the separate entry points
+    d_b = torch.empty(32 * ncols, dtype=torch.uint8, device="cuda")
+    d_c = torch.empty(32 * ncols, dtype=torch.uint8, device="cuda")
+    icc.audit_combine_device(d_rows.data_ptr(), d_idx.data_ptr(), d_coef.data_ptr(), n_points, 0, 0, 0, 0, ncols, "bn254",
+                             d_aligned_be=d_b.data_ptr(), d_scalars=d_c.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    b_be, c_be = bytes(d_b.cpu().numpy()), bytes(d_c.cpu().numpy())
+    sc = b"".join(c.to_bytes(32, "big") for c in coef)
+    want = dict(combined_mac=common.oracle_msm(sc, b"".join(macs[64 * i:64 * i + 64] for i in idx), n_points),
+                align_value=mx.compute_digest_from_srs(c_be), b=b_be)
+    want["commitment"], want["proof_h"], want["point"], want["claim"] = mx.create_proof(z, b_be)
+    args = (d_rows.data_ptr(), d_idx.data_ptr(), d_coef.data_ptr(), n_points, 0, 0, 0, 0, d_macs.data_ptr(), d_align.data_ptr(),
+            d_idx.data_ptr(), d_coef.data_ptr(), n_points, z)
+    got = [None, None]
+
+    def worker(k):
+        for _ in range(20):
+            got[k] = mx.kzg_audit_device(*args)
+    ts = [threading.Thread(target=worker, args=(k,)) for k in (0, 1)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for g in got:
+        assert all(g[k] == v for k, v in want.items())
+    # no MACs asked for: both sums are infinity, the rest unchanged
+    nm = mx.kzg_audit_device(*args[:12], 0, z)
+    assert nm["combined_mac"] == nm["combined_align"] == bytes(64) and nm["commitment"] == want["commitment"]
+    # two-phase pair: argument and state errors
+    vp = ctypes.c_void_p
+    beg = lib.porla_bn254_audit_msm_pair_begin
+    a = (vp(d_macs.data_ptr()), vp(d_align.data_ptr()), vp(d_idx.data_ptr()), vp(d_coef.data_ptr()))
+    assert beg(0, *a, n_points, None) != 0 and beg(4, *a, n_points, None) != 0        # slots 1..3 only
+    assert beg(1, *a, 0, None) != 0                                                    # nothing to do is an error here
+    assert beg(1, *a, n_points, None) == 0
+    assert beg(1, *a, n_points, None) != 0                                             # already begun
+    assert mx.audit_msm_pair_end(1, "bn254")[0] == want["combined_mac"]
