@@ -318,6 +318,10 @@ static int peak_line() {
     (void)hipMemcpy(buf, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     // 4 waves per SIMD is what the accumulation kernels run at (103 .. 128 registers); 8 is the most the chip holds: the rate at
     // 8 is the multiplier's own ceiling, the rate at 4 what a kernel of that register footprint can reach
+    // warm-up: ~0.1 s of the same work first -- measured cold, the first configuration came out 13 % low (159 instead of 183 G/s at
+    // 4 waves per SIMD) while the clocks were still rising
+    for (int r = 0; r < 40; r++) hipLaunchKernelGGL((k_bench<Bn254Fp, 0>), dim3(CUS * 8), dim3(256), 0, 0, buf, it);
+    (void)hipDeviceSynchronize();
     printf("{\"compute_units\": %d", CUS);
     for (int w = 4; w <= 8; w *= 2) {
         const int blocks = CUS * w;
@@ -334,8 +338,31 @@ static int peak_line() {
     return 0;
 }
 
+// --occupancy: the 8M + 2S product mix of a mixed addition (G products per second, whole chip) by waves per SIMD, 1 .. 8 -- what one
+// more resident wave would buy a kernel that is bound by the multiplier
+static int occupancy_lines() {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return 1;
+    const int CUS = prop.multiProcessorCount, it = 512;
+    uint32_t* buf;
+    if (hipMalloc(&buf, (size_t)CUS * 8 * 256 * 9 * 4) != hipSuccess) return 1;
+    std::vector<uint32_t> h((size_t)CUS * 8 * 256 * 9);
+    for (size_t i = 0; i < h.size(); i++) h[i] = (uint32_t)(i * 2654435761u + 12345);
+    (void)hipMemcpy(buf, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    for (int w = 1; w <= 8; w++) {
+        const int blocks = CUS * w;
+        auto rate = [&](double ms) { return (double)blocks * 256 * it * 2 / ms / 1e6; };
+        const double bm = rate(time_ms([&] { hipLaunchKernelGGL((k_bench<Bn254Fp, 0>), dim3(blocks), dim3(256), 0, 0, buf, it); }, 5));
+        const double bs = rate(time_ms([&] { hipLaunchKernelGGL((k_bench<Bn254Fp, 1>), dim3(blocks), dim3(256), 0, 0, buf, it); }, 5));
+        printf("waves/SIMD=%d  f30_mul<Bn254Fp> %.1f G/s  f30_sqr %.1f G/s  8M+2S mix %.1f G/s\n", w, bm, bs, 10.0 / (8.0 / bm + 2.0 / bs));
+    }
+    (void)hipFree(buf);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc > 1 && !strcmp(argv[1], "--peak")) return peak_line();
+    if (argc > 1 && !strcmp(argv[1], "--occupancy")) return occupancy_lines();
     int bad = 0;
     bad += check_inv<Bn254Fp>("bn254_p");
     bad += check_inv<Secp256k1Fp>("secp256k1_p");
