@@ -190,6 +190,17 @@ int  porla_fixed_base_commit_device(porla_fixed_base *fb, const void *d_rows, si
                                     size_t row_stride, void *d_out, void *hip_stream);
 int  porla_fixed_base_commit_host(porla_fixed_base *fb, const uint8_t *rows, size_t n_rows, size_t n_coeffs,
                                   size_t row_stride, uint8_t *out);
+/* Server::audit for the IPA build up to the inner-product proof, in ONE call (porla/Server/Server.hpp:790-857): row combine and
+ * alignment scalars, the two secp256k1 MSMs over the challenged MACs (arguments as porla_secp256k1_audit_msm_pair_device), and the
+ * two Pedersen commitments over the fixed generators -- compute_commitment(c) of align_MAC (:495-529) and compute_commitment(B)
+ * (:856) -- as one two-row launch.  generators_fb = porla_fixed_base_create(1, generators, n_cols, ...).  b_out (may be NULL): B mod
+ * p_icc as n_cols 32-byte big-endian values, the input of inner_product_prove.  Outputs on the host; blocking. */
+int porla_ipa_audit_device(porla_fixed_base *generators_fb, const void *d_rows64, const uint64_t *d_idx64,
+                           const uint32_t *d_coef64, size_t n64, const void *d_rows32, const uint64_t *d_idx32,
+                           const uint32_t *d_coef32, size_t n32, size_t n_cols, const void *d_mac_store,
+                           const void *d_align_store, const uint64_t *d_mac_idx, const uint32_t *d_mac_coef, size_t n_macs,
+                           uint8_t combined_mac[64], uint8_t combined_align[64], uint8_t align_value[64],
+                           uint8_t commitment[64], uint8_t *b_out, void *hip_stream);
 void porla_fixed_base_destroy(porla_fixed_base *fb);
 /* KZG: rows of n_samples coefficients (4096 bytes per row for NUM_CHUNKS = 128) against the resident SRS */
 int  porla_kzg_commit_batch_device(const void *d_rows, size_t n_rows, void *d_out, void *hip_stream);

@@ -535,6 +535,87 @@ int porla_fixed_base_commit_host(porla_fixed_base* fb, const uint8_t* rows, size
     std::lock_guard<std::mutex> lk(fb->secp.mu);
     return fb->secp.commit_host(rows, n_rows, n_coeffs, row_stride, out, s);
 }
+// Server::audit for the IPA build up to the inner-product proof (porla/Server/Server.hpp:790-857): the row combine and alignment
+// scalars, the two secp256k1 MSMs over the challenged MACs (on the audit slot's own stream), and the two Pedersen commitments over
+// the fixed generators -- compute_commitment(c) inside align_MAC (:495-529) and compute_commitment(B) (:856) -- as ONE two-row
+// launch.  generators_fb: porla_fixed_base_create(1, generators, n_cols, ...).  B (n_cols 32-byte big-endian values mod p_icc) goes
+// back to the caller for inner_product_prove (its L / R points: INTEGRATION.md s3c).
+static std::mutex g_ipa_audit_mu;
+static uint8_t* g_ipa_pin = nullptr;
+static size_t g_ipa_pin_cap = 0;
+static int g_ipa_pin_dev = -1;
+int porla_ipa_audit_device(porla_fixed_base* generators_fb, const void* d_rows64, const uint64_t* d_idx64, const uint32_t* d_coef64,
+                           size_t n64, const void* d_rows32, const uint64_t* d_idx32, const uint32_t* d_coef32, size_t n32, size_t n_cols,
+                           const void* d_mac_store, const void* d_align_store, const uint64_t* d_mac_idx, const uint32_t* d_mac_coef,
+                           size_t n_macs, uint8_t combined_mac[64], uint8_t combined_align[64], uint8_t align_value[64],
+                           uint8_t commitment[64], uint8_t* b_out, void* hip_stream) {
+    if (!generators_fb || generators_fb->curve != 1 || !combined_mac || !combined_align || !align_value || !commitment || n_cols == 0 ||
+        (n_macs && (!d_mac_store || !d_align_store || !d_mac_idx || !d_mac_coef))) {
+        set_last_error("porla: bad argument to porla_ipa_audit_device (generators_fb must be a secp256k1 fixed base)");
+        return PORLA_ERR_ARG;
+    }
+    int rc = ensure_device();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_ipa_audit_mu);
+    int dev = 0;
+    PORLA_HIP(hipGetDevice(&dev));
+    if (g_ipa_pin_cap < 64 * n_cols || g_ipa_pin_dev != dev) {
+        if (g_ipa_pin) PORLA_HIP(hipHostFree(g_ipa_pin));
+        g_ipa_pin = nullptr; g_ipa_pin_cap = 0;
+        PORLA_HIP(hipHostMalloc((void**)&g_ipa_pin, 64 * n_cols, hipHostMallocMapped | hipHostMallocCoherent));
+        g_ipa_pin_cap = 64 * n_cols;
+        g_ipa_pin_dev = dev;
+    }
+    void* pin_dev = nullptr;
+    PORLA_HIP(hipHostGetDevicePointer(&pin_dev, g_ipa_pin, 0));
+    hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : engine_stream();
+    // the combine first (its short kernels take their compute units before the pair's long-lived blocks), then the pair
+    rc = porla_audit_combine_device(d_rows64, d_idx64, d_coef64, n64, d_rows32, d_idx32, d_coef32, n32, n_cols, 1, nullptr, nullptr,
+                                    pin_dev, (uint8_t*)pin_dev + 32 * n_cols, stream);
+    const bool pair = n_macs >= 1 && n_macs <= 32768;
+    bool pair_begun = false;
+    if (rc == PORLA_OK && pair) {
+        Workspace* aw = nullptr;
+        if ((rc = get_workspace_slot(MSM_AUDIT_SLOT, &aw)) == PORLA_OK)
+            rc = msm_pair_gather_begin<Secp256k1G>(MSM_AUDIT_SLOT, (const uint8_t*)d_mac_store, (const uint8_t*)d_align_store, d_mac_idx,
+                                                   d_mac_coef, n_macs, aw->own_stream);
+        pair_begun = rc == PORLA_OK;
+    }
+    auto collect_pair = [&]() -> int {
+        if (!pair_begun) return PORLA_OK;
+        XYZZ<Secp256k1Fp> ta, tb;
+        int r2 = msm_pair_end<Secp256k1G>(MSM_AUDIT_SLOT, &ta, &tb);
+        if (r2) return r2;
+        h_affine_to_bytes<Secp256k1Fp>(combined_mac, h_xyzz_to_affine64<Secp256k1Fp>(ta));
+        h_affine_to_bytes<Secp256k1Fp>(combined_align, h_xyzz_to_affine64<Secp256k1Fp>(tb));
+        return PORLA_OK;
+    };
+    if (rc == PORLA_OK && hipStreamSynchronize(stream) != hipSuccess) {
+        set_last_error("porla: hipStreamSynchronize failed in the audit");
+        rc = PORLA_ERR_HIP;
+    }
+    if (rc) { (void)collect_pair(); return rc; }
+    // rows: the alignment scalars, then B (both already 32-byte big-endian per column)
+    std::vector<uint8_t> two(64 * n_cols);
+    memcpy(two.data(), g_ipa_pin + 32 * n_cols, 32 * n_cols);
+    memcpy(two.data() + 32 * n_cols, g_ipa_pin, 32 * n_cols);
+    if (b_out) memcpy(b_out, g_ipa_pin, 32 * n_cols);
+    uint8_t outs[128];
+    {
+        std::lock_guard<std::mutex> lkfb(generators_fb->secp.mu);
+        rc = generators_fb->secp.commit_host(two.data(), 2, n_cols, 32 * n_cols, outs, engine_stream());
+    }
+    int rc2 = collect_pair();
+    if (rc) return rc;
+    if (rc2) return rc2;
+    if (!pair && (rc = porla_secp256k1_audit_msm_pair_device(d_mac_store, d_align_store, d_mac_idx, d_mac_coef, n_macs, combined_mac,
+                                                             combined_align, stream)))
+        return rc;
+    memcpy(align_value, outs, 64);
+    memcpy(commitment, outs + 64, 64);
+    return PORLA_OK;
+}
+
 void porla_fixed_base_destroy(porla_fixed_base* fb) {
     if (!fb) return;
     fb->bn.release();

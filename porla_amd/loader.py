@@ -107,6 +107,8 @@ def _declare(L):
     L.porla_kzg_commit_batch_device.argtypes = [vp, sz, vp, vp]; L.porla_kzg_commit_batch_device.restype = ctypes.c_int
     L.porla_kzg_commit_batch_host.argtypes = [u8p, sz, u8p]; L.porla_kzg_commit_batch_host.restype = ctypes.c_int
     L.porla_kzg_commit_batch_device_to_host.argtypes = [vp, sz, u8p, vp]; L.porla_kzg_commit_batch_device_to_host.restype = ctypes.c_int
+    L.porla_ipa_audit_device.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp, sz, sz, vp, vp, vp, vp, sz] + [u8p] * 5 + [vp]
+    L.porla_ipa_audit_device.restype = ctypes.c_int
     L.porla_kzg_audit_device.argtypes = [vp, vp, vp, sz, vp, vp, vp, sz, vp, vp, vp, vp, sz, ctypes.c_ulonglong] + [u8p] * 8 + [vp]
     L.porla_kzg_audit_device.restype = ctypes.c_int
     L.porla_kzg_digest_batch_device.argtypes = [vp, sz, vp, vp]; L.porla_kzg_digest_batch_device.restype = ctypes.c_int

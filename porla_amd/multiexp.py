@@ -288,6 +288,17 @@ class FixedBase:
                                                   row_stride or 32 * n_coeffs, ctypes.c_void_p(d_out),
                                                   ctypes.c_void_p(stream)))
 
+    def ipa_audit_device(self, d_rows64, d_idx64, d_coef64, n64, d_rows32, d_idx32, d_coef32, n32, n_cols, d_mac_store, d_align_store,
+                         d_mac_idx, d_mac_coef, n_macs, stream=0):
+        """Server::audit (IPA build) up to the proof, self = the generators' fixed base ->
+        dict(combined_mac, combined_align, align_value, commitment, b)"""
+        vp = ctypes.c_void_p
+        o = [ctypes.create_string_buffer(k) for k in (64, 64, 64, 64, 32 * n_cols)]
+        _check(lib.porla_ipa_audit_device(self.h, vp(d_rows64 or None), vp(d_idx64 or None), vp(d_coef64 or None), n64,
+                                          vp(d_rows32 or None), vp(d_idx32 or None), vp(d_coef32 or None), n32, n_cols, vp(d_mac_store),
+                                          vp(d_align_store), vp(d_mac_idx), vp(d_mac_coef), n_macs, *o, vp(stream)))
+        return dict(zip(("combined_mac", "combined_align", "align_value", "commitment", "b"), (x.raw for x in o)))
+
     def close(self):
         if self.h:
             lib.porla_fixed_base_destroy(self.h)

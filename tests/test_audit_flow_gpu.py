@@ -153,3 +153,50 @@ def test_one_call_audit_edges_and_two_threads():
     assert beg(1, *a, n_points, None) == 0
     assert beg(1, *a, n_points, None) != 0                                             # already begun
     assert mx.audit_msm_pair_end(1, "bn254")[0] == want["combined_mac"]
+
+
+def test_ipa_audit_in_one_call():
+    """porla_ipa_audit_device (Server::audit of the IPA build up to the inner-product proof, Server.hpp:790-857): B and the alignment
+    scalars against the Python restatement, both MSMs and both Pedersen commitments over the generators against the oracle's secp256k1
+    MSM; a 256-bit-row level mixed in"""
+    import numpy as np
+    import torch
+    import icc_py
+    from porla_amd import multiexp as mx
+    ncols, n_rows, n64, n32 = 128, 96, 150, 50
+    rnd = random.Random(857)
+    lcm, p = icc_py.LCM["secp256k1"], icc_py.P_ICC
+    s64 = [[rnd.randrange(lcm) for _ in range(ncols)] for _ in range(n_rows)]
+    s32 = [[rnd.randrange(p) for _ in range(ncols)] for _ in range(n_rows)]
+    gens = common.secp_bench_points(ncols)
+    macs = common.secp_bench_points(2 * n_rows + 1)[64:]                 # some other valid points
+    mac_store, align_store = macs[:64 * n_rows], macs[64 * n_rows:64 * 2 * n_rows]
+    i64, i32 = [rnd.randrange(n_rows) for _ in range(n64)], [rnd.randrange(n_rows) for _ in range(n32)]
+    c64, c32 = [rnd.getrandbits(31) for _ in range(n64)], [rnd.getrandbits(31) for _ in range(n32)]
+    dev = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda()
+    d_s64 = dev(b"".join(v.to_bytes(64, "little") for r in s64 for v in r))
+    d_s32 = dev(b"".join(v.to_bytes(32, "little") for r in s32 for v in r))
+    d_i64, d_i32 = torch.tensor(i64, dtype=torch.int64).cuda(), torch.tensor(i32, dtype=torch.int64).cuda()
+    d_c64 = torch.tensor(np.array(c64, dtype=np.uint32).view(np.int32)).cuda()
+    d_c32 = torch.tensor(np.array(c32, dtype=np.uint32).view(np.int32)).cuda()
+    # the MACs of the challenged rows: one index / coefficient array over both levels' rows (the server concatenates them)
+    m_idx, m_coef = i64 + i32, c64 + c32
+    d_mi = torch.tensor(m_idx, dtype=torch.int64).cuda()
+    d_mc = torch.tensor(np.array(m_coef, dtype=np.uint32).view(np.int32)).cuda()
+    d_ms, d_as = dev(mac_store), dev(align_store)
+    torch.cuda.synchronize()
+    fb = mx.FixedBase("secp256k1", gens, ncols)
+    got = fb.ipa_audit_device(d_s64.data_ptr(), d_i64.data_ptr(), d_c64.data_ptr(), n64, d_s32.data_ptr(), d_i32.data_ptr(), d_c32.data_ptr(),
+                              n32, ncols, d_ms.data_ptr(), d_as.data_ptr(), d_mi.data_ptr(), d_mc.data_ptr(), len(m_idx))
+    B, mods, cs = icc_py.audit_combine([s64[i] for i in i64] + [s32[i] for i in i32], c64 + c32, "secp256k1")
+    be = lambda vals: b"".join(v.to_bytes(32, "big") for v in vals)
+    assert got["b"] == be(mods)
+    sc = be(m_coef)
+    assert got["combined_mac"] == common.oracle_secp_msm(sc, b"".join(mac_store[64 * i:64 * i + 64] for i in m_idx), len(m_idx))
+    assert got["combined_align"] == common.oracle_secp_msm(sc, b"".join(align_store[64 * i:64 * i + 64] for i in m_idx), len(m_idx))
+    assert got["align_value"] == common.oracle_secp_msm(be(cs), gens, ncols)
+    assert got["commitment"] == common.oracle_secp_msm(be(mods), gens, ncols)
+    # wrong kind of fixed base
+    bn = mx.FixedBase("bn254", common.synth_points(4), 4)
+    with pytest.raises(RuntimeError):
+        bn.ipa_audit_device(0, 0, 0, 0, 0, 0, 0, 0, 4, d_ms.data_ptr(), d_as.data_ptr(), d_mi.data_ptr(), d_mc.data_ptr(), 1)
