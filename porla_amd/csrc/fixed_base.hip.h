@@ -207,6 +207,10 @@ k_fb_commit(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_coeffs
     };
     Affine<M> cur;
     bool cur_valid = false, cur_neg = false;
+#ifndef PORLA_FB_DEPTH1
+    Affine<M> mid;
+    bool mid_valid = false, mid_neg = false;
+#endif
     uint32_t tn[8];
     if (i0 < i1) load_be256(tn, row + (size_t)i0 * 32);
     for (uint32_t i = i0; i < i1; i++) {
@@ -253,13 +257,26 @@ k_fb_commit(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_coeffs
                 nxt_valid = true;
                 nxt = load_affine<M>(tab_i + (size_t)w * Bh, mag - 1);
             }
+#ifndef PORLA_FB_DEPTH1
+            // two gathers in flight: the entry added now was requested two windows ago (18.6 -> 18.4 ms for 2^17 rows against one
+            // in flight, profiles/r03_q_fb_commit_4waves_ab.txt; 160 registers, still three waves per SIMD)
+            if (cur_valid) madd_entry(cur, cur_neg);
+            if (mid_valid) cur = mid;
+            cur_valid = mid_valid; cur_neg = mid_neg;
+            if (nxt_valid) mid = nxt;
+            mid_valid = nxt_valid; mid_neg = nxt_neg;
+#else
             if (cur_valid) madd_entry(cur, cur_neg);
             if (nxt_valid) cur = nxt;
             cur_valid = nxt_valid;
             cur_neg = nxt_neg;
+#endif
         }
     }
     if (cur_valid) madd_entry(cur, cur_neg);
+#ifndef PORLA_FB_DEPTH1
+    if (mid_valid) madd_entry(mid, mid_neg);
+#endif
     if constexpr (C::F30_BUCKETS) {
         // a slice partial goes to k_fb_fold in the reduced-radix memory form (no conversion products here, reduced-radix additions
         // there); a whole row's sum (S = 1) in the 2^256 form k_fb_finish and the host read
