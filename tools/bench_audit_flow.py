@@ -21,7 +21,6 @@ pair of MSMs on its own stream beside combine -> host opening -> ONE three-row c
 commitment -> create_proof), `separate_calls_each_waited_for_ms` = every call waited for before the next; `steps_ms` = each alone.  cpu_baseline: the oracle's
 pieces of the same audit (oracle/bn254_ref.c MSMs over 16 threads, oracle/icc_py.py combine in Python integers)."""
 import argparse
-import ctypes
 import json
 import os
 import sys
