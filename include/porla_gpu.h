@@ -312,6 +312,9 @@ int porla_icc_mix_device(const void *d_a0, const void *d_a1, size_t len, size_t 
                          void *hip_stream);
 int porla_icc_mix_host(const uint8_t *a0, const uint8_t *a1, size_t len, size_t n_cols, size_t n_total, int curve, uint8_t *out);
 int porla_icc_mac_mix_device(const void *d_a0, const void *d_a1, size_t len, size_t n_total, int curve, void *d_out, void *hip_stream);
+/* both point butterflies of a mix -- the MAC commitments (a) and the MAC alignments (b), same v^i -- in one launch */
+int porla_icc_mac_mix_pair_device(const void *d_a0, const void *d_a1, const void *d_b0, const void *d_b1, size_t len, size_t n_total,
+                                  int curve, void *d_out_a, void *d_out_b, void *hip_stream);
 int porla_icc_mac_mix_host(const uint8_t *a0, const uint8_t *a1, size_t len, size_t n_total, int curve, uint8_t *out);
 
 /* ---- Server::HAdd / Client::HAdd and the HRebuild chains (Server.hpp:1388-1477, 1329-1386; Client.hpp:978-1038) ----

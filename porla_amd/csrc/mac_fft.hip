@@ -74,21 +74,23 @@ static int ensure_mac_twiddles(MacWs* ws, int curve, size_t n, hipStream_t strea
 
 template <class C, class Q>
 static int mac_mix_core(MacWs* ws, int curve, const uint8_t* d_a0, const uint8_t* d_a1, size_t len, size_t n_total, uint8_t* d_out,
-                        hipStream_t stream) {
+                        hipStream_t stream, const uint8_t* d_b0 = nullptr, const uint8_t* d_b1 = nullptr, uint8_t* d_out_b = nullptr) {
     int rc;
     if ((rc = ensure_mac_twiddles<Q>(ws, curve, n_total, stream))) return rc;
     ProfScope ps("mac_mix", stream);
     static const bool quad = !(getenv("PORLA_MAC_QUAD") && getenv("PORLA_MAC_QUAD")[0] == '0');
+    const unsigned sets = d_b0 ? 2u : 1u;               // the second array pair (MAC alignments beside the MAC commitments)
     if constexpr (C::F30_LAZY) {
-        if (quad && len <= ((size_t)1 << 14)) {        // latency bound: four lanes per element (k_mac_stage30_quad's ladder)
-            hipLaunchKernelGGL((k_mac_mix_quad<C>), dim3((unsigned)((len + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), 0, stream, d_a0,
-                               d_a1, (uint32_t)len, (const uint32_t*)ws->tws.p, (uint32_t)(n_total / len), d_out);
+        static const int quad_max_log = getenv("PORLA_MAC_MIX_QUAD_MAX") ? atoi(getenv("PORLA_MAC_MIX_QUAD_MAX")) : 14;
+        if (quad && len * sets <= ((size_t)1 << quad_max_log)) {   // latency bound: four lanes per element (k_mac_stage30_quad's ladder)
+            hipLaunchKernelGGL((k_mac_mix_quad<C>), dim3((unsigned)((len + MACQ_BF - 1) / MACQ_BF), sets), dim3(4 * MACQ_BF), 0, stream, d_a0,
+                               d_a1, (uint32_t)len, (const uint32_t*)ws->tws.p, (uint32_t)(n_total / len), d_out, d_b0, d_b1, d_out_b);
             PORLA_HIP(hipGetLastError());
             return PORLA_OK;
         }
     }
-    hipLaunchKernelGGL((k_mac_mix<C>), dim3((unsigned)((len + 63) / 64)), dim3(64), 0, stream, d_a0, d_a1, (uint32_t)len,
-                       (const uint32_t*)ws->tws.p, (uint32_t)(n_total / len), d_out);
+    hipLaunchKernelGGL((k_mac_mix<C>), dim3((unsigned)((len + 63) / 64), sets), dim3(64), 0, stream, d_a0, d_a1, (uint32_t)len,
+                       (const uint32_t*)ws->tws.p, (uint32_t)(n_total / len), d_out, d_b0, d_b1, d_out_b);
     PORLA_HIP(hipGetLastError());
     return PORLA_OK;
 }
@@ -287,6 +289,29 @@ int porla_icc_mac_mix_device(const void* d_a0, const void* d_a1, size_t len, siz
     if ((rc = ws->fence.enter((hipStream_t)hip_stream))) return rc;
     rc = curve == 0 ? mac_mix_core<Bn254G1, IccBn254Fr>(ws, 0, (const uint8_t*)d_a0, (const uint8_t*)d_a1, len, n_total, (uint8_t*)d_out, (hipStream_t)hip_stream)
                     : mac_mix_core<Secp256k1G, IccSecp256k1Fn>(ws, 1, (const uint8_t*)d_a0, (const uint8_t*)d_a1, len, n_total, (uint8_t*)d_out, (hipStream_t)hip_stream);
+    if (rc) return rc;
+    return ws->fence.leave((hipStream_t)hip_stream);
+}
+
+// Server::mix's two point butterflies -- MAC commitments and MAC alignments, same v^i (Server.hpp:1281-1318) -- as one launch
+int porla_icc_mac_mix_pair_device(const void* d_a0, const void* d_a1, const void* d_b0, const void* d_b1, size_t len, size_t n_total,
+                                  int curve, void* d_out_a, void* d_out_b, void* hip_stream) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    const int ll = ilog2u(len), ln = ilog2u(n_total);
+    if (!d_a0 || !d_a1 || !d_b0 || !d_b1 || !d_out_a || !d_out_b || len == 0 || ((size_t)1 << ll) != len || ((size_t)1 << ln) != n_total ||
+        len > n_total || n_total < 2 || (curve != 0 && curve != 1)) {
+        set_last_error("porla: bad argument to porla_icc_mac_mix_pair_device (len and n_total must be powers of two, len <= n_total)");
+        return PORLA_ERR_ARG;
+    }
+    std::lock_guard<std::mutex> lk(g_mac_mu);
+    MacWs* ws;
+    if ((rc = get_mac_ws(&ws))) return rc;
+    if ((rc = ws->fence.enter((hipStream_t)hip_stream))) return rc;
+    rc = curve == 0 ? mac_mix_core<Bn254G1, IccBn254Fr>(ws, 0, (const uint8_t*)d_a0, (const uint8_t*)d_a1, len, n_total, (uint8_t*)d_out_a,
+                                                        (hipStream_t)hip_stream, (const uint8_t*)d_b0, (const uint8_t*)d_b1, (uint8_t*)d_out_b)
+                    : mac_mix_core<Secp256k1G, IccSecp256k1Fn>(ws, 1, (const uint8_t*)d_a0, (const uint8_t*)d_a1, len, n_total, (uint8_t*)d_out_a,
+                                                               (hipStream_t)hip_stream, (const uint8_t*)d_b0, (const uint8_t*)d_b1, (uint8_t*)d_out_b);
     if (rc) return rc;
     return ws->fence.leave((hipStream_t)hip_stream);
 }

@@ -430,9 +430,13 @@ __device__ __forceinline__ void store_affine_be(uint8_t* dst, const XYZZ<M>& p);
 template <class C>
 __global__ void __launch_bounds__(4 * MACQ_BF)
 k_mac_mix_quad(const uint8_t* __restrict__ a0, const uint8_t* __restrict__ a1, uint32_t len, const uint32_t* __restrict__ tws,
-               uint32_t tw_step, uint8_t* __restrict__ out) {
+               uint32_t tw_step, uint8_t* __restrict__ out, const uint8_t* __restrict__ b0, const uint8_t* __restrict__ b1,
+               uint8_t* __restrict__ out_b) {
     using M = typename C::Fp;
     __shared__ MacQuadLds<M> L;
+    // gridDim.y == 2: Server::mix runs this butterfly on the MAC commitments AND on the MAC alignments with the same v^i
+    // (Server.hpp:1281-1318) -- the second array pair rides in the same launch (a stage this short is latency: two for the price of one)
+    if (blockIdx.y) { a0 = b0; a1 = b1; out = out_b; }
     const uint32_t q = threadIdx.x >> 2, r = threadIdx.x & 3u, lane = threadIdx.x & 63u;
     uint32_t i = blockIdx.x * MACQ_BF + q;
     const bool valid = i < len;
@@ -539,8 +543,10 @@ __device__ __forceinline__ XYZZ<M> load_affine_be(const uint8_t* src) {
 template <class C>
 __global__ void __launch_bounds__(64)
 k_mac_mix(const uint8_t* __restrict__ a0, const uint8_t* __restrict__ a1, uint32_t len, const uint32_t* __restrict__ tws,
-          uint32_t tw_step, uint8_t* __restrict__ out) {
+          uint32_t tw_step, uint8_t* __restrict__ out, const uint8_t* __restrict__ b0, const uint8_t* __restrict__ b1,
+          uint8_t* __restrict__ out_b) {
     using M = typename C::Fp;
+    if (blockIdx.y) { a0 = b0; a1 = b1; out = out_b; }          // the second array pair of a mix (see k_mac_mix_quad)
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= len) return;
     uint32_t sc[8];

@@ -61,3 +61,31 @@ def test_mac_mix_with_an_empty_upper_block():
     a0 = macs_for("bn254", length)
     got = icc.mac_mix_host(a0, bytes(64 * length), length, 64, "bn254")
     assert got == a0 + a0
+
+
+@pytest.mark.parametrize("curve", ["bn254", "secp256k1"])
+@pytest.mark.parametrize("length,n_total", [(1, 2), (64, 1024), (8192, 16384), (16384, 1 << 17)])
+def test_mac_mix_pair_in_one_launch(curve, length, n_total):
+    """porla_icc_mac_mix_pair_device: Server::mix's butterfly on the MAC commitments and on the MAC alignments (same v^i,
+    Server.hpp:1281-1318) in one launch -- each output against the oracle (up to 2^13 butterflies in total the four-lane kernel,
+    above it one lane per butterfly)"""
+    import torch
+    from porla_amd import icc, lib
+    from tests.test_mac_fft_gpu import macs_for
+    pool = macs_for(curve, min(4 * length, 2048))
+    arr = bytearray((pool * (4 * length * 64 // len(pool) + 1))[:64 * 4 * length])
+    if length >= 64:
+        arr[64 * 5:64 * 6] = bytes(64)                                     # infinity in the first array's A0
+        arr[64 * (3 * length + 7):64 * (3 * length + 8)] = bytes(64)       # ... and in the second array's A1
+    parts = [bytes(arr[64 * length * k:64 * length * (k + 1)]) for k in range(4)]
+    d = [torch.frombuffer(bytearray(p), dtype=torch.uint8).cuda() for p in parts]
+    oa, ob = (torch.empty(128 * length, dtype=torch.uint8, device="cuda") for _ in range(2))
+    vp = ctypes.c_void_p
+    rc = lib.porla_icc_mac_mix_pair_device(vp(d[0].data_ptr()), vp(d[1].data_ptr()), vp(d[2].data_ptr()), vp(d[3].data_ptr()), length, n_total,
+                                           icc.CURVE[curve], vp(oa.data_ptr()), vp(ob.data_ptr()), vp(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    for out, (a0, a1) in ((oa, parts[0:2]), (ob, parts[2:4])):
+        want = ctypes.create_string_buffer(2 * length * 64)
+        common.oracle().oracle_icc_mac_mix(a0, a1, ctypes.c_size_t(length), ctypes.c_size_t(n_total), icc.CURVE[curve], want, common.ncpu())
+        assert bytes(out.cpu().numpy()) == want.raw
