@@ -254,7 +254,7 @@ k_mac_stage30(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restric
 // ladder is the same (endomorphism split, 33 signed 4-bit windows, one table of multiples, phi(P)'s entries by scaling X with
 // beta), its state -- table, accumulator, the operand being added -- lives in LDS, and the control flow is the same for every
 // butterfly of the block (a zero digit computes its addition and does not store it), so block barriers order the LDS traffic.
-constexpr int MACQ_BF = 32;                       // butterflies per block (128 lanes): 11 slots of 128 B each = 44 KiB of LDS
+constexpr int MACQ_BF = 64;                       // butterflies per block: 256 lanes = one wave on each SIMD of a compute unit; 11 slots of 128 B each = 88 KiB of LDS
 
 // signed 4-bit digit i (0 .. 32) of the 128-bit magnitude m: ((m >> 4i) & 15) + carry, minus 16 above 8.  The carry into
 // window i is 1 exactly when the bits below it exceed 0x88..8 (the recoding with digits in (-8, 8] is unique: msm_small.hip.h).
