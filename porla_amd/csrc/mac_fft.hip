@@ -161,13 +161,14 @@ static int mac_encode_core(MacWs* ws, int curve, const uint8_t* d_in, size_t n, 
     for (int s = 1; s <= logn; s++) {
         ProfScope ps("mac_stage", stream);
         if constexpr (C::F30_LAZY) {
-            // up to 2^15 rows a stage is latency bound (one wave per SIMD even with four lanes per butterfly): the quad-lane ladder
-            // (2^16 rows: 22.2 ms against 18.8 ms with one lane per butterfly)
+            // up to 2^16 rows a stage is latency bound (one or two waves per SIMD even with four lanes per butterfly): the quad-lane
+            // ladder (2^16 rows: 16.7 ms against 18.5 ms with one lane per butterfly; 2^17 rows: 35.4 against 22.2)
             static const bool quad = !(getenv("PORLA_MAC_QUAD") && getenv("PORLA_MAC_QUAD")[0] == '0');
+            static const int quad_max_log = getenv("PORLA_MAC_QUAD_MAX") ? atoi(getenv("PORLA_MAC_QUAD_MAX")) : 16;
             if (quad && s == 1)      // every twiddle of stage 1 is w^0 = 1: two additions per butterfly, no ladder
                 hipLaunchKernelGGL((k_mac_stage1_quad<C>), dim3((unsigned)((n / 2 + 63) / 64)), dim3(256), 0, stream, (XYZZ<M>*)ws->work.p,
                                    (uint32_t)n);
-            else if (quad && n <= ((size_t)1 << 15))
+            else if (quad && n <= ((size_t)1 << quad_max_log))
                 hipLaunchKernelGGL((k_mac_stage30_quad<C>), dim3((unsigned)((n / 2 + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), 0, stream,
                                    (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->tws.p, (uint32_t)n, s);
             else
