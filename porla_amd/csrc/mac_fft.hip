@@ -189,7 +189,8 @@ static int mac_encode_core(MacWs* ws, int curve, const uint8_t* d_in, size_t n, 
             {
                 ProfScope ps("mac_scale", stream);
                 static const bool quad = !(getenv("PORLA_MAC_QUAD") && getenv("PORLA_MAC_QUAD")[0] == '0');
-                if (quad && n <= ((size_t)1 << 14))
+                static const int scale_quad_max = getenv("PORLA_MAC_SCALE_QUAD_MAX") ? atoi(getenv("PORLA_MAC_SCALE_QUAD_MAX")) : 15;
+                if (quad && n <= ((size_t)1 << scale_quad_max))
                     hipLaunchKernelGGL((k_mac_load30_quad<C, true>), dim3((unsigned)((n + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), 0, stream,
                                        (const uint8_t*)ws->work.p, (uint32_t)n, (XYZZ<M>*)ws->work_y.p, wt);
                 else
