@@ -383,7 +383,7 @@ k_mac_stage30_quad(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __re
 }
 
 // Stage 1 of the network with four lanes per butterfly: every twiddle is w^0 = 1 (tm = MAC[k+1]), so the stage is its two
-// additions and nothing else -- the 0.86 ms ladder of a general stage would multiply by one.  256 lanes = 64 butterflies per block.
+// additions and nothing else -- the 0.54 ms ladder of a general stage would multiply by one.  256 lanes = 64 butterflies per block.
 template <class C>
 __global__ void __launch_bounds__(256)
 k_mac_stage1_quad(XYZZ<typename C::Fp>* __restrict__ work, uint32_t n) {
