@@ -142,8 +142,9 @@ int FixedBase<C>::commit_device(const uint8_t* d_rows, size_t n_rows, size_t n_c
         int rcf = fence.enter(stream);
         if (rcf) return rcf;
     }
-    // slices per row: enough lanes to fill 256 CUs x 4 SIMDs x 3 waves
-    static const size_t target = getenv("PORLA_COMMIT_LANES") ? (size_t)atol(getenv("PORLA_COMMIT_LANES")) : (size_t)196608;
+    // slices per row: enough lanes for TWO to three rounds of 256 CUs x 4 SIMDs x 3 waves -- with 196 608 (one round and a third:
+    // 1024 blocks where 768 are resident) the last third ran at one wave per SIMD: 18.1-18.3 ms for 2^17 rows, 17.8 with 393 216
+    static const size_t target = getenv("PORLA_COMMIT_LANES") ? (size_t)atol(getenv("PORLA_COMMIT_LANES")) : (size_t)393216;
     uint32_t S = 1;
     while ((size_t)n_rows * S < target && S * 2 <= n_coeffs && S < 128) S *= 2;
     uint32_t G = S < 64 ? S : 64;
