@@ -122,7 +122,12 @@ static int msm_small_launch(Workspace* ws, const uint8_t* d_scalars, const uint8
     ((volatile uint32_t*)ws->h_windows)[0] = 0;
     {
         ProfScope ps("small_msm", stream, true);
-        hipLaunchKernelGGL((k_small_msm<C>), dim3(SMALL_BLOCKS), dim3(SMALL_THREADS), 0, stream, d_scalars, d_points_be, (uint32_t)n,
+        static const unsigned one_env = getenv("PORLA_MSM_SMALL_BLOCKS") ? (unsigned)atoi(getenv("PORLA_MSM_SMALL_BLOCKS")) : 0u;
+        // up to 4 096 pairs 192 blocks are as fast as 256 (3 200 pairs: 0.1045 / 0.1046 ms with abs(int32) coefficients, 0.163 / 0.171
+        // with 256-bit scalars; 16 384 pairs: 0.284 against 0.262) and leave a quarter of the chip to whatever short kernels run
+        // beside this one (PORLA_MSM_SMALL_BLOCKS overrides)
+        const unsigned one_blocks = (one_env >= 1 && one_env <= (unsigned)SMALL_BLOCKS) ? one_env : (n <= 4096 ? 192u : (unsigned)SMALL_BLOCKS);
+        hipLaunchKernelGGL((k_small_msm<C>), dim3(one_blocks), dim3(SMALL_THREADS), 0, stream, d_scalars, d_points_be, (uint32_t)n,
                            g_small_c | (g_use_glv == 0 ? 0x100 : 0), (XYZZ<M>*)ws->small_part.p, counters, (uint32_t*)h_dev,
                            (XYZZ<M>*)((uint8_t*)h_dev + SMALL_HDR_WORDS * 4), ws->small_seq, (const uint8_t*)nullptr, 0u);
     }
