@@ -192,8 +192,10 @@ struct FixedBase {
     // <= FB_SMALL_MAX_ROWS rows given by pointer (they need not be contiguous: the coalescing front of compute_digest_from_srs
     // hands over the callers' own buffers), one launch, results polled from pinned memory and normalised on the host
     // d_rows != nullptr: the rows are resident on the device (contiguous, 32 * n_coeffs bytes each) and row_ptrs is ignored
+    // raw_sums != nullptr: the rows' projective sums are handed back as they are (outs is ignored): the caller normalises them
+    // together with other points (one inversion for all)
     int commit_small(const uint8_t* const* row_ptrs, size_t n_rows, size_t n_coeffs, uint8_t* const* outs, hipStream_t stream,
-                     const uint8_t* d_rows = nullptr);
+                     const uint8_t* d_rows = nullptr, XYZZ<typename C::Fp>* raw_sums = nullptr);
     static bool small_ok(size_t n_rows, size_t n_coeffs);
 };
 

@@ -198,7 +198,7 @@ bool FixedBase<C>::small_ok(size_t n_rows, size_t n_coeffs) {
 }
 template <class C>
 int FixedBase<C>::commit_small(const uint8_t* const* row_ptrs, size_t n_rows, size_t n_coeffs, uint8_t* const* outs,
-                               hipStream_t stream, const uint8_t* d_rows) {
+                               hipStream_t stream, const uint8_t* d_rows, XYZZ<typename C::Fp>* raw_sums) {
     using M = typename C::Fp;
     if (!table || n_coeffs > n_points) { set_last_error("porla: fixed base not built / too few base points"); return PORLA_ERR_STATE; }
     int cur = -1;
@@ -250,6 +250,10 @@ int FixedBase<C>::commit_small(const uint8_t* const* row_ptrs, size_t n_rows, si
         if (hdr[0] != small_seq) { set_last_error("porla: the single-launch commitment left no result"); return PORLA_ERR_HIP; }
     }
     const XYZZ<M>* sums = (const XYZZ<M>*)(hs + FB_SMALL_SUMS);
+    if (raw_sums) {
+        for (size_t r = 0; r < n_rows; r++) raw_sums[r] = sums[r];
+        return PORLA_OK;
+    }
     Affine<M> aff[FB_SMALL_MAX_ROWS];
     h_batch_xyzz_to_affine64<M>(sums, n_rows, aff);       // one inversion for the whole batch
     for (size_t r = 0; r < n_rows; r++) h_affine_to_bytes<M>(outs[r], aff[r]);

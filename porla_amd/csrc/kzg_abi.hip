@@ -815,9 +815,38 @@ int porla_kzg_audit_device(const void* d_rows64, const uint64_t* d_idx64, const 
     if (b_out) memcpy(b_out, h_b, 32 * n);
     uint8_t outs[192];
     lap("opening on the host");
-    rc = commit_rows(three.data(), false, 3, n, outs, nullptr);
+    // the three row sums stay projective until the pair's two sums are in: ONE inversion normalises all five points
+    XYZZ<Fp> five[5];
+    bool raw3 = false;
+    if (pair_begun && FixedBase<Bn254G1>::small_ok(3, n)) {
+        std::unique_lock<std::mutex> lks(g.mu);
+        KzgState::Dev* kd = nullptr;
+        rc = refresh_srs_locked(&kd);
+        if (rc == PORLA_OK) {
+            std::unique_lock<std::mutex> lkfb(kd->fb.mu);
+            lks.unlock();
+            const uint8_t* rp[3] = {three.data(), three.data() + 32 * n, three.data() + 64 * n};
+            rc = kd->fb.commit_small(rp, 3, n, nullptr, engine_stream(), nullptr, five);
+            raw3 = rc == PORLA_OK;
+        }
+    } else {
+        rc = commit_rows(three.data(), false, 3, n, outs, nullptr);
+    }
     lap("three commitments");
-    int rc2 = collect_pair();
+    int rc2;
+    if (raw3) {
+        rc2 = msm_pair_end<Bn254G1>(MSM_AUDIT_SLOT, &five[3], &five[4]);
+        pair_begun = false;
+        if (rc2 == PORLA_OK) {
+            Affine<Fp> aff[5];
+            h_batch_xyzz_to_affine64<Fp>(five, 5, aff);
+            for (int i = 0; i < 3; i++) h_affine_to_bytes<Fp>(outs + 64 * i, aff[i]);
+            h_affine_to_bytes<Fp>(combined_mac, aff[3]);
+            h_affine_to_bytes<Fp>(combined_align, aff[4]);
+        }
+    } else {
+        rc2 = collect_pair();
+    }
     lap("pair collected");
     if (rc) return rc;
     if (rc2) return rc2;
