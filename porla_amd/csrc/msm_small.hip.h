@@ -6,7 +6,8 @@
 // tree over mostly empty buckets cost 0.3-0.5 ms whatever the input.  Here ONE kernel does everything and what is left is
 // a chain of ~15 dependent group additions:
 //
-//   grid = 256 blocks of 256 lanes (one block per CU, one wave per SIMD: dependent chains run at the lone-wave latency).
+//   grid = up to 256 blocks of 256 lanes (one block per CU, one wave per SIMD: dependent chains run at the lone-wave latency);
+//   192 up to 4 096 pairs and 2 x 96 for a pair of MSMs (msm_impl.hip.h): as fast, and the rest of the chip stays free.
 //   Every block first ORs all n scalars (<= 128 KB, L2 resident) to learn their bit length -- no host round trip: the audit's
 //   abs(int32) coefficients (utils.h:271-275) then need 9 windows of 4 bits instead of 32 -- and derives the shape from it:
 //   scalars longer than 128 bits are split with the curve endomorphism (k = k1 + lambda k2, glv.hip.h; 2n sub-scalars of
@@ -42,7 +43,7 @@ constexpr int SMALL_DONE_SLOT = 255;                 // counters[0 .. W): arriva
 constexpr uint32_t SMALL_HDR_WORDS = 32;             // pinned header in front of fin: [0] = sequence, [1] = W, [2] = c, [3] = glv
 
 // the single-launch commitment of fixed_base.hip.h (k_fb_commit_small): rows per launch, slices per row
-constexpr int FB_SMALL_MAX_ROWS = 64;            // 64 rows x 4 slices = 256 blocks: one round on the chip (96 rows: 0.19 ms, the batch kernels 0.22)
+constexpr int FB_SMALL_MAX_ROWS = 64;            // 64 rows x 8 slices = 512 blocks, two per compute unit (96 rows: 0.19 ms, the batch kernels 0.22)
 constexpr int FB_SMALL_MAX_SLICES = 8;
 
 struct SmallCfg {
@@ -96,7 +97,7 @@ __host__ __device__ inline SmallCfg small_cfg(uint32_t n, int used_bits, int c_f
                            0.01f * (float)W;
         if (cost < best_cost) { best_cost = cost; best_c = c; g.c = c; g.W = W; g.S = (int)S; }
     }
-    if (best_c == 0) {                                   // cannot happen for 256 blocks (c = 8: W <= 32, S >= 8 slices of <= 4096); keep a valid shape
+    if (best_c == 0) {                                   // no admissible shape (a forced width with more windows than blocks): c = 8 always fits (W <= 32)
         g.c = SMALL_MAX_C; g.W = (g.L + 1 + g.c - 1) / g.c;
         g.S = blocks / g.W < 1 ? 1 : (blocks / g.W > SMALL_MAX_S ? SMALL_MAX_S : blocks / g.W);
     }
