@@ -172,7 +172,7 @@ static int mac_encode_core(MacWs* ws, int curve, const uint8_t* d_in, size_t n, 
                 hipLaunchKernelGGL((k_mac_stage30_quad<C>), dim3((unsigned)((n / 2 + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), 0, stream,
                                    (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->tws.p, (uint32_t)n, s);
             else
-                hipLaunchKernelGGL((k_mac_stage30<C>), dim3((unsigned)((n / 2 + 63) / 64)), dim3(64), 0, stream, (XYZZ<M>*)ws->work.p,
+                hipLaunchKernelGGL((k_mac_stage30<C>), dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, stream, (XYZZ<M>*)ws->work.p,
                                    (const uint32_t*)ws->tws.p, (uint32_t)n, s);
         } else
             hipLaunchKernelGGL((k_mac_stage<C>), dim3((unsigned)((n / 2 + 63) / 64)), dim3(64), 0, stream, (XYZZ<M>*)ws->work.p,
