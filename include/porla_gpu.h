@@ -316,6 +316,11 @@ int porla_icc_mac_mix_device(const void *d_a0, const void *d_a1, size_t len, siz
 int porla_icc_mac_mix_pair_device(const void *d_a0, const void *d_a1, const void *d_b0, const void *d_b1, size_t len, size_t n_total,
                                   int curve, void *d_out_a, void *d_out_b, void *hip_stream);
 int porla_icc_mac_mix_host(const uint8_t *a0, const uint8_t *a1, size_t len, size_t n_total, int curve, uint8_t *out);
+/* Server::mix(is_x, level) in one call: the data rows on hip_stream, both point arrays on a second stream beside them; asynchronous
+ * (hip_stream continues when all three outputs are written) */
+int porla_server_mix_device(const void *d_data_a0, const void *d_data_a1, const void *d_mac_a0, const void *d_mac_a1,
+                            const void *d_align_a0, const void *d_align_a1, size_t len, size_t n_cols, size_t n_total, int curve,
+                            void *d_data_out, void *d_mac_out, void *d_align_out, void *hip_stream);
 
 /* ---- Server::HAdd / Client::HAdd and the HRebuild chains (Server.hpp:1388-1477, 1329-1386; Client.hpp:978-1038) ----
  * HAdd's arithmetic on ONE incoming block (the level bookkeeping around it stays the caller's):

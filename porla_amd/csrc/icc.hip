@@ -487,6 +487,48 @@ int porla_icc_mix_device(const void* d_a0, const void* d_a1, size_t len, size_t 
     return icc_mix_core<IccSecp256k1Fn>(ws, 1, (const uint8_t*)d_a0, (const uint8_t*)d_a1, len, n_cols, n_total, (uint8_t*)d_out, (hipStream_t)hip_stream);
 }
 
+// Server::mix(is_x, level) in ONE call (porla/Server/Server.hpp:1209-1328): the data rows on hip_stream, both point arrays (MAC
+// commitments, MAC alignments: porla_icc_mac_mix_pair_device) on a second stream beside them -- the point butterflies are a chain
+// of ~200 dependent group operations (0.63 ms whatever the length up to 2^13 rows), the data part is short and wide.  Asynchronous:
+// hip_stream continues when both are done; nothing waits on the host.
+namespace {
+struct MixSide { int device = -1; hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+std::mutex g_mix_side_mu;
+std::vector<MixSide> g_mix_side;
+}  // namespace
+int porla_server_mix_device(const void* d_data_a0, const void* d_data_a1, const void* d_mac_a0, const void* d_mac_a1, const void* d_align_a0,
+                            const void* d_align_a1, size_t len, size_t n_cols, size_t n_total, int curve, void* d_data_out, void* d_mac_out,
+                            void* d_align_out, void* hip_stream) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    int dev = 0;
+    PORLA_HIP(hipGetDevice(&dev));
+    MixSide side;
+    {
+        std::lock_guard<std::mutex> lk(g_mix_side_mu);
+        MixSide* found = nullptr;
+        for (auto& m : g_mix_side) if (m.device == dev) found = &m;
+        if (!found) {
+            MixSide m;
+            m.device = dev;
+            PORLA_HIP(hipStreamCreateWithFlags(&m.s, hipStreamNonBlocking));
+            PORLA_HIP(hipEventCreateWithFlags(&m.fork, hipEventDisableTiming));
+            PORLA_HIP(hipEventCreateWithFlags(&m.join, hipEventDisableTiming));
+            g_mix_side.push_back(m);
+            found = &g_mix_side.back();
+        }
+        side = *found;
+    }
+    hipStream_t stream = (hipStream_t)hip_stream;
+    PORLA_HIP(hipEventRecord(side.fork, stream));
+    PORLA_HIP(hipStreamWaitEvent(side.s, side.fork, 0));
+    if ((rc = porla_icc_mac_mix_pair_device(d_mac_a0, d_mac_a1, d_align_a0, d_align_a1, len, n_total, curve, d_mac_out, d_align_out, side.s))) return rc;
+    PORLA_HIP(hipEventRecord(side.join, side.s));
+    if ((rc = porla_icc_mix_device(d_data_a0, d_data_a1, len, n_cols, n_total, curve, d_data_out, stream))) return rc;
+    PORLA_HIP(hipStreamWaitEvent(stream, side.join, 0));
+    return PORLA_OK;
+}
+
 int porla_icc_mix_host(const uint8_t* a0, const uint8_t* a1, size_t len, size_t n_cols, size_t n_total, int curve, uint8_t* out) {
     int rc = ensure_device();
     if (rc) return rc;

@@ -88,6 +88,16 @@ static int mac_mix_core(MacWs* ws, int curve, const uint8_t* d_a0, const uint8_t
             PORLA_HIP(hipGetLastError());
             return PORLA_OK;
         }
+        if (quad && sets == 2 && len <= ((size_t)1 << quad_max_log)) {
+            // two arrays of a length the four-lane kernel still takes one at a time (2^14 rows: 0.63 ms each; both in one launch of
+            // the one-lane kernel: 1.36 ms): two launches, one after the other
+            hipLaunchKernelGGL((k_mac_mix_quad<C>), dim3((unsigned)((len + MACQ_BF - 1) / MACQ_BF), 1), dim3(4 * MACQ_BF), 0, stream, d_a0, d_a1,
+                               (uint32_t)len, (const uint32_t*)ws->tws.p, (uint32_t)(n_total / len), d_out, d_b0, d_b1, d_out_b);
+            hipLaunchKernelGGL((k_mac_mix_quad<C>), dim3((unsigned)((len + MACQ_BF - 1) / MACQ_BF), 1), dim3(4 * MACQ_BF), 0, stream, d_b0, d_b1,
+                               (uint32_t)len, (const uint32_t*)ws->tws.p, (uint32_t)(n_total / len), d_out_b, d_b0, d_b1, d_out_b);
+            PORLA_HIP(hipGetLastError());
+            return PORLA_OK;
+        }
     }
     hipLaunchKernelGGL((k_mac_mix<C>), dim3((unsigned)((len + 63) / 64), sets), dim3(64), 0, stream, d_a0, d_a1, (uint32_t)len,
                        (const uint32_t*)ws->tws.p, (uint32_t)(n_total / len), d_out, d_b0, d_b1, d_out_b);

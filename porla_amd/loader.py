@@ -133,6 +133,7 @@ def _declare(L):
     L.porla_icc_mac_set_matrix_max.argtypes = [sz]; L.porla_icc_mac_set_matrix_max.restype = ctypes.c_int
     L.porla_icc_mix_device.argtypes = [vp, vp, sz, sz, sz, ctypes.c_int, vp, vp]; L.porla_icc_mix_device.restype = ctypes.c_int
     L.porla_icc_mix_host.argtypes = [u8p, u8p, sz, sz, sz, ctypes.c_int, u8p]; L.porla_icc_mix_host.restype = ctypes.c_int
+    L.porla_server_mix_device.argtypes = [vp] * 6 + [sz, sz, sz, ctypes.c_int, vp, vp, vp, vp]; L.porla_server_mix_device.restype = ctypes.c_int
     L.porla_icc_mac_mix_pair_device.argtypes = [vp, vp, vp, vp, sz, sz, ctypes.c_int, vp, vp, vp]; L.porla_icc_mac_mix_pair_device.restype = ctypes.c_int
     L.porla_icc_mac_mix_device.argtypes = [vp, vp, sz, sz, ctypes.c_int, vp, vp]; L.porla_icc_mac_mix_device.restype = ctypes.c_int
     L.porla_icc_mac_mix_host.argtypes = [u8p, u8p, sz, sz, ctypes.c_int, u8p]; L.porla_icc_mac_mix_host.restype = ctypes.c_int

@@ -89,3 +89,37 @@ def test_mac_mix_pair_in_one_launch(curve, length, n_total):
         want = ctypes.create_string_buffer(2 * length * 64)
         common.oracle().oracle_icc_mac_mix(a0, a1, ctypes.c_size_t(length), ctypes.c_size_t(n_total), icc.CURVE[curve], want, common.ncpu())
         assert bytes(out.cpu().numpy()) == want.raw
+
+
+@pytest.mark.parametrize("curve,length,n_total", [("bn254", 32, 256), ("secp256k1", 8, 64), ("bn254", 4096, 16384)])
+def test_server_mix_in_one_call(curve, length, n_total):
+    """porla_server_mix_device = Server::mix(is_x, level) (Server.hpp:1209-1328): data rows, MAC commitments and MAC alignments of
+    one mix from one call (two streams inside) -- each output against its oracle"""
+    import torch
+    import icc_py
+    from porla_amd import icc, lib
+    from tests.test_mac_fft_gpu import macs_for
+    ncols = 128 if length <= 64 else 8
+    rnd = random.Random(length + n_total)
+    lcm = icc_py.LCM[curve]
+    a0 = b"".join(rnd.randrange(lcm).to_bytes(64, "little") for _ in range(length * ncols))
+    a1 = b"".join(rnd.randrange(lcm).to_bytes(64, "little") for _ in range(length * ncols))
+    pool = macs_for(curve, min(4 * length, 2048))
+    arr = (pool * (4 * length * 64 // len(pool) + 1))[:64 * 4 * length]
+    parts = [arr[64 * length * k:64 * length * (k + 1)] for k in range(4)]
+    dev = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda()
+    d = [dev(a0), dev(a1)] + [dev(p) for p in parts]
+    o_data = torch.empty(2 * length * ncols * 64, dtype=torch.uint8, device="cuda")
+    o_mac, o_al = (torch.empty(128 * length, dtype=torch.uint8, device="cuda") for _ in range(2))
+    vp = ctypes.c_void_p
+    rc = lib.porla_server_mix_device(*[vp(t.data_ptr()) for t in d], length, ncols, n_total, icc.CURVE[curve], vp(o_data.data_ptr()),
+                                     vp(o_mac.data_ptr()), vp(o_al.data_ptr()), vp(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    want = ctypes.create_string_buffer(2 * length * ncols * 64)
+    common.oracle().oracle_icc_mix(a0, a1, ctypes.c_size_t(length), ctypes.c_size_t(ncols), ctypes.c_size_t(n_total), icc.CURVE[curve], want)
+    assert bytes(o_data.cpu().numpy()) == want.raw
+    for out, (p0, p1) in ((o_mac, parts[0:2]), (o_al, parts[2:4])):
+        w = ctypes.create_string_buffer(2 * length * 64)
+        common.oracle().oracle_icc_mac_mix(p0, p1, ctypes.c_size_t(length), ctypes.c_size_t(n_total), icc.CURVE[curve], w, common.ncpu())
+        assert bytes(out.cpu().numpy()) == w.raw
