@@ -40,10 +40,9 @@ int FixedBase<C>::build(const Affine<typename C::Fp>* d_base, size_t n, int wind
     // windows (56 GB, 13 additions per coefficient instead of 15: 7.4 against 6.65 M commits/s; build 0.43 s against 0.14 s).
     int cc = window_bits;
     const bool automatic = cc <= 0;
-    if (automatic) {
-        const char* e = getenv("PORLA_COMMIT_WINDOW");
-        cc = e ? atoi(e) : 20;
-    }
+    const char* env_w = getenv("PORLA_COMMIT_WINDOW");
+    const bool env_set = env_w && atoi(env_w) > 0;          // (PORLA_COMMIT_WINDOW=0 means what leaving it unset means: automatic)
+    if (automatic) cc = env_set ? atoi(env_w) : 20;
     if (cc < 2) cc = 2;
     if (cc > 20) cc = 20;
     PORLA_HIP(hipGetDevice(&device));
@@ -55,7 +54,7 @@ int FixedBase<C>::build(const Affine<typename C::Fp>* d_base, size_t n, int wind
     PORLA_HIP(hipMemGetInfo(&free_b, &total_b));
     free_b += table_cap;
     size_t budget = free_b / 4;
-    if (automatic && !getenv("PORLA_COMMIT_WINDOW")) {
+    if (automatic && !env_set) {
         const char* g = getenv("PORLA_COMMIT_TABLE_GB");
         const size_t cap = (size_t)((g ? atof(g) : 16.0) * 1073741824.0);
         if (cap < budget) budget = cap;
@@ -67,7 +66,7 @@ int FixedBase<C>::build(const Affine<typename C::Fp>* d_base, size_t n, int wind
     }
     // a narrower window that needs no more windows per coefficient halves the table for the same number of additions
     // (BN254: 255 signed bits are 15 windows of 18 bits -- and 15 of 17)
-    if (automatic && !getenv("PORLA_COMMIT_WINDOW"))
+    if (automatic && !env_set)
         while (cc > 4 && (C::SCALAR_BITS + 1 + (cc - 1) - 1) / (cc - 1) == (C::SCALAR_BITS + 1 + cc - 1) / cc) cc--;
     c = cc;
     W = (C::SCALAR_BITS + 1 + c - 1) / c;
