@@ -661,13 +661,40 @@ def main():
             cpu = {"value": round(n / cpu_s / 1e6, 4), "unit": "Mmul/s", "cores": cores, "kind": "port",
                    "sample": "the same 2^%d pairs, oracle/secp256k1_ref.c bucket MSM over %d threads (CPU restatement, "
                              "not libsecp256k1); %.1f s wall" % (args.log2n, cores, cpu_s)}
+        # the IPA build's own sizes (NUM_CHECK_AUDIT * height = 1 408 at 2^10 blocks, 3 200 at 2^24; abs(int32) coefficients,
+        # Server.hpp:838-848): one blocking MSM and the audit's pair over one scalar array, device-resident, against the oracle
+        ipa_sizes = None
+        if rank == 0 and world == 1 and not args.no_cpu:
+            try:
+                import random
+                rnd = random.Random(7)
+                a_sc = b"".join(rnd.getrandbits(31).to_bytes(32, "big") for _ in range(3200))
+                d_a = to_dev(a_sc)
+                ipa_sizes = {}
+                for m in (1408, 3200):
+                    pb = d_pt.data_ptr() + 64 * 64
+                    for _ in range(3):
+                        r1 = mx.msm_device("secp256k1", d_a.data_ptr(), d_pt.data_ptr(), m, stream)
+                        r2 = mx.msm_pair_device("secp256k1", d_a.data_ptr(), d_pt.data_ptr(), pb, m, stream)
+                    t1 = time.perf_counter()
+                    for _ in range(20):
+                        r1 = mx.msm_device("secp256k1", d_a.data_ptr(), d_pt.data_ptr(), m, stream)
+                    ms1 = (time.perf_counter() - t1) / 20 * 1e3
+                    t1 = time.perf_counter()
+                    for _ in range(20):
+                        r2 = mx.msm_pair_device("secp256k1", d_a.data_ptr(), d_pt.data_ptr(), pb, m, stream)
+                    ms2 = (time.perf_counter() - t1) / 20 * 1e3
+                    ok = r1 == common.oracle_secp_msm(a_sc, pt, m) and r2 == (r1, common.oracle_secp_msm(a_sc, pt[64 * 64:], m))
+                    ipa_sizes[str(m)] = {"ms": round(ms1, 4), "pair_ms": round(ms2, 4), "bit_exact_vs_oracle": ok}
+            except Exception as e:  # noqa: BLE001
+                ipa_sizes = {"error": repr(e)}
         return line("secp256k1 MSM Mscalar-mul/s at 2^20 pts", round(world * n * args.steps / el / 1e6, 3), "Mmul/s", el, "weak",
                     "u32x8 (256-bit modular integer)",
                     {"workload": "IPA scheme, 2^%d-point secp256k1 ecmult_multi per GPU (points 2^i*G, scalars "
                                  "SHA-256(\"ecmult\"||i) as bench_ecmult.c), blocking calls, inputs resident in HBM" % args.log2n,
                      "pairs_per_gpu": n, "input_gen_s": round(gen_s, 1)},
                     roofline(kern, MSM_BYTES_PER_PAIR * n, "secp256k1_msm", fe_mults), cpu, verified,
-                    result=result.hex() if result else None)
+                    result=result.hex() if result else None, audit_size_msm=ipa_sizes)
 
     # ---------------------------------------------------------------- ICC encode (config 5)
     def leg_icc():
