@@ -22,6 +22,15 @@
  *   porla_icc_encode_*       the CRebuild_Cached butterfly network, porla/Server/Server.hpp:1548-1687, and the
  *                            align_MAC scalar derivation, Server.hpp:531-541 (no function boundary exists
  *                            in the reference: INTEGRATION.md documents the patch site)
+ *   porla_icc_mac_encode_*   the MAC halves of the same network ("FFT in the exponent"), Server.hpp:1590-1609, 1658-1676
+ *   porla_icc_mix_*, porla_icc_mac_mix_*, porla_server_mix_device
+ *                            Server::mix, Server.hpp:1209-1328 (data rows, MAC commitments, MAC alignments; the last: all three)
+ *   porla_audit_combine_device, porla_*_msm_pair_*, porla_*_audit_msm_pair_*, porla_kzg_audit_device, porla_ipa_audit_device
+ *                            Server::audit after the challenge, Server.hpp:790-907: the row combine (:790-828), the two MSMs over
+ *                            one scalar array (:842-848 / :900-901), and -- the last two -- the whole audit in one call
+ *   porla_kzg_digest_batch_device, porla_kzg_complement_batch_device
+ *                            compute_digest / compute_digest_complement hoisted over the blocks of Client::initialize,
+ *                            Client.hpp:408-455
  *
  * Byte formats (identical to the reference's wire formats):
  *   scalar   32 bytes big-endian (bn254_scalar, utils.h:64,307-318); reduced mod the group order
