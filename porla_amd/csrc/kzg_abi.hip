@@ -34,7 +34,7 @@ namespace {
 // coefficients of 32 big-endian bytes (fr.SetBytes: reduced mod r), Horner from the top coefficient.  One lane per row.
 __global__ void __launch_bounds__(256)
 k_kzg_eval_rows(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_coeffs, Fe<Bn254Fr> tau, Fe<Bn254Fr> alpha,
-                uint8_t* __restrict__ out) {
+                uint8_t* __restrict__ out, uint32_t out_stride, const uint8_t* __restrict__ second) {
     using F = Bn254Fr;
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
@@ -47,7 +47,12 @@ k_kzg_eval_rows(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_co
         acc = fe_add<F>(fe_mul<F>(acc, tau), fe_to_mont<F>(c));
     }
     acc = fe_from_mont<F>(fe_mul<F>(acc, alpha));
-    store_be256(out + (size_t)r * 32, acc.v);
+    store_be256(out + (size_t)r * out_stride, acc.v);
+    if (second) {           // the MAC batch: the row's second scalar rides along (out_stride = 64)
+        const uint4* src = (const uint4*)(second + (size_t)r * 32);
+        uint4* dst = (uint4*)(out + (size_t)r * out_stride + 32);
+        dst[0] = src[0]; dst[1] = src[1];
+    }
 }
 
 // The same evaluation with EIGHT lanes per row in the reduced-radix plain stream of icc30.hip.h (modulus r = IccBn254Fr's q):
@@ -63,7 +68,8 @@ struct KzgEvalConsts {
     uint32_t alpha[8];   // alpha * 2^270 mod r
 };
 __global__ void __launch_bounds__(256)
-k_kzg_eval_rows30(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_coeffs, KzgEvalConsts K, uint8_t* __restrict__ out) {
+k_kzg_eval_rows30(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_coeffs, KzgEvalConsts K, uint8_t* __restrict__ out,
+                  uint32_t out_stride, const uint8_t* __restrict__ second) {
     using Q = IccBn254Fr;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t j = t & 7u;
@@ -74,6 +80,7 @@ k_kzg_eval_rows30(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_
     F30<Q> acc;
 #pragma unroll
     for (int l = 0; l < 9; l++) acc.v[l] = 0;
+    // (issuing the loads of four steps ahead of their products changes nothing: the chain is bound by its products, not its reads)
     for (uint32_t k = (n_coeffs + 7) / 8; k-- > 0;) {
         const uint32_t i = 8 * k + j;
         uint32_t c[8];
@@ -97,9 +104,15 @@ k_kzg_eval_rows30(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_
         for (int l = 0; l < 9; l++) o.v[l] = (uint32_t)__shfl_xor((int)acc.v[l], m);
         acc = icc30_add<Q>(acc, o);
     }
-    if (j != 0 || !live) return;
+    if (!live) return;
+    if (j == 1 && second) {     // the MAC batch: the row's second scalar rides along (out_stride = 64)
+        const uint4* src = (const uint4*)(second + (size_t)r * 32);
+        uint4* dst = (uint4*)(out + (size_t)r * out_stride + 32);
+        dst[0] = src[0]; dst[1] = src[1];
+    }
+    if (j != 0) return;
     const Fe<Q> res = icc30_canonical<Q>(icc30_reduce_top<Q>(icc30_mul<Q>(acc, f30_unpack<Q>(K.alpha))));
-    store_be256(out + (size_t)r * 32, res.v);
+    store_be256(out + (size_t)r * out_stride, res.v);
 }
 
 struct KzgState {
@@ -119,7 +132,9 @@ struct KzgState {
         size_t d_srs_cap = 0;
         unsigned long long srs_version = 0, g_version = 0, h_version = 0;   // what the tables below were built from
         FixedBase<Bn254G1> fb;        // window-multiples table of the SRS (fixed_base.hip.h)
+        unsigned long long gh_version = 0;
         FixedBase<Bn254G1> fb_g, fb_h;   // one-point tables of G1[0] and of the MAC hiding base (client-side batches)
+        FixedBase<Bn254G1> fb_gh;        // the two of them as one 2-point table (porla_kzg_mac_batch_device)
         void* d_eval = nullptr;       // scratch: evaluated scalars of a digest batch
         size_t d_eval_cap = 0;
     };
@@ -608,6 +623,48 @@ static int one_point_table(FixedBase<Bn254G1>& fb, unsigned long long& built_ver
     return PORLA_OK;
 }
 
+// alpha * f_r(tau) of n_rows rows into kd->d_eval at out_stride bytes per row (32, or 64 with a second scalar copied beside it).
+// g.mu and the mutex of the table whose commit reads d_eval are held by the caller.
+static int kzg_eval_rows_launch(KzgState::Dev* kd, const void* d_rows, size_t n_rows, uint32_t out_stride, const void* d_second,
+                                hipStream_t stream) {
+    int rc;
+    if (kd->d_eval_cap < n_rows * out_stride) {
+        if (kd->d_eval) PORLA_HIP(hipFree(kd->d_eval));      // hipFree waits for the work that still uses it
+        kd->d_eval = nullptr; kd->d_eval_cap = 0;
+        PORLA_HIP(hipMalloc(&kd->d_eval, n_rows * out_stride + 256));
+        kd->d_eval_cap = n_rows * out_stride + 256;
+    }
+    // d_eval is read by the commit that follows: a previous batch on another stream must have finished with it (each table's
+    // fence is recorded after its commit's last kernel; the three client-side tables share d_eval, so enter all of them)
+    if ((rc = kd->fb_g.fence.enter(stream))) return rc;
+    if ((rc = kd->fb_gh.fence.enter(stream))) return rc;
+    static const bool eval30 = !(getenv("PORLA_KZG_EVAL30") && getenv("PORLA_KZG_EVAL30")[0] == '0');
+    ProfScope ps("kzg_eval_rows", stream);
+    if (eval30) {
+        // tau^j, tau^8 and alpha in the 2^270 form: x 2^270 mod r = from_mont(x R * (2^270 R) / R)
+        static constexpr uint32_t C270[8] = {0x0ffead6fu, 0x36c69455u, 0x37577218u, 0xb1e9be3cu, 0xdf11f427u, 0x9e7d8ca3u, 0xed6d3304u, 0x279be39au};   // 2^270 mod r
+        Fe<Fr> c270;
+        for (int w = 0; w < 8; w++) c270.v[w] = C270[w];
+        c270 = fe_to_mont<Fr>(c270);
+        auto to270 = [&](const Fe<Fr>& xm, uint32_t* dst) {
+            const Fe<Fr> v = fe_from_mont<Fr>(fe_mul<Fr>(xm, c270));
+            for (int w = 0; w < 8; w++) dst[w] = v.v[w];
+        };
+        KzgEvalConsts K;
+        Fe<Fr> pw = fe_one<Fr>();
+        for (int jj = 0; jj < 8; jj++) { to270(pw, K.tj[jj]); pw = fe_mul<Fr>(pw, g.tau); }
+        to270(pw, K.t8);
+        to270(g.alpha, K.alpha);
+        hipLaunchKernelGGL(k_kzg_eval_rows30, dim3((unsigned)((8 * n_rows + 255) / 256)), dim3(256), 0, stream, (const uint8_t*)d_rows,
+                           (uint32_t)n_rows, (uint32_t)g.n_samples, K, (uint8_t*)kd->d_eval, out_stride, (const uint8_t*)d_second);
+    } else {
+        hipLaunchKernelGGL(k_kzg_eval_rows, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, (const uint8_t*)d_rows,
+                           (uint32_t)n_rows, (uint32_t)g.n_samples, g.tau, g.alpha, (uint8_t*)kd->d_eval, out_stride,
+                           (const uint8_t*)d_second);
+    }
+    return PORLA_OK;
+}
+
 int porla_kzg_digest_batch_device(const void* d_rows, size_t n_rows, void* d_out, void* hip_stream) {
     if (n_rows && (!d_rows || !d_out)) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
     int rc = ensure_device();
@@ -620,41 +677,35 @@ int porla_kzg_digest_batch_device(const void* d_rows, size_t n_rows, void* d_out
     if ((rc = one_point_table(kd->fb_g, kd->g_version, g.srs[0]))) return rc;
     hipStream_t stream = (hipStream_t)hip_stream;
     std::lock_guard<std::mutex> lk2(kd->fb_g.mu);
-    if (kd->d_eval_cap < n_rows * 32) {
-        if (kd->d_eval) PORLA_HIP(hipFree(kd->d_eval));      // hipFree waits for the work that still uses it
-        kd->d_eval = nullptr; kd->d_eval_cap = 0;
-        PORLA_HIP(hipMalloc(&kd->d_eval, n_rows * 32 + 256));
-        kd->d_eval_cap = n_rows * 32 + 256;
-    }
-    // d_eval is read by the commit below: a previous batch on another stream must have finished with it (the table's fence
-    // is recorded after that commit's last kernel)
-    if ((rc = kd->fb_g.fence.enter(stream))) return rc;
-    static const bool eval30 = !(getenv("PORLA_KZG_EVAL30") && getenv("PORLA_KZG_EVAL30")[0] == '0');
-    {
-        ProfScope ps("kzg_eval_rows", stream);
-        if (eval30) {
-            // tau^j, tau^8 and alpha in the 2^270 form: x 2^270 mod r = from_mont(x R * (2^270 R) / R)
-            static constexpr uint32_t C270[8] = {0x0ffead6fu, 0x36c69455u, 0x37577218u, 0xb1e9be3cu, 0xdf11f427u, 0x9e7d8ca3u, 0xed6d3304u, 0x279be39au};   // 2^270 mod r
-            Fe<Fr> c270;
-            for (int w = 0; w < 8; w++) c270.v[w] = C270[w];
-            c270 = fe_to_mont<Fr>(c270);
-            auto to270 = [&](const Fe<Fr>& xm, uint32_t* dst) {
-                const Fe<Fr> v = fe_from_mont<Fr>(fe_mul<Fr>(xm, c270));
-                for (int w = 0; w < 8; w++) dst[w] = v.v[w];
-            };
-            KzgEvalConsts K;
-            Fe<Fr> pw = fe_one<Fr>();
-            for (int jj = 0; jj < 8; jj++) { to270(pw, K.tj[jj]); pw = fe_mul<Fr>(pw, g.tau); }
-            to270(pw, K.t8);
-            to270(g.alpha, K.alpha);
-            hipLaunchKernelGGL(k_kzg_eval_rows30, dim3((unsigned)((8 * n_rows + 255) / 256)), dim3(256), 0, stream, (const uint8_t*)d_rows,
-                               (uint32_t)n_rows, (uint32_t)g.n_samples, K, (uint8_t*)kd->d_eval);
-        } else {
-            hipLaunchKernelGGL(k_kzg_eval_rows, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, (const uint8_t*)d_rows,
-                               (uint32_t)n_rows, (uint32_t)g.n_samples, g.tau, g.alpha, (uint8_t*)kd->d_eval);
-        }
-    }
+    if ((rc = kzg_eval_rows_launch(kd, d_rows, n_rows, 32, nullptr, stream))) return rc;
     return kd->fb_g.commit_device((const uint8_t*)kd->d_eval, n_rows, 1, 32, (uint8_t*)d_out, stream);
+}
+
+// The MAC of a block as the client forms it (Client.hpp:229/471 compute_commitment, :424-455 compute_MAC_complement, then add_point):
+//   out[r] = alpha * f_r(tau) * G1[0] + s_r * h_MAC
+// as ONE two-coefficient commitment per row against the table of (G1[0], h_MAC): one affine conversion per block where the two
+// batches spend two and the host one more for the sum.
+int porla_kzg_mac_batch_device(const void* d_rows, const void* d_scalars, size_t n_rows, void* d_out, void* hip_stream) {
+    if (n_rows && (!d_rows || !d_scalars || !d_out)) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!g.have_key || g.srs.empty()) { set_last_error("porla: init_key / init_SRS first"); return PORLA_ERR_STATE; }
+    if (n_rows == 0) return PORLA_OK;
+    KzgState::Dev* kd;
+    if ((rc = current_dev(&kd))) return rc;
+    if (kd->gh_version != g.version) {
+        uint8_t be[128];
+        h_affine_to_bytes<Fp>(be, g.srs[0]);
+        h_affine_to_bytes<Fp>(be + 64, g.h_mac);
+        std::lock_guard<std::mutex> lkb(kd->fb_gh.mu);
+        if ((rc = kd->fb_gh.build_from_host_bytes(be, 2, 0, engine_stream()))) return rc;
+        kd->gh_version = g.version;
+    }
+    hipStream_t stream = (hipStream_t)hip_stream;
+    std::lock_guard<std::mutex> lk2(kd->fb_gh.mu);
+    if ((rc = kzg_eval_rows_launch(kd, d_rows, n_rows, 64, d_scalars, stream))) return rc;
+    return kd->fb_gh.commit_device((const uint8_t*)kd->d_eval, n_rows, 2, 64, (uint8_t*)d_out, stream);
 }
 
 int porla_kzg_complement_batch_device(const void* d_scalars, size_t n, void* d_out, void* hip_stream) {

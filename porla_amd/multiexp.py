@@ -363,6 +363,12 @@ def kzg_complement_batch_device(d_scalars, n, d_out, stream=0):
     _check(lib.porla_kzg_complement_batch_device(ctypes.c_void_p(d_scalars), n, ctypes.c_void_p(d_out), ctypes.c_void_p(stream)))
 
 
+def kzg_mac_batch_device(d_rows, d_scalars, n_rows, d_out, stream=0):
+    """digest(row) + complement(scalar) per block, the MAC Client::initialize / update send (Client.hpp:229-236, 468-478)"""
+    _check(lib.porla_kzg_mac_batch_device(ctypes.c_void_p(d_rows), ctypes.c_void_p(d_scalars), n_rows, ctypes.c_void_p(d_out),
+                                          ctypes.c_void_p(stream)))
+
+
 def profile_enable(on=True):
     """False/0: off; True/1: HIP events around every kernel; 2: around the workload's dominant kernel only"""
     lib.porla_gpu_profile_enable(int(on))

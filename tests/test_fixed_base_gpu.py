@@ -200,6 +200,23 @@ def test_client_side_digest_and_complement_batches(mx):
     comp = bytes(d_out.cpu().numpy())
     for r in (0, 7, 299):
         assert comp[64 * r:64 * r + 64] == mx.compute_digest_complement(prf[r])
+    # the MAC batch: digest + complement joined as the client does with add_point (Client.hpp:229-236), every row; scalar 3 is
+    # zero (MAC = digest), row 1 is the zero block (MAC = complement), and the eval switch off gives the same bytes
+    scal = bytearray(scal)
+    scal[32 * 3:32 * 4] = bytes(32)
+    scal[32 * 5:32 * 6] = (R + 9).to_bytes(32, "big")          # a scalar >= r
+    d_sc = torch.frombuffer(scal, dtype=torch.uint8).cuda()
+    d_mac = torch.empty(64 * n_rows, dtype=torch.uint8, device="cuda")
+    mx.kzg_complement_batch_device(d_sc.data_ptr(), n_rows, d_out.data_ptr(), s)
+    mx.kzg_mac_batch_device(d_rows.data_ptr(), d_sc.data_ptr(), n_rows, d_mac.data_ptr(), s)
+    torch.cuda.synchronize()
+    comp = bytes(d_out.cpu().numpy())
+    macs = bytes(d_mac.cpu().numpy())
+    for r in range(n_rows):
+        assert macs[64 * r:64 * r + 64] == mx.bn254_add(got[64 * r:64 * r + 64], comp[64 * r:64 * r + 64]), r
+    assert macs[64 * 3:64 * 4] == got[64 * 3:64 * 4] and macs[64:128] == comp[64:128]
+    assert macs[64 * 5:64 * 6] == mx.bn254_add(got[64 * 5:64 * 6], mx.compute_digest_complement((9).to_bytes(16, "big")))
+    mx.kzg_mac_batch_device(d_rows.data_ptr(), d_sc.data_ptr(), 0, d_mac.data_ptr(), s)       # empty batch: nothing to do
 
 
 def test_eight_threads_call_the_plugin_concurrently(mx, srs128):

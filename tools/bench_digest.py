@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Client::initialize's block MACs in batches (porla_kzg_digest_batch_device = compute_digest hoisted over rows, main.go:70-89,
-Client.hpp:408-419; porla_kzg_complement_batch_device, main.go:91-101, Client.hpp:445-455) on device-resident blocks: ms per batch,
+Client.hpp:408-419; porla_kzg_complement_batch_device, main.go:91-101, Client.hpp:445-455; porla_kzg_mac_batch_device = both and the
+add_point that joins them, Client.hpp:229-236) on device-resident blocks: ms per batch,
 blocks/s, per-kernel HIP-event times and the HBM roofline of the evaluation kernel (4 096 algorithmic bytes in + 32 out per block).
 Rows 0, 1 and the last are checked against the library's own one-row symbol compute_digest (itself checked against the oracle by
 tests/test_fixed_base_gpu.py).
@@ -33,7 +34,8 @@ def main():
         d_sc[:, :16] = 0                              # 16-byte PRF outputs left-padded to 32 bytes
         res = {"blocks": n}
         for name, fn in (("digest", lambda: mx.kzg_digest_batch_device(d_rows.data_ptr(), n, d_out.data_ptr(), s)),
-                         ("complement", lambda: mx.kzg_complement_batch_device(d_sc.data_ptr(), n, d_out.data_ptr(), s))):
+                         ("complement", lambda: mx.kzg_complement_batch_device(d_sc.data_ptr(), n, d_out.data_ptr(), s)),
+                         ("mac", lambda: mx.kzg_mac_batch_device(d_rows.data_ptr(), d_sc.data_ptr(), n, d_out.data_ptr(), s))):
             for _ in range(3):
                 fn()
             torch.cuda.synchronize()
@@ -41,6 +43,12 @@ def main():
                 got = bytes(d_out.cpu().numpy())
                 ok = all(got[64 * r:64 * r + 64] == mx.compute_digest(bytes(d_rows[r].cpu().numpy())) for r in (0, 1, n - 1))
                 res["bit_exact_vs_compute_digest_rows_0_1_last"] = ok
+            if name == "mac":           # digest + complement joined on the host, three blocks
+                got = bytes(d_out.cpu().numpy())
+                res["mac_bit_exact_vs_digest_plus_complement_rows_0_1_last"] = all(
+                    got[64 * r:64 * r + 64] == mx.bn254_add(mx.compute_digest(bytes(d_rows[r].cpu().numpy())),
+                                                            mx.compute_digest_complement(bytes(d_sc[r, 16:].cpu().numpy())))
+                    for r in (0, 1, n - 1))
             reps = 20
             t0 = time.perf_counter()
             for _ in range(reps):
