@@ -3,7 +3,8 @@
 1 .. 20 000 challenged rows of both row formats, 1 .. 200 columns, edge-valued symbols and coefficients; oracle/icc_py.py), the
 gathered pair of MSMs (porla_*_audit_msm_pair_device: repeated indices, infinity entries, a point and its negative; oracle MSMs on the
 host-gathered arrays, both curves) and the digest batch (porla_kzg_digest_batch_device: coefficients >= r, zero rows; against the
-one-row symbol compute_digest, itself pinned to the oracle by tests/test_fixed_base_gpu.py).  usage: fuzz_audit.py [seconds] [seed]"""
+one-row symbol compute_digest, itself pinned to the oracle by tests/test_fixed_base_gpu.py; the MAC batch on the same rows against
+add_point(digest, complement), the complements against mult_point(h_MAC, scalar)).  usage: fuzz_audit.py [seconds] [seed]"""
 import os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -115,7 +116,21 @@ def digest_case():
     torch.cuda.synchronize()
     got = bytes(d_out.cpu().numpy())
     check = sorted(set([0, n - 1] + [rnd.randrange(n) for _ in range(4)]))
-    return all(got[64 * r:64 * r + 64] == mx.compute_digest(rows[4096 * r:4096 * r + 4096]) for r in check), ("digest", n)
+    ok = all(got[64 * r:64 * r + 64] == mx.compute_digest(rows[4096 * r:4096 * r + 4096]) for r in check)
+    # the MAC batch on the same rows: digest + complement(scalar), scalars with the edge values too
+    sc = bytearray(b"".join(bytes(16) + rnd.randbytes(16) for _ in range(n)))
+    for _ in range(rnd.randrange(0, 4)):
+        r = rnd.randrange(n)
+        sc[32 * r:32 * r + 32] = rnd.choice([0, 1, R - 1, R, R + 1, (1 << 256) - 1]).to_bytes(32, "big")
+    d_sc, d_mac = dev(bytes(sc)), torch.empty(64 * n, dtype=torch.uint8, device="cuda")
+    mx.kzg_complement_batch_device(d_sc.data_ptr(), n, d_out.data_ptr(), stream)
+    mx.kzg_mac_batch_device(d_rows.data_ptr(), d_sc.data_ptr(), n, d_mac.data_ptr(), stream)
+    torch.cuda.synchronize()
+    comp, macs = bytes(d_out.cpu().numpy()), bytes(d_mac.cpu().numpy())
+    ok = ok and all(macs[64 * r:64 * r + 64] == mx.bn254_add(got[64 * r:64 * r + 64], comp[64 * r:64 * r + 64]) for r in range(n))
+    ok = ok and all(comp[64 * r:64 * r + 64] == mx.bn254_mult(mx.compute_digest_complement((1).to_bytes(16, "big")), bytes(sc[32 * r:32 * r + 32]))
+                    for r in check)
+    return ok, ("digest", n)
 
 
 t_end = time.time() + seconds
