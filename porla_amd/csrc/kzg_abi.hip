@@ -115,6 +115,116 @@ k_kzg_eval_rows30(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_
     store_be256(out + (size_t)r * out_stride, res.v);
 }
 
+// The evaluation as a DOT PRODUCT with the reduction left to the end: f(tau) = sum_i c_i tau^i with the powers of tau in a table
+// (9 limbs of 29 bits each, staged in LDS), lane j of a row's eight taking i = 8k + j.  A coefficient times a power is 81
+// multiply-adds into 17 64-bit columns and nothing else -- no reduction, no carries: limbs below 2^29 make a column's nine
+// products of one coefficient < 2^61.2, so SIX coefficients accumulate before the columns are rippled (6 * 9 * 2^58 + 2^29 <
+// 2^64) -- where the Horner form above pays a full modular product (81 + 90 multiply-adds and the carries) per coefficient.
+// The lane's sum (< steps * 2^510) is then three 256-bit pieces hi, mid, lo joined by two products with 2^256 in the 2^270 form,
+// and from there the lanes are summed, multiplied by alpha and reduced exactly as in k_kzg_eval_rows30.
+constexpr int KZG_LAZY_ENTRY_WORDS = 12;      // 9 limbs + 3 words of padding: three 16-byte LDS reads per power
+constexpr uint32_t KZG_LAZY_MAX_COEFFS = 1024;
+constexpr uint32_t KZG_M29 = (1u << 29) - 1u;
+constexpr int KZG_LAZY_GROUP = 6;              // coefficients accumulated between two ripples of the columns
+// (reading all six coefficients of a group ahead of their products: 142 registers, 0.51 ms against 0.46 at 2^19 rows; one step
+// ahead, as below: 0.44)
+__device__ __forceinline__ void kzg_unpack29(const uint32_t w[8], uint32_t out[9]) {
+#pragma unroll
+    for (int l = 0; l < 9; l++) {
+        const int bit = 29 * l, i = bit >> 5, sft = bit & 31;
+        const uint64_t two = (uint64_t)w[i] | (i + 1 < 8 ? (uint64_t)w[i + 1] << 32 : 0ull);
+        out[l] = (uint32_t)(two >> sft) & KZG_M29;
+    }
+}
+__device__ __forceinline__ void kzg_ripple29(uint64_t (&col)[19]) {
+    uint64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 19; k++) {
+        const uint64_t t = col[k] + carry;
+        col[k] = t & KZG_M29;
+        carry = t >> 29;
+    }
+}
+struct KzgAlpha270 { uint32_t w[8]; };       // alpha * 2^270 mod r
+__global__ void __launch_bounds__(256)
+k_kzg_eval_rows_lazy(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_coeffs, const uint32_t* __restrict__ tau29,
+                     KzgAlpha270 A, uint8_t* __restrict__ out, uint32_t out_stride, const uint8_t* __restrict__ second) {
+    using Q = IccBn254Fr;
+    extern __shared__ uint4 kzg_lds_tau[];            // [8 * steps][KZG_LAZY_ENTRY_WORDS] words, zero beyond n_coeffs
+    const uint32_t steps = (n_coeffs + 7) / 8;
+    for (uint32_t i = threadIdx.x; i < steps * 8u * (KZG_LAZY_ENTRY_WORDS / 4); i += blockDim.x)
+        kzg_lds_tau[i] = reinterpret_cast<const uint4*>(tau29)[i];
+    __syncthreads();
+    const uint32_t j = threadIdx.x & 7u;
+    const F30<Q> C526 = f30_const<Q>(Icc30Const<Q>::C526);
+    // a block takes 32 rows at a time, grid-strided: the table above is staged once per block, not once per 32 rows
+    for (uint32_t r0 = blockIdx.x * (blockDim.x >> 3); r0 < n_rows; r0 += gridDim.x * (blockDim.x >> 3)) {
+        const uint32_t rr = r0 + (threadIdx.x >> 3);
+        const bool live = rr < n_rows;
+        const uint32_t r = live ? rr : n_rows - 1;            // idle lanes redo the last row (the lane sum below is wave-wide)
+        const uint8_t* row = rows + (size_t)r * n_coeffs * 32;
+        uint64_t col[19];
+#pragma unroll
+        for (int k = 0; k < 19; k++) col[k] = 0;
+        uint32_t since = 0;
+        uint4 nhi = make_uint4(0, 0, 0, 0), nlo = nhi;        // the next step's coefficient, read one step ahead of its products
+        if (j < n_coeffs) { nhi = reinterpret_cast<const uint4*>(row + (size_t)j * 32)[0]; nlo = reinterpret_cast<const uint4*>(row + (size_t)j * 32)[1]; }
+        for (uint32_t k = 0; k < steps; k++) {
+            const uint32_t i = 8 * k + j;
+            const uint4 chi = nhi, clo = nlo;
+            nhi = make_uint4(0, 0, 0, 0); nlo = nhi;
+            if (i + 8 < n_coeffs) {
+                const uint4* q = reinterpret_cast<const uint4*>(row + (size_t)(i + 8) * 32);
+                nhi = q[0]; nlo = q[1];
+            }
+            const uint32_t c[8] = {__builtin_bswap32(clo.w), __builtin_bswap32(clo.z), __builtin_bswap32(clo.y), __builtin_bswap32(clo.x),
+                                   __builtin_bswap32(chi.w), __builtin_bswap32(chi.z), __builtin_bswap32(chi.y), __builtin_bswap32(chi.x)};
+            uint32_t x[9];
+            kzg_unpack29(c, x);
+            const uint4* tp = kzg_lds_tau + (size_t)i * (KZG_LAZY_ENTRY_WORDS / 4);
+            const uint4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+            const uint32_t y[9] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x};
+#pragma unroll
+            for (int a = 0; a < 9; a++)
+#pragma unroll
+                for (int b = 0; b < 9; b++) col[a + b] += (uint64_t)x[a] * y[b];
+            if (++since == KZG_LAZY_GROUP) { kzg_ripple29(col); since = 0; }
+        }
+        kzg_ripple29(col);
+        // 19 limbs of 29 bits -> 17 words of 32: lo = words 0..7, mid = 8..15, hi = word 16 (the sum is below 2^517 for 1024 coefficients)
+        uint32_t W[17];
+#pragma unroll
+        for (int w = 0; w < 17; w++) {
+            const int bit = 32 * w, l = bit / 29, sft = bit % 29;
+            uint64_t v = col[l] >> sft;
+            if (l + 1 < 19) v |= col[l + 1] << (29 - sft);
+            if (l + 2 < 19 && 58 - sft < 32) v |= col[l + 2] << (58 - sft);
+            W[w] = (uint32_t)v;
+        }
+        uint32_t hi[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) hi[w] = w == 0 ? W[16] : 0u;
+        F30<Q> acc = icc30_add<Q>(icc30_mul<Q>(f30_unpack<Q>(hi), C526), f30_unpack<Q>(W + 8));
+        acc = icc30_add<Q>(icc30_mul<Q>(acc, C526), f30_unpack<Q>(W));
+#pragma unroll
+        for (int m = 1; m < 8; m <<= 1) {
+            F30<Q> o;
+#pragma unroll
+            for (int l = 0; l < 9; l++) o.v[l] = (uint32_t)__shfl_xor((int)acc.v[l], m);
+            acc = icc30_add<Q>(acc, o);
+        }
+        if (!live) continue;
+        if (j == 1 && second) {     // the MAC batch: the row's second scalar rides along (out_stride = 64)
+            const uint4* src = (const uint4*)(second + (size_t)r * 32);
+            uint4* dst = (uint4*)(out + (size_t)r * out_stride + 32);
+            dst[0] = src[0]; dst[1] = src[1];
+        }
+        if (j != 0) continue;
+        const Fe<Q> res = icc30_canonical<Q>(icc30_reduce_top<Q>(icc30_mul<Q>(acc, f30_unpack<Q>(A.w))));
+        store_be256(out + (size_t)r * out_stride, res.v);
+    }
+}
+
 struct KzgState {
     std::mutex mu;
     bool have_key = false;
@@ -137,6 +247,9 @@ struct KzgState {
         FixedBase<Bn254G1> fb_gh;        // the two of them as one 2-point table (porla_kzg_mac_batch_device)
         void* d_eval = nullptr;       // scratch: evaluated scalars of a digest batch
         size_t d_eval_cap = 0;
+        void* d_tau29 = nullptr;      // powers of tau in 29-bit limbs (k_kzg_eval_rows_lazy), for the key and row length below
+        Fe<Fr> tau29_tau;
+        uint32_t tau29_n = 0;
     };
     Dev* devs[16] = {nullptr};
     bool have_g2 = false;
@@ -639,10 +752,48 @@ static int kzg_eval_rows_launch(KzgState::Dev* kd, const void* d_rows, size_t n_
     if ((rc = kd->fb_g.fence.enter(stream))) return rc;
     if ((rc = kd->fb_gh.fence.enter(stream))) return rc;
     static const bool eval30 = !(getenv("PORLA_KZG_EVAL30") && getenv("PORLA_KZG_EVAL30")[0] == '0');
+    static const bool lazy = eval30 && !(getenv("PORLA_KZG_EVAL_LAZY") && getenv("PORLA_KZG_EVAL_LAZY")[0] == '0');
+    // x 2^270 mod r = from_mont(x R * (2^270 R) / R)
+    static constexpr uint32_t C270[8] = {0x0ffead6fu, 0x36c69455u, 0x37577218u, 0xb1e9be3cu, 0xdf11f427u, 0x9e7d8ca3u, 0xed6d3304u, 0x279be39au};   // 2^270 mod r
+    const uint32_t n_coeffs = (uint32_t)g.n_samples;
+    if (lazy && n_coeffs <= KZG_LAZY_MAX_COEFFS) {
+        const uint32_t entries = (n_coeffs + 7) / 8 * 8;
+        if (!kd->d_tau29 || kd->tau29_n != n_coeffs || memcmp(kd->tau29_tau.v, g.tau.v, sizeof(g.tau.v)) != 0) {
+            std::vector<uint32_t> tab((size_t)entries * KZG_LAZY_ENTRY_WORDS, 0u);
+            Fe<Fr> pw = fe_one<Fr>();
+            for (uint32_t i = 0; i < n_coeffs; i++) {
+                const Fe<Fr> plain = fe_from_mont<Fr>(pw);
+                for (int l = 0; l < 9; l++) {
+                    const int bit = 29 * l, w = bit >> 5, sft = bit & 31;
+                    const uint64_t two = (uint64_t)plain.v[w] | (w + 1 < 8 ? (uint64_t)plain.v[w + 1] << 32 : 0ull);
+                    tab[(size_t)i * KZG_LAZY_ENTRY_WORDS + l] = (uint32_t)(two >> sft) & KZG_M29;
+                }
+                pw = fe_mul<Fr>(pw, g.tau);
+            }
+            if (kd->d_tau29) PORLA_HIP(hipFree(kd->d_tau29));     // waits for the evaluations that still read the old table
+            kd->d_tau29 = nullptr; kd->tau29_n = 0;
+            PORLA_HIP(hipMalloc(&kd->d_tau29, tab.size() * 4));
+            PORLA_HIP(hipMemcpy(kd->d_tau29, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+            kd->tau29_tau = g.tau;
+            kd->tau29_n = n_coeffs;
+        }
+        Fe<Fr> c270;
+        for (int w = 0; w < 8; w++) c270.v[w] = C270[w];
+        c270 = fe_to_mont<Fr>(c270);
+        const Fe<Fr> a270 = fe_from_mont<Fr>(fe_mul<Fr>(g.alpha, c270));
+        KzgAlpha270 A;
+        for (int w = 0; w < 8; w++) A.w[w] = a270.v[w];
+        ProfScope ps("kzg_eval_rows", stream);
+        constexpr size_t lazy_grid = 2048;        // 1024 .. 16384 blocks measure the same (profiles/r03_zw_bench_digest_lazy_grid.log)
+        const size_t groups = (n_rows + 31) / 32;
+        hipLaunchKernelGGL(k_kzg_eval_rows_lazy, dim3((unsigned)(groups < lazy_grid ? groups : lazy_grid)), dim3(256),
+                           (size_t)entries * KZG_LAZY_ENTRY_WORDS * 4, stream, (const uint8_t*)d_rows, (uint32_t)n_rows, n_coeffs,
+                           (const uint32_t*)kd->d_tau29, A, (uint8_t*)kd->d_eval, out_stride, (const uint8_t*)d_second);
+        return PORLA_OK;
+    }
     ProfScope ps("kzg_eval_rows", stream);
     if (eval30) {
-        // tau^j, tau^8 and alpha in the 2^270 form: x 2^270 mod r = from_mont(x R * (2^270 R) / R)
-        static constexpr uint32_t C270[8] = {0x0ffead6fu, 0x36c69455u, 0x37577218u, 0xb1e9be3cu, 0xdf11f427u, 0x9e7d8ca3u, 0xed6d3304u, 0x279be39au};   // 2^270 mod r
+        // tau^j, tau^8 and alpha in the 2^270 form
         Fe<Fr> c270;
         for (int w = 0; w < 8; w++) c270.v[w] = C270[w];
         c270 = fe_to_mont<Fr>(c270);
@@ -987,6 +1138,8 @@ int porla_kzg_release_device_memory(void) {
         kd->d_srs = nullptr; kd->d_srs_cap = 0;
         if (kd->d_eval) (void)hipFree(kd->d_eval);
         kd->d_eval = nullptr; kd->d_eval_cap = 0;
+        if (kd->d_tau29) (void)hipFree(kd->d_tau29);
+        kd->d_tau29 = nullptr; kd->tau29_n = 0;
         kd->srs_version = kd->g_version = kd->h_version = 0;
     }
     (void)hipSetDevice(cur);

@@ -219,6 +219,32 @@ def test_client_side_digest_and_complement_batches(mx):
     mx.kzg_mac_batch_device(d_rows.data_ptr(), d_sc.data_ptr(), 0, d_mac.data_ptr(), s)       # empty batch: nothing to do
 
 
+@pytest.mark.parametrize("n_coeffs", [1, 7, 8, 9, 100, 1024, 1025])
+def test_digest_batch_row_lengths(mx, n_coeffs):
+    """the digest batch's evaluation kernels at row lengths other than the reference's 128 (init_SRS takes any size): lengths that
+    are not a multiple of the eight lanes of a row, the longest row the dot-product kernel stages in LDS (1024) and one beyond it
+    (Horner form); coefficients >= r and all-ones among them; a key change between two batches must not reuse the powers of tau"""
+    import torch
+    n_rows = 19
+    rows = bytearray(hashlib.shake_256(b"rowlen%d" % n_coeffs).digest(32 * n_coeffs * n_rows))
+    rows[0:32] = b"\xff" * 32
+    rows[32 * (n_coeffs - 1):32 * n_coeffs] = (R + 1).to_bytes(32, "big")
+    rows = bytes(rows)
+    s = torch.cuda.current_stream().cuda_stream
+    d_rows = torch.frombuffer(bytearray(rows), dtype=torch.uint8).cuda()
+    d_out = torch.empty(64 * n_rows, dtype=torch.uint8, device="cuda")
+    for key in ((TAU, ALPHA), (ALPHA, TAU)):
+        mx.init_key(*key)
+        mx.init_SRS(n_coeffs)
+        mx.kzg_digest_batch_device(d_rows.data_ptr(), n_rows, d_out.data_ptr(), s)
+        torch.cuda.synchronize()
+        got = bytes(d_out.cpu().numpy())
+        for r in range(n_rows):
+            assert got[64 * r:64 * r + 64] == mx.compute_digest(rows[32 * n_coeffs * r:32 * n_coeffs * (r + 1)]), (n_coeffs, r)
+    mx.init_key(TAU, ALPHA)
+    mx.init_SRS(128)
+
+
 def test_eight_threads_call_the_plugin_concurrently(mx, srs128):
     """the server calls compute_digest_from_srs / add_point / mult_point / neg_point from 8 pool threads at once
     (porla/Server/Server.hpp:1054-1078, 1530-1535, 1600-1608); ctypes releases the GIL, so these really overlap"""
