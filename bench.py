@@ -28,6 +28,8 @@ cpu_baseline and bit_exact_vs_oracle, timed separately after the headline region
   kzg_audit       ONE server-side KZG audit at the reference's size (3 200 challenged rows of a 2^15-block level resident in HBM):
                   row combine, the two MSMs over the challenged MACs, align_MAC's commitment and create_proof behind
                   porla_kzg_audit_device; audits/s, checked against what the client verifies; N = 1 only            
+  client_mac_batch  the block MACs of Client::initialize (digest + complement + add_point per block) for 2^17 blocks resident in
+                  HBM behind porla_kzg_mac_batch_device; blocks/s, three blocks checked on the oracle's arithmetic; N = 1 only (s8 a4)
 and, for the headline MSM: `blocking_ms_per_step` + `blocking_kernels_ms` (one MSM in flight: what a caller that waits for
 every result sees, with its own per-kernel breakdown), `audit_size_msm` (128 / 1 408 / 3 200 pairs: the sizes the reference
 issues), `host_boundary` (compute_multi_exp on caller-owned pageable host buffers, PCIe included).
@@ -123,7 +125,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="bn254_msm",
-                    choices=["bn254_msm", "kzg_commit", "secp256k1_msm", "icc", "config3", "crebuild", "audit_combine", "kzg_audit"])
+                    choices=["bn254_msm", "kzg_commit", "secp256k1_msm", "icc", "config3", "crebuild", "audit_combine", "kzg_audit",
+                             "client_mac_batch"])
     ap.add_argument("--log2n", type=int, default=20, help="MSM pairs per GPU = 2^log2n (default: the 2^20 of BASELINE.json)")
     ap.add_argument("--log2rows", type=int, default=17, help="kzg_commit rows per GPU = 2^log2rows; icc rows = 2^(log2rows-2)")
     ap.add_argument("--log2job", type=int, default=24, help="config3: pairs of the whole job = 2^log2job, split over the ranks")
@@ -332,7 +335,11 @@ def main():
         return d
 
     # ---------------------------------------------------------------- KZG batched commitments
+    kzg_cache = []
+
     def kzg_setup():
+        if kzg_cache:                                               # one key, one SRS per run: the legs share them
+            return kzg_cache[0]
         tau = bytes.fromhex("ffeeddccbbaa99887766554433221100")     # TAU_KEY, config.hpp:39
         alpha = bytes.fromhex("00112233445566778899aabbccddeeff")   # SECRET_KEY, config.hpp:38
         mx.init_key(tau, alpha)
@@ -343,6 +350,7 @@ def main():
         o.oracle_kzg_init_srs(ctypes.c_size_t(128), (1).to_bytes(32, "big"))
         raw = ctypes.create_string_buffer(64 * 128)
         o.oracle_kzg_srs_g1_raw(raw)
+        kzg_cache.append(raw.raw)
         return raw.raw
 
     def leg_kzg_commit():
@@ -784,9 +792,69 @@ def main():
             raise RuntimeError("bench_audit_flow.py failed: rc=%d %s" % (r.returncode, r.stderr[-400:]))
         return json.loads(lines[-1])
 
+    # ---------------------------------------------------------------- the client's block MACs in batches
+    def leg_client_mac_batch():
+        kzg_setup()
+        o = common.oracle()
+        n = 1 << 17
+        gen = torch.Generator(device="cuda").manual_seed(11)
+        d_rows = torch.randint(0, 256, (n, 4096), dtype=torch.uint8, device="cuda", generator=gen)
+        d_sc = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=gen)
+        d_sc[:, :16] = 0                                            # 16-byte PRF outputs (Client.hpp:424-455), left-padded
+        d_out = torch.empty(64 * n, dtype=torch.uint8, device="cuda")
+        s = torch.cuda.current_stream().cuda_stream
+        calls = {"digest_batch": lambda: mx.kzg_digest_batch_device(d_rows.data_ptr(), n, d_out.data_ptr(), s),
+                 "complement_batch": lambda: mx.kzg_complement_batch_device(d_sc.data_ptr(), n, d_out.data_ptr(), s),
+                 "mac_batch": lambda: mx.kzg_mac_batch_device(d_rows.data_ptr(), d_sc.data_ptr(), n, d_out.data_ptr(), s)}
+        ms = {}
+        for name, fn in calls.items():
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
+            ms[name] = (time.perf_counter() - t0) / 20 * 1e3
+        got = bytes(d_out.cpu().numpy())                            # the MAC batch ran last
+        mx.profile_enable(True)
+        for _ in range(5):
+            calls["mac_batch"]()
+        torch.cuda.synchronize()
+        prof = {k: round(t / c, 4) for k, t, c in mx.profile_get()}
+        mx.profile_enable(False)
+        verified = None
+        if not args.no_cpu:
+            # MAC = compute_digest(block) + PRF * h_MAC on the oracle's arithmetic; the hiding base is this run's (drawn by init_SRS)
+            h_mac = mx.compute_digest_complement((1).to_bytes(16, "big"))
+            verified = True
+            for r in (0, 1, n - 1):
+                want = ctypes.create_string_buffer(64)
+                o.oracle_kzg_compute_digest(bytes(d_rows[r].cpu().numpy()), want)
+                comp = ctypes.create_string_buffer(h_mac, 64)
+                o.oracle_bn254_mult_point(comp, bytes(d_sc[r].cpu().numpy()))
+                o.oracle_bn254_add_point(want, comp.raw)
+                verified = verified and got[64 * r:64 * r + 64] == want.raw
+        alg = n * (4096 + 32 + 64)
+        ev = prof.get("kzg_eval_rows")
+        return {"metric": "client block MACs/s (digest + complement + add_point per block, 2^17 blocks of 128 coefficients)",
+                "value": round(n / ms["mac_batch"] * 1e3, 1), "unit": "blocks/s", "n_gpus": world, "steps": 20, "warmup": 5,
+                "ms_per_step": round(ms["mac_batch"], 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "data": "synthetic",
+                "dtype": "u32 limbs (29-bit columns, exact; 256-bit modular)",
+                "config": {"workload": "Client::initialize's block MACs (Client.hpp:216-236, 408-455) as one batch on blocks resident "
+                                       "in HBM", "blocks": n},
+                "separate_batches_ms": {"digest_batch": round(ms["digest_batch"], 4), "complement_batch": round(ms["complement_batch"], 4),
+                                        "note": "plus one host add_point per block (3.7 us each) without the MAC batch"},
+                "kernels_ms": prof,
+                "roofline": {"bound": "hbm", "kernel": "k_kzg_eval_rows_lazy", "achieved": round(n * 4128 / ev / 1e6, 1) if ev else None,
+                             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(n * 4128 / ev / 1e6 / HBM_PEAK_GBPS, 4) if ev else None,
+                             "traffic": None, "algorithmic_bytes_per_batch": alg},
+                "bit_exact_vs_oracle": verified}
+
     # ---------------------------------------------------------------- the line
     legs = {"bn254_msm": leg_bn254_msm, "kzg_commit": leg_kzg_commit, "secp256k1_msm": leg_secp256k1_msm, "icc": leg_icc,
-            "config3": leg_config3, "audit_combine": leg_audit_combine}
+            "config3": leg_config3, "audit_combine": leg_audit_combine, "client_mac_batch": leg_client_mac_batch}
     out = legs[args.workload]()
     if args.workload == "bn254_msm":
         # every other BASELINE.json configuration rides on the default line
@@ -798,6 +866,8 @@ def main():
             if world == 1:
                 extra.append(("audit_combine", leg_audit_combine))
                 extra.append(("kzg_audit", leg_kzg_audit))
+                if not args.no_commits:
+                    extra.append(("client_mac_batch", leg_client_mac_batch))
             if not args.no_config3:
                 extra.append(("config3", leg_config3))
         for name, fn in extra:
