@@ -1129,18 +1129,19 @@ int porla_kzg_release_device_memory(void) {
     (void)hipGetDevice(&cur);
     for (KzgState::Dev* kd : g.devs) {
         if (!kd) continue;
-        std::lock_guard<std::mutex> l1(kd->fb.mu), l2(kd->fb_g.mu), l3(kd->fb_h.mu);
+        std::lock_guard<std::mutex> l1(kd->fb.mu), l2(kd->fb_g.mu), l3(kd->fb_h.mu), l4(kd->fb_gh.mu);
         (void)hipSetDevice(kd->device);
         kd->fb.release();
         kd->fb_g.release();
         kd->fb_h.release();
+        kd->fb_gh.release();
         if (kd->d_srs) (void)hipFree(kd->d_srs);
         kd->d_srs = nullptr; kd->d_srs_cap = 0;
         if (kd->d_eval) (void)hipFree(kd->d_eval);
         kd->d_eval = nullptr; kd->d_eval_cap = 0;
         if (kd->d_tau29) (void)hipFree(kd->d_tau29);
         kd->d_tau29 = nullptr; kd->tau29_n = 0;
-        kd->srs_version = kd->g_version = kd->h_version = 0;
+        kd->srs_version = kd->g_version = kd->h_version = kd->gh_version = 0;
     }
     (void)hipSetDevice(cur);
     return PORLA_OK;

@@ -291,6 +291,21 @@ def test_release_device_memory_and_rebuild(mx, srs128):
     assert lib.porla_kzg_release_device_memory() == 0
     assert torch.cuda.mem_get_info()[0] > free0 + (1 << 30)          # the table alone is tens of GB
     assert mx.kzg_commit_batch_host(rows, 3) == a
+    # the client-side batches keep tables and the powers of tau on the device too: same bytes before and after a release
+    mx.init_key(TAU, ALPHA)
+    blob = mx.init_SRS(128)
+    d_rows = torch.frombuffer(bytearray(rows), dtype=torch.uint8).cuda()
+    d_sc = torch.frombuffer(bytearray(b"".join(bytes(16) + hashlib.sha256(b"rel%d" % i).digest()[:16] for i in range(3))), dtype=torch.uint8).cuda()
+    outs = []
+    for _ in range(2):
+        d_out = torch.zeros(64 * 3 * 2, dtype=torch.uint8, device="cuda")
+        mx.kzg_digest_batch_device(d_rows.data_ptr(), 3, d_out.data_ptr(), 0)
+        mx.kzg_mac_batch_device(d_rows.data_ptr(), d_sc.data_ptr(), 3, d_out.data_ptr() + 192, 0)
+        torch.cuda.synchronize()
+        outs.append(bytes(d_out.cpu().numpy()))
+        assert lib.porla_kzg_release_device_memory() == 0
+    assert outs[0] == outs[1] and outs[0][:64] == mx.compute_digest(rows[:4096])
+    mx.init_SRS_from_data(128, blob)
 
 
 @pytest.mark.parametrize("n_rows", [1, 2, 31, 32, 33, 63, 64, 65])
