@@ -10,7 +10,7 @@ namespace porla {
 // Inversion without the exponentiation: Bernstein-Yang division steps ("Fast constant-time gcd computation and modular
 // inversion", 2019) on (f, g) = (p, V), 30 steps at a time on the low words with the steps' 2 x 2 transition matrix applied to
 // the full-size f, g and -- modulo p -- to the cofactors d, e (d V = f mod p throughout).  741 steps suffice for 256-bit inputs
-// (Theorem 11.2: floor((49 * 256 + 57) / 17)); 25 rounds of 30 are run, every lane the same instructions.  Numbers are nine
+// (Theorem 11.2: floor((49 * 256 + 57) / 17)); at most 25 rounds of 30 are run, every lane of a wave the same instructions.  Numbers are nine
 // signed limbs of 30 bits (limbs 0..7 in [0, 2^30), limb 8 carries the sign); all products fit 64-bit signed accumulators
 // because |u| + |v| <= 2^30 for a matrix row.  ~22 k simple instructions against the 381 dependent field products of a^(p-2)
 // (fixed_base.hip.h:fe_inv_dev: 0.32 ms for a lone wave in the 8 x 32-bit form, 0.18 ms with the reduced-radix product).  tools/safegcd_model.py is the same procedure on Python integers with the 32 / 64-bit ranges asserted.
@@ -34,6 +34,15 @@ __device__ __noinline__ F30<M> f30_inv_safegcd_raw(Fe<M> a) {
     int32_t delta = 1;
 #pragma unroll 1
     for (int round = 0; round < 25; round++) {
+        // once g = 0 a round changes nothing that matters: its matrix is [[2^30, 0], [0, 1]], so f stays and d stays modulo p (a
+        // negative d becomes d + p) -- the wave leaves as soon as every lane is there (~20 rounds for random inputs, not 25); the
+        // result bytes are those of the full 25 rounds
+        if (round >= 8) {
+            int32_t nz = g[0];
+#pragma unroll
+            for (int i = 1; i < 9; i++) nz |= g[i];
+            if (!__any(nz != 0)) break;
+        }
         uint32_t f0 = (uint32_t)f[0] | ((uint32_t)f[1] << 30), g0 = (uint32_t)g[0] | ((uint32_t)g[1] << 30);
         int32_t u = 1, v = 0, q = 0, r = 1;
 #pragma unroll 6
