@@ -472,8 +472,12 @@ k_fb_fold_quad(XYZZ<typename C::Fp>* __restrict__ partial, uint32_t n_rows, uint
 // a lane takes FB_FINISH_ROWS rows: partial[row * S] -> affine with ONE inversion for the lane's rows (Montgomery's trick: the
 // inversion is a chain of ~380 dependent products, a row's share of the trick three), Montgomery -> big-endian X||Y (64 zero
 // bytes = infinity).  Rows of a lane are block-strided so that neighbouring lanes still read neighbouring rows.
-constexpr int FB_FINISH_ROWS = 4;
-template <class C>
+// Up to FB_FINISH_SPREAD rows (two waves per compute unit) a lane takes ONE row, up to twice that two: the chip is idle otherwise,
+// and the three products per row of the trick plus the conversions of four rows are a third of the lane's dependent chain
+// (0.078 -> 0.054 ms up to 16 384 rows, 0.057 at 32 768; at 65 536 rows one row per lane loses: 0.085 against 0.080).
+constexpr int FB_FINISH_ROWS_MAX = 4;
+constexpr size_t FB_FINISH_SPREAD = 32768;
+template <class C, int FB_FINISH_ROWS>
 __global__ void __launch_bounds__(64)
 k_fb_finish(const XYZZ<typename C::Fp>* __restrict__ partial, uint32_t n_rows, uint32_t S, uint8_t* __restrict__ out) {
     using M = typename C::Fp;

@@ -174,8 +174,17 @@ int FixedBase<C>::commit_device(const uint8_t* d_rows, size_t n_rows, size_t n_c
     last_S = S;
     if (d_out) {
         ProfScope ps("fb_finish", stream);
-        hipLaunchKernelGGL((k_fb_finish<C>), dim3((unsigned)((n_rows + 64 * FB_FINISH_ROWS - 1) / (64 * FB_FINISH_ROWS))), dim3(64), 0, stream,
-                           (const XYZZ<M>*)partial, (uint32_t)n_rows, S, d_out);
+        static const size_t spread = getenv("PORLA_FB_FINISH_SPREAD") ? (size_t)atol(getenv("PORLA_FB_FINISH_SPREAD")) : FB_FINISH_SPREAD;
+        if (n_rows <= spread)
+            hipLaunchKernelGGL((k_fb_finish<C, 1>), dim3((unsigned)((n_rows + 63) / 64)), dim3(64), 0, stream,
+                               (const XYZZ<M>*)partial, (uint32_t)n_rows, S, d_out);
+        else if (n_rows <= 2 * spread)
+            hipLaunchKernelGGL((k_fb_finish<C, 2>), dim3((unsigned)((n_rows + 127) / 128)), dim3(64), 0, stream,
+                               (const XYZZ<M>*)partial, (uint32_t)n_rows, S, d_out);
+        else
+            hipLaunchKernelGGL((k_fb_finish<C, FB_FINISH_ROWS_MAX>),
+                               dim3((unsigned)((n_rows + 64 * FB_FINISH_ROWS_MAX - 1) / (64 * FB_FINISH_ROWS_MAX))), dim3(64), 0, stream,
+                               (const XYZZ<M>*)partial, (uint32_t)n_rows, S, d_out);
     }
     PORLA_HIP(hipGetLastError());
     return fence.leave(stream);
