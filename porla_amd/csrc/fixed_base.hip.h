@@ -19,7 +19,7 @@
 //   k_fb_commit        lane = row (x slice): scalar -> reduce mod order -> signed digits -> gather + 8M+2S mixed add
 //   k_fb_fold_quad     fold a row's slice partials (reduced-radix memory form): in-place pairwise tree, four lanes per addition
 //                      (k_fb_fold: the same with G lanes per row on 8 x 32-bit limbs, for a curve without the reduced-radix form)
-//   k_fb_finish        lane = 4 rows: one division-step inversion (fe_inv_safegcd), Montgomery -> big-endian X||Y (64 zero bytes = infinity)
+//   k_fb_finish        lane = 1, 2 or 4 rows (by batch size): one division-step inversion (fe_inv_safegcd), Montgomery -> big-endian X||Y (64 zero bytes = infinity)
 //   k_fb_commit_small  <= 64 host rows in ONE launch (block = row x slice), sums polled from pinned memory
 #pragma once
 #include "msm.hip.h"
