@@ -144,8 +144,12 @@ int FixedBase<C>::commit_device(const uint8_t* d_rows, size_t n_rows, size_t n_c
     // slices per row: enough lanes for TWO to three rounds of 256 CUs x 4 SIMDs x 3 waves -- with 196 608 (one round and a third:
     // 1024 blocks where 768 are resident) the last third ran at one wave per SIMD: 18.1-18.3 ms for 2^17 rows, 17.8 with 393 216
     static const size_t target = getenv("PORLA_COMMIT_LANES") ? (size_t)atol(getenv("PORLA_COMMIT_LANES")) : (size_t)393216;
+    // ... but not below 16 additions per lane once every SIMD has two waves anyway (131 072 rows): the fold of a slice pair costs
+    // what the shorter chains save (the two-coefficient rows of the MAC batch: 0.455 -> 0.437 ms at 131 072 rows, no difference
+    // at 65 536, and below that the slices win)
     uint32_t S = 1;
-    while ((size_t)n_rows * S < target && S * 2 <= n_coeffs && S < 128) S *= 2;
+    while ((size_t)n_rows * S < target && S * 2 <= n_coeffs && S < 128 &&
+           !(n_rows >= 131072 && (size_t)(n_coeffs / (2 * S)) * (size_t)W < 16)) S *= 2;
     uint32_t G = S < 64 ? S : 64;
     size_t need = n_rows * (size_t)S * sizeof(XYZZ<M>);
     if (need > partial_cap) {
