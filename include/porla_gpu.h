@@ -28,7 +28,7 @@
  *   porla_audit_combine_device, porla_*_msm_pair_*, porla_*_audit_msm_pair_*, porla_kzg_audit_device, porla_ipa_audit_device
  *                            Server::audit after the challenge, Server.hpp:790-907: the row combine (:790-828), the two MSMs over
  *                            one scalar array (:842-848 / :900-901), and -- the last two -- the whole audit in one call
- *   porla_kzg_digest_batch_device, porla_kzg_complement_batch_device, porla_kzg_mac_batch_device
+ *   porla_kzg_{digest,complement,mac}_batch_{device,host}
  *                            compute_digest / compute_digest_complement hoisted over the blocks of Client::initialize,
  *                            Client.hpp:408-455; the last: both and the add_point that joins them (Client.hpp:229-236, 468-478)
  *
@@ -246,6 +246,11 @@ int  porla_kzg_complement_batch_device(const void *d_scalars, size_t n, void *d_
 /* the block's MAC as the client sends it -- digest(row r) + complement(scalar r), the add_point of Client.hpp:229-236 / 468-478
  * included -- as one two-coefficient commitment per row against the table of (G1[0], h_MAC): d_out[r] = 64 bytes */
 int  porla_kzg_mac_batch_device(const void *d_rows, const void *d_scalars, size_t n_rows, void *d_out, void *hip_stream);
+/* the three batches on caller-owned host buffers (pageable is fine): staged, computed on the engine's stream, copied back; blocking.
+ * The copies dominate -- 4 KiB per block over PCIe */
+int  porla_kzg_digest_batch_host(const uint8_t *rows, size_t n_rows, uint8_t *out);
+int  porla_kzg_complement_batch_host(const uint8_t *scalars, size_t n, uint8_t *out);
+int  porla_kzg_mac_batch_host(const uint8_t *rows, const uint8_t *scalars, size_t n_rows, uint8_t *out);
 /* diagnostics of the host pairing behind verify_proof (main.go:177-193): scalar * G2 generator as 128 bytes
  * X.A1 || X.A0 || Y.A1 || Y.A0 big-endian; e(p1, q1) * e(p2, q2) == 1 ? (returns 1 / 0; slow = 1: the literal form with
  * affine Miller steps and the exponent (p^12 - 1)/r, kept as the reference for the fast form) */

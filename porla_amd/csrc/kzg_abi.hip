@@ -878,6 +878,67 @@ static size_t kzg_n_samples() {
     std::lock_guard<std::mutex> lk(g.mu);
     return (size_t)g.n_samples;
 }
+
+// ---- the same three batches on caller-owned host buffers: staged into a device buffer kept between calls, computed by the
+// device entry on the engine's stream, copied back; blocking.  (The copies dominate: 4 KiB per block over PCIe.)
+namespace {
+struct ClientIo {
+    std::mutex mu;                 // one host batch per device at a time: the staging buffer is shared
+    void* d = nullptr;
+    size_t cap = 0;
+    int device = -1;
+};
+ClientIo g_client_io[16];
+
+int client_batch_host(int kind /* 0 digest, 1 complement, 2 MAC */, const uint8_t* rows, const uint8_t* scalars, size_t n, uint8_t* out) {
+    if (n && (!out || (kind != 1 && !rows) || (kind != 0 && !scalars))) { set_last_error("porla: null argument"); return PORLA_ERR_ARG; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n == 0) return PORLA_OK;
+    const size_t row_bytes = kzg_n_samples() * 32;
+    if (kind != 1 && row_bytes == 0) { set_last_error("porla: init_key / init_SRS first"); return PORLA_ERR_STATE; }
+    int dev = 0;
+    PORLA_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) { set_last_error("porla: device index out of range"); return PORLA_ERR_STATE; }
+    ClientIo& io = g_client_io[dev];
+    std::lock_guard<std::mutex> lk(io.mu);
+    // chunks of 16 384 blocks (64 MiB of rows): a pageable copy of that size runs at 44 GB/s, one of 512 MiB at 15
+    // (tools/bench_client_host.py); one stream, so the chunks follow each other through the same staging buffer
+    constexpr size_t CHUNK = 16384;
+    const size_t per = n < CHUNK ? n : CHUNK;
+    const size_t rows_b = kind != 1 ? per * row_bytes : 0, sc_b = kind != 0 ? per * 32 : 0, out_b = per * 64;
+    const size_t half = ((rows_b + 255) & ~(size_t)255) + ((sc_b + 255) & ~(size_t)255) + ((out_b + 255) & ~(size_t)255);
+    const size_t need = half;
+    if (io.cap < need) {
+        if (io.d) PORLA_HIP(hipFree(io.d));
+        io.d = nullptr; io.cap = 0;
+        PORLA_HIP(hipMalloc(&io.d, need));
+        io.cap = need;
+    }
+    hipStream_t stream = engine_stream();
+    for (size_t lo = 0; lo < n; lo += CHUNK) {
+        const size_t m = n - lo < CHUNK ? n - lo : CHUNK;
+        uint8_t* d_rows = (uint8_t*)io.d;
+        uint8_t* d_sc = d_rows + ((rows_b + 255) & ~(size_t)255);
+        uint8_t* d_out = d_sc + ((sc_b + 255) & ~(size_t)255);
+        if (rows_b) PORLA_HIP(hipMemcpyAsync(d_rows, rows + lo * row_bytes, m * row_bytes, hipMemcpyHostToDevice, stream));
+        if (sc_b) PORLA_HIP(hipMemcpyAsync(d_sc, scalars + lo * 32, m * 32, hipMemcpyHostToDevice, stream));
+        if (kind == 0) rc = porla_kzg_digest_batch_device(d_rows, m, d_out, stream);
+        else if (kind == 1) rc = porla_kzg_complement_batch_device(d_sc, m, d_out, stream);
+        else rc = porla_kzg_mac_batch_device(d_rows, d_sc, m, d_out, stream);
+        if (rc) { (void)hipStreamSynchronize(stream); return rc; }
+        PORLA_HIP(hipMemcpyAsync(out + lo * 64, d_out, m * 64, hipMemcpyDeviceToHost, stream));
+    }
+    PORLA_HIP(hipStreamSynchronize(stream));
+    return PORLA_OK;
+}
+}  // namespace
+int porla_kzg_digest_batch_host(const uint8_t* rows, size_t n_rows, uint8_t* out) { return client_batch_host(0, rows, nullptr, n_rows, out); }
+int porla_kzg_complement_batch_host(const uint8_t* scalars, size_t n, uint8_t* out) { return client_batch_host(1, nullptr, scalars, n, out); }
+int porla_kzg_mac_batch_host(const uint8_t* rows, const uint8_t* scalars, size_t n_rows, uint8_t* out) {
+    return client_batch_host(2, rows, scalars, n_rows, out);
+}
+
 // coefficients per commitment row = SRS size (0 before init_SRS*): callers that slice a row-major batch derive the row stride
 // (32 bytes per coefficient) from it instead of assuming the reference's 128 (config.hpp NUM_CHUNKS)
 int porla_kzg_row_coefficients(size_t* n_out) {
@@ -1124,6 +1185,13 @@ int porla_kzg_set_commit_window(int window_bits) {
 int porla_kzg_release_device_memory(void) {
     // lock order as everywhere: the state, then the tables -- a commit that has dropped g.mu still holds its table's mutex
     // (compute_digest_from_srs is called from 8 pool threads, Server.hpp:550-560)
+    // the host batches' staging buffers first, outside g.mu: a host batch holds its staging mutex while the device entry it calls
+    // takes g.mu
+    for (ClientIo& io : g_client_io) {
+        std::lock_guard<std::mutex> lio(io.mu);
+        if (io.d) (void)hipFree(io.d);
+        io.d = nullptr; io.cap = 0;
+    }
     std::lock_guard<std::mutex> lk(g.mu);
     int cur = 0;
     (void)hipGetDevice(&cur);

@@ -114,6 +114,9 @@ def _declare(L):
     L.porla_kzg_digest_batch_device.argtypes = [vp, sz, vp, vp]; L.porla_kzg_digest_batch_device.restype = ctypes.c_int
     L.porla_kzg_complement_batch_device.argtypes = [vp, sz, vp, vp]; L.porla_kzg_complement_batch_device.restype = ctypes.c_int
     L.porla_kzg_mac_batch_device.argtypes = [vp, vp, sz, vp, vp]; L.porla_kzg_mac_batch_device.restype = ctypes.c_int
+    L.porla_kzg_digest_batch_host.argtypes = [ctypes.c_char_p, sz, ctypes.c_char_p]; L.porla_kzg_digest_batch_host.restype = ctypes.c_int
+    L.porla_kzg_complement_batch_host.argtypes = [ctypes.c_char_p, sz, ctypes.c_char_p]; L.porla_kzg_complement_batch_host.restype = ctypes.c_int
+    L.porla_kzg_mac_batch_host.argtypes = [ctypes.c_char_p, ctypes.c_char_p, sz, ctypes.c_char_p]; L.porla_kzg_mac_batch_host.restype = ctypes.c_int
     L.porla_bn254_g2_mul_generator.argtypes = [u8p, u8p]; L.porla_bn254_g2_mul_generator.restype = ctypes.c_int
     L.porla_bn254_pairing_product_is_one.argtypes = [u8p, u8p, u8p, u8p, ctypes.c_int]; L.porla_bn254_pairing_product_is_one.restype = ctypes.c_int
     L.porla_kzg_set_commit_window.argtypes = [ctypes.c_int]; L.porla_kzg_set_commit_window.restype = ctypes.c_int

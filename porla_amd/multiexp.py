@@ -369,6 +369,27 @@ def kzg_mac_batch_device(d_rows, d_scalars, n_rows, d_out, stream=0):
                                           ctypes.c_void_p(stream)))
 
 
+def kzg_digest_batch_host(rows, n_rows):
+    """compute_digest over n_rows rows in host memory -> n_rows * 64 bytes"""
+    out = ctypes.create_string_buffer(64 * n_rows)
+    _check(lib.porla_kzg_digest_batch_host(rows, n_rows, out))
+    return out.raw
+
+
+def kzg_complement_batch_host(scalars, n):
+    """compute_digest_complement over n 32-byte big-endian scalars in host memory -> n * 64 bytes"""
+    out = ctypes.create_string_buffer(64 * n)
+    _check(lib.porla_kzg_complement_batch_host(scalars, n, out))
+    return out.raw
+
+
+def kzg_mac_batch_host(rows, scalars, n_rows):
+    """digest(row) + complement(scalar) per block, host buffers -> n_rows * 64 bytes"""
+    out = ctypes.create_string_buffer(64 * n_rows)
+    _check(lib.porla_kzg_mac_batch_host(rows, scalars, n_rows, out))
+    return out.raw
+
+
 def profile_enable(on=True):
     """False/0: off; True/1: HIP events around every kernel; 2: around the workload's dominant kernel only"""
     lib.porla_gpu_profile_enable(int(on))

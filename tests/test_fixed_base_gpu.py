@@ -217,6 +217,22 @@ def test_client_side_digest_and_complement_batches(mx):
     assert macs[64 * 3:64 * 4] == got[64 * 3:64 * 4] and macs[64:128] == comp[64:128]
     assert macs[64 * 5:64 * 6] == mx.bn254_add(got[64 * 5:64 * 6], mx.compute_digest_complement((9).to_bytes(16, "big")))
     mx.kzg_mac_batch_device(d_rows.data_ptr(), d_sc.data_ptr(), 0, d_mac.data_ptr(), s)       # empty batch: nothing to do
+    # the same three batches on host buffers
+    assert mx.kzg_digest_batch_host(rows, n_rows) == got
+    assert mx.kzg_complement_batch_host(bytes(scal), n_rows) == comp
+    assert mx.kzg_mac_batch_host(rows, bytes(scal), n_rows) == macs
+    assert mx.kzg_mac_batch_host(rows, bytes(scal), 1) == macs[:64] and mx.kzg_mac_batch_host(b"", b"", 0) == b""
+    # more than one staging chunk (16 384 blocks) against the device entry
+    n_big = 16384 + 77
+    big = hashlib.shake_256(b"bigrows").digest(4096 * 64) * (n_big // 64 + 1)
+    big = big[:4096 * n_big]
+    big_sc = hashlib.shake_256(b"bigsc").digest(32 * n_big)
+    d_big = torch.frombuffer(bytearray(big), dtype=torch.uint8).cuda()
+    d_bsc = torch.frombuffer(bytearray(big_sc), dtype=torch.uint8).cuda()
+    d_bout = torch.empty(64 * n_big, dtype=torch.uint8, device="cuda")
+    mx.kzg_mac_batch_device(d_big.data_ptr(), d_bsc.data_ptr(), n_big, d_bout.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert mx.kzg_mac_batch_host(big, big_sc, n_big) == bytes(d_bout.cpu().numpy())
 
 
 @pytest.mark.parametrize("n_coeffs", [1, 7, 8, 9, 100, 1024, 1025])
