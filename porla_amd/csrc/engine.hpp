@@ -171,6 +171,7 @@ struct FixedBase {
     size_t io_rows_cap = 0;
     uint8_t* io_out = nullptr;
     size_t io_out_cap = 0;
+    hipStream_t io_stream2 = nullptr;         // commit_host: the second of the two streams the chunks alternate on
     uint32_t last_S = 1;                      // slices per row of the last commit_device (layout of `partial`)
     UseFence fence;                           // orders `partial` (and the table after a rebuild) between calls on different streams
     static constexpr size_t HOST_FINISH_MAX_ROWS = 256;   // batches up to this size are normalised on the host (commit_host)

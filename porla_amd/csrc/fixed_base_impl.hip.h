@@ -18,6 +18,8 @@ void FixedBase<C>::release() {
     if (partial) (void)hipFree(partial);
     if (io_rows) (void)hipFree(io_rows);
     if (io_out) (void)hipFree(io_out);
+    if (io_stream2) (void)hipStreamDestroy(io_stream2);
+    io_stream2 = nullptr;
     table = nullptr; partial = nullptr; io_rows = nullptr; io_out = nullptr;
     partial_cap = io_rows_cap = io_out_cap = 0;
     n_points = 0;
@@ -283,25 +285,36 @@ int FixedBase<C>::commit_host(const uint8_t* rows, size_t n_rows, size_t n_coeff
         for (size_t r = 0; r < n_rows; r++) { rp[r] = rows + r * row_stride; op[r] = out + 64 * r; }
         return commit_small(rp, n_rows, n_coeffs, op, stream);
     }
-    size_t in_bytes = (n_rows - 1) * row_stride + n_coeffs * 32;
-    if (in_bytes > io_rows_cap) {
+    // Large batches go through the staging buffers in chunks of 64 MiB of rows, two staging halves on two streams: chunk k + 1 is
+    // copied in while chunk k is committed (the commits follow each other through `fence`), and chunk k's results are copied out
+    // only after chunk k + 1 has been enqueued -- a pageable device-to-host copy holds the host thread until the data is there.
+    // One copy of 512 MiB, then one commit, then one copy back took 48-51 ms for 2^17 rows (tools/bench_commit_host.py).
+    static const size_t chunk_bytes = getenv("PORLA_COMMIT_HOST_CHUNK") ? (size_t)atol(getenv("PORLA_COMMIT_HOST_CHUNK")) : ((size_t)64 << 20);
+    size_t chunk_rows = row_stride ? chunk_bytes / row_stride : n_rows;
+    if (chunk_rows < HOST_FINISH_MAX_ROWS + 1) chunk_rows = HOST_FINISH_MAX_ROWS + 1;
+    if (chunk_rows > n_rows) chunk_rows = n_rows;
+    const size_t n_chunks = (n_rows + chunk_rows - 1) / chunk_rows;
+    const size_t halves = n_chunks > 1 ? 2 : 1;
+    const size_t in_bytes = (chunk_rows - 1) * row_stride + n_coeffs * 32;
+    const size_t in_half = (in_bytes + 255) & ~(size_t)255, out_half = (chunk_rows * 64 + 255) & ~(size_t)255;
+    if (halves * in_half > io_rows_cap) {
         if (io_rows) PORLA_HIP(hipFree(io_rows));
         io_rows = nullptr; io_rows_cap = 0;
-        PORLA_HIP(hipMalloc((void**)&io_rows, in_bytes + 256));
-        io_rows_cap = in_bytes + 256;
+        PORLA_HIP(hipMalloc((void**)&io_rows, halves * in_half + 256));
+        io_rows_cap = halves * in_half + 256;
     }
-    if (n_rows * 64 > io_out_cap) {
+    if (halves * out_half > io_out_cap) {
         if (io_out) PORLA_HIP(hipFree(io_out));
         io_out = nullptr; io_out_cap = 0;
-        PORLA_HIP(hipMalloc((void**)&io_out, n_rows * 64 + 256));
-        io_out_cap = n_rows * 64 + 256;
+        PORLA_HIP(hipMalloc((void**)&io_out, halves * out_half + 256));
+        io_out_cap = halves * out_half + 256;
     }
-    if (in_bytes) PORLA_HIP(hipMemcpyAsync(io_rows, rows, in_bytes, hipMemcpyHostToDevice, stream));
     if (n_rows <= HOST_FINISH_MAX_ROWS && n_coeffs > 0) {
         // up to a few hundred rows: the projective sums come back (one strided copy) and the host normalises them with one
-        // inversion per 64 rows (h_batch_xyzz_to_affine64, ~0.3 us per row) -- the device's finish kernel costs 0.09 ms whatever
+        // inversion per 64 rows (h_batch_xyzz_to_affine64, ~0.3 us per row) -- the device's finish kernel costs 0.05 ms whatever
         // the batch (one division-step inversion on lone waves) plus the output copy: level at ~256 rows
         using M = typename C::Fp;
+        if (in_bytes) PORLA_HIP(hipMemcpyAsync(io_rows, rows, in_bytes, hipMemcpyHostToDevice, stream));
         int rc = commit_device(io_rows, n_rows, n_coeffs, row_stride, nullptr, stream);
         if (rc) return rc;
         std::vector<XYZZ<M>> sums(n_rows);
@@ -313,11 +326,28 @@ int FixedBase<C>::commit_host(const uint8_t* rows, size_t n_rows, size_t n_coeff
         for (size_t r = 0; r < n_rows; r++) h_affine_to_bytes<M>(out + 64 * r, aff[r]);
         return PORLA_OK;
     }
-    int rc = commit_device(io_rows, n_rows, n_coeffs, row_stride, io_out, stream);
-    if (rc) return rc;
-    PORLA_HIP(hipMemcpyAsync(out, io_out, n_rows * 64, hipMemcpyDeviceToHost, stream));
-    PORLA_HIP(hipStreamSynchronize(stream));
-    return PORLA_OK;
+    if (halves == 2 && !io_stream2) PORLA_HIP(hipStreamCreateWithFlags(&io_stream2, hipStreamNonBlocking));
+    hipStream_t st[2] = {stream, halves == 2 ? io_stream2 : stream};
+    auto enqueue = [&](size_t k) -> int {
+        const size_t lo = k * chunk_rows, m = n_rows - lo < chunk_rows ? n_rows - lo : chunk_rows;
+        const size_t bytes = (m - 1) * row_stride + n_coeffs * 32;
+        uint8_t* d_in = io_rows + (k & 1) * in_half;
+        if (bytes) PORLA_HIP(hipMemcpyAsync(d_in, rows + lo * row_stride, bytes, hipMemcpyHostToDevice, st[k & 1]));
+        return commit_device(d_in, m, n_coeffs, row_stride, io_out + (k & 1) * out_half, st[k & 1]);
+    };
+    int rc = enqueue(0);
+    for (size_t k = 0; k < n_chunks && rc == PORLA_OK; k++) {
+        if (k + 1 < n_chunks) rc = enqueue(k + 1);
+        if (rc != PORLA_OK) break;
+        const size_t lo = k * chunk_rows, m = n_rows - lo < chunk_rows ? n_rows - lo : chunk_rows;
+        if (hipMemcpyAsync(out + lo * 64, io_out + (k & 1) * out_half, m * 64, hipMemcpyDeviceToHost, st[k & 1]) != hipSuccess) {
+            set_last_error("porla: copy of the commitments to the host failed");
+            rc = PORLA_ERR_HIP;
+        }
+    }
+    const hipError_t e0 = hipStreamSynchronize(st[0]), e1 = halves == 2 ? hipStreamSynchronize(st[1]) : hipSuccess;
+    if (rc == PORLA_OK && (e0 != hipSuccess || e1 != hipSuccess)) { set_last_error("porla: commit batch failed on the device"); rc = PORLA_ERR_HIP; }
+    return rc;
 }
 
 // base given as 64-byte big-endian affine points on the host (the reference's wire format)
