@@ -384,6 +384,23 @@ def main():
                                                         "consistent": d["consistent"]}
                 except Exception as e:  # noqa: BLE001
                     per_call["threads_%d" % threads] = {"error": repr(e)}
+        # the same batch from pageable host rows through porla_kzg_commit_batch_host (INTEGRATION.md s3's call), PCIe in and out
+        # included: never `value`
+        host_rows = None
+        if world == 1 and not args.no_host_boundary:
+            try:
+                h_rows = bytes(d_rows.cpu().numpy())
+                h_out = mx.kzg_commit_batch_host(h_rows, rows_n)
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    mx.kzg_commit_batch_host(h_rows, rows_n)
+                h_ms = (time.perf_counter() - t1) / 3 * 1e3
+                host_rows = {"ms_per_call": round(h_ms, 3), "commits_per_s": round(rows_n / h_ms * 1e3, 1),
+                             "same_bytes_as_device_rows": h_out == bytes(d_out.cpu().numpy()),
+                             "note": "pageable host rows in, 64-byte commitments out, 64 MiB chunks on two streams"}
+                del h_rows, h_out
+            except Exception as e:  # noqa: BLE001
+                host_rows = {"error": repr(e)}
         cshape = mx.kzg_commit_shape()
         cpu = None
         ok = None
@@ -398,6 +415,8 @@ def main():
             cpu = {"value": round(sample / cpu_s, 1), "unit": "commits/s", "cores": cores, "kind": "port",
                    "sample": "the first %d rows, one 128-point bucket MSM per row (oracle/bn254_ref.c, CPU restatement of "
                              "compute_digest_from_srs, not gnark) over %d threads; %.2f s wall" % (sample, cores, cpu_s)}
+        if host_rows and host_rows.get("same_bytes_as_device_rows") is False:
+            ok = False                  # the device rows are checked against the oracle above; the host path must give the same bytes
         return line("KZG commits/s (128-coefficient rows against the resident SRS)", round(world * rows_n * args.steps / el, 1),
                     "commits/s", el, "weak", "u32x8 (256-bit modular integer)",
                     {"workload": "2^%d rows x 128 coefficients per GPU, compute_digest_from_srs hoisted over rows "
@@ -405,7 +424,7 @@ def main():
                      "rows_per_gpu": rows_n, "sharding": "row range per rank, no collective" if world > 1 else "single GPU",
                      "table_build_s": round(build_s, 3)},
                     roofline(kern, COMMIT_BYTES_PER_ROW * rows_n, "kzg_commit", 10.0 * rows_n * 128 * cshape[1]), cpu, ok,
-                    rows_per_gpu=rows_n, coefficients_per_row=128, per_call_compute_digest_from_srs=per_call,
+                    rows_per_gpu=rows_n, coefficients_per_row=128, per_call_compute_digest_from_srs=per_call, host_rows=host_rows,
                     table={"window_bits": cshape[0], "windows_per_coefficient": cshape[1],
                            "GiB": round(128 * cshape[1] * (1 << (cshape[0] - 1)) * 64 / 2**30, 2) if cshape[0] else None,
                            "budget": "PORLA_COMMIT_TABLE_GB (default 16 GiB)"},
