@@ -235,6 +235,30 @@ def test_client_side_digest_and_complement_batches(mx):
     assert mx.kzg_mac_batch_host(big, big_sc, n_big) == bytes(d_bout.cpu().numpy())
 
 
+def test_host_batch_larger_than_the_staging_chunks(mx, srs128):
+    """commit_host stages host rows in 64 MiB chunks on two streams (16 384 rows of 128 coefficients each): three chunks with a
+    ragged last one give the bytes of the device entry on the same rows; first, last and chunk-boundary rows against the oracle"""
+    import torch
+    mx.init_key(TAU, ALPHA)
+    blob = mx.init_SRS(128)
+    mx.init_SRS_from_data(128, blob)
+    n_rows = 2 * 16384 + 1234
+    rows = hashlib.shake_256(b"chunks").digest(4096 * 97) * (n_rows // 97 + 1)
+    rows = bytearray(rows[:4096 * n_rows])
+    for r in (0, 16383, 16384, 32767, 32768, n_rows - 1):          # make the probed rows distinct
+        rows[4096 * r:4096 * r + 32] = hashlib.sha256(b"row%d" % r).digest()
+    rows = bytes(rows)
+    got = mx.kzg_commit_batch_host(rows, n_rows)
+    d_rows = torch.frombuffer(bytearray(rows), dtype=torch.uint8).cuda()
+    d_out = torch.empty(64 * n_rows, dtype=torch.uint8, device="cuda")
+    mx.kzg_commit_batch_device(d_rows.data_ptr(), n_rows, d_out.data_ptr(), 0)
+    torch.cuda.synchronize()
+    assert got == bytes(d_out.cpu().numpy())
+    for r in (0, 16383, 16384, 32767, 32768, n_rows - 1):
+        assert got[64 * r:64 * r + 64] == common.oracle_commit_batch("bn254", rows[4096 * r:4096 * r + 4096], 1, 128, srs128), r
+    assert mx.kzg_commit_batch_host(rows, n_rows) == got           # and again through the warm staging buffers
+
+
 @pytest.mark.parametrize("n_coeffs", [1, 7, 8, 9, 100, 1024, 1025])
 def test_digest_batch_row_lengths(mx, n_coeffs):
     """the digest batch's evaluation kernels at row lengths other than the reference's 128 (init_SRS takes any size): lengths that
