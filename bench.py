@@ -69,6 +69,7 @@ KERNEL_SYMBOL = {  # profile slot -> substring of the kernel symbol in the rocpr
     "fb_commit": "k_fb_commit", "digits_partition": "k_digits_partition", "points_to_mont": "k_points_to_mont",
     "icc_fused": "k_icc_split30", "icc_stages_r4": "k_icc_stages", "icc_stages_r2": "k_icc_stages", "icc_load": "k_icc_load", "icc_finish": "k_icc_finish",
     "audit_accumulate": "k_audit_accumulate<8>",     # the large-challenge instantiation (8 row slices per block)
+    "kzg_eval_rows": "k_kzg_eval_rows_lazy",
 }
 
 
@@ -868,7 +869,9 @@ def main():
                 "kernels_ms": prof,
                 "roofline": {"bound": "hbm", "kernel": "k_kzg_eval_rows_lazy", "achieved": round(n * 4128 / ev / 1e6, 1) if ev else None,
                              "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(n * 4128 / ev / 1e6 / HBM_PEAK_GBPS, 4) if ev else None,
-                             "traffic": None, "algorithmic_bytes_per_batch": alg},
+                             "traffic": pmc_traffic("kzg_eval_rows", "client_mac_batch"),
+                             "traffic_source": "committed rocprofv3 --pmc passes of this leg (profiles/pmc_latest_client_mac_batch.json)",
+                             "algorithmic_bytes_per_launch": n * 4128, "algorithmic_bytes_per_batch": alg},
                 "bit_exact_vs_oracle": verified}
 
     # ---------------------------------------------------------------- the line

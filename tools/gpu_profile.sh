@@ -26,7 +26,10 @@ for name in ("fetch", "write"):
     agg = collections.defaultdict(lambda: [0.0, 0])
     for f in files:
         for row in csv.DictReader(open(f)):
-            k = row.get("Kernel_Name", "?").split("(")[0]
+            k = row.get("Kernel_Name", "?")
+            if k.startswith("(anonymous namespace)::"):      # kernels of an unnamed namespace (kzg_abi.hip)
+                k = k[len("(anonymous namespace)::"):]
+            k = k.split("(")[0]
             agg[(k, row.get("Counter_Name"))][0] += float(row.get("Counter_Value", 0))
             agg[(k, row.get("Counter_Name"))][1] += 1
     out[name] = {"%s|%s" % k: {"sum": v[0], "dispatches": v[1], "per_dispatch": v[0] / max(v[1], 1)} for k, v in agg.items()}
