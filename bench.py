@@ -388,7 +388,7 @@ def main():
         # the same batch from pageable host rows through porla_kzg_commit_batch_host (INTEGRATION.md s3's call), PCIe in and out
         # included: never `value`
         host_rows = None
-        if world == 1 and not args.no_host_boundary:
+        if world == 1 and not args.no_host_boundary and not args.no_cpu:      # (--no-cpu: the profiler passes; only the batch kernel's launches)
             try:
                 h_rows = bytes(d_rows.cpu().numpy())
                 h_out = mx.kzg_commit_batch_host(h_rows, rows_n)
