@@ -73,3 +73,26 @@ def test_single_rank_bench_line_prices_the_kernel_it_timed():
     assert abs(ac["roofline"]["achieved"] - ac["roofline"]["algorithmic_bytes"] / ac["kernels_ms"]["audit_accumulate"] / 1e6) < 0.02 * ac["roofline"]["achieved"]
     ka = d["kzg_audit"]
     assert ka["bit_exact_vs_oracle"] is True and ka["unit"] == "audits/s" and ka["value"] > 100 and "True" in ka["client_checks"]
+
+
+def test_client_mac_batch_and_host_rows_lines():
+    """the two figures outside the BASELINE configurations that ride on the default line: the client's block MACs in one batch
+    (checked on the oracle's arithmetic, roofline of the evaluation kernel with the committed counter traffic) and the commit
+    batch from pageable host rows (same bytes as from device rows)"""
+    r = subprocess.run([sys.executable, os.path.join(common.ROOT, "bench.py"), "--workload", "client_mac_batch"],
+                       capture_output=True, text=True, timeout=600, cwd=common.ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["bit_exact_vs_oracle"] is True and d["unit"] == "blocks/s" and d["value"] > 1e6
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["kernel"] == "k_kzg_eval_rows_lazy" and 0.1 < rf["frac"] <= 1.0
+    assert rf["traffic"] is None or 0.9 < rf["traffic"] / rf["algorithmic_bytes_per_launch"] < 1.5
+    assert d["separate_batches_ms"]["digest_batch"] > 0 and d["kernels_ms"]["fb_commit"] > 0
+    r = subprocess.run([sys.executable, os.path.join(common.ROOT, "bench.py"), "--workload", "kzg_commit", "--log2rows", "15", "--steps", "3",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=600, cwd=common.ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["bit_exact_vs_oracle"] is True
+    assert d["host_rows"]["same_bytes_as_device_rows"] is True and d["host_rows"]["commits_per_s"] > 1e5
