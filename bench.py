@@ -64,6 +64,9 @@ FE_MUL_PEAK_FALLBACK = {"bn254": 186.5, "secp256k1": 199.9}
 WORKLOAD_FIELD = {"bn254_msm": "bn254", "kzg_commit": "bn254", "secp256k1_msm": "secp256k1", "config3": "bn254"}
 PMC_FILE = {"bn254_msm": "pmc_latest.json", "config3": "pmc_latest.json"}
 
+# legs of the default line that measure a BASELINE.json configuration (or the metric's second half): one of them throwing fails the run
+BASELINE_CONFIG_LEGS = ("kzg_commits", "secp256k1_msm", "icc", "config3")
+
 KERNEL_SYMBOL = {  # profile slot -> substring of the kernel symbol in the rocprofv3 output
     "bucket_sum": "k_bucket_sum30", "tree_levels": "k_tree_level", "tree_tail": "k_tree_tail", "partition_sort": "k_partition_sort",
     "fb_commit": "k_fb_commit", "digits_partition": "k_digits_partition", "points_to_mont": "k_points_to_mont",
@@ -120,6 +123,52 @@ def measure_fe_mul_peak():
                 for f, v in FE_MUL_PEAK_FALLBACK.items()}
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` started by hand (no WORLD_SIZE in the environment): start the N ranks as ONE child
+    `python -m torch.distributed.run` -- the same command line the driver uses -- BEFORE this process has touched the GPU
+    (it never does: a child, never an exec), relay its output (rank 0 prints the one JSON line) and return its exit code.
+    A rank that dies takes the group down through torchrun; a group that hangs is killed at PORLA_BENCH_LAUNCH_TIMEOUT_S."""
+    import signal
+    import socket
+    import torch                                          # device_count() does not initialise the GPU on this image
+    backend = os.environ.get("PORLA_DIST_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < n:
+        print("ERROR: --gpus %d but this node shows %d GPU(s): RCCL needs one device per rank.  (To rehearse the N-rank path with "
+              "ranks sharing a device, partials over gloo on the host: PORLA_DIST_BACKEND=gloo.)" % (n, have), file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_ADDR="127.0.0.1")
+    # the ranks are host-light between launches; without this torchrun pins OMP_NUM_THREADS=1, which would starve the oracle's
+    # range-split check on rank 0 (common.ncpu() still honours affinity and the cgroup quota)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    limit = float(os.environ.get("PORLA_BENCH_LAUNCH_TIMEOUT_S", "3000"))
+    p = subprocess.Popen(cmd, env=env, cwd=ROOT, start_new_session=True)   # own process group: killed as a group, by its pgid only
+    try:
+        return p.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        print("ERROR: the %d-rank run did not finish within %.0f s; killing process group %d" % (n, limit, p.pid), file=sys.stderr)
+        try:
+            os.killpg(p.pid, signal.SIGTERM)
+            p.wait(timeout=20)
+        except (subprocess.TimeoutExpired, ProcessLookupError):
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+        return 124
+    except KeyboardInterrupt:
+        try:
+            os.killpg(p.pid, signal.SIGTERM)
+        except ProcessLookupError:
+            pass
+        raise
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,6 +188,10 @@ def main():
     ap.add_argument("--in-flight", type=int, default=2, help="bn254_msm: independent MSMs in flight (1 = blocking calls; 2 = the "
                     "audit's pair of MSMs, Server.hpp:900-901, overlapped on two streams)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started by hand with --gpus N: this process becomes the launcher of the N ranks (nothing below runs in it)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     if args.workload == "kzg_audit":
         # one whole server-side audit at the reference's size has its own driver too (tools/bench_audit_flow.py, same JSON contract)
@@ -165,12 +218,20 @@ def main():
     backend = os.environ.get("PORLA_DIST_BACKEND", "nccl")
     dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl" and torch.cuda.device_count() <= dev_index:
+            # a rank without a device of its own leaves at once (non-zero): torchrun then ends the other ranks instead of letting
+            # them wait in the rendezvous
+            print("ERROR: rank %d needs cuda:%d but this node shows %d GPU(s)" % (rank, dev_index, torch.cuda.device_count()), file=sys.stderr)
+            sys.exit(2)
+        # a bounded rendezvous / collective wait: a rank that cannot come up makes the others fail, not hang
+        wait = datetime.timedelta(seconds=float(os.environ.get("PORLA_DIST_TIMEOUT_S", "300")))
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index), timeout=wait)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=wait)
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     torch.cuda.set_device(dev_index)
@@ -644,6 +705,12 @@ def main():
             cpu = {"value": round(total / cpu_s / 1e6, 4), "unit": "Mmul/s", "cores": cores, "kind": "port",
                    "sample": "the whole 2^%d-pair job, oracle/bn254_ref.c bucket MSM range-split over %d threads (CPU restatement, "
                              "not gnark); %.1f s wall" % (args.log2job, cores, cpu_s)}
+        rl3 = roofline(kern, MSM_BYTES_PER_PAIR * n_local / launches, "config3", fe_mults / launches)
+        if rl3:
+            # the committed counter pass is of a 2^20-pair launch; this leg's launches cover up to 2^22 pairs each: no figure
+            # rather than one from a launch of another size
+            rl3["traffic"] = None
+            rl3["traffic_source"] = "not collected at this leg's range size (profiles/pmc_latest.json is a 2^20-pair launch)"
         return line("BN254 G1 MSM Mscalar-mul/s, one 2^%d-pair job over all GPUs" % args.log2job,
                     round(total * args.steps / el / 1e6, 3), "Mmul/s", el, "strong", "u32x8 (256-bit modular integer)",
                     {"workload": "KZG audit over 2^%d blocks: ONE 2^%d-pair BN254 G1 MSM, pair range [g 2^%d / N, (g+1) 2^%d / N) on "
@@ -651,8 +718,7 @@ def main():
                                  % (args.log2job, args.log2job, args.log2job, args.log2job),
                      "pairs_total": total, "pairs_per_gpu": n_local, "collective": collective, "input_gen_s": round(gen_s, 1),
                      "accumulation_launches_per_step": launches},
-                    roofline(kern, MSM_BYTES_PER_PAIR * n_local / launches, "config3", fe_mults / launches), cpu, verified,
-                    result=result.hex() if result else None)
+                    rl3, cpu, verified, result=result.hex() if result else None)
 
     # ---------------------------------------------------------------- secp256k1 MSM (config 4)
     def leg_secp256k1_msm():
@@ -878,6 +944,7 @@ def main():
     legs = {"bn254_msm": leg_bn254_msm, "kzg_commit": leg_kzg_commit, "secp256k1_msm": leg_secp256k1_msm, "icc": leg_icc,
             "config3": leg_config3, "audit_combine": leg_audit_combine, "client_mac_batch": leg_client_mac_batch}
     out = legs[args.workload]()
+    legs_failed = []
     if args.workload == "bn254_msm":
         # every other BASELINE.json configuration rides on the default line
         extra = []
@@ -895,13 +962,16 @@ def main():
         for name, fn in extra:
             torch.cuda.empty_cache()
             try:
+                if os.environ.get("PORLA_BENCH_FAIL_LEG") == name:      # test hook: the failed-leg path of this loop
+                    raise RuntimeError("injected failure (PORLA_BENCH_FAIL_LEG)")
                 leg = fn()
-            except Exception as e:  # noqa: BLE001  (a leg must not take the headline down with it: it is reported as failed)
+            except Exception as e:  # noqa: BLE001  (a leg must not take the headline down with it: the line is still printed)
                 if world > 1:
                     raise                      # ... except where the ranks would fall out of step
-                # (reported in the line; only a result that DIFFERS from the oracle fails the run -- an allocation or child-process
-                # hiccup in a leg is not a parity failure)
+                import traceback
+                traceback.print_exc()
                 leg = {"error": repr(e), "bit_exact_vs_oracle": None}
+                legs_failed.append(name)
             for k in ("n_gpus", "steps", "warmup", "higher_is_better", "vs_baseline", "data"):
                 leg.pop(k, None)               # the leg shares the line's
             out[name] = leg
@@ -911,9 +981,14 @@ def main():
             isinstance(v, dict) and v.get("bit_exact_vs_oracle") is False for v in out.values())
         if fe_peak:
             out["fe_mul_peak"] = fe_peak
+        # a leg that threw is named on the line; one that measures a BASELINE.json configuration also fails the run (rc 3) -- a
+        # missing configuration must not pass silently.  A result that differs from the oracle fails the run with rc 1.
+        out["legs_failed"] = legs_failed
         print(json.dumps(out))
         if failed:
             print("ERROR: GPU result differs from the oracle", file=sys.stderr)
+        if legs_failed:
+            print("ERROR: legs failed: %s" % ", ".join(legs_failed), file=sys.stderr)
     if world > 1:
         if use_cxx_dist:
             mx.dist_finalize()
@@ -921,6 +996,8 @@ def main():
         dist.destroy_process_group()
     if failed:
         sys.exit(1)
+    if any(l in BASELINE_CONFIG_LEGS for l in legs_failed):
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -173,7 +173,9 @@ int porla_secp256k1_tree_fold(const uint8_t *sums_affine, int windows, int windo
  *   all   : porla_gpu_set_device(local_rank); porla_dist_init(id, rank, world)      [collective]
  *   all   : porla_bn254_msm_device_dist(my range ...) -> the whole job's 64-byte result on every rank   [collective]
  *           or a partial from porla_*_msm_device_partial / _device_end(slot, out, 1) handed to porla_*_dist_fold
- *   all   : porla_dist_finalize() */
+ *   all   : porla_dist_finalize()
+ * porla_dist_init is bounded: a peer that never arrives makes it fail with PORLA_ERR_STATE after PORLA_DIST_INIT_TIMEOUT_S
+ * (default 180 s) instead of waiting forever; the process should then exit (the pending RCCL call cannot be cancelled). */
 int porla_dist_unique_id(uint8_t id_out[PORLA_DIST_ID_BYTES]);
 int porla_dist_init(const uint8_t id[PORLA_DIST_ID_BYTES], int rank, int world);
 int porla_dist_info(int *rank, int *world);     /* world = 0 before porla_dist_init */
@@ -219,7 +221,10 @@ int  porla_kzg_commit_batch_host(const uint8_t *rows, size_t n_rows, uint8_t *ou
  * (arguments as porla_bn254_audit_msm_pair_device; they run on a stream of their own beside the rest), align_MAC's commitment and
  * create_proof(random_point, B) -- the three commitments as one launch.  Outputs on the host: combined_MAC, combined_align,
  * align_value = Commit(c), and the proof (commitment = Commit(B), H, point, claim; main.go:153-175); b_out (may be NULL): B mod
- * p_icc as n_cols 32-byte big-endian values.  Everything else device pointers; blocking; one audit at a time per process. */
+ * p_icc as n_cols 32-byte big-endian values.  Everything else device pointers; blocking; one audit at a time per process.
+ * Stream contract (also porla_ipa_audit_device): hip_stream orders the INPUTS -- every kernel of the audit, on whichever
+ * internal stream it runs, waits for what the caller had enqueued on hip_stream (NULL: the null stream) when the call was made,
+ * so index / coefficient arrays uploaded asynchronously on that stream just before the call are safe. */
 int  porla_kzg_audit_device(const void *d_rows64, const uint64_t *d_idx64, const uint32_t *d_coef64, size_t n64,
                             const void *d_rows32, const uint64_t *d_idx32, const uint32_t *d_coef32, size_t n32,
                             const void *d_mac_store, const void *d_align_store, const uint64_t *d_mac_idx,

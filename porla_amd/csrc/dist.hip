@@ -9,9 +9,14 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>   // types and prototypes only; nothing links against librccl
 
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -152,9 +157,34 @@ int porla_dist_init(const uint8_t id_in[PORLA_DIST_ID_BYTES], int rank, int worl
     PORLA_HIP(hipGetDevice(&D.device));
     ncclUniqueId id;
     memcpy(id.internal, id_in, NCCL_UNIQUE_ID_BYTES);
+    // ncclCommInitRank is collective and has no timeout of its own: a peer that never arrives would leave this rank waiting
+    // forever.  It runs on a helper thread; if it has not returned after PORLA_DIST_INIT_TIMEOUT_S (default 180 s) the call
+    // fails with PORLA_ERR_STATE -- the helper cannot be cancelled and stays behind, so the caller is expected to exit.
+    double limit_s = 180.0;
+    if (const char* t = getenv("PORLA_DIST_INIT_TIMEOUT_S")) { double v = atof(t); if (v > 0) limit_s = v; }
+    struct Pending { std::mutex mu; std::condition_variable cv; bool done = false; ncclResult_t r = ncclSuccess; ncclComm_t comm = nullptr; };
+    auto pend = std::make_shared<Pending>();
+    const int device = D.device;
+    auto init_fn = D.lib.CommInitRank;
+    std::thread([pend, device, init_fn, world, id, rank]() {
+        ncclComm_t c = nullptr;
+        ncclResult_t r = hipSetDevice(device) == hipSuccess ? init_fn(&c, world, id, rank) : ncclUnhandledCudaError;
+        std::lock_guard<std::mutex> lk(pend->mu);
+        pend->r = r; pend->comm = c; pend->done = true;
+        pend->cv.notify_all();
+    }).detach();
     ncclComm_t comm = nullptr;
-    ncclResult_t r = D.lib.CommInitRank(&comm, world, id, rank);
-    if (r != ncclSuccess) return nccl_fail(r, "ncclCommInitRank");
+    {
+        std::unique_lock<std::mutex> lk(pend->mu);
+        if (!pend->cv.wait_for(lk, std::chrono::duration<double>(limit_s), [&] { return pend->done; })) {
+            char buf[160];
+            snprintf(buf, sizeof buf, "porla: ncclCommInitRank (rank %d of %d) did not return within %.0f s", rank, world, limit_s);
+            set_last_error(buf);
+            return PORLA_ERR_STATE;
+        }
+        if (pend->r != ncclSuccess) return nccl_fail(pend->r, "ncclCommInitRank");
+        comm = pend->comm;
+    }
     D.comm = comm; D.rank = rank; D.world = world;
     hipError_t e = hipStreamCreateWithFlags(&D.stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void**)&D.d_send, PORLA_JACOBIAN_BYTES);

@@ -219,6 +219,14 @@ static int abi_jac_sum(const uint8_t* jacs, size_t count, uint8_t* out) {
     return PORLA_OK;
 }
 
+int order_after_caller(Workspace* ws, hipStream_t caller, hipStream_t a, hipStream_t b) {
+    if (!ws->caller_ev) PORLA_HIP(hipEventCreateWithFlags(&ws->caller_ev, hipEventDisableTiming));
+    PORLA_HIP(hipEventRecord(ws->caller_ev, caller));
+    if (a && a != caller) PORLA_HIP(hipStreamWaitEvent(a, ws->caller_ev, 0));
+    if (b && b != caller && b != a) PORLA_HIP(hipStreamWaitEvent(b, ws->caller_ev, 0));
+    return PORLA_OK;
+}
+
 hipStream_t engine_stream() {
     Workspace* ws;
     if (get_workspace(&ws)) return nullptr;
@@ -568,16 +576,20 @@ int porla_ipa_audit_device(porla_fixed_base* generators_fb, const void* d_rows64
     }
     void* pin_dev = nullptr;
     PORLA_HIP(hipHostGetDevicePointer(&pin_dev, g_ipa_pin, 0));
+    // hip_stream orders the INPUTS: the combine runs on it (on the engine's stream when it is the null stream), the pair on the
+    // audit slot's own stream -- both behind an event recorded on hip_stream now, so index / coefficient arrays the caller has
+    // just uploaded asynchronously on it are complete before any kernel of the audit reads them
     hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : engine_stream();
+    Workspace* aw = nullptr;
+    if ((rc = get_workspace_slot(MSM_AUDIT_SLOT, &aw))) return rc;
+    if ((rc = order_after_caller(aw, (hipStream_t)hip_stream, stream, aw->own_stream))) return rc;
     // the combine first (its short kernels take their compute units before the pair's long-lived blocks), then the pair
     rc = porla_audit_combine_device(d_rows64, d_idx64, d_coef64, n64, d_rows32, d_idx32, d_coef32, n32, n_cols, 1, nullptr, nullptr,
                                     pin_dev, (uint8_t*)pin_dev + 32 * n_cols, stream);
     const bool pair = n_macs >= 1 && n_macs <= 32768;
     bool pair_begun = false;
     if (rc == PORLA_OK && pair) {
-        Workspace* aw = nullptr;
-        if ((rc = get_workspace_slot(MSM_AUDIT_SLOT, &aw)) == PORLA_OK)
-            rc = msm_pair_gather_begin<Secp256k1G>(MSM_AUDIT_SLOT, (const uint8_t*)d_mac_store, (const uint8_t*)d_align_store, d_mac_idx,
+        rc = msm_pair_gather_begin<Secp256k1G>(MSM_AUDIT_SLOT, (const uint8_t*)d_mac_store, (const uint8_t*)d_align_store, d_mac_idx,
                                                    d_mac_coef, n_macs, aw->own_stream);
         pair_begun = rc == PORLA_OK;
     }

@@ -130,6 +130,7 @@ struct Workspace {
     hipStream_t aux_stream = nullptr;            // second stream of the reduction tree (msm_tree_launch)
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     hipEvent_t front_fork_ev = nullptr, front_join_ev = nullptr;   // points_to_mont beside the digit / sort chain (msm_launch)
+    hipEvent_t caller_ev = nullptr;  // order_after_caller: the caller's stream at the time of the call
     int slot = 0;
     hipEvent_t done = nullptr;  // recorded after the last kernel + D2H copy of a launched MSM
     int pend_W = 0, pend_c = 0; // window count / width of the launched, not yet folded MSM (0 = none)
@@ -148,6 +149,10 @@ constexpr int MSM_USER_SLOTS = 4;
 constexpr int MSM_MULTI_SLOT0 = 4;
 constexpr int MSM_MULTI_SLOTS = 4;
 constexpr int MSM_POOL_SLOT0 = 8;
+// Makes `a` (and `b`, if given) wait for everything enqueued so far on `caller` -- the stream the entry point was handed, which
+// may be the null stream -- so that work the library runs on its own non-blocking streams sees the caller's earlier copies and
+// kernels (the audit entry points read index / coefficient arrays the caller may just have uploaded asynchronously).
+int order_after_caller(Workspace* ws, hipStream_t caller, hipStream_t a, hipStream_t b = nullptr);
 constexpr size_t MSM_SCAN_MAX = 1u << 16;  // inputs up to this size are scanned for their longest scalar first
 constexpr size_t MSM_RANGE_MAX = 1u << 22; // larger inputs run as ranges of this size into one bucket array (msm_launch)
 // Batched fixed-base commitments (fixed_base.hip.h): resident table of window multiples of one base.

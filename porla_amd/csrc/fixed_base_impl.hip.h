@@ -236,7 +236,12 @@ int FixedBase<C>::commit_small(const uint8_t* const* row_ptrs, size_t n_rows, si
     volatile uint32_t* hdr = (volatile uint32_t*)hs;
     hdr[0] = 0;
     const uint32_t P = (uint32_t)(n_coeffs * (size_t)W);
-    static const uint32_t per_slice = getenv("PORLA_COMMIT_SMALL_PAIRS") ? (uint32_t)atoi(getenv("PORLA_COMMIT_SMALL_PAIRS")) : 256u;   // (512: one row 0.0615 ms, the audit 0.150 ms; 256: 0.060 / 0.142)
+    // (512: one row 0.0615 ms, the audit 0.150 ms; 256: 0.060 / 0.142); anything outside 64..4096 -- or not a number -- means 256
+    static const uint32_t per_slice = []() -> uint32_t {
+        const char* e = getenv("PORLA_COMMIT_SMALL_PAIRS");
+        const long v = e ? strtol(e, nullptr, 10) : 256;
+        return v >= 64 && v <= 4096 ? (uint32_t)v : 256u;
+    }();
     uint32_t SL = (P + per_slice - 1) / per_slice;
     if (SL < 1) SL = 1;
     if (SL > (uint32_t)FB_SMALL_MAX_SLICES) SL = FB_SMALL_MAX_SLICES;

@@ -504,8 +504,10 @@ int porla_server_mix_device(const void* d_data_a0, const void* d_data_a1, const 
     int dev = 0;
     PORLA_HIP(hipGetDevice(&dev));
     MixSide side;
+    // held across fork -> side launches -> join: the events and the side stream are one set per device, and two host threads
+    // mixing on different streams must not interleave their records and waits (everything below only ENQUEUES)
+    std::lock_guard<std::mutex> lk(g_mix_side_mu);
     {
-        std::lock_guard<std::mutex> lk(g_mix_side_mu);
         MixSide* found = nullptr;
         for (auto& m : g_mix_side) if (m.device == dev) found = &m;
         if (!found) {

@@ -1037,7 +1037,13 @@ int porla_kzg_audit_device(const void* d_rows64, const uint64_t* d_idx64, const 
     PORLA_HIP(hipHostGetDevicePointer(&pin_dev, pin->h, 0));
     uint8_t* h_b = pin->h;                  // B mod p_icc, n 32-byte big-endian values
     uint8_t* h_c = pin->h + 32 * n;         // the alignment scalars
+    // hip_stream orders the INPUTS: the combine runs on it (on the engine's stream when it is the null stream), the pair on the
+    // audit slot's own stream -- both behind an event recorded on hip_stream now, so index / coefficient arrays the caller has
+    // just uploaded asynchronously on it are complete before any kernel of the audit reads them
     hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : engine_stream();
+    Workspace* aw = nullptr;
+    if ((rc = get_workspace_slot(MSM_AUDIT_SLOT, &aw))) return rc;
+    if ((rc = order_after_caller(aw, (hipStream_t)hip_stream, stream, aw->own_stream))) return rc;
     const bool pair = n_macs >= 1 && n_macs <= 32768;
     bool pair_begun = false;
     auto collect_pair = [&]() -> int {
@@ -1058,9 +1064,7 @@ int porla_kzg_audit_device(const void* d_rows64, const uint64_t* d_idx64, const 
                                     pin_dev, (uint8_t*)pin_dev + 32 * n, stream);
     lap("combine enqueued");
     if (rc == PORLA_OK && pair) {
-        Workspace* aw = nullptr;
-        if ((rc = get_workspace_slot(MSM_AUDIT_SLOT, &aw)) == PORLA_OK)
-            rc = msm_pair_gather_begin<Bn254G1>(MSM_AUDIT_SLOT, (const uint8_t*)d_mac_store, (const uint8_t*)d_align_store, d_mac_idx,
+        rc = msm_pair_gather_begin<Bn254G1>(MSM_AUDIT_SLOT, (const uint8_t*)d_mac_store, (const uint8_t*)d_align_store, d_mac_idx,
                                                 d_mac_coef, n_macs, aw->own_stream);
         pair_begun = rc == PORLA_OK;
         lap("pair begun");

@@ -343,9 +343,15 @@ def kzg_commit_batch_device_to_host(d_rows, n_rows, stream=0):
 
 
 def kzg_audit_device(d_rows64, d_idx64, d_coef64, n64, d_rows32, d_idx32, d_coef32, n32, d_mac_store, d_align_store, d_mac_idx,
-                     d_mac_coef, n_macs, z, n_cols=128, stream=0):
-    """Server::audit (KZG) in one call -> dict(combined_mac, combined_align, align_value, commitment, proof_h, point, claim, b)"""
+                     d_mac_coef, n_macs, z, n_cols=None, stream=0):
+    """Server::audit (KZG) in one call -> dict(combined_mac, combined_align, align_value, commitment, proof_h, point, claim, b).
+    The library writes 32 bytes per SRS coefficient into `b`: n_cols, if given, must be the SRS size"""
     vp = ctypes.c_void_p
+    srs_n = kzg_row_coefficients()
+    if n_cols is None:
+        n_cols = srs_n
+    elif n_cols != srs_n:
+        raise ValueError("kzg_audit_device: n_cols=%d but the SRS holds %d coefficients" % (n_cols, srs_n))
     o = [ctypes.create_string_buffer(k) for k in (64, 64, 64, 64, 64, 32, 32, 32 * n_cols)]
     _check(lib.porla_kzg_audit_device(vp(d_rows64 or None), vp(d_idx64 or None), vp(d_coef64 or None), n64, vp(d_rows32 or None),
                                       vp(d_idx32 or None), vp(d_coef32 or None), n32, vp(d_mac_store), vp(d_align_store), vp(d_mac_idx),

@@ -14,15 +14,7 @@ from tests import common
 pytestmark = pytest.mark.gpu
 
 
-def test_two_rank_bench_line_is_bit_exact():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ, PORLA_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(common.ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--no-commits", "--log2job", "21"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=common.ROOT)
+def _check_two_rank_line(r):
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
     d = json.loads(lines[0])
@@ -31,11 +23,47 @@ def test_two_rank_bench_line_is_bit_exact():
     assert d["cpu_baseline"] is None                 # reported at N = 1 only
     assert d["roofline"]["kernel"] and d["value"] > 0
     assert 0 < d["roofline"]["int_multiplier"]["frac"] <= 1.0
-    # BASELINE config 3 in small: ONE 2^21-pair job, half of it per rank (strong scaling), the whole job against the oracle
+    assert d["legs_failed"] == []
+    return d
+
+
+def test_bench_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` run DIRECTLY (no torchrun around it, WORLD_SIZE unset): the process starts the two ranks itself as
+    a child torch.distributed.run, relays the one JSON line and the exit code.  BASELINE config 3 at full size: ONE 2^24-pair job,
+    2^23 pairs per rank (Client.hpp:761-787's range split), the whole job against the oracle."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(PORLA_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(common.ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-commits"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=common.ROOT)
+    d = _check_two_rank_line(r)
     c3 = d["config3"]
-    assert c3["scaling"] == "strong" and c3["config"]["pairs_total"] == 1 << 21 and c3["config"]["pairs_per_gpu"] == 1 << 20
+    assert c3["scaling"] == "strong" and c3["config"]["pairs_total"] == 1 << 24 and c3["config"]["pairs_per_gpu"] == 1 << 23
     assert c3["bit_exact_vs_oracle"] is True and c3["value"] > 0
     assert d["secp256k1_msm"]["value"] > 0 and d["icc"]["value"] > 0
+
+
+def test_two_rank_bench_line_under_an_external_torchrun():
+    """the driver's form: the ranks started by torch.distributed.run around bench.py"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PORLA_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(common.ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-commits", "--no-legs"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=common.ROOT)
+    _check_two_rank_line(r)
+
+
+def test_a_failed_baseline_leg_fails_the_run():
+    """a BASELINE-config leg that throws is named in `legs_failed` and the run exits non-zero -- the line is still printed"""
+    env = dict(os.environ, PORLA_BENCH_FAIL_LEG="icc")
+    r = subprocess.run([sys.executable, os.path.join(common.ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-commits", "--no-config3",
+                        "--no-cpu", "--no-host-boundary"], capture_output=True, text=True, timeout=600, env=env, cwd=common.ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 3 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["legs_failed"] == ["icc"] and "injected" in d["icc"]["error"] and d["value"] > 0
 
 
 def test_single_rank_bench_line_prices_the_kernel_it_timed():
