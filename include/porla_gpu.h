@@ -262,6 +262,10 @@ int  porla_kzg_mac_batch_host(const uint8_t *rows, const uint8_t *scalars, size_
 int  porla_bn254_g2_mul_generator(const uint8_t scalar_be[32], uint8_t out[128]);
 int  porla_bn254_pairing_product_is_one(const uint8_t p1[64], const uint8_t q1[128], const uint8_t p2[64], const uint8_t q2[128],
                                         int slow);
+/* the same predicate on EIP-197's own input layout, any number of pairs: n_pairs x 192 bytes (G1 X || Y, then G2
+ * x_im || x_re || y_im || y_re, 32-byte big-endian each; zeros = infinity).  1 / 0; PORLA_ERR_ARG for inputs the precompile
+ * rejects (coordinate >= p, point off its curve, G2 point outside the order-r subgroup).  Host code, no device needed. */
+int  porla_bn254_pairing_check(const uint8_t *input, size_t n_pairs, int slow);
 /* window bits used when the SRS table is (re)built; 0 = automatic */
 int  porla_kzg_set_commit_window(int window_bits);
 /* diagnostic: window bits / windows per coefficient of the SRS table currently resident (0, 0 before the first batch) */

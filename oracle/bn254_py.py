@@ -260,6 +260,21 @@ class KZG:
         """G1 part of SRS.WriteTo (main.go:48): 4-byte BE count + n compressed points."""
         return len(self.srs_g1).to_bytes(4, "big") + b"".join(g1_compress(p) for p in self.srs_g1)
 
+    def srs_blob(self):
+        """the whole SRS.WriteTo blob (main.go:48; 32 n + 132 bytes, Client.hpp:350-357): the G1 part, then G2[0] = the G2
+        generator and G2[1] = tau * generator, 64 bytes compressed each (oracle/bn254_pairing_py.py)"""
+        import bn254_pairing_py as pp
+        return self.srs_g1_blob() + pp.srs_g2_blob(self.tau)
+
+    def verify_proof_with_pairing(self, commitment, proof_h, point, claim):
+        """kzg.Verify (main.go:177-193) as gnark states it: e(C - y G1, G2) * e(-H, tau G2 - z G2) == 1, on the Python pairing"""
+        import bn254_pairing_py as pp
+        c, hh = g1_unmarshal(commitment), g1_unmarshal(proof_h)
+        z, y = fr_from_bytes(point), fr_from_bytes(claim)
+        lhs = g1_add(c, g1_neg(g1_mul(G1, y)))
+        q = pp.g2_add(pp.g2_mul(pp.G2_GEN, self.tau), pp.g2_neg(pp.g2_mul(pp.G2_GEN, z)))
+        return pp.pairing_product_is_one([(lhs, pp.G2_GEN), (g1_neg(hh), q)])
+
     def init_srs_from_points(self, pts):
         self.n = len(pts)
         self.srs_g1 = list(pts)

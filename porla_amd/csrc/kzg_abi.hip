@@ -724,6 +724,44 @@ int porla_bn254_pairing_product_is_one(const uint8_t p1[64], const uint8_t q1[12
                                   slow != 0) ? 1 : 0;
 }
 
+// the EIP-197 predicate on its own input layout: n pairs of 192 bytes (G1 X || Y, G2 x_im || x_re || y_im || y_re, all 32-byte
+// big-endian; zeros = infinity).  PORLA_ERR_ARG for what the precompile rejects (a coordinate >= p, a point off its curve, a G2
+// point outside the order-r subgroup); else 1 / 0.  Pairs go two at a time through the shared Miller loop of verify_proof.
+int porla_bn254_pairing_check(const uint8_t* input, size_t n_pairs, int slow) {
+    if (!input && n_pairs) return PORLA_ERR_ARG;
+    static const uint8_t P_BE[32] = {0x30, 0x64, 0x4e, 0x72, 0xe1, 0x31, 0xa0, 0x29, 0xb8, 0x50, 0x45, 0xb6, 0x81, 0x81, 0x58, 0x5d,
+                                     0x97, 0x81, 0x6a, 0x91, 0x68, 0x71, 0xca, 0x8d, 0x3c, 0x20, 0x8c, 0x16, 0xd8, 0x7c, 0xfd, 0x47};
+    static const uint32_t R_LE[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    std::vector<Affine<Fp>> ps(n_pairs);
+    std::vector<G2Affine> qs(n_pairs);
+    for (size_t i = 0; i < n_pairs; i++) {
+        const uint8_t* in = input + 192 * i;
+        for (int w = 0; w < 6; w++)
+            if (memcmp(in + 32 * w, P_BE, 32) >= 0) { set_last_error("porla: pairing input coordinate >= p"); return PORLA_ERR_ARG; }
+        ps[i] = h_affine_from_bytes<Fp>(in);
+        if (!aff_is_inf<Fp>(ps[i])) {
+            const Fe<Fp> rhs = fe_add<Fp>(fe_mul<Fp>(fe_mul<Fp>(ps[i].x, ps[i].x), ps[i].x), fp_small(3));
+            if (!fe_eq<Fp>(fe_mul<Fp>(ps[i].y, ps[i].y), rhs)) { set_last_error("porla: pairing input G1 point not on the curve"); return PORLA_ERR_ARG; }
+        }
+        qs[i] = g2_from_bytes(in + 64);
+        if (!qs[i].inf) {
+            const Fp2 rhs = f2_add(f2_mul(f2_sqr(qs[i].x), qs[i].x), g2_b());
+            if (!f2_eq(f2_sqr(qs[i].y), rhs)) { set_last_error("porla: pairing input G2 point not on the twist"); return PORLA_ERR_ARG; }
+            if (!g2_scalar_mul(qs[i], R_LE).inf) { set_last_error("porla: pairing input G2 point not in the order-r subgroup"); return PORLA_ERR_ARG; }
+        }
+    }
+    const Affine<Fp> p_inf = h_affine_from_bytes<Fp>(std::vector<uint8_t>(64, 0).data());
+    const G2Affine q_inf{f2_zero(), f2_zero(), true};
+    Fp12 f = f12_one();
+    if (slow) {
+        for (size_t i = 0; i < n_pairs; i++) f = f12_mul(f, miller_ate_affine(ps[i], qs[i]));
+        return f12_is_one(f12_pow_final(f)) ? 1 : 0;
+    }
+    for (size_t i = 0; i < n_pairs; i += 2)
+        f = f12_mul(f, i + 1 < n_pairs ? miller_opt_ate2(ps[i], qs[i], ps[i + 1], qs[i + 1]) : miller_opt_ate2(ps[i], qs[i], p_inf, q_inf));
+    return f12_is_one(f12_final_exp(f)) ? 1 : 0;
+}
+
 // ---- client side, batched: compute_digest (main.go:70-89) and compute_digest_complement (main.go:91-101) over many rows ----
 static int one_point_table(FixedBase<Bn254G1>& fb, unsigned long long& built_version, const Affine<Fp>& point) {
     if (built_version == g.version) return PORLA_OK;

@@ -65,6 +65,7 @@ def test_kzg_host_side_matches_golden():
     blob = mx.init_SRS(n)
     assert len(blob) == 32 * n + 132          # Client.hpp:350-357
     assert blob[:4 + 32 * n].hex() == kz["srs_g1_blob"]
+    assert blob.hex() == kz["srs_blob"]       # the WHOLE blob: the two compressed G2 points too (generator, tau * generator)
     for c in kz["cases"]:
         assert mx.compute_digest(bytes.fromhex(c["f"])).hex() == c["digest"]
         for op in c["open"]:

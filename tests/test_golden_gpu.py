@@ -60,6 +60,7 @@ def test_kzg_fixture_through_the_plugin_symbols_and_the_batches():
     mx.init_key(tau, alpha)
     blob = mx.init_SRS(n)                                                         # client side
     assert blob[:4 + 32 * n].hex() == kz["srs_g1_blob"]
+    assert blob.hex() == kz["srs_blob"]       # all 32 n + 132 bytes (main.go:42-50, Client.hpp:350-357): the G2 half included
     for side in ("client", "server"):
         if side == "server":
             mx.init_SRS_from_data(n, blob)                                        # Server.hpp:183-188

@@ -44,3 +44,102 @@ def test_bilinearity_fast_and_reference_forms_agree():
     for _ in range(5):
         lib.porla_bn254_pairing_product_is_one(*cases[0][:4], 0)
     assert (time.perf_counter() - t0) / 5 < 0.05
+
+
+# ---------------------------------------------------------------- external known answers
+def _eip197():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "eip197_kat.json")))["vectors"]
+
+
+def test_geth_pairing_vectors_through_the_engine():
+    """go-ethereum's bn256Pairing precompile vectors (tests/golden/eip197_kat.json) through the host pairing behind verify_proof:
+    the fast form, the literal form, and -- for the two-pair vectors -- the very function verify_proof calls.  This is what pins
+    the G2 encoding (x_im || x_re || y_im || y_re), the G2 generator and the pairing to an implementation that is not ours."""
+    from porla_amd import lib
+    lib.porla_bn254_pairing_check.restype = ctypes.c_int
+    for v in _eip197():
+        raw = bytes.fromhex(v["input"])
+        assert lib.porla_bn254_pairing_check(raw, ctypes.c_size_t(v["pairs"]), 0) == v["expected"], v["name"]
+        if v["name"] in ("jeff1", "jeff4", "jeff6", "one_point"):
+            assert lib.porla_bn254_pairing_check(raw, ctypes.c_size_t(v["pairs"]), 1) == v["expected"], v["name"]
+        if v["pairs"] == 2:
+            assert lib.porla_bn254_pairing_product_is_one(raw[:64], raw[64:192], raw[192:256], raw[256:384], 0) == v["expected"], v["name"]
+
+
+def test_pairing_check_rejects_what_the_precompile_rejects():
+    from porla_amd import lib
+    lib.porla_bn254_pairing_check.restype = ctypes.c_int
+    good = bytearray(bytes.fromhex(_eip197()[0]["input"]))
+    assert lib.porla_bn254_pairing_check(bytes(good), ctypes.c_size_t(2), 0) == 1
+    bad = bytearray(good); bad[63] ^= 1                                   # G1 y off the curve
+    assert lib.porla_bn254_pairing_check(bytes(bad), ctypes.c_size_t(2), 0) < 0
+    bad = bytearray(good); bad[64 + 127] ^= 1                             # G2 y_re off the twist
+    assert lib.porla_bn254_pairing_check(bytes(bad), ctypes.c_size_t(2), 0) < 0
+    bad = bytearray(good); bad[0:32] = P.to_bytes(32, "big")              # a coordinate >= p
+    assert lib.porla_bn254_pairing_check(bytes(bad), ctypes.c_size_t(2), 0) < 0
+    # a point ON the twist but outside the order-r subgroup (the twist's cofactor is not 1): x = 1 + 0i happens to work or the next does
+    import bn254_pairing_py as pp
+    x = 1
+    while True:
+        y = pp.f2_sqrt(pp.f2_add(pp.f2_mul(pp.f2_mul((x, 0), (x, 0)), (x, 0)), pp.B2))
+        if y is not None and not pp.g2_in_subgroup(((x, 0), y)):
+            break
+        x += 1
+    bad = bytearray(good); bad[64:192] = pp.g2_to_eip197(((x, 0), y))
+    assert lib.porla_bn254_pairing_check(bytes(bad), ctypes.c_size_t(2), 0) < 0
+
+
+def test_srs_g2_half_against_the_fixture_and_the_python_oracle():
+    """SRS.G2[1] = tau * G2gen (kzg.NewSRS, main.go:46): the engine's G2 scalar multiplication against the committed fixture, and
+    the fixture's compressed pair (the last 128 bytes of the wire blob) against the Python (de)compression"""
+    import json
+    import os
+    import bn254_pairing_py as pp
+    from porla_amd import lib
+    kz = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bn254_golden.json")))["kzg"]
+    tau = int(kz["tau"], 16)
+    out = ctypes.create_string_buffer(128)
+    assert lib.porla_bn254_g2_mul_generator((tau % R).to_bytes(32, "big"), out) == 0
+    assert out.raw.hex() == kz["srs_g2_tau_eip197"]
+    assert lib.porla_bn254_g2_mul_generator((1).to_bytes(32, "big"), out) == 0 and out.raw == pp.g2_to_eip197(pp.G2_GEN)
+    blob = bytes.fromhex(kz["srs_blob"])
+    assert len(blob) == 32 * kz["n"] + 132
+    g2a, g2b = pp.g2_decompress(blob[-128:-64]), pp.g2_decompress(blob[-64:])
+    assert g2a == pp.G2_GEN and pp.g2_to_eip197(g2b).hex() == kz["srs_g2_tau_eip197"]
+    assert pp.g2_compress(g2a) == blob[-128:-64] and pp.g2_compress(g2b) == blob[-64:]
+    assert pp.g2_compress(pp.g2_neg(g2b))[0] & 0xC0 != blob[-64] & 0xC0 and pp.g2_compress(None)[0] == 0x40
+
+
+def test_python_pairing_oracle_on_the_geth_vectors():
+    """pins oracle/bn254_pairing_py.py itself (three vectors; gen_eip197_kat.py runs all of them)"""
+    import bn254_pairing_py as pp
+    vs = {v["name"]: v for v in _eip197()}
+    for name in ("jeff2", "jeff6", "two_point_match_2"):
+        raw = bytes.fromhex(vs[name]["input"])
+        pairs = []
+        for k in range(vs[name]["pairs"]):
+            c = raw[192 * k:192 * (k + 1)]
+            x, y = int.from_bytes(c[:32], "big"), int.from_bytes(c[32:64], "big")
+            pairs.append((None if x == 0 and y == 0 else (x, y), pp.g2_from_eip197(c[64:])))
+        assert pp.pairing_product_is_one(pairs) == bool(vs[name]["expected"]), name
+
+
+def test_verify_proof_agrees_with_the_python_pairing():
+    """verify_proof (main.go:177-193) through the 14-symbol boundary on a fixture opening -- accepted -- and on the same opening with
+    the claim off by one -- rejected; the Python pairing gives the same two answers on the same bytes"""
+    import json
+    import os
+    import bn254_py as o
+    from porla_amd import multiexp as mx
+    kz = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bn254_golden.json")))["kzg"]
+    mx.init_key(bytes.fromhex(kz["tau"]), bytes.fromhex(kz["alpha"]))
+    mx.init_SRS_from_data(kz["n"], bytes.fromhex(kz["srs_blob"]))           # the FIXTURE's blob, G2 half included
+    op = kz["cases"][0]["open"][1]
+    cm, h, zb, y = (bytes.fromhex(op[k]) for k in ("commitment", "H", "point", "claim"))
+    y_bad = ((int.from_bytes(y, "big") + 1) % R).to_bytes(32, "big")
+    k = o.KZG()
+    k.init_key(bytes.fromhex(kz["tau"]), bytes.fromhex(kz["alpha"]))
+    assert mx.verify_proof(cm, h, zb, y) is True and k.verify_proof_with_pairing(cm, h, zb, y) is True
+    assert mx.verify_proof(cm, h, zb, y_bad) is False and k.verify_proof_with_pairing(cm, h, zb, y_bad) is False
