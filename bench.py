@@ -28,6 +28,10 @@ cpu_baseline and bit_exact_vs_oracle, timed separately after the headline region
   kzg_audit       ONE server-side KZG audit at the reference's size (3 200 challenged rows of a 2^15-block level resident in HBM):
                   row combine, the two MSMs over the challenged MACs, align_MAC's commitment and create_proof behind
                   porla_kzg_audit_device; audits/s, checked against what the client verifies; N = 1 only            
+  ipa_commits     the IPA build's twin of kzg_commits: 2^17 rows x 128 coefficients against the 128 secp256k1 generators
+                  (Client::compute_commitment, Client.hpp:374-406, hoisted over blocks); N = 1 only                  (s8 f-1)
+  mac_encode      the MAC halves of CRebuild_Cached for 2^15 MACs, both curves; N = 1 only                            (s8 f-2)
+  server_mix      Server::mix in one call (data rows + MAC commitments + MAC alignments of two 2^12-row blocks), both curves; N = 1 only
   client_mac_batch  the block MACs of Client::initialize (digest + complement + add_point per block) for 2^17 blocks resident in
                   HBM behind porla_kzg_mac_batch_device; blocks/s, three blocks checked on the oracle's arithmetic; N = 1 only (s8 a4)
 and, for the headline MSM: `blocking_ms_per_step` + `blocking_kernels_ms` (one MSM in flight: what a caller that waits for
@@ -176,7 +180,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="bn254_msm",
                     choices=["bn254_msm", "kzg_commit", "secp256k1_msm", "icc", "config3", "crebuild", "audit_combine", "kzg_audit",
-                             "client_mac_batch"])
+                             "client_mac_batch", "ipa_commits", "mac_encode", "server_mix"])
     ap.add_argument("--log2n", type=int, default=20, help="MSM pairs per GPU = 2^log2n (default: the 2^20 of BASELINE.json)")
     ap.add_argument("--log2rows", type=int, default=17, help="kzg_commit rows per GPU = 2^log2rows; icc rows = 2^(log2rows-2)")
     ap.add_argument("--log2job", type=int, default=24, help="config3: pairs of the whole job = 2^log2job, split over the ranks")
@@ -940,10 +944,215 @@ def main():
                              "algorithmic_bytes_per_launch": n * 4128, "algorithmic_bytes_per_batch": alg},
                 "bit_exact_vs_oracle": verified}
 
+    # ---------------------------------------------------------------- the IPA build's side of the path (N = 1 only)
+    def wall_and_kernels(call, reps=20, warm=5):
+        """ms per call back to back + HIP-event ms per launch / per call of every kernel of `call` (5 extra untimed calls)"""
+        for _ in range(warm):
+            call()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            call()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        mx.profile_enable(True)
+        for _ in range(5):
+            call()
+        torch.cuda.synchronize()
+        prof = mx.profile_get()
+        mx.profile_enable(False)
+        return ms, {k: round(t / max(c, 1), 4) for k, t, c in prof}, {k: round(t / 5, 4) for k, t, c in prof}
+
+    def hbm_roofline(per_launch, per_call, algo_bytes_per_call, note):
+        if not per_launch:
+            return None
+        dom = max(per_call, key=per_call.get)
+        launches = max(1, round(per_call[dom] / per_launch[dom])) if per_launch[dom] else 1
+        ach = algo_bytes_per_call / launches / (per_launch[dom] * 1e-3) / 1e9 if per_launch[dom] else None
+        return {"bound": "hbm", "kernel": KERNEL_SYMBOL.get(dom, dom), "achieved": round(ach, 3) if ach else None, "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 6) if ach else None, "traffic": None,
+                "traffic_source": "no counter pass committed for this leg", "kernel_ms": per_launch[dom],
+                "launches_per_call": launches, "algorithmic_bytes_per_call": algo_bytes_per_call,
+                "all_kernels_ms_per_call": per_call, "note": note}
+
+    def ipa_generators(n):
+        # the 128 Pedersen generators of the IPA build (Client.hpp:112-117 draws them at random): k_i * G, k_i = SHA-256("ecmult" || i)
+        sc = common.secp_bench_scalars(n, start=77000)
+        out = ctypes.create_string_buffer(64 * n)
+        common.oracle().oracle_secp256k1_mul_g_batch(sc, ctypes.c_size_t(n), out, common.ncpu())
+        return out.raw
+
+    def leg_ipa_commits():
+        rows_n = 1 << args.log2rows
+        gens = ipa_generators(128)
+        fb = mx.FixedBase("secp256k1", gens, 128)
+        try:
+            g = torch.Generator(device=dev).manual_seed(4321)
+            d_rows = torch.randint(0, 256, (rows_n * 4096,), dtype=torch.uint8, device=dev, generator=g)
+            d_out = torch.empty(rows_n * 64, dtype=torch.uint8, device=dev)
+            t_b = time.perf_counter()
+            fb.commit_device(d_rows.data_ptr(), rows_n, 128, d_out.data_ptr(), stream)
+            torch.cuda.synchronize()
+            first_s = time.perf_counter() - t_b
+            ms, per_launch, per_call = wall_and_kernels(lambda: fb.commit_device(d_rows.data_ptr(), rows_n, 128, d_out.data_ptr(), stream),
+                                                        reps=max(3, min(args.steps, 20)), warm=max(1, min(args.warmup, 5)))
+            info = fb.info()
+            cpu = None
+            ok = None
+            if not args.no_cpu:
+                sample = 2048
+                rows = bytes(d_rows[:sample * 4096].cpu().numpy())
+                cores = common.ncpu()
+                t1 = time.perf_counter()
+                want = common.oracle_commit_batch("secp256k1", rows, sample, 128, gens, threads=cores)
+                cpu_s = time.perf_counter() - t1
+                ok = want == bytes(d_out[:sample * 64].cpu().numpy())
+                cpu = {"value": round(sample / cpu_s, 1), "unit": "commits/s", "cores": cores, "kind": "port",
+                       "sample": "the first %d rows, one 128-point bucket MSM per row (oracle/secp256k1_ref.c, CPU restatement of "
+                                 "compute_commitment, not libsecp256k1) over %d threads; %.2f s wall" % (sample, cores, cpu_s)}
+            rl = hbm_roofline(per_launch, per_call, COMMIT_BYTES_PER_ROW * rows_n,
+                              "algorithmic bytes = 4 096 B of coefficients + 64 B out per row (generator table resident); the kernel "
+                              "is bound by the integer multiplier, as k_fb_commit of the KZG leg")
+            return {"metric": "IPA Pedersen commitments/s (128-coefficient rows against the 128 secp256k1 generators)",
+                    "value": round(rows_n / ms * 1e3, 1), "unit": "commits/s", "ms_per_step": round(ms, 4), "scaling": "weak",
+                    "dtype": "u32x9 (30-bit limbs, 256-bit modular integer)",
+                    "config": {"workload": "Client::compute_commitment (Client.hpp:374-406) hoisted over 2^%d blocks: rows of 128 "
+                                           "coefficients resident in HBM against the fixed generators (window table resident)" % args.log2rows,
+                               "rows_per_gpu": rows_n, "table": info, "table_build_and_first_call_s": round(first_s, 3)},
+                    "roofline": rl, "cpu_baseline": cpu, "bit_exact_vs_oracle": ok,
+                    "equiv_Mmul_per_s": round(rows_n * 128 / ms / 1e3, 1)}
+        finally:
+            fb.close()
+
+    def leg_mac_encode():
+        from porla_amd import icc
+        n = 1 << 15
+        out = {"metric": "MAC-side ICC encode, M point butterflies/s (2^15 MACs)", "unit": "Mbutterflies/s", "scaling": "weak",
+               "dtype": "u32x9 (30-bit limbs, 256-bit modular integer)",
+               "config": {"workload": "the MAC halves of CRebuild_Cached (Server.hpp:1523-1536, 1590-1609, 1658-1676): 2^15 MACs "
+                                      "resident in HBM through the radix-2 network in the exponent, X part; both curves", "macs": n},
+               "curves": {}}
+        all_ok = None
+        for curve in ("bn254", "secp256k1"):
+            if curve == "bn254":
+                base = common.synth_points(4096, start=9000)
+            else:
+                sc = common.secp_bench_scalars(4096, start=300)
+                buf = ctypes.create_string_buffer(64 * 4096)
+                common.oracle().oracle_secp256k1_mul_g_batch(sc, ctypes.c_size_t(4096), buf, common.ncpu())
+                base = buf.raw
+            macs = (base * (n // 4096))[:64 * n]
+            d_in = to_dev(macs)
+            d_o = torch.empty(64 * n, dtype=torch.uint8, device=dev)
+            ms, per_launch, per_call = wall_and_kernels(lambda: icc.mac_crebuild_device(d_in.data_ptr(), n, curve, 0, 0, d_o.data_ptr(), stream),
+                                                        reps=10, warm=3)
+            bfly = (n // 2) * 15
+            cpu = None
+            ok = None
+            if not args.no_cpu:
+                cores = common.ncpu()
+                want = ctypes.create_string_buffer(64 * n)
+                t1 = time.perf_counter()
+                common.oracle().oracle_icc_mac_crebuild(macs, ctypes.c_size_t(n), 0 if curve == "bn254" else 1, 0, ctypes.c_uint64(0),
+                                                        want, cores)
+                cpu_s = time.perf_counter() - t1
+                ok = want.raw == bytes(d_o.cpu().numpy())
+                all_ok = ok if all_ok is None else (all_ok and ok)
+                cpu = {"value": round(bfly / cpu_s / 1e6, 4), "unit": "Mbutterflies/s", "cores": cores, "kind": "port",
+                       "sample": "the same 2^15-MAC encode, oracle/mac_ref.c (one scalar multiplication + two additions per butterfly, "
+                                 "CPU restatement, not gnark / libsecp256k1) over %d threads; %.1f s wall" % (cores, cpu_s)}
+            out["curves"][curve] = {"value": round(bfly / ms / 1e3, 3), "ms_per_step": round(ms, 4),
+                                    "roofline": hbm_roofline(per_launch, per_call, 128 * n,
+                                                             "algorithmic bytes = 64 B in + 64 B out per MAC; the network is a chain of "
+                                                             "dependent group operations bound by the integer multiplier"),
+                                    "cpu_baseline": cpu, "bit_exact_vs_oracle": ok}
+        out["value"] = out["curves"]["bn254"]["value"]
+        out["ms_per_step"] = out["curves"]["bn254"]["ms_per_step"]
+        out["roofline"] = out["curves"]["bn254"]["roofline"]
+        out["cpu_baseline"] = out["curves"]["bn254"]["cpu_baseline"]
+        out["bit_exact_vs_oracle"] = all_ok
+        return out
+
+    def leg_server_mix():
+        from porla_amd import icc
+        lib_ = __import__("porla_amd.loader", fromlist=["lib"]).lib
+        length, n_cols, n_total = 1 << 12, 128, 1 << 17
+        vp = ctypes.c_void_p
+        out = {"metric": "Server::mix G data symbols/s (two blocks of 2^12 rows x 128 symbols + their MACs and alignments)", "unit": "Gsymbols/s",
+               "scaling": "weak", "dtype": "u32x9 residue pair (data) / u32x9 30-bit limbs (points)",
+               "config": {"workload": "Server::mix(is_x, level) (Server.hpp:1209-1328) in one call: data rows, MAC commitments and MAC "
+                                      "alignments of two 2^12-row blocks resident in HBM", "rows_per_block": length, "columns": n_cols},
+               "curves": {}}
+        all_ok = None
+        for curve in ("bn254", "secp256k1"):
+            g = torch.Generator(device=dev).manual_seed(17)
+            blocks = []
+            for _ in range(2):
+                t = torch.randint(0, 256, (length, n_cols, 64), dtype=torch.uint8, device=dev, generator=g)
+                t[:, :, 63] &= 0x1f                                # < 2^509 < LCM of either build
+                blocks.append(t)
+            if curve == "bn254":
+                pool = common.synth_points(2048, start=5000)
+            else:
+                sc = common.secp_bench_scalars(2048, start=300)
+                buf = ctypes.create_string_buffer(64 * 2048)
+                common.oracle().oracle_secp256k1_mul_g_batch(sc, ctypes.c_size_t(2048), buf, common.ncpu())
+                pool = buf.raw
+            arr = (pool * (4 * length // 2048))[:64 * 4 * length]
+            parts = [arr[64 * length * k:64 * length * (k + 1)] for k in range(4)]
+            d_parts = [to_dev(x) for x in parts]
+            o_data = torch.empty(2 * length * n_cols * 64, dtype=torch.uint8, device=dev)
+            o_mac, o_al = (torch.empty(128 * length, dtype=torch.uint8, device=dev) for _ in range(2))
+
+            def call():
+                rc = lib_.porla_server_mix_device(vp(blocks[0].data_ptr()), vp(blocks[1].data_ptr()), *[vp(t.data_ptr()) for t in d_parts],
+                                                  length, n_cols, n_total, icc.CURVE[curve], vp(o_data.data_ptr()), vp(o_mac.data_ptr()),
+                                                  vp(o_al.data_ptr()), vp(stream))
+                if rc:
+                    raise RuntimeError("porla_server_mix_device rc=%d" % rc)
+            ms, per_launch, per_call = wall_and_kernels(call, reps=20, warm=5)
+            cpu = None
+            ok = None
+            if not args.no_cpu:
+                cores = common.ncpu()
+                a0, a1 = bytes(blocks[0].cpu().numpy()), bytes(blocks[1].cpu().numpy())
+                want = ctypes.create_string_buffer(2 * length * n_cols * 64)
+                t1 = time.perf_counter()
+                common.oracle().oracle_icc_mix(a0, a1, ctypes.c_size_t(length), ctypes.c_size_t(n_cols), ctypes.c_size_t(n_total),
+                                               icc.CURVE[curve], want)
+                cpu_data_s = time.perf_counter() - t1
+                ok = want.raw == bytes(o_data.cpu().numpy())
+                t1 = time.perf_counter()
+                for o_t, (p0, p1) in ((o_mac, parts[0:2]), (o_al, parts[2:4])):
+                    w = ctypes.create_string_buffer(2 * length * 64)
+                    common.oracle().oracle_icc_mac_mix(p0, p1, ctypes.c_size_t(length), ctypes.c_size_t(n_total), icc.CURVE[curve], w, cores)
+                    ok = ok and w.raw == bytes(o_t.cpu().numpy())
+                cpu_mac_s = time.perf_counter() - t1
+                all_ok = ok if all_ok is None else (all_ok and ok)
+                cpu = {"value": round(2 * length * n_cols / (cpu_data_s + cpu_mac_s) / 1e9, 6), "unit": "Gsymbols/s", "cores": cores,
+                       "kind": "port", "sample": "the same mix: data rows on oracle/icc_ref.c (1 thread, %.2f s), the two point arrays on "
+                                                 "oracle/mac_ref.c (%d threads, %.2f s); CPU restatement, not NTL / gnark / libsecp256k1"
+                                                 % (cpu_data_s, cores, cpu_mac_s)}
+            data_k = {k: v for k, v in per_call.items() if "mix" in k and "mac" not in k}
+            out["curves"][curve] = {"value": round(2 * length * n_cols / ms / 1e6, 3), "ms_per_step": round(ms, 4),
+                                    "roofline": hbm_roofline({k: per_launch[k] for k in data_k} or per_launch, data_k or per_call,
+                                                             256 * length * n_cols,
+                                                             "the data kernel: 2 x 64 B in + 2 x 64 B out per butterfly; the call's wall time is "
+                                                             "set by the point butterflies beside it (a chain of dependent group operations)"),
+                                    "kernels_ms_per_call": per_call, "cpu_baseline": cpu, "bit_exact_vs_oracle": ok}
+        for k in ("value", "ms_per_step", "roofline", "cpu_baseline"):
+            out[k] = out["curves"]["bn254"][k]
+        out["bit_exact_vs_oracle"] = all_ok
+        return out
+
     # ---------------------------------------------------------------- the line
     legs = {"bn254_msm": leg_bn254_msm, "kzg_commit": leg_kzg_commit, "secp256k1_msm": leg_secp256k1_msm, "icc": leg_icc,
-            "config3": leg_config3, "audit_combine": leg_audit_combine, "client_mac_batch": leg_client_mac_batch}
+            "config3": leg_config3, "audit_combine": leg_audit_combine, "client_mac_batch": leg_client_mac_batch,
+            "ipa_commits": leg_ipa_commits, "mac_encode": leg_mac_encode, "server_mix": leg_server_mix}
     out = legs[args.workload]()
+    for k, v in (("n_gpus", world), ("steps", args.steps), ("warmup", args.warmup), ("higher_is_better", True), ("vs_baseline", None),
+                 ("data", "synthetic")):
+        out.setdefault(k, v)               # (a leg printed alone as the line: the contract's keys it leaves to the line)
     legs_failed = []
     if args.workload == "bn254_msm":
         # every other BASELINE.json configuration rides on the default line
@@ -957,6 +1166,8 @@ def main():
                 extra.append(("kzg_audit", leg_kzg_audit))
                 if not args.no_commits:
                     extra.append(("client_mac_batch", leg_client_mac_batch))
+                    extra.append(("ipa_commits", leg_ipa_commits))
+                extra += [("mac_encode", leg_mac_encode), ("server_mix", leg_server_mix)]
             if not args.no_config3:
                 extra.append(("config3", leg_config3))
         for name, fn in extra:
