@@ -107,6 +107,47 @@ __device__ __forceinline__ F30<M> f30_sqr_portable(const F30<M>& a) {
     return r;
 }
 
+// (a b + c d) / 2^270 mod p with ONE reduction.  The products of c d join the accumulator of a b's product-and-reduce chain
+// directly where the column still fits 64 bits; in the three widest columns (6..8: 18 + 8 full-size products) they run in a side
+// chain `u` with its own carries, which hands its low 30 bits to `t` per column and its carry to column 9
+// (tools/check_fe30_bounds.py: check_mul2).  Operands as for f30_mul_portable; result: limbs < 2^30, value < p + 2^247.
+constexpr int F30_MUL2_CHAIN_LO = 6, F30_MUL2_CHAIN_HI = 8;
+template <class M>
+__device__ __forceinline__ F30<M> f30_mul2_portable(const F30<M>& a, const F30<M>& b, const F30<M>& c, const F30<M>& d) {
+    uint64_t t = 0, u = 0;
+    uint32_t m[9];
+    F30<M> r;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+        const bool chained = k >= F30_MUL2_CHAIN_LO && k <= F30_MUL2_CHAIN_HI;
+        if (k == F30_MUL2_CHAIN_HI + 1) t += u >> 30;
+        if (chained) {
+            if (k > F30_MUL2_CHAIN_LO) u >>= 30;
+#pragma unroll
+            for (int i = (k > 8 ? k - 8 : 0); i <= (k < 8 ? k : 8); i++) f30_mac(u, c.v[i], d.v[k - i]);
+            t += (uint32_t)u & F30_MASK;
+        }
+#pragma unroll
+        for (int i = (k > 8 ? k - 8 : 0); i <= (k < 8 ? k : 8); i++) {
+            f30_mac(t, a.v[i], b.v[k - i]);
+            if (!chained) f30_mac(t, c.v[i], d.v[k - i]);
+        }
+        if (k < 9) {
+#pragma unroll
+            for (int i = 0; i < k; i++) f30_mac_const(t, m[i], P30<M>::limb(k - i));
+            m[k] = ((uint32_t)t * P30<M>::INV) & F30_MASK;
+            f30_mac_const(t, m[k], P30<M>::limb(0));
+        } else {
+#pragma unroll
+            for (int i = k - 8; i <= 8; i++) f30_mac_const(t, m[i], P30<M>::limb(k - i));
+            r.v[k - 9] = (uint32_t)t & F30_MASK;
+        }
+        t >>= 30;
+    }
+    r.v[8] = (uint32_t)t;
+    return r;
+}
+
 // ---------------------------------------------------------------- special-form modulus p = 2^256 - 2^32 - FOLD (secp256k1)
 // Plain residues (no Montgomery factor), as in fe.hip.h and in the reference's field_5x52.  The 18-limb schoolbook product is
 // folded with 2^270 = 2^14 (2^32 + FOLD) = C1 2^30 + C0 (mod p), then everything above 2^256 once more with
@@ -198,6 +239,10 @@ template <class M>
 __device__ __forceinline__ F30<M> f30_sqr_pm(const F30<M>& a) { return f30_sqr_pm_portable<M>(a); }
 template <class M>
 __device__ __forceinline__ F30<M> f30_mul_icc(const F30<M>& a, const F30<M>& b) { return f30_mul_portable<M>(a, b); }
+template <class M>
+__device__ __forceinline__ F30<M> f30_mul2_mont(const F30<M>& a, const F30<M>& b, const F30<M>& c, const F30<M>& d) {
+    return f30_mul2_portable<M>(a, b, c, d);
+}
 #endif
 template <class M>
 __device__ __forceinline__ F30<M> f30_mul(const F30<M>& a, const F30<M>& b) {

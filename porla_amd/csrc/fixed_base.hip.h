@@ -197,12 +197,16 @@ k_fb_commit(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_coeffs
     // before the addition of the previous one -- also across the boundary between two coefficients -- and the next
     // coefficient's 32 bytes are requested a whole coefficient ahead (a pipeline that restarted per coefficient left one
     // gather and one row read exposed per 15 additions).
+    // (reduced-radix form: the accumulator changes sign with every addition, ec30.hip.h:xyzz30_madd_flip -- the sign it carries is
+    // folded into the digit's sign of the incoming entry and undone once at the end)
+    bool flip = false;
     auto madd_entry = [&](const Affine<M>& e, bool neg) {
-        Affine<M> a = aff_neg_if<M>(e, neg);
         if constexpr (C::F30_BUCKETS) {
-            if (!aff_is_inf<M>(a)) xyzz30_madd<M>(acc, f30_from_fe<M>(a.x), f30_from_fe<M>(a.y));
+            if (aff_is_inf<M>(e)) return;
+            Affine<M> a = aff_neg_if<M>(e, xyzz30_flip_neg<M>(neg, flip));
+            xyzz30_madd_flip<M>(acc, flip, f30_from_fe<M>(a.x), f30_from_fe<M>(a.y));
         } else {
-            xyzz_madd<M>(acc, a);
+            xyzz_madd<M>(acc, aff_neg_if<M>(e, neg));
         }
     };
     Affine<M> cur;
@@ -278,6 +282,7 @@ k_fb_commit(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_coeffs
     if (mid_valid) madd_entry(mid, mid_neg);
 #endif
     if constexpr (C::F30_BUCKETS) {
+        xyzz30_flip_finish<M>(acc, flip);
         // a slice partial goes to k_fb_fold in the reduced-radix memory form (no conversion products here, reduced-radix additions
         // there); a whole row's sum (S = 1) in the 2^256 form k_fb_finish and the host read
         if (C::F30_LAZY && S > 1) xyzz30_store_lazy<M>(partial + (size_t)r * S + s, acc);

@@ -683,15 +683,19 @@ k_bucket_sum30(const Affine<typename C::Fp>* __restrict__ pts, const uint32_t* _
     if constexpr (C::F30_LAZY) {
         if (accumulate && cb == NO_CHUNK) acc = xyzz30_load_lazy<M>(buckets + b);
     }
+    // the accumulator changes sign with every addition (ec30.hip.h:xyzz30_madd_flip: Y3 from ONE two-product reduction); the sign
+    // it currently carries is folded into the digit's sign of the incoming point
+    bool flip = false;
     uint32_t ent = e[0];
     for (uint32_t k = 0; k < cnt; k++) {
         uint32_t cur = ent;
         if (k + 1 < cnt) ent = e[k + 1];
         Affine<M> a = load_affine<M>(pts, cur & 0x7fffffffu);
         if (aff_is_inf<M>(a)) continue;
-        a = aff_neg_if<M>(a, (cur >> 31) != 0);
-        xyzz30_madd<M>(acc, f30_from_fe<M>(a.x), f30_from_fe<M>(a.y));
+        a = aff_neg_if<M>(a, xyzz30_flip_neg<M>((cur >> 31) != 0, flip));
+        xyzz30_madd_flip<M>(acc, flip, f30_from_fe<M>(a.x), f30_from_fe<M>(a.y));
     }
+    xyzz30_flip_finish<M>(acc, flip);
     XYZZ<M>* dst = cb == NO_CHUNK ? buckets + b : chunk_out + cb + item.y;
     if constexpr (C::F30_LAZY) xyzz30_store_lazy<M>(dst, acc);
     else store_xyzz<M>(dst, xyzz30_to_xyzz<M>(acc));

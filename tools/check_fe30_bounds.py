@@ -38,9 +38,32 @@ def check(name, p, top_bits=18, top_bits_b=None):
     ok = worst < 2**64
     print("%-8s worst column %.4f x 2^64  %s" % (name, worst / 2**64, "ok" if ok else "OVERFLOW"))
     return ok
+MUL2_CHAIN = (6, 8)     # = tools/gen_fe30_asm.py:MUL2_CHAIN = fe30.hip.h:F30_MUL2_CHAIN_LO / _HI
+def check_mul2(name, p, top_bits=18, chain=MUL2_CHAIN):
+    """f30_mul2: t = a b + reduction (+ c d outside the chained columns, + one 30-bit digit of u inside them, + u's carry after them);
+    u = the products of c d in the chained columns with its own carries"""
+    k0, k1 = chain
+    P = [(p >> (30 * i)) & MASK for i in range(9)]
+    amax = [MASK] * 8 + [2**top_bits - 1]
+    ct = cu = 0
+    worst_t = worst_u = 0
+    for k in range(17):
+        ab = sum(amax[i] * amax[k - i] for i in range(9) if 0 <= k - i <= 8)
+        mp = sum(MASK * P[k - i] for i in range(9) if 0 <= k - i <= 8)
+        if k0 <= k <= k1:
+            u = cu + ab
+            worst_u, cu = max(worst_u, u), u >> 30
+            t = ct + MASK + ab + mp
+        else:
+            t = ct + 2 * ab + mp + (cu if k == k1 + 1 else 0)
+        worst_t, ct = max(worst_t, t), t >> 30
+    ok = worst_t < 2**64 and worst_u < 2**64
+    print("%-8s mul2: worst t column %.4f x 2^64, worst u column %.4f x 2^64  %s" % (name, worst_t / 2**64, worst_u / 2**64, "ok" if ok else "OVERFLOW"))
+    return ok
 if __name__ == "__main__":
     import sys
     ok = all([check(n, p) for n, p in MODULI.items()])
+    ok = all([check_mul2(n, p) for n, p in MODULI.items() if n != "p_icc"]) and ok
     ok = all([check("icc:" + n, p, 23, 17) for n, p in ICC_MODULI.items()]) and ok
     # result bound of the ICC product: a b / 2^270 + p < p + 2^249 for a < 2^263, b < 2^256: limb 8 stays far below 2^30
     sys.exit(0 if ok else 1)

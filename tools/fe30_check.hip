@@ -21,8 +21,19 @@ __global__ void k_mul30(const uint32_t* a, const uint32_t* b, uint32_t* out, int
     if (i >= n) return;
     F30<M> x, y;
     for (int k = 0; k < 9; k++) { x.v[k] = a[i * 9 + k]; y.v[k] = b[i * 9 + k]; }
-    F30<M> z = square ? f30_sqr<M>(x) : f30_mul<M>(x, y);
-    F30<M> zp;                                  // the assembly must equal the portable form limb for limb
+    F30<M> z, zp;                               // the assembly must equal the portable form limb for limb
+    if constexpr (!M::PSEUDO_MERSENNE) {
+        if (square == 2) {                      // x y + c d with one reduction; (c, d) = the next lane's operands
+            const int j = (i + 1) % n;
+            F30<M> c, d;
+            for (int k = 0; k < 9; k++) { c.v[k] = a[j * 9 + k]; d.v[k] = b[j * 9 + k]; }
+            z = f30_mul2_mont<M>(x, y, c, d);
+            zp = f30_mul2_portable<M>(x, y, c, d);
+            for (int k = 0; k < 9; k++) out[i * 9 + k] = z.v[k] | (z.v[k] != zp.v[k] ? 0x80000000u : 0u);
+            return;
+        }
+    }
+    z = square ? f30_sqr<M>(x) : f30_mul<M>(x, y);
     if constexpr (M::PSEUDO_MERSENNE) zp = square ? f30_sqr_pm_portable<M>(x) : f30_mul_pm_portable<M>(x, y);
     else zp = square ? f30_sqr_portable<M>(x) : f30_mul_portable<M>(x, y);
     for (int k = 0; k < 9; k++) out[i * 9 + k] = z.v[k] | (z.v[k] != zp.v[k] ? 0x80000000u : 0u);
@@ -148,13 +159,17 @@ static int check(const char* name) {
     Fe<M> r2; for (int k = 0; k < 8; k++) r2.v[k] = M::R2[k];
     Fe<M> c14 = fe_mul_generic<M>(two14, r2);
     int bad = 0;
-    for (int square = 0; square < 2; square++) {
+    for (int square = 0; square < 3; square++) {          // 2: the two-product form f30_mul2 (x y + c d, one reduction)
         hipLaunchKernelGGL(k_mul30<M>, dim3(n / 256), dim3(256), 0, 0, da, db, dout, n, square);
         CK(hipMemcpy(got.data(), dout, n * 36, hipMemcpyDeviceToHost));
         for (int i = 0; i < n; i++) {
             Fe<M> x = limbs_mod_p<M>(&a[i * 9]);
-            Fe<M> y = square ? x : limbs_mod_p<M>(&b[i * 9]);
+            Fe<M> y = square == 1 ? x : limbs_mod_p<M>(&b[i * 9]);
             Fe<M> want = fe_mul_generic<M>(x, y);                      // x*y / 2^256
+            if (square == 2) {
+                const int j = (i + 1) % n;
+                want = fe_add<M>(want, fe_mul_generic<M>(limbs_mod_p<M>(&a[j * 9]), limbs_mod_p<M>(&b[j * 9])));
+            }
             const uint32_t* z = &got[i * 9];
             bool limbs_ok = true;
             for (int k = 0; k < 9; k++) if (z[k] > F30_MASK) limbs_ok = false;
@@ -163,7 +178,8 @@ static int check(const char* name) {
             // value bound: z < p + 2^247 (operands < 2^258: a*b / 2^270 < 2^246, m*p / 2^270 < p)
             uint32_t zw[9]; limbs_to_words(z, zw);
             uint32_t lim[9]; uint64_t cy = 0;
-            for (int k = 0; k < 9; k++) { cy += (uint64_t)(k < 8 ? M::P[k] : 0u) + (k == 7 ? (1u << 23) : 0u); lim[k] = (uint32_t)cy; cy >>= 32; }
+            // (the two-product form: < p + 2^248)
+            for (int k = 0; k < 9; k++) { cy += (uint64_t)(k < 8 ? M::P[k] : 0u) + (k == 7 ? (1u << (square == 2 ? 24 : 23)) : 0u); lim[k] = (uint32_t)cy; cy >>= 32; }
             bool le_p = false;
             for (int k = 8; k >= 0; k--) { if (zw[k] < lim[k]) { le_p = true; break; } if (zw[k] > lim[k]) break; }
             if (!limbs_ok || !le_p || !fe_eq<M>(want, have)) {
