@@ -135,6 +135,42 @@ __device__ __forceinline__ void xyzz30_madd_flip(XYZZ30<M>& p, bool& flip, const
         flip = !flip;
     }
 }
+// The form the accumulation loops call FIRST: the addition above as straight-line code.  Returns false -- with p and flip untouched --
+// when this lane meets an exceptional case (accumulator or point at infinity, equal x); the caller then leaves its fast loop and
+// finishes the lane's entries with the general form xyzz30_madd_flip.  With the exceptional cases as branches INSIDE the hot loop
+// the compiler staged the whole accumulator through a second register set at their joins (~42 copies per addition on the common
+// path); a loop exit has no join per iteration.  Both forms leave the same group element under the same sign convention.
+template <class M>
+__device__ __forceinline__ bool xyzz30_madd_flip_fast(XYZZ30<M>& p, bool& flip, const F30<M>& ax, const F30<M>& ay, bool a_is_inf) {
+    static_assert(!M::PSEUDO_MERSENNE, "two-product form: Montgomery moduli only");
+    // (an accumulator at infinity holds zeros: the products below are then meaningless and unused)
+    F30<M> U2 = f30_mul<M>(ax, p.zz);
+    F30<M> S2 = f30_mul<M>(ay, p.zzz);
+    F30<M> Pp = f30_sub<M, 6>(U2, p.x);
+    F30<M> Rn = f30_sub<M, 2>(p.y, S2);
+    F30<M> PP = f30_sqr<M>(Pp);
+    if (a_is_inf || p.inf || f30_product_is_zero<M>(PP)) return false;
+    F30<M> PPP = f30_mul<M>(Pp, PP);
+    F30<M> Q = f30_mul<M>(p.x, PP);
+    F30<M> RR = f30_sqr<M>(Rn);
+    F30<M> E = f30_add2<M>(PPP, Q);
+    F30<M> X3 = f30_sub<M, 4>(RR, E);
+    F30<M> D = f30_sub<M, 6>(Q, X3);
+    p.y = f30_mul2_mont<M>(Rn, D, p.y, PPP);        // -Y3
+    p.x = X3;
+    p.zz = f30_mul<M>(p.zz, PP);
+    p.zzz = f30_mul<M>(p.zzz, PPP);
+    flip = !flip;
+    return true;
+}
+template <class M>
+__device__ __forceinline__ XYZZ30<M> xyzz30_infinity() {
+    XYZZ30<M> p;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { p.x.v[i] = 0; p.y.v[i] = 0; p.zz.v[i] = 0; p.zzz.v[i] = 0; }
+    p.inf = true;
+    return p;
+}
 // the true sum: Y -> 4p - Y (<= 4p < 2^256, still storable in the lazy memory form) when the accumulator holds its negative
 template <class M>
 __device__ __forceinline__ void xyzz30_flip_finish(XYZZ30<M>& p, bool flip) {

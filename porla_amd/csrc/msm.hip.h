@@ -676,8 +676,7 @@ k_bucket_sum30(const Affine<typename C::Fp>* __restrict__ pts, const uint32_t* _
     if (cnt > CHUNK) cnt = CHUNK;
     const uint32_t* e = entries + starts[b] + first;
     const uint32_t cb = chunk_base[b];
-    XYZZ30<M> acc;
-    acc.inf = true;
+    XYZZ30<M> acc = xyzz30_infinity<M>();
     // accumulate: the bucket array holds the sums of earlier pair ranges of the same input (msm_host_multi) -- the bucket's only
     // item continues from that sum (multi-item buckets: k_bucket_combine adds it)
     if constexpr (C::F30_LAZY) {
@@ -687,8 +686,37 @@ k_bucket_sum30(const Affine<typename C::Fp>* __restrict__ pts, const uint32_t* _
     // it currently carries is folded into the digit's sign of the incoming point
     bool flip = false;
     uint32_t ent = e[0];
-    for (uint32_t k = 0; k < cnt; k++) {
-        uint32_t cur = ent;
+    uint32_t k = 0;
+    if (acc.inf) {
+        // the item's first entry is a copy, taken here so that the loop's straight-line form does not meet an accumulator at infinity
+        // once per item
+        const uint32_t cur = ent;
+        if (cnt > 1) ent = e[1];
+        Affine<M> a = load_affine<M>(pts, cur & 0x7fffffffu);
+        if (!aff_is_inf<M>(a)) {
+            a = aff_neg_if<M>(a, (cur >> 31) != 0);
+            acc.x = f30_from_fe<M>(a.x); acc.y = f30_from_fe<M>(a.y);
+            acc.zz = f30_const<M>(M::R1_30); acc.zzz = acc.zz;
+            acc.inf = false;
+        }
+        k = 1;
+    }
+    if constexpr (!M::PSEUDO_MERSENNE) {
+        // the fast loop: straight-line additions; a lane that meets an exceptional case leaves it with that entry still to do
+        for (; k < cnt; k++) {
+            const uint32_t cur = ent;
+            uint32_t nxt = cur;
+            if (k + 1 < cnt) nxt = e[k + 1];           // the next index is in flight while this point is accumulated
+            Affine<M> a = load_affine<M>(pts, cur & 0x7fffffffu);
+            const bool a_inf = aff_is_inf<M>(a);
+            a = aff_neg_if<M>(a, xyzz30_flip_neg<M>((cur >> 31) != 0, flip));
+            if (!xyzz30_madd_flip_fast<M>(acc, flip, f30_from_fe<M>(a.x), f30_from_fe<M>(a.y), a_inf)) break;
+            ent = nxt;
+        }
+    }
+    // the general form: every exceptional case, for the entries the fast loop left (none for uniformly random inputs)
+    for (; k < cnt; k++) {
+        const uint32_t cur = ent;
         if (k + 1 < cnt) ent = e[k + 1];
         Affine<M> a = load_affine<M>(pts, cur & 0x7fffffffu);
         if (aff_is_inf<M>(a)) continue;
