@@ -232,6 +232,17 @@ int  porla_kzg_audit_device(const void *d_rows64, const uint64_t *d_idx64, const
                             uint8_t combined_mac[64], uint8_t combined_align[64], uint8_t align_value[64],
                             uint8_t commitment[64], uint8_t proof_h[64], uint8_t proof_point[32], uint8_t proof_claim[32],
                             uint8_t *b_out, void *hip_stream);
+/* The last encode stage of a large CRebuild (KZG build) in ONE call, everything resident in HBM (porla/Server/Server.hpp:1487-1833,
+ * :2059-2065): rows_in = n_rows x n_samples raw 32-byte chunks; outputs per part (X, Y): the rows mod p_icc (aligned_x / aligned_y:
+ * n_rows * n_samples * 32 bytes each, may be NULL), the alignment scalars of BOTH parts back to back (scalars_xy: 2 * n_rows *
+ * n_samples * 32 bytes, X first), their commitments (commits_xy: 2 * n_rows * 64 bytes: compute_digest_from_srs per row), and the
+ * two MAC encodes (macs_in / macs_x / macs_y: n_rows points of 64 bytes).  = porla_icc_encode_xy_device + ONE
+ * porla_kzg_commit_batch_device over the 2 n rows + porla_icc_mac_encode_xy_device, the MAC network on a second stream inside,
+ * started first and with register room kept for it on every SIMD (the two sides overlap instead of queueing).  Asynchronous on
+ * hip_stream; same bytes as the separate calls. */
+int  porla_kzg_crebuild_stage_device(const void *d_rows_in, size_t n_rows, unsigned long long write_step, void *d_aligned_x,
+                                     void *d_aligned_y, void *d_scalars_xy, void *d_commits_xy, const void *d_macs_in,
+                                     void *d_macs_x, void *d_macs_y, void *hip_stream);
 /* rows resident on the device, results wanted on the host at once (the audit's align_MAC commitment on the scalars
  * porla_audit_combine_device left in HBM, Server.hpp:903 -> :550-560): up to 64 rows run as ONE launch on hip_stream, behind whatever
  * produced the rows there, and the call returns when the pinned result has arrived; blocking */

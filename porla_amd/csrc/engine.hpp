@@ -191,8 +191,10 @@ struct FixedBase {
     int build(const Affine<typename C::Fp>* d_base, size_t n, int window_bits, hipStream_t stream);
     int build_from_host_bytes(const uint8_t* points_be, size_t n, int window_bits, hipStream_t stream);
     // d_out == nullptr: stop after the slice fold; the row sums stay in `partial` (row r at partial[r * last_S])
+    // guest_room: launch the commitment kernel in its two-waves-per-SIMD form, which leaves register room for one wave of a
+    // kernel running beside it (fixed_base.hip.h:k_fb_commit<C, true>)
     int commit_device(const uint8_t* d_rows, size_t n_rows, size_t n_coeffs, size_t row_stride, uint8_t* d_out,
-                      hipStream_t stream);
+                      hipStream_t stream, bool guest_room = false);
     int commit_host(const uint8_t* rows, size_t n_rows, size_t n_coeffs, size_t row_stride, uint8_t* out,
                     hipStream_t stream);
     // <= FB_SMALL_MAX_ROWS rows given by pointer (they need not be contiguous: the coalescing front of compute_digest_from_srs

@@ -173,12 +173,18 @@ k_fb_normalize(const XYZZ<typename C::Fp>* __restrict__ scratch, size_t n, Affin
 #else
 #define PORLA_FB_COMMIT_ATTR
 #endif
-template <class C>
+// GUEST_ROOM: the kernel declares 192 vector registers (it uses ~161): a SIMD then holds TWO of its waves instead of three and
+// keeps 128 registers free -- room for one wave of another kernel.  The last stage of a CRebuild runs the MAC butterflies (one
+// latency-bound wave per SIMD, 123 registers, 15 dependent launches) BESIDE the commitments: with three 161-register waves per
+// SIMD the chip had no slot for them, and every one of the 15 stage launches waited for a block of this kernel to retire
+// (3.6-4.8 ms instead of 0.6): the two streams ran one after the other.
+template <class C, bool GUEST_ROOM = false>
 __global__ void __launch_bounds__(256) PORLA_FB_COMMIT_ATTR
 k_fb_commit(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_coeffs, size_t row_stride,
             const Affine<typename C::Fp>* __restrict__ table, int c, int W, uint32_t S,
             XYZZ<typename C::Fp>* __restrict__ partial) {
     using M = typename C::Fp;
+    if constexpr (GUEST_ROOM) asm volatile("" ::: "v191");
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t s = blockIdx.y;
     if (r >= n_rows) return;

@@ -130,7 +130,7 @@ int FixedBase<C>::build(const Affine<typename C::Fp>* d_base, size_t n, int wind
 
 template <class C>
 int FixedBase<C>::commit_device(const uint8_t* d_rows, size_t n_rows, size_t n_coeffs, size_t row_stride, uint8_t* d_out,
-                                hipStream_t stream) {
+                                hipStream_t stream, bool guest_room) {
     using M = typename C::Fp;
     if (n_rows == 0) return PORLA_OK;
     if (!table || n_coeffs > n_points) { set_last_error("porla: fixed base not built / too few base points"); return PORLA_ERR_STATE; }
@@ -162,8 +162,12 @@ int FixedBase<C>::commit_device(const uint8_t* d_rows, size_t n_rows, size_t n_c
     }
     {
         ProfScope ps("fb_commit", stream, true);
-        hipLaunchKernelGGL((k_fb_commit<C>), dim3((unsigned)((n_rows + 255) / 256), S), dim3(256), 0, stream, d_rows,
-                           (uint32_t)n_rows, (uint32_t)n_coeffs, row_stride, (const Affine<M>*)table, c, W, S, partial);
+        if (guest_room)
+            hipLaunchKernelGGL((k_fb_commit<C, true>), dim3((unsigned)((n_rows + 255) / 256), S), dim3(256), 0, stream, d_rows,
+                               (uint32_t)n_rows, (uint32_t)n_coeffs, row_stride, (const Affine<M>*)table, c, W, S, partial);
+        else
+            hipLaunchKernelGGL((k_fb_commit<C>), dim3((unsigned)((n_rows + 255) / 256), S), dim3(256), 0, stream, d_rows,
+                               (uint32_t)n_rows, (uint32_t)n_coeffs, row_stride, (const Affine<M>*)table, c, W, S, partial);
     }
     if (S > 1) {
         ProfScope ps("fb_fold", stream);

@@ -318,7 +318,7 @@ int refresh_srs_locked(KzgState::Dev** out) {
 }
 
 // kzg.Commit(f, srs) (main.go:114,164) for `n_rows` coefficient rows: fixed-base table path, len <= n_samples
-int commit_rows(const uint8_t* rows, bool device_ptrs, size_t n_rows, size_t len, uint8_t* out, hipStream_t stream) {
+int commit_rows(const uint8_t* rows, bool device_ptrs, size_t n_rows, size_t len, uint8_t* out, hipStream_t stream, bool guest_room = false) {
     // lock order: the state, then the table; the table's mutex is taken BEFORE the state is let go, so that neither
     // init_SRS_from_data / porla_kzg_set_commit_window nor porla_kzg_release_device_memory can rebuild or free the table between
     // the checks and the commit (compute_digest_from_srs comes from 8 pool threads, Server.hpp:550-560)
@@ -332,7 +332,7 @@ int commit_rows(const uint8_t* rows, bool device_ptrs, size_t n_rows, size_t len
     if (len > g.srs.size()) { set_last_error("porla: more coefficients than SRS points"); return PORLA_ERR_STATE; }
     std::unique_lock<std::mutex> lkfb(kd->fb.mu);
     lk.unlock();
-    if (device_ptrs) return kd->fb.commit_device(rows, n_rows, len, len * 32, out, stream);
+    if (device_ptrs) return kd->fb.commit_device(rows, n_rows, len, len * 32, out, stream, guest_room);
     return kd->fb.commit_host(rows, n_rows, len, len * 32, out, engine_stream());
 }
 
@@ -991,6 +991,57 @@ int porla_kzg_commit_batch_device(const void* d_rows, size_t n_rows, void* d_out
     if (rc) return rc;
     return commit_rows((const uint8_t*)d_rows, true, n_rows, kzg_n_samples(), (uint8_t*)d_out, (hipStream_t)hip_stream);
 }
+// The last encode stage of a large CRebuild for the KZG build in ONE call (porla/Server/Server.hpp:1487-1833 cached, :1899-2254
+// on disk): per part (X, Y): the data butterflies, align_MAC's row mod p_icc and alignment scalars (:531-541), one
+// compute_digest_from_srs per row on those scalars (:550-560, :2059-2065) -- and, beside them, the MAC butterflies (:1590-1609,
+// :1658-1676).  Two streams inside: the MAC network (15 dependent stages, one latency-bound wave per SIMD) starts FIRST on a side
+// stream and keeps its slot on every SIMD for the length of the call, because the commitments of the 2 n rows run in the
+// two-waves-per-SIMD form of their kernel (k_fb_commit<C, true>).  Asynchronous: hip_stream continues when both sides are done.
+namespace {
+struct StageSide { int device = -1; hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+std::mutex g_stage_side_mu;
+std::vector<StageSide> g_stage_side;
+}  // namespace
+int porla_kzg_crebuild_stage_device(const void* d_rows_in, size_t n_rows, unsigned long long write_step, void* d_aligned_x,
+                                    void* d_aligned_y, void* d_scalars_xy, void* d_commits_xy, const void* d_macs_in, void* d_macs_x,
+                                    void* d_macs_y, void* hip_stream) {
+    if (!d_rows_in || !d_scalars_xy || !d_commits_xy || !d_macs_in || !d_macs_x || !d_macs_y) {
+        set_last_error("porla: null argument");
+        return PORLA_ERR_ARG;
+    }
+    int rc = ensure_device();
+    if (rc) return rc;
+    const size_t n_cols = kzg_n_samples();
+    if (n_cols == 0) { set_last_error("porla: SRS not initialised (call init_SRS / init_SRS_from_data first)"); return PORLA_ERR_STATE; }
+    int dev = 0;
+    PORLA_HIP(hipGetDevice(&dev));
+    // one set of side stream + events per device, held across fork -> launches -> join (everything below only enqueues)
+    std::lock_guard<std::mutex> lk(g_stage_side_mu);
+    StageSide* side = nullptr;
+    for (auto& m : g_stage_side) if (m.device == dev) side = &m;
+    if (!side) {
+        StageSide m;
+        m.device = dev;
+        PORLA_HIP(hipStreamCreateWithFlags(&m.s, hipStreamNonBlocking));
+        PORLA_HIP(hipEventCreateWithFlags(&m.fork, hipEventDisableTiming));
+        PORLA_HIP(hipEventCreateWithFlags(&m.join, hipEventDisableTiming));
+        g_stage_side.push_back(m);
+        side = &g_stage_side.back();
+    }
+    hipStream_t stream = (hipStream_t)hip_stream;
+    PORLA_HIP(hipEventRecord(side->fork, stream));
+    PORLA_HIP(hipStreamWaitEvent(side->s, side->fork, 0));
+    if ((rc = porla_icc_mac_encode_xy_device(d_macs_in, n_rows, 0, write_step, d_macs_x, d_macs_y, side->s))) return rc;
+    PORLA_HIP(hipEventRecord(side->join, side->s));
+    uint8_t* sc = (uint8_t*)d_scalars_xy;
+    if ((rc = porla_icc_encode_xy_device(d_rows_in, n_rows, n_cols, 0, write_step, nullptr, d_aligned_x, sc, nullptr, d_aligned_y,
+                                         sc + 32 * n_rows * n_cols, 0, stream))) return rc;
+    // both parts' alignment scalars lie back to back: ONE batch of 2 n rows
+    if ((rc = commit_rows(sc, true, 2 * n_rows, n_cols, (uint8_t*)d_commits_xy, stream, /*guest_room=*/true))) return rc;
+    PORLA_HIP(hipStreamWaitEvent(stream, side->join, 0));
+    return PORLA_OK;
+}
+
 // rows resident on the device, results wanted on the host NOW (the audit's align_MAC commitment, Server.hpp:903 -> :550-560, on the
 // scalars porla_audit_combine_device left in HBM): up to 64 rows go through the single-launch kernel on `hip_stream` -- behind
 // whatever produced the rows there -- and the host polls the pinned result; more rows: the batch kernels and one copy back

@@ -105,6 +105,27 @@ static int mac_mix_core(MacWs* ws, int curve, const uint8_t* d_a0, const uint8_t
     return PORLA_OK;
 }
 
+// dynamic LDS of the quad-lane stage / load kernels (mac_fft.hip.h:MACQ_LDS); above 64 KiB a kernel must be told once per device
+template <class C>
+static size_t macq_lds_bytes() {
+    using M = typename C::Fp;
+    static std::mutex mu;
+    static std::vector<int> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return sizeof(MacQuadLds<M>);
+    std::lock_guard<std::mutex> lk(mu);
+    bool seen = false;
+    for (int d : done) seen = seen || d == dev;
+    if (!seen) {
+        const int bytes = (int)sizeof(MacQuadLds<M>);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mac_stage30_quad<C>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mac_load30_quad<C, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mac_load30_quad<C, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        done.push_back(dev);
+    }
+    return sizeof(MacQuadLds<M>);
+}
+
 // d_out_y != nullptr (with part == 0): BOTH parts from one butterfly network.  The network is linear over Z_q and the Y part is
 // the X part's network applied to inputs scaled by wt (Server.hpp:1494-1536: Y = wt * MAC_U, then the same stages, :1691-1830),
 // so Y_k = wt * X_k as group elements: one scalar multiplication per row on the X part's work array instead of a second run of
@@ -159,7 +180,7 @@ static int mac_encode_core(MacWs* ws, int curve, const uint8_t* d_in, size_t n, 
         if constexpr (C::F30_LAZY) {
             static const bool quad = !(getenv("PORLA_MAC_QUAD") && getenv("PORLA_MAC_QUAD")[0] == '0');
             if (use_wt && quad && n <= ((size_t)1 << 14))
-                hipLaunchKernelGGL((k_mac_load30_quad<C>), dim3((unsigned)((n + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), 0, stream, d_in,
+                hipLaunchKernelGGL((k_mac_load30_quad<C>), dim3((unsigned)((n + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream, d_in,
                                    (uint32_t)n, (XYZZ<M>*)ws->work.p, wt);
             else
                 hipLaunchKernelGGL((k_mac_load30<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_in, (uint32_t)n,
@@ -179,7 +200,7 @@ static int mac_encode_core(MacWs* ws, int curve, const uint8_t* d_in, size_t n, 
                 hipLaunchKernelGGL((k_mac_stage1_quad<C>), dim3((unsigned)((n / 2 + 63) / 64)), dim3(256), 0, stream, (XYZZ<M>*)ws->work.p,
                                    (uint32_t)n);
             else if (quad && n <= ((size_t)1 << quad_max_log))
-                hipLaunchKernelGGL((k_mac_stage30_quad<C>), dim3((unsigned)((n / 2 + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), 0, stream,
+                hipLaunchKernelGGL((k_mac_stage30_quad<C>), dim3((unsigned)((n / 2 + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream,
                                    (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->tws.p, (uint32_t)n, s);
             else
                 hipLaunchKernelGGL((k_mac_stage30<C>), dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, stream, (XYZZ<M>*)ws->work.p,
@@ -201,7 +222,7 @@ static int mac_encode_core(MacWs* ws, int curve, const uint8_t* d_in, size_t n, 
                 static const bool quad = !(getenv("PORLA_MAC_QUAD") && getenv("PORLA_MAC_QUAD")[0] == '0');
                 static const int scale_quad_max = getenv("PORLA_MAC_SCALE_QUAD_MAX") ? atoi(getenv("PORLA_MAC_SCALE_QUAD_MAX")) : 15;
                 if (quad && n <= ((size_t)1 << scale_quad_max))
-                    hipLaunchKernelGGL((k_mac_load30_quad<C, true>), dim3((unsigned)((n + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), 0, stream,
+                    hipLaunchKernelGGL((k_mac_load30_quad<C, true>), dim3((unsigned)((n + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream,
                                        (const uint8_t*)ws->work.p, (uint32_t)n, (XYZZ<M>*)ws->work_y.p, wt);
                 else
                     hipLaunchKernelGGL((k_mac_scale30<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, (const XYZZ<M>*)ws->work.p,

@@ -278,6 +278,16 @@ __device__ __forceinline__ int mac_signed_digit(const uint32_t m[4], int i) {
     return raw > 8u ? (int)raw - 16 : (int)raw;
 }
 
+// The quad-lane kernels run one wave per SIMD (LDS: one block per compute unit), so the compiler would happily spend 212 registers
+// on them -- and then they fit beside nothing: next to the commitments of the same CRebuild (two 192-register waves per SIMD in the
+// guest-room form of k_fb_commit) 128 registers are free.  Held to 128 they start at once there (the arithmetic is one field
+// product per lane at a time: no spills).
+#define MACQ_GUEST_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+// ... and their LDS state is DYNAMIC shared memory (sizeof(MacQuadLds<M>) at the launch, mac_fft.hip:macq_lds_bytes): with the
+// 88 KiB declared statically the compiler knows that one block fits a compute unit, concludes "occupancy 1" and gives the kernel
+// descriptor 264 registers whatever the code uses (.amdhsa_next_free_vgpr 257 for 125 used) -- the guest would not fit again
+#define MACQ_LDS(L) extern __shared__ __align__(16) unsigned char macq_lds_raw[]; \
+    MacQuadLds<M>& L = *reinterpret_cast<MacQuadLds<M>*>(macq_lds_raw)
 // LDS state of a block of MACQ_BF quads: table of multiples, accumulator, the operand being added, the butterfly's upper input
 template <class M>
 struct MacQuadLds {
@@ -349,10 +359,10 @@ __device__ __forceinline__ void macq_ladder(MacQuadLds<typename C::Fp>& L, uint3
 }
 
 template <class C>
-__global__ void __launch_bounds__(4 * MACQ_BF)
+__global__ void __launch_bounds__(4 * MACQ_BF) MACQ_GUEST_ATTR
 k_mac_stage30_quad(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restrict__ tws, uint32_t n, int s) {
     using M = typename C::Fp;
-    __shared__ MacQuadLds<M> L;
+    MACQ_LDS(L);
     // a stage is one wave per SIMD walking ~200 dependent group operations: when another kernel shares the chip (the
     // commitments of the same CRebuild on a second stream) this wave must win the SIMD's issue arbitration every time it is
     // ready -- the wide kernel's waves fill the cycles in between (beside k_fb_commit a stage took 1.45 ms without this, 0.9 alone)
@@ -385,7 +395,7 @@ k_mac_stage30_quad(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __re
 // Stage 1 of the network with four lanes per butterfly: every twiddle is w^0 = 1 (tm = MAC[k+1]), so the stage is its two
 // additions and nothing else -- the 0.54 ms ladder of a general stage would multiply by one.  256 lanes = 64 butterflies per block.
 template <class C>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) MACQ_GUEST_ATTR
 k_mac_stage1_quad(XYZZ<typename C::Fp>* __restrict__ work, uint32_t n) {
     using M = typename C::Fp;
     __shared__ XYZZ<M> tp[64], tn[64];                                     // tm and -tm
@@ -404,10 +414,10 @@ k_mac_stage1_quad(XYZZ<typename C::Fp>* __restrict__ work, uint32_t n) {
 // init scaling of the Y part (k_mac_load30 with use_wt) with four lanes per MAC: work[i] = wt * MAC[i]
 // FROM_WORK: `in` is a work array (n points in the lazy memory form) instead of 64-byte big-endian affine MACs
 template <class C, bool FROM_WORK = false>
-__global__ void __launch_bounds__(4 * MACQ_BF)
+__global__ void __launch_bounds__(4 * MACQ_BF) MACQ_GUEST_ATTR
 k_mac_load30_quad(const uint8_t* __restrict__ in, uint32_t n, XYZZ<typename C::Fp>* __restrict__ work, MacScalar wt) {
     using M = typename C::Fp;
-    __shared__ MacQuadLds<M> L;
+    MACQ_LDS(L);
     const uint32_t q = threadIdx.x >> 2, r = threadIdx.x & 3u, lane = threadIdx.x & 63u;
     uint32_t i = blockIdx.x * MACQ_BF + q;
     const bool valid = i < n;
@@ -428,7 +438,7 @@ __device__ __forceinline__ void store_affine_be(uint8_t* dst, const XYZZ<M>& p);
 // Server::mix's MAC part (k_mac_mix below) with four lanes per i: the butterfly out[i] = A0[i] + v^i A1[i], out[i + len] = A0[i] -
 // v^i A1[i] on 64-byte affine points -- lanes 0 / 1 convert the two inputs on the way in and invert for the two outputs
 template <class C>
-__global__ void __launch_bounds__(4 * MACQ_BF)
+__global__ void __launch_bounds__(4 * MACQ_BF) MACQ_GUEST_ATTR
 k_mac_mix_quad(const uint8_t* __restrict__ a0, const uint8_t* __restrict__ a1, uint32_t len, const uint32_t* __restrict__ tws,
                uint32_t tw_step, uint8_t* __restrict__ out, const uint8_t* __restrict__ b0, const uint8_t* __restrict__ b1,
                uint8_t* __restrict__ out_b) {

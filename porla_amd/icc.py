@@ -85,6 +85,16 @@ def mac_crebuild_xy_device(d_macs, n_rows, curve, write_step, d_out_x, d_out_y, 
                                               ctypes.c_void_p(d_out_y), ctypes.c_void_p(stream)))
 
 
+def kzg_crebuild_stage_device(d_rows, n_rows, write_step, d_aligned_x, d_aligned_y, d_scalars_xy, d_commits_xy, d_macs, d_macs_x,
+                              d_macs_y, stream=0):
+    """the last encode stage of a CRebuild (KZG build) in one call: both parts' encode + alignment scalars + commitments and, beside
+    them on a second stream inside, both MAC encodes (include/porla_gpu.h: porla_kzg_crebuild_stage_device)"""
+    vp = ctypes.c_void_p
+    _check(lib.porla_kzg_crebuild_stage_device(vp(d_rows), n_rows, ctypes.c_ulonglong(write_step), vp(d_aligned_x or None),
+                                               vp(d_aligned_y or None), vp(d_scalars_xy), vp(d_commits_xy), vp(d_macs), vp(d_macs_x),
+                                               vp(d_macs_y), vp(stream)))
+
+
 def mac_crebuild_device(d_macs, n_rows, curve, write_step, part, d_out, stream=0):
     _check(lib.porla_icc_mac_encode_device(ctypes.c_void_p(d_macs), n_rows, CURVE[curve], write_step, part,
                                            ctypes.c_void_p(d_out), ctypes.c_void_p(stream)))

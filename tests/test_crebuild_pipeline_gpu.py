@@ -37,6 +37,10 @@ def test_chain_matches_the_oracle_chain(log2rows, write_step):
     side = torch.cuda.Stream(device=dev)
     if log2rows == 8:       # the calls in the reference's order, one MAC encode per part, one stream
         bc.run_chain(torch, icc, mx, d_rows, d_macs, n, write_step, bufs, stream, reference_order=True)
+    elif log2rows == 11:    # the whole stage as ONE call (porla_kzg_crebuild_stage_device: MAC network first, commitments in the
+        #                     two-waves-per-SIMD form of their kernel beside it)
+        icc.kzg_crebuild_stage_device(d_rows.data_ptr(), n, write_step, bufs[0][0].data_ptr(), bufs[1][0].data_ptr(), bufs[0][1].data_ptr(),
+                                      bufs[0][2].data_ptr(), d_macs.data_ptr(), bufs[0][3].data_ptr(), bufs[1][3].data_ptr(), stream)
     else:                   # both MAC halves from one network, on a second stream beside the data side
         bc.run_chain(torch, icc, mx, d_rows, d_macs, n, write_step, bufs, stream, side.cuda_stream)
     torch.cuda.synchronize()
@@ -87,3 +91,4 @@ def test_bench_line_of_the_crebuild_workload():
     ks = d["kernels_ms_per_step"]
     assert any("icc" in k for k in ks) and any("fb_commit" in k for k in ks) and any("mac" in k for k in ks)
     assert d["sum_kernels_ms_per_step"] > 0 and d["roofline"]["frac"] > 0
+    assert "porla_kzg_crebuild_stage_device" in d["entry_point"] and d["separate_calls_two_streams_ms_per_step"] > 0

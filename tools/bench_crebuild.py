@@ -99,7 +99,13 @@ def main():
     side = torch.cuda.Stream(device=dev, priority=-1)
 
     def step(mode):
-        if mode == "reference_order":
+        if mode == "stage_call":
+            # ONE call: the MAC network first, on a stream of its own inside the library, the commitments in the form of their
+            # kernel that leaves register room for it (the two parts' scalars / commitments are contiguous: alloc())
+            icc.kzg_crebuild_stage_device(d_rows.data_ptr(), n, args.write_step, bufs[0][0].data_ptr(), bufs[1][0].data_ptr(),
+                                          bufs[0][1].data_ptr(), bufs[0][2].data_ptr(), d_macs.data_ptr(), bufs[0][3].data_ptr(),
+                                          bufs[1][3].data_ptr(), stream)
+        elif mode == "reference_order":
             run_chain(torch, icc, mx, d_rows, d_macs, n, args.write_step, bufs, stream, reference_order=True)
         else:
             run_chain(torch, icc, mx, d_rows, d_macs, n, args.write_step, bufs, stream, side.cuda_stream if mode == "two_streams" else None)
@@ -114,9 +120,14 @@ def main():
         torch.cuda.synchronize()
         return time.perf_counter() - t0
 
+    if os.environ.get("PORLA_CREBUILD_ONLY_STAGE"):      # (the kernel-trace script: only the one-call form, nothing else in the trace)
+        el = region("stage_call")
+        print(json.dumps({"stage_call_ms_per_step": round(el / args.steps * 1e3, 4)}))
+        return
     el_ref = region("reference_order")   # per part: encode, commitments, MAC encode; one stream
     el_one = region("one_stream")        # both MAC halves from one network, one stream
-    el = region("two_streams")           # ... and on a second stream beside the data side (the reported value)
+    el_two = region("two_streams")       # ... and on a second stream beside the data side, as three separate calls
+    el = region("stage_call")            # porla_kzg_crebuild_stage_device: the whole stage as ONE call (the reported value)
     # per-kernel split: HIP events around every kernel of two more steps
     mx.profile_enable(True)
     for _ in range(2):
@@ -136,8 +147,15 @@ def main():
         rows = bytes(d_rows[:m * NCOLS * 32].cpu().numpy())
         macs = bytes(d_macs[:64 * m].cpu().numpy())
         sbufs = alloc(torch, m, dev)
-        run_chain(torch, icc, mx, d_rows[:m * NCOLS * 32], d_macs[:64 * m], m, args.write_step, sbufs, stream, side.cuda_stream)
+        icc.kzg_crebuild_stage_device(d_rows.data_ptr(), m, args.write_step, sbufs[0][0].data_ptr(), sbufs[1][0].data_ptr(),
+                                      sbufs[0][1].data_ptr(), sbufs[0][2].data_ptr(), d_macs.data_ptr(), sbufs[0][3].data_ptr(),
+                                      sbufs[1][3].data_ptr(), stream)
         torch.cuda.synchronize()
+        # the separate calls (porla_icc_encode_xy_device, porla_kzg_commit_batch_device, porla_icc_mac_encode_xy_device) leave the same bytes
+        tbufs = alloc(torch, m, dev)
+        run_chain(torch, icc, mx, d_rows[:m * NCOLS * 32], d_macs[:64 * m], m, args.write_step, tbufs, stream, side.cuda_stream)
+        torch.cuda.synchronize()
+        same_as_separate = all(bool((a == b).all().item()) for part in (0, 1) for a, b in zip(sbufs[part], tbufs[part]))
         L = common.oracle()
         L.oracle_kzg_init_key(TAU, ctypes.c_size_t(16), ALPHA, ctypes.c_size_t(16))
         L.oracle_kzg_init_srs(ctypes.c_size_t(NCOLS), (1).to_bytes(32, "big"))
@@ -157,6 +175,7 @@ def main():
             got = [bytes(t.cpu().numpy()) for t in sbufs[part]]
             verified = verified and got[0] == al.raw and got[1] == sc.raw and got[2] == am and got[3] == mh.raw
         cpu_s = time.perf_counter() - t1
+        verified = verified and same_as_separate
         cpu = {"value": round(m / cpu_s, 2), "unit": "rows/s", "cores": cores, "kind": "port",
                "sample": "a %d-row chain, both parts: oracle/icc_ref.c encode + alignment scalars, oracle/bn254_ref.c commitment "
                          "per row, oracle/mac_ref.c MAC encode (CPU restatements, not NTL / gnark) over %d threads; %.2f s wall"
@@ -181,7 +200,10 @@ def main():
            "config": {"workload": "Server::CRebuild_Cached last stage, device-resident: per part porla_icc_encode_device -> "
                                   "porla_kzg_commit_batch_device (align_MAC), and porla_icc_mac_encode_xy_device (both MAC halves from one network), no host sync",
                       "rows": n, "columns": NCOLS, "write_step": args.write_step, "commitments_per_row": 2,
-                      "streams": "2: data side (encode, commitments) and MAC encodes side by side, no host sync"},
+                      "streams": "2 inside the call: the MAC network (started first) beside the data side (encode, commitments in their "
+                                 "two-waves-per-SIMD form), no host sync"},
+           "entry_point": "porla_kzg_crebuild_stage_device (one call per step)",
+           "separate_calls_two_streams_ms_per_step": round(el_two / args.steps * 1e3, 4),
            "one_stream_ms_per_step": round(el_one / args.steps * 1e3, 4), "one_stream_rows_per_s": round(n * args.steps / el_one, 1),
            "reference_order_ms_per_step": round(el_ref / args.steps * 1e3, 4),
            "reference_order_rows_per_s": round(n * args.steps / el_ref, 1),
