@@ -243,6 +243,8 @@ template <class M>
 __device__ __forceinline__ F30<M> f30_mul2_mont(const F30<M>& a, const F30<M>& b, const F30<M>& c, const F30<M>& d) {
     return f30_mul2_portable<M>(a, b, c, d);
 }
+template <class M>
+__device__ __forceinline__ F30<M> f30_mul_mont_tied(const F30<M>& a, const F30<M>& b) { return f30_mul_portable<M>(a, b); }
 #endif
 template <class M>
 __device__ __forceinline__ F30<M> f30_mul(const F30<M>& a, const F30<M>& b) {
