@@ -97,14 +97,13 @@ __device__ __forceinline__ void xyzz30_madd(XYZZ30<M>& p, const F30<M>& ax, cons
 //   xyzz30_flip_neg), and xyzz30_flip_finish undoes an odd count at the end.  Same group elements as xyzz30_madd, 154 instructions
 //   fewer per addition (one Montgomery reduction and one subtraction-with-ripple).
 // Bounds: as xyzz30_madd, with Rn = Y1 - S2 + 2p <= 5 (Y1 <= 3 when the accumulator was loaded from memory, <= 1 after an
-// addition here) and Y3 <= 1.  Curves without the two-product form (special-form modulus) run xyzz30_madd and never flip.
+// addition here) and Y3 <= 1.  Both field forms have the two-product reduction (f30_mul2: Montgomery f30_mul2_mont, special form
+// f30_mul2_pm with one fold).
 template <class M>
 __device__ __forceinline__ bool xyzz30_flip_neg(bool digit_negative, bool flip) { return digit_negative != flip; }
 template <class M>
 __device__ __forceinline__ void xyzz30_madd_flip(XYZZ30<M>& p, bool& flip, const F30<M>& ax, const F30<M>& ay) {
-    if constexpr (M::PSEUDO_MERSENNE) {
-        xyzz30_madd<M>(p, ax, ay);
-    } else {
+    {
         if (p.inf) {                                    // the first point: the sum is (flip ? -a : a) as the caller negated it
             p.x = ax; p.y = ay;
             p.zz = f30_const<M>(M::R1_30); p.zzz = p.zz;
@@ -128,7 +127,7 @@ __device__ __forceinline__ void xyzz30_madd_flip(XYZZ30<M>& p, bool& flip, const
         F30<M> E = f30_add2<M>(PPP, Q);
         F30<M> X3 = f30_sub<M, 4>(RR, E);
         F30<M> D = f30_sub<M, 6>(Q, X3);
-        p.y = f30_mul2_mont<M>(Rn, D, p.y, PPP);        // -Y3
+        p.y = f30_mul2<M>(Rn, D, p.y, PPP);             // -Y3
         p.x = X3;
         p.zz = f30_mul<M>(p.zz, PP);
         p.zzz = f30_mul<M>(p.zzz, PPP);
@@ -142,7 +141,6 @@ __device__ __forceinline__ void xyzz30_madd_flip(XYZZ30<M>& p, bool& flip, const
 // path); a loop exit has no join per iteration.  Both forms leave the same group element under the same sign convention.
 template <class M>
 __device__ __forceinline__ bool xyzz30_madd_flip_fast(XYZZ30<M>& p, bool& flip, const F30<M>& ax, const F30<M>& ay, bool a_is_inf) {
-    static_assert(!M::PSEUDO_MERSENNE, "two-product form: Montgomery moduli only");
     // (an accumulator at infinity holds zeros: the products below are then meaningless and unused)
     F30<M> U2 = f30_mul<M>(ax, p.zz);
     F30<M> S2 = f30_mul<M>(ay, p.zzz);
@@ -156,7 +154,7 @@ __device__ __forceinline__ bool xyzz30_madd_flip_fast(XYZZ30<M>& p, bool& flip, 
     F30<M> E = f30_add2<M>(PPP, Q);
     F30<M> X3 = f30_sub<M, 4>(RR, E);
     F30<M> D = f30_sub<M, 6>(Q, X3);
-    p.y = f30_mul2_mont<M>(Rn, D, p.y, PPP);        // -Y3
+    p.y = f30_mul2<M>(Rn, D, p.y, PPP);             // -Y3
     p.x = X3;
     p.zz = f30_mul<M>(p.zz, PP);
     p.zzz = f30_mul<M>(p.zzz, PPP);

@@ -224,6 +224,32 @@ __device__ __forceinline__ F30<M> f30_mul_pm_portable(const F30<M>& a, const F30
 }
 template <class M>
 __device__ __forceinline__ F30<M> f30_sqr_pm_portable(const F30<M>& a) { return f30_mul_pm_portable<M>(a, a); }
+// a b + c d mod p with ONE fold (the special-form twin of f30_mul2_portable).  The double-width sum is < 2^519, its high part
+// hi < 2^249: hi (C1 2^30 + C0) < 2^296, so the fold's R[9] stays below 2^26 and its result below 2^256 + 2^50 (limbs normal).
+// Column 7 holds 2 x 8 full-size products -- within 2^34 of 2^64 in one accumulator -- so its c d terms go through a side chain.
+constexpr int F30_PM_MUL2_CHAIN = 7;
+template <class M>
+__device__ __forceinline__ F30<M> f30_mul2_pm_portable(const F30<M>& a, const F30<M>& b, const F30<M>& c, const F30<M>& d) {
+    uint64_t t = 0, u = 0;
+    uint32_t L[18];
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+        if (k == F30_PM_MUL2_CHAIN + 1) t += u >> 30;
+#pragma unroll
+        for (int i = (k > 8 ? k - 8 : 0); i <= (k < 8 ? k : 8); i++) {
+            t += (uint64_t)a.v[i] * b.v[k - i];
+            if (k == F30_PM_MUL2_CHAIN) u += (uint64_t)c.v[i] * d.v[k - i];
+            else t += (uint64_t)c.v[i] * d.v[k - i];
+        }
+        if (k == F30_PM_MUL2_CHAIN) t += (uint32_t)u & F30_MASK;
+        L[k] = (uint32_t)t & F30_MASK;
+        t >>= 30;
+    }
+    L[17] = (uint32_t)t;
+    F30<M> r;
+    f30_pm_fold<M>(r, L);
+    return r;
+}
 
 // The device forms: generated assembly blocks (tools/gen_fe30_asm.py), 205 / 169 instructions per product / square.
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -245,7 +271,17 @@ __device__ __forceinline__ F30<M> f30_mul2_mont(const F30<M>& a, const F30<M>& b
 }
 template <class M>
 __device__ __forceinline__ F30<M> f30_mul_mont_tied(const F30<M>& a, const F30<M>& b) { return f30_mul_portable<M>(a, b); }
+template <class M>
+__device__ __forceinline__ F30<M> f30_mul2_pm(const F30<M>& a, const F30<M>& b, const F30<M>& c, const F30<M>& d) {
+    return f30_mul2_pm_portable<M>(a, b, c, d);
+}
 #endif
+// a b + c d with one reduction / one fold
+template <class M>
+__device__ __forceinline__ F30<M> f30_mul2(const F30<M>& a, const F30<M>& b, const F30<M>& c, const F30<M>& d) {
+    if constexpr (M::PSEUDO_MERSENNE) return f30_mul2_pm<M>(a, b, c, d);
+    else return f30_mul2_mont<M>(a, b, c, d);
+}
 template <class M>
 __device__ __forceinline__ F30<M> f30_mul(const F30<M>& a, const F30<M>& b) {
     if constexpr (M::PSEUDO_MERSENNE) return f30_mul_pm<M>(a, b);

@@ -701,7 +701,7 @@ k_bucket_sum30(const Affine<typename C::Fp>* __restrict__ pts, const uint32_t* _
         }
         k = 1;
     }
-    if constexpr (!M::PSEUDO_MERSENNE) {
+    {
         // the fast loop: straight-line additions; a lane that meets an exceptional case leaves it with that entry still to do
         for (; k < cnt; k++) {
             const uint32_t cur = ent;

@@ -22,16 +22,15 @@ __global__ void k_mul30(const uint32_t* a, const uint32_t* b, uint32_t* out, int
     F30<M> x, y;
     for (int k = 0; k < 9; k++) { x.v[k] = a[i * 9 + k]; y.v[k] = b[i * 9 + k]; }
     F30<M> z, zp;                               // the assembly must equal the portable form limb for limb
-    if constexpr (!M::PSEUDO_MERSENNE) {
-        if (square == 2) {                      // x y + c d with one reduction; (c, d) = the next lane's operands
-            const int j = (i + 1) % n;
-            F30<M> c, d;
-            for (int k = 0; k < 9; k++) { c.v[k] = a[j * 9 + k]; d.v[k] = b[j * 9 + k]; }
-            z = f30_mul2_mont<M>(x, y, c, d);
-            zp = f30_mul2_portable<M>(x, y, c, d);
-            for (int k = 0; k < 9; k++) out[i * 9 + k] = z.v[k] | (z.v[k] != zp.v[k] ? 0x80000000u : 0u);
-            return;
-        }
+    if (square == 2) {                          // x y + c d with one reduction / one fold; (c, d) = the next lane's operands
+        const int j = (i + 1) % n;
+        F30<M> c, d;
+        for (int k = 0; k < 9; k++) { c.v[k] = a[j * 9 + k]; d.v[k] = b[j * 9 + k]; }
+        z = f30_mul2<M>(x, y, c, d);
+        if constexpr (M::PSEUDO_MERSENNE) zp = f30_mul2_pm_portable<M>(x, y, c, d);
+        else zp = f30_mul2_portable<M>(x, y, c, d);
+        for (int k = 0; k < 9; k++) out[i * 9 + k] = z.v[k] | (z.v[k] != zp.v[k] ? 0x80000000u : 0u);
+        return;
     }
     z = square ? f30_sqr<M>(x) : f30_mul<M>(x, y);
     if constexpr (M::PSEUDO_MERSENNE) zp = square ? f30_sqr_pm_portable<M>(x) : f30_mul_pm_portable<M>(x, y);
@@ -225,19 +224,26 @@ static int check_pm(const char* name) {
     CK(hipMemcpy(da, a.data(), n * 36, hipMemcpyHostToDevice));
     CK(hipMemcpy(db, b.data(), n * 36, hipMemcpyHostToDevice));
     int bad = 0;
-    for (int square = 0; square < 2; square++) {
+    for (int square = 0; square < 3; square++) {          // 2: the two-product form f30_mul2 (x y + c d, one fold)
         hipLaunchKernelGGL(k_mul30<M>, dim3(n / 256), dim3(256), 0, 0, da, db, dout, n, square);
         CK(hipMemcpy(got.data(), dout, n * 36, hipMemcpyDeviceToHost));
         for (int i = 0; i < n; i++) {
+            auto full_product = [](const Fe<M>& x, const Fe<M>& y) {   // schoolbook product, then long division
+                uint32_t t[16] = {0};
+                for (int p = 0; p < 8; p++) {
+                    uint64_t c = 0;
+                    for (int q = 0; q < 8; q++) { c += (uint64_t)x.v[p] * y.v[q] + t[p + q]; t[p + q] = (uint32_t)c; c >>= 32; }
+                    t[p + 8] = (uint32_t)c;
+                }
+                return mod_p<M>(t, 16);
+            };
             Fe<M> x = limbs_mod_p<M>(&a[i * 9]);
-            Fe<M> y = square ? x : limbs_mod_p<M>(&b[i * 9]);
-            uint32_t t[16] = {0};                                      // schoolbook product, then long division
-            for (int p = 0; p < 8; p++) {
-                uint64_t c = 0;
-                for (int q = 0; q < 8; q++) { c += (uint64_t)x.v[p] * y.v[q] + t[p + q]; t[p + q] = (uint32_t)c; c >>= 32; }
-                t[p + 8] = (uint32_t)c;
+            Fe<M> y = square == 1 ? x : limbs_mod_p<M>(&b[i * 9]);
+            Fe<M> want = full_product(x, y);
+            if (square == 2) {
+                const int j = (i + 1) % n;
+                want = fe_add<M>(want, full_product(limbs_mod_p<M>(&a[j * 9]), limbs_mod_p<M>(&b[j * 9])));
             }
-            Fe<M> want = mod_p<M>(t, 16);
             const uint32_t* z = &got[i * 9];
             bool limbs_ok = true;
             for (int k = 0; k < 8; k++) if (z[k] > F30_MASK) limbs_ok = false;
