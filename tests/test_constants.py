@@ -60,6 +60,12 @@ def test_reduced_radix_column_sums_fit_64_bits():
     """fe30.hip.h accumulates the 16..18 products of a column in one 64-bit register without carries: the worst case must fit"""
     import check_fe30_bounds as cb
     assert all(cb.check(name, p) for name, p in cb.MODULI.items())
-    # and the generated assembly is what the generator produces
+    # the two-product forms (one reduction / one fold for a b + c d): their side-chain columns are the ones the generator uses
     import gen_fe30_asm as g30
+    assert cb.MUL2_CHAIN == g30.MUL2_CHAIN and cb.PM_MUL2_CHAIN == g30.PM_MUL2_CHAIN[0] == g30.PM_MUL2_CHAIN[1]
+    assert all(cb.check_mul2(name, p) for name, p in cb.MODULI.items() if name != "p_icc") and cb.check_pm_mul2()
+    assert not cb.check_mul2("no chain", cb.MODULI["bn254_p"], chain=(99, 99))       # ... and they are needed
+    src = open(os.path.join(CSRC, "fe30.hip.h")).read()
+    assert "F30_MUL2_CHAIN_LO = %d, F30_MUL2_CHAIN_HI = %d" % cb.MUL2_CHAIN in src and "F30_PM_MUL2_CHAIN = %d" % cb.PM_MUL2_CHAIN in src
+    # and the generated assembly is what the generator produces
     assert open(os.path.join(CSRC, "fe30_mul_gfx950.inc")).read() == g30.whole()

@@ -60,10 +60,34 @@ def check_mul2(name, p, top_bits=18, chain=MUL2_CHAIN):
     ok = worst_t < 2**64 and worst_u < 2**64
     print("%-8s mul2: worst t column %.4f x 2^64, worst u column %.4f x 2^64  %s" % (name, worst_t / 2**64, worst_u / 2**64, "ok" if ok else "OVERFLOW"))
     return ok
+PM_MUL2_CHAIN = 7        # = tools/gen_fe30_asm.py:PM_MUL2_CHAIN = fe30.hip.h:F30_PM_MUL2_CHAIN
+def check_pm_mul2(top_bits=19, chain=PM_MUL2_CHAIN):
+    """f30_mul2_pm (special-form modulus, no reduction terms in the columns): both products' terms in t, except the chained column,
+    whose c d terms run in u; then the fold of a double-width value < 2^519: R[9] < 2^26"""
+    amax = [MASK] * 8 + [2**top_bits - 1]
+    ct = cu = 0
+    worst = 0
+    for k in range(17):
+        ab = sum(amax[i] * amax[k - i] for i in range(9) if 0 <= k - i <= 8)
+        if k == chain:
+            cu = ab >> 30
+            t = ct + ab + MASK
+        else:
+            t = ct + 2 * ab + (cu if k == chain + 1 else 0)
+        worst, ct = max(worst, t), t >> 30
+    unchained = max(2 * sum(amax[i] * amax[k - i] for i in range(9) if 0 <= k - i <= 8) for k in range(17)) + 2**35
+    # the fold: hi = bits 270.. of the sum (< 2^519 / 2^270), times 2^14 (2^32 + FOLD) with FOLD < 2^16
+    hi_max = (2 * (2**259 - 1) ** 2) >> 270
+    r9_ok = (hi_max * (2**14 * (2**32 + 2**16)) + 2**270) >> 270 < 2**26
+    ok = worst < 2**64 and r9_ok
+    print("special-form mul2: worst column %.6f x 2^64 (a single accumulator would reach %.10f), fold R[9] < 2^26: %s  %s"
+          % (worst / 2**64, unchained / 2**64, r9_ok, "ok" if ok else "OVERFLOW"))
+    return ok
 if __name__ == "__main__":
     import sys
     ok = all([check(n, p) for n, p in MODULI.items()])
     ok = all([check_mul2(n, p) for n, p in MODULI.items() if n != "p_icc"]) and ok
+    ok = check_pm_mul2() and ok
     ok = all([check("icc:" + n, p, 23, 17) for n, p in ICC_MODULI.items()]) and ok
     # result bound of the ICC product: a b / 2^270 + p < p + 2^249 for a < 2^263, b < 2^256: limb 8 stays far below 2^30
     sys.exit(0 if ok else 1)
