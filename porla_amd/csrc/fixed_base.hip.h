@@ -335,6 +335,7 @@ k_fb_commit_small(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_
     const uint8_t* row = rows + (size_t)r * row_stride;
     XYZZ30<M> acc;
     acc.inf = true;
+    bool flip = false;
     for (uint32_t p = p0 + tid; p < p1; p += SMALL_THREADS) {
         const uint32_t i = p / (uint32_t)W, w = p % (uint32_t)W;
         uint32_t t[8];
@@ -379,13 +380,12 @@ k_fb_commit_small(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_
         if (!mag) continue;
         Affine<M> a = load_affine<M>(table + ((size_t)i * W + w) * Bh, mag - 1);
         if (aff_is_inf<M>(a)) continue;
-        a = aff_neg_if<M>(a, neg);
-        if constexpr (C::F30_BUCKETS) {
-            xyzz30_madd<M>(acc, f30_from_fe<M>(a.x), f30_from_fe<M>(a.y));
-        } else {
-            static_assert(C::F30_BUCKETS, "k_fb_commit_small needs the reduced-radix form");
-        }
+        static_assert(C::F30_BUCKETS, "k_fb_commit_small needs the reduced-radix form");
+        // (the sign-alternating addition with one reduction for Y3, ec30.hip.h:xyzz30_madd_flip: a lone wave pays for every instruction)
+        a = aff_neg_if<M>(a, xyzz30_flip_neg<M>(neg, flip));
+        xyzz30_madd_flip<M>(acc, flip, f30_from_fe<M>(a.x), f30_from_fe<M>(a.y));
     }
+    xyzz30_flip_finish<M>(acc, flip);
     xyzz30_store_lazy<M>(&pts[tid], acc);
     __syncthreads();
     for (uint32_t h = 1; h < SMALL_THREADS; h <<= 1) {            // 256 lane sums -> pts[0]

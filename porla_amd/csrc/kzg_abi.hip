@@ -1126,10 +1126,10 @@ int porla_kzg_audit_device(const void* d_rows64, const uint64_t* d_idx64, const 
     PORLA_HIP(hipHostGetDevicePointer(&pin_dev, pin->h, 0));
     uint8_t* h_b = pin->h;                  // B mod p_icc, n 32-byte big-endian values
     uint8_t* h_c = pin->h + 32 * n;         // the alignment scalars
-    // hip_stream orders the INPUTS: the combine runs on it (on the engine's stream when it is the null stream), the pair on the
-    // audit slot's own stream -- both behind an event recorded on hip_stream now, so index / coefficient arrays the caller has
-    // just uploaded asynchronously on it are complete before any kernel of the audit reads them
-    hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : engine_stream();
+    // hip_stream orders the INPUTS: the combine runs on it as given (NULL = the null stream), the pair on the audit slot's own
+    // stream behind an event recorded on hip_stream now -- index / coefficient arrays the caller has just uploaded asynchronously
+    // on it are complete before any kernel of the audit reads them (one record + one wait: ~4 us of a 150 us call)
+    hipStream_t stream = (hipStream_t)hip_stream;
     Workspace* aw = nullptr;
     if ((rc = get_workspace_slot(MSM_AUDIT_SLOT, &aw))) return rc;
     if ((rc = order_after_caller(aw, (hipStream_t)hip_stream, stream, aw->own_stream))) return rc;

@@ -317,6 +317,7 @@ k_small_msm(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ poi
     {
         XYZZ30<M> acc;
         acc.inf = true;
+        bool flip = false;
         // the next entry's point is in flight while this one is converted and added (a gather is an L2 / HBM round trip)
         uint32_t en = 0;
         Affine<M> nx;
@@ -338,7 +339,8 @@ k_small_msm(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ poi
             fe_reduce_plain<M>(a.x.v, 6);                      // G1Affine.Unmarshal: SetBytes reduces (main.go:130)
             fe_reduce_plain<M>(a.y.v, 6);
             if (aff_is_inf<M>(a)) continue;
-            a = aff_neg_if<M>(a, (cur >> 31) != 0);            // on the plain residue: -y = p - y in any form
+            // (the accumulator alternates sign with every addition, ec30.hip.h:xyzz30_madd_flip; folded into the digit's sign)
+            a = aff_neg_if<M>(a, xyzz30_flip_neg<M>((cur >> 31) != 0, flip));   // on the plain residue: -y = p - y in any form
             // into the 2^270 form the reduced-radix addition computes in: one product by 2^540 mod p per coordinate (the special-form
             // field keeps plain residues: nothing to do); phi(P) = (beta x, y) for the second sub-scalar
             F30<M> ax = f30_from_fe<M>(a.x), ay = f30_from_fe<M>(a.y);
@@ -347,8 +349,9 @@ k_small_msm(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ poi
                 ay = f30_mul<M>(ay, f30_const<M>(M::RR_30));
             }
             if (g.glv && (cur & 1u)) ax = f30_mul<M>(ax, f30_const<M>(C::Glv::BETA_30));
-            xyzz30_madd<M>(acc, ax, ay);
+            xyzz30_madd_flip<M>(acc, flip, ax, ay);
         }
+        xyzz30_flip_finish<M>(acc, flip);
         xyzz30_store_lazy<M>(&pts[tid], acc);
     }
     __syncthreads();
