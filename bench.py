@@ -383,8 +383,10 @@ def main():
             pk = fe_peak[WORKLOAD_FIELD[workload]]
             r["int_multiplier"] = {"achieved": round(g, 2), "peak": pk["mix_8M_2S"], "unit": "G fe_mul/s (256-bit modular)",
                                    "frac": round(g / pk["mix_8M_2S"], 4), "peak_source": pk["source"],
-                                   "note": "mixed addition = 8M + 2S = 10 fe_mul; peak = back-to-back product rate "
-                                           "of the field form the kernel uses (8M + 2S mix)"}
+                                   "note": "mixed addition = 8M + 2S = 10 fe_mul (the ALGORITHMIC count of the group law; since "
+                                           "round 4 the kernel computes R D - Y1 PPP with one reduction, ~9.4 product-equivalents of "
+                                           "instructions per addition); peak = back-to-back product rate of the field form the kernel "
+                                           "uses (8M + 2S mix)"}
         return r
 
     def msm_fe_mults(n):

@@ -489,7 +489,11 @@ static int msm_tree_launch(Workspace* ws, const XYZZ<typename C::Fp>* buckets, i
                 a.l = l; a.nlev = nlev; a.last = 0;
                 const size_t tasks = (size_t)(l + 1) * a.n;
                 if constexpr (C::F30_LAZY) {
-                    if (quad && tasks <= TREE_QUAD_MAX_TASKS) {
+                    // a caller that waits for this MSM alone has idle lanes to spend on latency: more levels on four lanes per
+                    // addition (PORLA_TREE_QUAD_MAX_LONE); with another MSM in flight the extra lane work would cost throughput
+                    static const size_t quad_max_lone = getenv("PORLA_TREE_QUAD_MAX_LONE") ? (size_t)atol(getenv("PORLA_TREE_QUAD_MAX_LONE"))
+                                                                                            : (size_t)TREE_QUAD_MAX_TASKS;
+                    if (quad && tasks <= (ws->lone ? quad_max_lone : (size_t)TREE_QUAD_MAX_TASKS)) {
                         hipLaunchKernelGGL((k_tree_level_quad<C>), dim3((unsigned)((4 * tasks + 255) / 256)), dim3(256), 0, st, a);
                         PORLA_TRACE("tree_level");
                         continue;
