@@ -977,12 +977,22 @@ def main():
                 "launches_per_call": launches, "algorithmic_bytes_per_call": algo_bytes_per_call,
                 "all_kernels_ms_per_call": per_call, "note": note}
 
+    SECP_G = bytes.fromhex("79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798"
+                           "483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8")      # group_impl.h:28-33
+
+    def secp_multiples_of_g(n, start):
+        """n secp256k1 points k_i * G, k_i = SHA-256("ecmult" || LE32(start + i)): inputs for the IPA-side legs, produced by the
+        ENGINE (rows of one coefficient against the one-point base [G]; tests/test_reference_kats_gpu.py ties that kernel to the
+        reference's own hash) -- no oracle call for input generation"""
+        fbg = mx.FixedBase("secp256k1", SECP_G, 1)
+        try:
+            return fbg.commit_host(common.secp_bench_scalars(n, start=start), n, 1)
+        finally:
+            fbg.close()
+
     def ipa_generators(n):
-        # the 128 Pedersen generators of the IPA build (Client.hpp:112-117 draws them at random): k_i * G, k_i = SHA-256("ecmult" || i)
-        sc = common.secp_bench_scalars(n, start=77000)
-        out = ctypes.create_string_buffer(64 * n)
-        common.oracle().oracle_secp256k1_mul_g_batch(sc, ctypes.c_size_t(n), out, common.ncpu())
-        return out.raw
+        # the 128 Pedersen generators of the IPA build (Client.hpp:112-117 draws them at random)
+        return secp_multiples_of_g(n, 77000)
 
     def leg_ipa_commits():
         rows_n = 1 << args.log2rows
@@ -1039,10 +1049,7 @@ def main():
             if curve == "bn254":
                 base = common.synth_points(4096, start=9000)
             else:
-                sc = common.secp_bench_scalars(4096, start=300)
-                buf = ctypes.create_string_buffer(64 * 4096)
-                common.oracle().oracle_secp256k1_mul_g_batch(sc, ctypes.c_size_t(4096), buf, common.ncpu())
-                base = buf.raw
+                base = secp_multiples_of_g(4096, 300)
             macs = (base * (n // 4096))[:64 * n]
             d_in = to_dev(macs)
             d_o = torch.empty(64 * n, dtype=torch.uint8, device=dev)
@@ -1096,10 +1103,7 @@ def main():
             if curve == "bn254":
                 pool = common.synth_points(2048, start=5000)
             else:
-                sc = common.secp_bench_scalars(2048, start=300)
-                buf = ctypes.create_string_buffer(64 * 2048)
-                common.oracle().oracle_secp256k1_mul_g_batch(sc, ctypes.c_size_t(2048), buf, common.ncpu())
-                pool = buf.raw
+                pool = secp_multiples_of_g(2048, 300)
             arr = (pool * (4 * length // 2048))[:64 * 4 * length]
             parts = [arr[64 * length * k:64 * length * (k + 1)] for k in range(4)]
             d_parts = [to_dev(x) for x in parts]
