@@ -182,9 +182,12 @@ static int mac_encode_core(MacWs* ws, int curve, const uint8_t* d_in, size_t n, 
             if (use_wt && quad && n <= ((size_t)1 << 14))
                 hipLaunchKernelGGL((k_mac_load30_quad<C>), dim3((unsigned)((n + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream, d_in,
                                    (uint32_t)n, (XYZZ<M>*)ws->work.p, wt);
+            else if (use_wt)
+                hipLaunchKernelGGL((k_mac_load30<C, true>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_in, (uint32_t)n,
+                                   (XYZZ<M>*)ws->work.p, wt);
             else
-                hipLaunchKernelGGL((k_mac_load30<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_in, (uint32_t)n,
-                                   (XYZZ<M>*)ws->work.p, wt, use_wt);
+                hipLaunchKernelGGL((k_mac_load30<C, false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_in, (uint32_t)n,
+                                   (XYZZ<M>*)ws->work.p, wt);
         } else
             hipLaunchKernelGGL((k_mac_load<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_in, (uint32_t)n,
                                (XYZZ<M>*)ws->work.p, wt, use_wt);

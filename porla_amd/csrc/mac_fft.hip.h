@@ -186,15 +186,17 @@ __device__ __forceinline__ XYZZ<M> load_affine_be_lazy(const uint8_t* src) {
     return p;
 }
 
-// 64-byte big-endian affine MACs -> work array in the lazy memory form; part 1 (Y): times wt
-template <class C>
+// 64-byte big-endian affine MACs -> work array in the lazy memory form; part 1 (Y): times wt.
+// USE_WT is a template parameter: the plain load (the X part, and both parts of the xy form) must not carry the ladder's 226
+// registers and 1.7 KB of scratch per lane -- with them a copy of 2^15 points took 0.28 ms (the scratch set-up), without 0.01.
+template <class C, bool USE_WT>
 __global__ void __launch_bounds__(64)
-k_mac_load30(const uint8_t* __restrict__ in, uint32_t n, XYZZ<typename C::Fp>* __restrict__ work, MacScalar wt, int use_wt) {
+k_mac_load30(const uint8_t* __restrict__ in, uint32_t n, XYZZ<typename C::Fp>* __restrict__ work, MacScalar wt) {
     using M = typename C::Fp;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     XYZZ<M> p = load_affine_be_lazy<M>(in + (size_t)i * 64);
-    if (use_wt) {
+    if constexpr (USE_WT) {
         uint32_t k[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) k[j] = wt.v[j];
