@@ -82,6 +82,24 @@ def test_kzg_audit_is_consistent_end_to_end(n_blocks, write_step, part):
                               d_align.data_ptr(), d_idx.data_ptr(), d_coef.data_ptr(), n_points, z)
     assert one["combined_mac"] == combined_mac and one["combined_align"] == bytes(64) and one["align_value"] == align_value
     assert (one["commitment"], one["proof_h"], one["point"], one["claim"]) == (commitment, proof_h, point, claim) and one["b"] == b_be
+    # the stream contract (include/porla_gpu.h): the challenge uploaded ASYNCHRONOUSLY on the call's stream, queued behind a long
+    # kernel, and NO host synchronisation before the call -- the pair's gather runs on a stream of the library's own and must still
+    # see the uploaded indices (it raced with the upload before the audits ordered their streams behind the caller's)
+    side = torch.cuda.Stream()
+    h_idx = torch.tensor(idx, dtype=torch.int64).pin_memory()
+    h_coef = torch.tensor(np.array(coef, dtype=np.uint32).view(np.int32)).pin_memory()
+    d_idx2 = torch.zeros(n_points, dtype=torch.int64, device="cuda")            # zeros = a wrong challenge until the copy lands
+    d_coef2 = torch.zeros(n_points, dtype=torch.int32, device="cuda")
+    big = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(4):
+            big.normal_()                                                          # a few ms of work in front of the copies
+        d_idx2.copy_(h_idx, non_blocking=True)
+        d_coef2.copy_(h_coef, non_blocking=True)
+        late = mx.kzg_audit_device(d_rows.data_ptr(), d_idx2.data_ptr(), d_coef2.data_ptr(), n_points, 0, 0, 0, 0, d_macs.data_ptr(),
+                                   d_align.data_ptr(), d_idx2.data_ptr(), d_coef2.data_ptr(), n_points, z, stream=side.cuda_stream)
+    assert late == one
     # a tampered row breaks it
     bad = bytearray(b_be)
     bad[31] ^= 1
