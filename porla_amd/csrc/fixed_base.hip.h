@@ -250,11 +250,18 @@ k_fb_commit(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_coeffs
             uint32_t raw = 0;
             if (lo < 256) {
                 const int limb = lo >> 5, sh = lo & 31;
+                // the two words the window straddles: `limb` is the same for every lane (it depends on w and c only), so this is a
+                // scalar branch to one of eight copies -- a select chain over the words cost 16 instructions per window
                 uint32_t a = 0, b = 0;
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    a = (k == limb) ? t[k] : a;
-                    b = (k == limb + 1) ? t[k] : b;
+                switch (limb) {
+                    case 0: a = t[0]; b = t[1]; break;
+                    case 1: a = t[1]; b = t[2]; break;
+                    case 2: a = t[2]; b = t[3]; break;
+                    case 3: a = t[3]; b = t[4]; break;
+                    case 4: a = t[4]; b = t[5]; break;
+                    case 5: a = t[5]; b = t[6]; break;
+                    case 6: a = t[6]; b = t[7]; break;
+                    default: a = t[7]; b = 0; break;
                 }
                 uint64_t v = ((uint64_t)b << 32) | a;
                 raw = (uint32_t)(v >> sh) & mask;
