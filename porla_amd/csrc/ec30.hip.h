@@ -96,43 +96,42 @@ __device__ __forceinline__ void xyzz30_madd(XYZZ30<M>& p, const F30<M>& ax, cons
 //   the true sum, the caller negates the incoming point when it does (that negation is folded into the digit's own sign:
 //   xyzz30_flip_neg), and xyzz30_flip_finish undoes an odd count at the end.  Same group elements as xyzz30_madd, 154 instructions
 //   fewer per addition (one Montgomery reduction and one subtraction-with-ripple).
-// Bounds: as xyzz30_madd, with Rn = Y1 - S2 + 2p <= 5 (Y1 <= 3 when the accumulator was loaded from memory, <= 1 after an
-// addition here) and Y3 <= 1.  Both field forms have the two-product reduction (f30_mul2: Montgomery f30_mul2_mont, special form
+// Bounds: as xyzz30_madd, with Rn = Y1 - S2 + 2p <= 6 (Y1 <= 4 when the accumulator was loaded from memory -- a sum this form
+// left there after an odd count: 4p - Y -- and <= 1 after an addition here) and Y3 <= 1; every operand of a product stays far
+// below 2^258.  Both field forms have the two-product reduction (f30_mul2: Montgomery f30_mul2_mont, special form
 // f30_mul2_pm with one fold).
 template <class M>
 __device__ __forceinline__ bool xyzz30_flip_neg(bool digit_negative, bool flip) { return digit_negative != flip; }
 template <class M>
 __device__ __forceinline__ void xyzz30_madd_flip(XYZZ30<M>& p, bool& flip, const F30<M>& ax, const F30<M>& ay) {
-    {
-        if (p.inf) {                                    // the first point: the sum is (flip ? -a : a) as the caller negated it
-            p.x = ax; p.y = ay;
-            p.zz = f30_const<M>(M::R1_30); p.zzz = p.zz;
-            p.inf = false;
-            return;
-        }
-        F30<M> U2 = f30_mul<M>(ax, p.zz);
-        F30<M> S2 = f30_mul<M>(ay, p.zzz);
-        F30<M> Pp = f30_sub<M, 6>(U2, p.x);
-        F30<M> Rn = f30_sub<M, 2>(p.y, S2);
-        F30<M> PP = f30_sqr<M>(Pp);
-        if (f30_product_is_zero<M>(PP)) {               // same x: the same point (double it) or its negative (infinity); no flip
-            F30<M> RR = f30_sqr<M>(Rn);
-            if (f30_product_is_zero<M>(RR)) p = xyzz30_double_affine<M>(ax, ay);
-            else p.inf = true;
-            return;
-        }
-        F30<M> PPP = f30_mul<M>(Pp, PP);
-        F30<M> Q = f30_mul<M>(p.x, PP);
-        F30<M> RR = f30_sqr<M>(Rn);
-        F30<M> E = f30_add2<M>(PPP, Q);
-        F30<M> X3 = f30_sub<M, 4>(RR, E);
-        F30<M> D = f30_sub<M, 6>(Q, X3);
-        p.y = f30_mul2<M>(Rn, D, p.y, PPP);             // -Y3
-        p.x = X3;
-        p.zz = f30_mul<M>(p.zz, PP);
-        p.zzz = f30_mul<M>(p.zzz, PPP);
-        flip = !flip;
+    if (p.inf) {                                        // the first point: the sum is (flip ? -a : a) as the caller negated it
+        p.x = ax; p.y = ay;
+        p.zz = f30_const<M>(M::R1_30); p.zzz = p.zz;
+        p.inf = false;
+        return;
     }
+    F30<M> U2 = f30_mul<M>(ax, p.zz);
+    F30<M> S2 = f30_mul<M>(ay, p.zzz);
+    F30<M> Pp = f30_sub<M, 6>(U2, p.x);
+    F30<M> Rn = f30_sub<M, 2>(p.y, S2);
+    F30<M> PP = f30_sqr<M>(Pp);
+    if (f30_product_is_zero<M>(PP)) {                   // same x: the same point (double it) or its negative (infinity); no flip
+        F30<M> RR = f30_sqr<M>(Rn);
+        if (f30_product_is_zero<M>(RR)) p = xyzz30_double_affine<M>(ax, ay);
+        else p.inf = true;
+        return;
+    }
+    F30<M> PPP = f30_mul<M>(Pp, PP);
+    F30<M> Q = f30_mul<M>(p.x, PP);
+    F30<M> RR = f30_sqr<M>(Rn);
+    F30<M> E = f30_add2<M>(PPP, Q);
+    F30<M> X3 = f30_sub<M, 4>(RR, E);
+    F30<M> D = f30_sub<M, 6>(Q, X3);
+    p.y = f30_mul2<M>(Rn, D, p.y, PPP);                 // -Y3
+    p.x = X3;
+    p.zz = f30_mul<M>(p.zz, PP);
+    p.zzz = f30_mul<M>(p.zzz, PPP);
+    flip = !flip;
 }
 // The form the accumulation loops call FIRST: the addition above as straight-line code.  Returns false -- with p and flip untouched --
 // when this lane meets an exceptional case (accumulator or point at infinity, equal x); the caller then leaves its fast loop and
