@@ -12,6 +12,8 @@ oracle between the vector and the kernel.  Nothing here impo
                           all-zero scalars, cancelling scalars on one point, one scalar on cancelling points, a scalar sum that
                           cancels; constant scalar / constant point; zero scalars among live ones; the exhaustive
                           s0*(t0*P) + s1*(t1*P) grid for 8 x 8 x 8 x 8 small signed values
+  test_ecmult_multi_random  tests.c:4055-4221  300 random instances: 0 .. 128 inputs, dead terms (0*P, a*INF), a G term or not, half of
+                          them built to sum to infinity by one compensating term
 
 The reference's "random group elements" are k*G for seeded k here, so every expected value is (closed-form scalar) * G, computed on the
 fixed-base [G] kernel that the first test ties to the reference's hash.  A G term (inp_g_sc) is one more (g_sc, G) pair: the engine's
@@ -196,3 +198,48 @@ def test_ecmult_multi_cases(mx, fb_g):
     want = mul_g(fb_g, [(small(t0) * small(s0) + small(t1) * small(s1)) * k for t0, t1, s0, s1 in cases])
     for (t0, t1, s0, s1), w in zip(cases, want):
         assert msm(mx, [small(s0), small(s1)], [tp[t0], tp[t1]]) == w, (t0, t1, s0, s1)
+
+
+def test_ecmult_multi_random_instances(mx, fb_g):
+    """in the spirit of test_ecmult_multi_random (tests.c:4055-4221): few or many inputs (0 .. 128, exponentially distributed), few
+    or many 0*P and a*INF terms, with or without a G term, an expected result that is infinity for about half of the instances --
+    every point is k*G for a known k, so the expected result is (sum of the live s_i k_i) * G on the fixed-base [G] kernel, and a
+    result forced to infinity by one compensating term (a r, -(1/a) G) as the reference builds it (tests.c:4110-4122)"""
+    rnd = random.Random(0x4055)
+    rs = lambda: rnd.randrange(1, N)
+    cases = []
+    for _ in range(300):
+        num = rnd.randrange((1 << (2 + rnd.randrange(6))) + 1)          # 0 .. 4..128
+        num_nonzero = rnd.randrange(num + 1)
+        nonzero_result = rnd.getrandbits(1)
+        g_nonzero = nonzero_result if num_nonzero == 0 else (1 if num_nonzero == 1 and not nonzero_result else rnd.getrandbits(1))
+        terms = []                                                          # (scalar, discrete log of the point or None = infinity)
+        live = num_nonzero
+        if g_nonzero:
+            terms.append((rs(), 1))                                         # the G term as one more pair
+        while live > (0 if nonzero_result else 1):
+            terms.append((rs(), rs()))
+            live -= 1
+        total = sum(s * k for s, k in terms) % N
+        if not nonzero_result:
+            if terms or live:
+                # one compensating term brings the sum to infinity: scalar a, point -(total / a) G
+                a = rs()
+                terms.append((a, (-total * pow(a, -1, N)) % N))
+                total = 0
+        # the dead terms: 0 * P and a * INF, shuffled in between
+        for _d in range(num - num_nonzero):
+            terms.append((0, rs()) if rnd.getrandbits(1) else (rs(), None))
+        rnd.shuffle(terms)
+        cases.append((terms, total))
+    # all the points and expected results in two batches of the fixed-base kernel
+    logs = [k for terms, _ in cases for _, k in terms if k is not None]
+    pts = iter(mul_g(fb_g, logs))
+    want = mul_g(fb_g, [t for _, t in cases])
+    zeros = 0
+    for (terms, total), w in zip(cases, want):
+        points = [INF if k is None else next(pts) for _, k in terms]
+        got = msm(mx, [s for s, _ in terms], points) if terms else mx.msm_host("secp256k1", b"", b"", 0)
+        assert got == w, (len(terms), total)
+        zeros += w == INF
+    assert 60 < zeros < 240                                                  # about half of the instances sum to infinity
