@@ -111,6 +111,23 @@ def test_eip196_precompile_vectors_through_the_plugin(mx):
         parts.append(int.from_bytes(k, "big") - sum(parts))
         sc = b"".join(x.to_bytes(32, "big") for x in parts)
         assert mx.bn254_multi_exp(p * 1000, sc, 1000) == want
+    # ... and through the kernels the headline runs (k_bucket_sum30, the reduction tree: more than 32 768 pairs leave the
+    # single-launch path) and through the fixed-base commitment kernel, again with geth's expected bytes and no oracle in between
+    for e in kat["mul"][:6]:
+        p, k, want = bytes.fromhex(e["p"]), bytes.fromhex(e["k"]), bytes.fromhex(e["r"])
+        kv = int.from_bytes(k, "big")
+        n = 40000
+        parts = [kv // n + 3 * i for i in range(n - 1)]
+        parts.append(kv - sum(parts))                       # may be negative: taken mod the group order, as fr.SetBytes would see it
+        r = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+        sc = b"".join((x % r).to_bytes(32, "big") for x in parts)
+        assert mx.bn254_multi_exp(p * n, sc, n) == want
+        fb = mx.FixedBase("bn254", p, 1)
+        try:
+            assert fb.commit_host(k, 1, 1) == want
+            assert fb.commit_host(sc[:32 * 300], 300, 1)[:64] == mx.bn254_mult(p, sc[:32])
+        finally:
+            fb.close()
 
 
 @pytest.mark.parametrize("curve", ["bn254", "secp256k1"])
