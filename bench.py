@@ -77,6 +77,7 @@ KERNEL_SYMBOL = {  # profile slot -> substring of the kernel symbol in the rocpr
     "icc_fused": "k_icc_split30", "icc_stages_r4": "k_icc_stages", "icc_stages_r2": "k_icc_stages", "icc_load": "k_icc_load", "icc_finish": "k_icc_finish",
     "audit_accumulate": "k_audit_accumulate<8>",     # the large-challenge instantiation (8 row slices per block)
     "kzg_eval_rows": "k_kzg_eval_rows_lazy",
+    "mac_stage": "k_mac_stage30_quad", "icc_mix": "k_icc_mix30", "mac_mix": "k_mac_mix_quad",
 }
 
 
@@ -965,15 +966,18 @@ def main():
         mx.profile_enable(False)
         return ms, {k: round(t / max(c, 1), 4) for k, t, c in prof}, {k: round(t / 5, 4) for k, t, c in prof}
 
-    def hbm_roofline(per_launch, per_call, algo_bytes_per_call, note):
+    def hbm_roofline(per_launch, per_call, algo_bytes_per_call, note, workload=None):
         if not per_launch:
             return None
         dom = max(per_call, key=per_call.get)
+        traffic = pmc_traffic(dom, workload) if workload else None
         launches = max(1, round(per_call[dom] / per_launch[dom])) if per_launch[dom] else 1
         ach = algo_bytes_per_call / launches / (per_launch[dom] * 1e-3) / 1e9 if per_launch[dom] else None
         return {"bound": "hbm", "kernel": KERNEL_SYMBOL.get(dom, dom), "achieved": round(ach, 3) if ach else None, "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 6) if ach else None, "traffic": None,
-                "traffic_source": "no counter pass committed for this leg", "kernel_ms": per_launch[dom],
+                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 6) if ach else None, "traffic": traffic,
+                "traffic_source": ("committed rocprofv3 --pmc passes (profiles/pmc_latest_%s.json), per launch of the kernel, not "
+                                   "collected in this run" % workload) if traffic else "no counter pass committed for this leg",
+                "kernel_ms": per_launch[dom],
                 "launches_per_call": launches, "algorithmic_bytes_per_call": algo_bytes_per_call,
                 "all_kernels_ms_per_call": per_call, "note": note}
 
@@ -1024,7 +1028,7 @@ def main():
                                  "compute_commitment, not libsecp256k1) over %d threads; %.2f s wall" % (sample, cores, cpu_s)}
             rl = hbm_roofline(per_launch, per_call, COMMIT_BYTES_PER_ROW * rows_n,
                               "algorithmic bytes = 4 096 B of coefficients + 64 B out per row (generator table resident); the kernel "
-                              "is bound by the integer multiplier, as k_fb_commit of the KZG leg")
+                              "is bound by the integer multiplier, as k_fb_commit of the KZG leg", workload="ipa_commits")
             return {"metric": "IPA Pedersen commitments/s (128-coefficient rows against the 128 secp256k1 generators)",
                     "value": round(rows_n / ms * 1e3, 1), "unit": "commits/s", "ms_per_step": round(ms, 4), "scaling": "weak",
                     "dtype": "u32x9 (30-bit limbs, 256-bit modular integer)",
@@ -1073,7 +1077,8 @@ def main():
             out["curves"][curve] = {"value": round(bfly / ms / 1e3, 3), "ms_per_step": round(ms, 4),
                                     "roofline": hbm_roofline(per_launch, per_call, 128 * n,
                                                              "algorithmic bytes = 64 B in + 64 B out per MAC; the network is a chain of "
-                                                             "dependent group operations bound by the integer multiplier"),
+                                                             "dependent group operations bound by the integer multiplier",
+                                                             workload="mac_encode" if curve == "bn254" else None),
                                     "cpu_baseline": cpu, "bit_exact_vs_oracle": ok}
         out["value"] = out["curves"]["bn254"]["value"]
         out["ms_per_step"] = out["curves"]["bn254"]["ms_per_step"]
@@ -1144,7 +1149,8 @@ def main():
                                     "roofline": hbm_roofline({k: per_launch[k] for k in data_k} or per_launch, data_k or per_call,
                                                              256 * length * n_cols,
                                                              "the data kernel: 2 x 64 B in + 2 x 64 B out per butterfly; the call's wall time is "
-                                                             "set by the point butterflies beside it (a chain of dependent group operations)"),
+                                                             "set by the point butterflies beside it (a chain of dependent group operations)",
+                                                             workload="server_mix" if curve == "bn254" else None),
                                     "kernels_ms_per_call": per_call, "cpu_baseline": cpu, "bit_exact_vs_oracle": ok}
         for k in ("value", "ms_per_step", "roofline", "cpu_baseline"):
             out[k] = out["curves"]["bn254"][k]

@@ -2,7 +2,7 @@
 # copies the summaries of a tools/gpu_profile_all.sh run from gpurun_out/ (scratch) into profiles/ (tracked), and refreshes
 # profiles/pmc_latest*.json, which bench.py reads for roofline.traffic.   usage: tools/collect_profiles.sh <tag>
 TAG=${1:-r03_z}
-for w in bn254_msm kzg_commit secp256k1_msm icc audit_combine client_mac_batch; do
+for w in bn254_msm kzg_commit secp256k1_msm icc audit_combine client_mac_batch ipa_commits mac_encode server_mix; do
   d=gpurun_out/${TAG}_$w
   [ -d "$d" ] || continue
   cp $d/bench_n1.json profiles/${TAG}_bench_n1_$w.json
