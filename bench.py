@@ -65,11 +65,11 @@ ICC_BYTES_PER_ELEMENT = 64    # 32 B in + 32 B out
 # form of fe30.hip.h (profiles/r01_l_ubench_fe30.txt): BN254 180.7 G products/s and 213.6 G squares/s -> 186.5 for the 8M + 2S
 # mix of a mixed addition; secp256k1 (special-form fold) 194.2 and 226.2 -> 199.9
 FE_MUL_PEAK_FALLBACK = {"bn254": 186.5, "secp256k1": 199.9}
-WORKLOAD_FIELD = {"bn254_msm": "bn254", "kzg_commit": "bn254", "secp256k1_msm": "secp256k1", "config3": "bn254"}
+WORKLOAD_FIELD = {"bn254_msm": "bn254", "kzg_commit": "bn254", "secp256k1_msm": "secp256k1", "config3": "bn254", "strong_2p20": "bn254"}
 PMC_FILE = {"bn254_msm": "pmc_latest.json", "config3": "pmc_latest.json"}
 
 # legs of the default line that measure a BASELINE.json configuration (or the metric's second half): one of them throwing fails the run
-BASELINE_CONFIG_LEGS = ("kzg_commits", "secp256k1_msm", "icc", "config3")
+BASELINE_CONFIG_LEGS = ("kzg_commits", "secp256k1_msm", "icc", "config3", "strong_2p20")
 
 KERNEL_SYMBOL = {  # profile slot -> substring of the kernel symbol in the rocprofv3 output
     "bucket_sum": "k_bucket_sum30", "tree_levels": "k_tree_level", "tree_tail": "k_tree_tail", "partition_sort": "k_partition_sort",
@@ -79,6 +79,127 @@ KERNEL_SYMBOL = {  # profile slot -> substring of the kernel symbol in the rocpr
     "kzg_eval_rows": "k_kzg_eval_rows_lazy",
     "mac_stage": "k_mac_stage30_quad", "icc_mix": "k_icc_mix30", "mac_mix": "k_mac_mix_quad",
 }
+
+LINE_LIMIT = 6000             # bytes: the driver keeps an 8 KB tail of stdout; the LAST line must fit in it whole
+LEG_KEYS = ("kzg_commits", "secp256k1_msm", "icc", "config3", "strong_2p20", "audit_combine", "kzg_audit", "client_mac_batch",
+            "ipa_commits", "mac_encode", "server_mix")
+
+
+def _short(s, n=80):
+    return s if not isinstance(s, str) or len(s) <= n else s[:n - 1] + "~"
+
+
+def _compact_roofline(rl):
+    if not isinstance(rl, dict):
+        return None
+    out = {k: rl.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms")}
+    im = rl.get("int_multiplier")
+    if isinstance(im, dict):
+        out["int_multiplier"] = {"achieved": im.get("achieved"), "peak": im.get("peak"), "unit": "G fe_mul/s", "frac": im.get("frac")}
+    return out
+
+
+def _compact_cpu(cpu):
+    if not isinstance(cpu, dict):
+        return None
+    out = {k: cpu.get(k) for k in ("value", "unit", "cores", "kind")}
+    out["sample"] = _short(cpu.get("sample"))
+    return out
+
+
+def _traffic_ratio(rl):
+    """counter bytes per launch / algorithmic bytes per launch (achieved x kernel time), or None"""
+    try:
+        return round(rl["traffic"] / (rl["achieved"] * rl["kernel_ms"] * 1e6), 2)
+    except (TypeError, KeyError, ZeroDivisionError):
+        return None
+
+
+def _compact_leg(leg):
+    if not isinstance(leg, dict):
+        return leg
+    if "error" in leg:
+        return {"error": _short(leg["error"], 160), "bit_exact": None}
+    rl = leg.get("roofline") if isinstance(leg.get("roofline"), dict) else {}
+    cpu = leg.get("cpu_baseline") if isinstance(leg.get("cpu_baseline"), dict) else None
+    out = {"value": leg.get("value"), "unit": leg.get("unit"), "ms_per_step": leg.get("ms_per_step"), "frac": rl.get("frac"),
+           "int_frac": (rl.get("int_multiplier") or {}).get("frac"), "traffic_ratio": _traffic_ratio(rl),
+           "cpu": {"value": cpu.get("value"), "cores": cpu.get("cores"), "kind": cpu.get("kind")} if cpu else None,
+           "bit_exact": leg.get("bit_exact_vs_oracle")}
+    if leg.get("scaling") == "strong":
+        out["scaling"] = "strong"
+        cfg = leg.get("config") or {}
+        out["pairs_total"], out["pairs_per_gpu"] = cfg.get("pairs_total"), cfg.get("pairs_per_gpu")
+    return out
+
+
+def compact_line(full, legs_file=None):
+    """the ONE line the driver parses: the contract's keys for the headline workload + roofline + cpu_baseline, and per leg only
+    {value, unit, ms_per_step, frac, int_frac, traffic_ratio, cpu, bit_exact}.  Everything else (per-kernel breakdowns, notes,
+    sample descriptions, host-boundary and audit-size figures) is in `legs_file` (bench_legs.json) and on the earlier `LEG ...`
+    stdout lines.  json.dumps of the result is <= LINE_LIMIT bytes by construction (checked; the config strings are cut further
+    if a future key pushes it over)."""
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data")}
+    cfg = full.get("config") or {}
+    out["config"] = {k: (_short(v, 160) if isinstance(v, str) else v) for k, v in cfg.items()
+                     if isinstance(v, (str, int, float, bool)) or v is None}
+    out["roofline"] = _compact_roofline(full.get("roofline"))
+    out["cpu_baseline"] = _compact_cpu(full.get("cpu_baseline"))
+    out["bit_exact_vs_oracle"] = full.get("bit_exact_vs_oracle")
+    for k in ("blocking_ms_per_step", "blocking_Mmul_s", "preflight"):
+        if k in full:
+            out[k] = full[k]
+    hb = full.get("host_boundary")
+    if isinstance(hb, dict):
+        out["host_boundary"] = {k: hb.get(k) for k in ("ms", "Mmul_s", "same_result") if k in hb}
+    for k in LEG_KEYS:
+        if k in full:
+            out[k] = _compact_leg(full[k])
+    fp = full.get("fe_mul_peak")
+    if isinstance(fp, dict):
+        out["fe_mul_peak"] = {f: (v.get("mix_8M_2S") if isinstance(v, dict) else v) for f, v in fp.items()}
+    out["legs_failed"] = full.get("legs_failed", [])
+    if legs_file:
+        out["legs_file"] = legs_file
+    if len(json.dumps(out)) > LINE_LIMIT:
+        for k, v in out["config"].items():
+            out["config"][k] = _short(v, 60)
+        if out.get("cpu_baseline"):
+            out["cpu_baseline"]["sample"] = _short(out["cpu_baseline"]["sample"], 40)
+    if len(json.dumps(out)) > LINE_LIMIT:      # last resort: legs down to value + bit_exact
+        for k in LEG_KEYS:
+            if isinstance(out.get(k), dict):
+                out[k] = {kk: out[k].get(kk) for kk in ("value", "unit", "frac", "bit_exact", "error") if kk in out[k]}
+    return out
+
+
+def emit(full, legs_out, single_leg=False):
+    """write the full result to `legs_out`, print every leg's full object on a `LEG <name> {...}` line (not a JSON line: the
+    driver and the tests take the LAST line that starts with `{`), then the compact line as the last line of stdout"""
+    legs_file = None
+    if legs_out:
+        try:
+            with open(legs_out + ".tmp", "w") as f:
+                json.dump(full, f, indent=1)
+            os.replace(legs_out + ".tmp", legs_out)
+            legs_file = os.path.basename(legs_out)
+        except OSError as e:
+            print("warning: cannot write %s: %s" % (legs_out, e), file=sys.stderr)
+    if single_leg:
+        # `--workload X`: the leg IS the line; printed whole while it fits, compact otherwise
+        text = json.dumps(full)
+        if len(text) <= LINE_LIMIT:
+            print(text, flush=True)
+            return full
+    head = {k: v for k, v in full.items() if k not in LEG_KEYS}
+    print("LEG headline " + json.dumps(head))
+    for k in LEG_KEYS:
+        if k in full:
+            print("LEG %s %s" % (k, json.dumps(full[k])))
+    out = compact_line(full, legs_file)
+    print(json.dumps(out), flush=True)
+    return out
 
 
 def pmc_traffic(slot, workload):
@@ -130,27 +251,31 @@ def measure_fe_mul_peak():
 
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` started by hand (no WORLD_SIZE in the environment): start the N ranks as ONE child
-    `python -m torch.distributed.run` -- the same command line the driver uses -- BEFORE this process has touched the GPU
+    `python -m torch.distributed.run` (the driver's launcher; rendezvous `--standalone` on 127.0.0.1) BEFORE this process has touched the GPU
     (it never does: a child, never an exec), relay its output (rank 0 prints the one JSON line) and return its exit code.
     A rank that dies takes the group down through torchrun; a group that hangs is killed at PORLA_BENCH_LAUNCH_TIMEOUT_S."""
     import signal
-    import socket
-    import torch                                          # device_count() does not initialise the GPU on this image
     backend = os.environ.get("PORLA_DIST_BACKEND", "nccl")
-    have = torch.cuda.device_count()
-    if backend == "nccl" and have < n:
-        print("ERROR: --gpus %d but this node shows %d GPU(s): RCCL needs one device per rank.  (To rehearse the N-rank path with "
-              "ranks sharing a device, partials over gloo on the host: PORLA_DIST_BACKEND=gloo.)" % (n, have), file=sys.stderr)
-        return 2
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    if backend == "nccl":
+        # the device count comes from a short-lived CHILD (on some ROCm wheels counting devices initialises the HIP runtime;
+        # this process must stay clear of it whatever the wheel does)
+        try:
+            r = subprocess.run([sys.executable, "-c", "import torch as t; print(t.cuda.device_count())"], capture_output=True,
+                               text=True, timeout=300)
+            have = int(r.stdout.strip().splitlines()[-1])
+        except Exception:  # noqa: BLE001  (no count: the rank-side check below still refuses a rank without a device)
+            have = n
+        if have < n:
+            print("ERROR: --gpus %d but this node shows %d GPU(s): RCCL needs one device per rank.  (To rehearse the N-rank path "
+                  "with ranks sharing a device, partials over gloo on the host: PORLA_DIST_BACKEND=gloo.)" % (n, have), file=sys.stderr)
+            return 2
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_ADDR="127.0.0.1")
     # the ranks are host-light between launches; without this torchrun pins OMP_NUM_THREADS=1, which would starve the oracle's
     # range-split check on rank 0 (common.ncpu() still honours affinity and the cgroup quota)
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    # --standalone: torchrun's own c10d rendezvous on a port IT picks and binds (no pick-then-rebind race), on 127.0.0.1
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(n), os.path.abspath(__file__)] + argv
     limit = float(os.environ.get("PORLA_BENCH_LAUNCH_TIMEOUT_S", "3000"))
     p = subprocess.Popen(cmd, env=env, cwd=ROOT, start_new_session=True)   # own process group: killed as a group, by its pgid only
     try:
@@ -181,7 +306,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="bn254_msm",
                     choices=["bn254_msm", "kzg_commit", "secp256k1_msm", "icc", "config3", "crebuild", "audit_combine", "kzg_audit",
-                             "client_mac_batch", "ipa_commits", "mac_encode", "server_mix"])
+                             "client_mac_batch", "ipa_commits", "mac_encode", "server_mix", "strong_2p20"])
     ap.add_argument("--log2n", type=int, default=20, help="MSM pairs per GPU = 2^log2n (default: the 2^20 of BASELINE.json)")
     ap.add_argument("--log2rows", type=int, default=17, help="kzg_commit rows per GPU = 2^log2rows; icc rows = 2^(log2rows-2)")
     ap.add_argument("--log2job", type=int, default=24, help="config3: pairs of the whole job = 2^log2job, split over the ranks")
@@ -192,6 +317,9 @@ def main():
     ap.add_argument("--no-host-boundary", action="store_true", help="bn254_msm: skip the compute_multi_exp-on-host-buffers leg")
     ap.add_argument("--in-flight", type=int, default=2, help="bn254_msm: independent MSMs in flight (1 = blocking calls; 2 = the "
                     "audit's pair of MSMs, Server.hpp:900-901, overlapped on two streams)")
+    ap.add_argument("--legs-out", default=os.path.join(ROOT, "bench_legs.json"),
+                    help="where the FULL result (every leg's per-kernel breakdown, notes, samples) is written; the last stdout line is "
+                         "the compact headline object (<= %d bytes)" % LINE_LIMIT)
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -288,6 +416,34 @@ def main():
         if use_cxx_dist:
             return mx.dist_fold(curve, part)
         return sharded.fold_partials(curve, sharded.gather_partials(part, coll_dev))
+
+    def rank_preflight():
+        """BEFORE any timed region with N > 1: prove the gather + fold on the N real ranks.  Rank g contributes (g + 1) * G as its
+        96-byte Jacobian partial (host arithmetic of the library: mult_point on the generator), the fold -- the same call the timed
+        steps use -- must equal N (N + 1) / 2 * G on EVERY rank (the reference folds its 8 workers' partials the same way,
+        Client.hpp:783-787).  A rank whose fold differs names itself and the whole job exits non-zero."""
+        gen = (1).to_bytes(32, "big") + (2).to_bytes(32, "big")                      # BN254 G1 generator (1, 2)
+        mine = mx.bn254_mult(gen, mx.bn254_scalar_set_int(rank + 1))
+        want = mx.bn254_mult(gen, mx.bn254_scalar_set_int(world * (world + 1) // 2))
+        t0 = time.perf_counter()
+        got = fold_across_ranks("bn254", sharded.affine_to_partial(mine))
+        ms = (time.perf_counter() - t0) * 1e3
+        ok = got == want
+        if not ok:
+            print("ERROR: rank preflight: rank %d folded %s, expected %s (N (N + 1) / 2 * G, N = %d)"
+                  % (rank, got.hex()[:32], want.hex()[:32], world), file=sys.stderr, flush=True)
+        flags = [None] * world
+        dist.all_gather_object(flags, bool(ok))
+        bad = [g for g, f in enumerate(flags) if not f]
+        if bad:
+            if rank == 0:
+                print("ERROR: rank preflight failed on rank(s) %s: no timed region is entered" % bad, file=sys.stderr, flush=True)
+            dist.barrier()
+            sys.exit(4)
+        return {"ok": True, "ranks": world, "fold": "sum_g (g+1) G == N(N+1)/2 G on every rank", "first_fold_ms": round(ms, 3),
+                "collective": collective}
+
+    preflight = rank_preflight() if world > 1 else None
 
     stream = torch.cuda.current_stream().cuda_stream
     # legs (never the headline, which does exactly W warmup steps): warm up for at least this long -- see timed()
@@ -648,6 +804,39 @@ def main():
                     blocking_ms_per_step=round(blocking_ms, 4) if blocking_ms else None,
                     blocking_Mmul_s=round(world * n / blocking_ms / 1e3, 1) if blocking_ms else None,
                     blocking_kernels_ms=blocking_kern, host_boundary=host_boundary, audit_size_msm=audit)
+
+    # ---------------------------------------------------------------- strong scaling at the metric's own size (N > 1)
+    def leg_strong_2p20():
+        """ONE 2^20-pair BN254 MSM over all ranks: 2^20 / N pairs per rank (the reference's own pattern: one MSM range-split over 8
+        workers, Client.hpp:761-787), the same gather + fold, blocking calls: the honest test of north_star's '>= 6x at 8 GPUs'.
+        The per-rank fixed cost (conversion, sort, reduction tree, host fold) does not shrink with the range, so this is expected to
+        scale far below N: the line carries the number."""
+        total = 1 << args.log2n
+        lo, hi = mx.shard_range(total, rank, world)
+        n_local = hi - lo
+        sc, pt = common.cached_inputs(total)
+        d_sc, d_pt = to_dev(sc[32 * lo:32 * hi]), to_dev(pt[64 * lo:64 * hi])
+
+        def step():
+            if world == 1:
+                return mx.msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n_local, stream)
+            return fold_across_ranks("bn254", mx.msm_device("bn254", d_sc.data_ptr(), d_pt.data_ptr(), n_local, stream, partial=True))
+
+        el, kern, result = timed(step, min_warm_s=leg_warm_s)
+        fe_mults = msm_fe_mults(n_local)
+        verified = None
+        if rank == 0 and not args.no_cpu:
+            verified = common.oracle_msm(sc, pt, total, threads=common.ncpu()) == result
+        rl = roofline(kern, MSM_BYTES_PER_PAIR * n_local, "strong_2p20", fe_mults)
+        if rl:
+            rl["traffic"] = None                      # the committed counter pass is of a 2^20-pair launch, not of this range size
+            rl["traffic_source"] = "not collected at this range size"
+        return line("BN254 G1 MSM Mscalar-mul/s, ONE 2^%d-pair MSM over all GPUs" % args.log2n,
+                    round(total * args.steps / el / 1e6, 3), "Mmul/s", el, "strong", "u32x8 (256-bit modular integer)",
+                    {"workload": "ONE 2^%d-pair BN254 G1 MSM, pair range [g n / N, (g+1) n / N) on GPU g, blocking calls, partials "
+                                 "all-gathered and folded on every host" % args.log2n,
+                     "pairs_total": total, "pairs_per_gpu": n_local, "collective": collective},
+                    rl, None, verified, result=result.hex() if result else None)
 
     # ---------------------------------------------------------------- config 3: ONE 2^24-pair MSM over all ranks
     def leg_config3():
@@ -1158,7 +1347,7 @@ def main():
         return out
 
     # ---------------------------------------------------------------- the line
-    legs = {"bn254_msm": leg_bn254_msm, "kzg_commit": leg_kzg_commit, "secp256k1_msm": leg_secp256k1_msm, "icc": leg_icc,
+    legs = {"bn254_msm": leg_bn254_msm, "strong_2p20": leg_strong_2p20, "kzg_commit": leg_kzg_commit, "secp256k1_msm": leg_secp256k1_msm, "icc": leg_icc,
             "config3": leg_config3, "audit_combine": leg_audit_combine, "client_mac_batch": leg_client_mac_batch,
             "ipa_commits": leg_ipa_commits, "mac_encode": leg_mac_encode, "server_mix": leg_server_mix}
     out = legs[args.workload]()
@@ -1171,6 +1360,8 @@ def main():
         extra = []
         if not args.no_commits:
             extra.append(("kzg_commits", leg_kzg_commit))
+        if world > 1:
+            extra.append(("strong_2p20", leg_strong_2p20))
         if not args.no_legs:
             extra += [("secp256k1_msm", leg_secp256k1_msm), ("icc", leg_icc)]
             if world == 1:
@@ -1207,7 +1398,9 @@ def main():
         # a leg that threw is named on the line; one that measures a BASELINE.json configuration also fails the run (rc 3) -- a
         # missing configuration must not pass silently.  A result that differs from the oracle fails the run with rc 1.
         out["legs_failed"] = legs_failed
-        print(json.dumps(out))
+        if preflight:
+            out["preflight"] = preflight
+        emit(out, args.legs_out, single_leg=args.workload != "bn254_msm")
         if failed:
             print("ERROR: GPU result differs from the oracle", file=sys.stderr)
         if legs_failed:

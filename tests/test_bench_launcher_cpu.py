@@ -50,4 +50,79 @@ def test_the_launcher_runs_before_any_device_call():
     for needle in ("measure_fe_mul_peak() if", "torch.cuda.set_device", "from porla_amd import multiexp"):
         assert launch < body.index(needle), needle
     lr = src[src.index("def launch_ranks"):src.index("def main():")]
-    assert "subprocess.Popen" in lr and "os.exec" not in lr and "torch.cuda.is_available" not in lr
+    assert "subprocess.Popen" in lr and "os.exec" not in lr
+    # the launcher itself makes no torch.cuda call at all (the device count comes from a short-lived child) and picks no port
+    assert "torch.cuda." not in lr and "import torch\n" not in lr and "s.bind(" not in lr and "--standalone" in lr
+
+
+# ---- the ONE line the driver parses: compact, <= 6 000 bytes whatever the legs carry
+def _canned_full_result():
+    import json
+    path = os.path.join(common.ROOT, "profiles", "r04_z_bench_default_line.json")     # round 4's 23 KB line: the one the driver could not parse
+    return json.loads([l for l in open(path).read().splitlines() if l.startswith("{")][-1])
+
+
+def test_compact_line_fits_the_drivers_tail_and_keeps_the_contract():
+    import json
+    sys.path.insert(0, common.ROOT)
+    import bench
+    full = _canned_full_result()
+    assert len(json.dumps(full)) > 20000
+    c = bench.compact_line(full, "bench_legs.json")
+    text = json.dumps(c)
+    assert len(text) < 6000 and bench.LINE_LIMIT == 6000
+    d = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "bit_exact_vs_oracle", "blocking_ms_per_step", "legs_failed"):
+        assert k in d, k
+    assert d["value"] == full["value"] and d["ms_per_step"] == full["ms_per_step"]
+    rl = d["roofline"]
+    assert rl["bound"] == "hbm" and rl["kernel"] == "k_bucket_sum30" and rl["frac"] == full["roofline"]["frac"]
+    assert rl["peak"] == 8000.0 and rl["unit"] == "GB/s" and rl["traffic"] == full["roofline"]["traffic"]
+    assert rl["int_multiplier"]["frac"] == full["roofline"]["int_multiplier"]["frac"]
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 16 and cb["value"] == full["cpu_baseline"]["value"] and len(cb["sample"]) <= 80
+    assert d["config"]["workload"].startswith("KZG scheme, single 2^20-point")
+    for leg in ("kzg_commits", "secp256k1_msm", "icc", "config3", "ipa_commits", "mac_encode", "server_mix"):
+        assert set(d[leg]) >= {"value", "unit", "ms_per_step", "frac", "int_frac", "traffic_ratio", "cpu", "bit_exact"}, leg
+        assert d[leg]["value"] == full[leg]["value"] and d[leg]["bit_exact"] is full[leg]["bit_exact_vs_oracle"]
+    assert d["config3"]["scaling"] == "strong" and d["config3"]["pairs_total"] == 1 << 24
+    # counter traffic of the headline kernel / its algorithmic bytes: 96 B x 2^20 per launch
+    assert abs(d["icc"]["traffic_ratio"] - 5.1) < 0.2 and abs(d["kzg_commits"]["traffic_ratio"] - 56) < 2
+
+
+def test_compact_line_survives_oversized_and_failed_legs():
+    import json
+    sys.path.insert(0, common.ROOT)
+    import bench
+    full = _canned_full_result()
+    full["config"]["workload"] = "x" * 5000
+    full["cpu_baseline"]["sample"] = "y" * 9000
+    full["icc"] = {"error": "RuntimeError(" + "z" * 4000 + ")", "bit_exact_vs_oracle": None}
+    full["legs_failed"] = ["icc"]
+    full["preflight"] = {"ok": True, "ranks": 8, "fold": "sum", "first_fold_ms": 1.0, "collective": "ncclAllGather from C++"}
+    full["strong_2p20"] = dict(full["config3"], config={"pairs_total": 1 << 20, "pairs_per_gpu": 1 << 17})
+    c = bench.compact_line(full, None)
+    text = json.dumps(c)
+    assert len(text) < 6000
+    assert c["legs_failed"] == ["icc"] and "RuntimeError" in c["icc"]["error"] and c["preflight"]["ranks"] == 8
+    assert c["strong_2p20"]["pairs_per_gpu"] == 1 << 17 and c["strong_2p20"]["scaling"] == "strong"
+
+
+def test_emit_prints_the_compact_line_last_and_writes_the_legs_file(tmp_path, capsys):
+    import json
+    sys.path.insert(0, common.ROOT)
+    import bench
+    full = _canned_full_result()
+    legs = str(tmp_path / "bench_legs.json")
+    bench.emit(full, legs)
+    out = capsys.readouterr().out.rstrip().splitlines()
+    json_lines = [l for l in out if l.startswith("{")]
+    assert len(json_lines) == 1 and out[-1] == json_lines[0] and len(out[-1]) < 6000
+    assert json.loads(out[-1])["legs_file"] == "bench_legs.json"
+    assert any(l.startswith("LEG mac_encode {") for l in out)
+    assert json.load(open(legs)) == full            # nothing is lost: the full result is beside bench.py
+    # a single-leg workload's line is the leg itself while it fits
+    bench.emit(full["icc"], str(tmp_path / "icc.json"), single_leg=True)
+    out = capsys.readouterr().out.rstrip().splitlines()
+    assert len(out) == 1 and json.loads(out[0]) == full["icc"]
