@@ -474,6 +474,88 @@ __device__ __forceinline__ void xyzz30_dbl_quad(const XYZZ<M>* p, XYZZ<M>* out, 
     else if (r == 3u) xyzz30_store_coord<M>(out, 3, M3, false);
 }
 
+// ---------------------------------------------------------------- the same two operations with the point IN REGISTERS
+// A scalar-multiplication ladder (mac_fft.hip.h) is ~200 dependent group operations on ONE accumulator: through memory every
+// operation paid a pack + store + barrier + load + unpack of the accumulator (and, for one wave per SIMD, the exposed LDS round
+// trip).  Here the accumulator stays distributed over the quad's registers between operations -- lane r holds coordinate r
+// (0 = X, 1 = Y, 2 = ZZ, 3 = ZZZ) as an F30 -- and only the OTHER operand (a table entry) comes from memory, one coordinate per
+// lane.  Same formulas, same bounds: X <= 5p, Y <= 4p, ZZ / ZZZ product results; nothing is reduced between operations
+// (8p < 2^258 for BN254, < 2^259 for secp256k1: tools/check_fe30_bounds.py).  Infinity is the caller's flag, not a value.
+//
+// c = 2 c.  Called by all four lanes of a quad whose accumulator is not infinity.  The lane roles are those of xyzz30_dbl_quad,
+// with Y3 formed on lane 1 (it holds T2 and receives T1), so the result lands where the next operation expects it: no permute.
+template <class M>
+__device__ __forceinline__ void xyzz30_dbl_quadreg(F30<M>& c, uint32_t r) {
+    const F30<M> U = f30_small_mul<M, 2>(c);                               // lane 1: 2Y
+    const F30<M> O1 = f30_sel<M>(r == 1u, U, c);
+    const F30<M> M1 = f30_mul<M>(O1, O1);                                  // XX, V, -, -
+    const F30<M> bV = f30_quad<M, 0x55>(M1);
+    const F30<M> bXX = f30_quad<M, 0x00>(M1);
+    const F30<M> Mm = f30_small_mul<M, 3>(bXX);                            // 3 X^2 (lanes 0 and 3 use it)
+    const F30<M> M2 = f30_mul<M>(r == 3u ? Mm : O1, r == 3u ? Mm : bV);    // S, W, ZZ3, MM
+    const F30<M> bW = f30_quad<M, 0x55>(M2);
+    const F30<M> bMM = f30_quad<M, 0xFF>(M2);
+    const F30<M> S2 = f30_small_mul<M, 2>(M2);                             // lane 0: 2S
+    const F30<M> X3 = f30_sub<M, 3>(bMM, S2);                              // lane 0
+    const F30<M> D = f30_sub<M, 5>(M2, X3);                                // lane 0: S - X3
+    const F30<M> M3 = f30_mul<M>(r == 0u ? Mm : bW, r == 0u ? D : c);      // T1, T2 = W Y, (W ZZ), ZZZ3 = W ZZZ
+    const F30<M> bT1 = f30_quad<M, 0x00>(M3);
+    const F30<M> Y3 = f30_sub<M, 2>(bT1, M3);                              // lane 1: T1 - T2
+    c = r == 0u ? X3 : (r == 1u ? Y3 : (r == 2u ? M2 : M3));
+}
+// c = c + (neg ? -1 : 1) * q, q a memory-form point (neither operand infinity -- the caller's flags); `qx`: where q's X is read
+// from (the table of X scaled by beta for the endomorphism's half, else q itself).  Lane roles (a, b, c, d of xyzz30_add_quad's
+// table) sit on lanes 1, 2, 3, 0, so that X3, Y3, ZZ3, ZZZ3 come out on lanes 0, 1, 2, 3: ONE permute of the accumulator on the
+// way in (lane 0 <- ZZZ1, lane 1 <- X1, lane 3 <- Y1), none on the way out; each lane loads one coordinate of q:
+//   lane          1 (a)          2 (b)            3 (c)             0 (d)
+//   operands  X1, ZZ2        X2, ZZ1          Y1, ZZZ2          Y2, ZZZ1
+//   round 1   U1             U2               S1                S2
+//   round 2   PP = P^2       ZZ1 ZZ2          ZZZ1 ZZZ2         RR = R^2
+//   round 3   PPP            ZZ3              -                 Q = U1 PP
+//   round 4   T2 = S1 PPP    -                ZZZ3              T1 = R (Q - X3)
+//   result    Y3 = T1 - T2   ZZ3              ZZZ3              X3
+// Returns false -- c untouched -- when the quad met equal x (p = +-q): the caller takes its general path.
+template <class M>
+__device__ __forceinline__ bool xyzz30_add_quadreg(F30<M>& c, const XYZZ<M>* q, const uint32_t* qx, bool neg, uint32_t r, uint32_t lane) {
+    bool z;
+    // lane 1: ZZ2, lane 2: X2, lane 3: ZZZ2, lane 0: Y2
+    const int coord = r == 1u ? 2 : (r == 2u ? 0 : (r == 3u ? 3 : 1));
+    const uint32_t* src = r == 2u ? qx : reinterpret_cast<const uint32_t*>(q) + 8 * coord;
+    F30<M> L;
+    {
+        const uint4* s4 = reinterpret_cast<const uint4*>(src);
+        const uint4 a = s4[0], b = s4[1];
+        const uint32_t t[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        L = f30_unpack<M>(t);
+    }
+    (void)z;
+    if (neg) L = f30_sel<M>(r == 0u, f30_sub<M, 4>(F30<M>{}, L), L);    // lane 0: 4p - Y2
+    const F30<M> t = f30_quad<M, 0x63>(c);                                // quad_perm [3, 0, 2, 1]: lane 0 <- ZZZ1, 1 <- X1, 2 <- ZZ1, 3 <- Y1
+    const bool first = (r & 1u) != 0u;                                    // lanes 1 and 3 hold the accumulator's coordinate as FIRST factor
+    const F30<M> A = f30_sel<M>(first, t, L);                             // X1, X2, Y1, Y2       (lanes 1, 2, 3, 0)
+    const F30<M> B = f30_sel<M>(first, L, t);                             // ZZ2, ZZ1, ZZZ2, ZZZ1
+    const F30<M> M1 = f30_mul<M>(A, B);                                   // U1, U2, S1, S2
+    const bool edge = (r == 1u) || (r == 0u);                             // roles a and d
+    const F30<M> rcv = f30_quad<M, 0x1B>(f30_sel<M>(edge, B, M1));        // quad_perm [3, 2, 1, 0]: a <-> b (lanes 1, 2), c <-> d (lanes 3, 0)
+    const F30<M> D = f30_sub<M, 2>(f30_sel<M>(r == 1u, rcv, M1), f30_sel<M>(r == 1u, M1, rcv));   // lane 1: P = U2 - U1, lane 0: R = S2 - S1
+    const F30<M> M2 = f30_mul<M>(f30_sel<M>(edge, D, B), f30_sel<M>(edge, D, rcv));               // PP, ZZ1 ZZ2, ZZZ1 ZZZ2, RR
+    const bool same_x = r == 1u && f30_product_is_zero<M>(M2);
+    if ((__ballot(same_x) >> (lane & 60u)) & 0xfull) return false;
+    const F30<M> bPP = f30_quad<M, 0x55>(M2);
+    const F30<M> bU1 = f30_quad<M, 0x55>(M1);
+    const F30<M> M3 = f30_mul<M>(r == 1u ? D : (r == 0u ? bU1 : M2), r == 1u ? M2 : bPP);         // PPP, ZZ3, -, Q
+    const F30<M> bPPP = f30_quad<M, 0x55>(M3);
+    const F30<M> bS1 = f30_quad<M, 0xFF>(M1);
+    const F30<M> E = f30_add2<M>(bPPP, M3);              // lane 0: PPP + 2Q
+    const F30<M> X3 = f30_sub<M, 4>(M2, E);              // lane 0: RR - E
+    const F30<M> Dq = f30_sub<M, 6>(M3, X3);             // lane 0: Q - X3
+    const F30<M> M4 = f30_mul<M>(r == 1u ? bS1 : (r == 0u ? D : M2), r == 0u ? Dq : bPPP);        // T2, -, ZZZ3, T1
+    const F30<M> bT1 = f30_quad<M, 0x00>(M4);
+    const F30<M> Y3 = f30_sub<M, 2>(bT1, M4);            // lane 1: T1 - T2
+    c = r == 0u ? X3 : (r == 1u ? Y3 : (r == 2u ? M3 : M4));
+    return true;
+}
+
 // the accumulator as an ec.hip.h XYZZ in the 2^256 Montgomery form (canonical residues); infinity = all zero
 template <class M>
 __device__ __forceinline__ XYZZ<M> xyzz30_to_xyzz(const XYZZ30<M>& p) {

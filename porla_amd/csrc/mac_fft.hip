@@ -72,39 +72,6 @@ static int ensure_mac_twiddles(MacWs* ws, int curve, size_t n, hipStream_t strea
     return PORLA_OK;
 }
 
-template <class C, class Q>
-static int mac_mix_core(MacWs* ws, int curve, const uint8_t* d_a0, const uint8_t* d_a1, size_t len, size_t n_total, uint8_t* d_out,
-                        hipStream_t stream, const uint8_t* d_b0 = nullptr, const uint8_t* d_b1 = nullptr, uint8_t* d_out_b = nullptr) {
-    int rc;
-    if ((rc = ensure_mac_twiddles<Q>(ws, curve, n_total, stream))) return rc;
-    ProfScope ps("mac_mix", stream);
-    static const bool quad = !(getenv("PORLA_MAC_QUAD") && getenv("PORLA_MAC_QUAD")[0] == '0');
-    const unsigned sets = d_b0 ? 2u : 1u;               // the second array pair (MAC alignments beside the MAC commitments)
-    if constexpr (C::F30_LAZY) {
-        static const int quad_max_log = getenv("PORLA_MAC_MIX_QUAD_MAX") ? atoi(getenv("PORLA_MAC_MIX_QUAD_MAX")) : 14;
-        if (quad && len * sets <= ((size_t)1 << quad_max_log)) {   // latency bound: four lanes per element (k_mac_stage30_quad's ladder)
-            hipLaunchKernelGGL((k_mac_mix_quad<C>), dim3((unsigned)((len + MACQ_BF - 1) / MACQ_BF), sets), dim3(4 * MACQ_BF), 0, stream, d_a0,
-                               d_a1, (uint32_t)len, (const uint32_t*)ws->tws.p, (uint32_t)(n_total / len), d_out, d_b0, d_b1, d_out_b);
-            PORLA_HIP(hipGetLastError());
-            return PORLA_OK;
-        }
-        if (quad && sets == 2 && len <= ((size_t)1 << quad_max_log)) {
-            // two arrays of a length the four-lane kernel still takes one at a time (2^14 rows: 0.63 ms each; both in one launch of
-            // the one-lane kernel: 1.36 ms): two launches, one after the other
-            hipLaunchKernelGGL((k_mac_mix_quad<C>), dim3((unsigned)((len + MACQ_BF - 1) / MACQ_BF), 1), dim3(4 * MACQ_BF), 0, stream, d_a0, d_a1,
-                               (uint32_t)len, (const uint32_t*)ws->tws.p, (uint32_t)(n_total / len), d_out, d_b0, d_b1, d_out_b);
-            hipLaunchKernelGGL((k_mac_mix_quad<C>), dim3((unsigned)((len + MACQ_BF - 1) / MACQ_BF), 1), dim3(4 * MACQ_BF), 0, stream, d_b0, d_b1,
-                               (uint32_t)len, (const uint32_t*)ws->tws.p, (uint32_t)(n_total / len), d_out_b, d_b0, d_b1, d_out_b);
-            PORLA_HIP(hipGetLastError());
-            return PORLA_OK;
-        }
-    }
-    hipLaunchKernelGGL((k_mac_mix<C>), dim3((unsigned)((len + 63) / 64), sets), dim3(64), 0, stream, d_a0, d_a1, (uint32_t)len,
-                       (const uint32_t*)ws->tws.p, (uint32_t)(n_total / len), d_out, d_b0, d_b1, d_out_b);
-    PORLA_HIP(hipGetLastError());
-    return PORLA_OK;
-}
-
 // dynamic LDS of the quad-lane stage / load kernels (mac_fft.hip.h:MACQ_LDS); above 64 KiB a kernel must be told once per device
 template <class C>
 static size_t macq_lds_bytes() {
@@ -121,9 +88,43 @@ static size_t macq_lds_bytes() {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mac_stage30_quad<C>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mac_load30_quad<C, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mac_load30_quad<C, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mac_mix_quad<C>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         done.push_back(dev);
     }
     return sizeof(MacQuadLds<M>);
+}
+
+template <class C, class Q>
+static int mac_mix_core(MacWs* ws, int curve, const uint8_t* d_a0, const uint8_t* d_a1, size_t len, size_t n_total, uint8_t* d_out,
+                        hipStream_t stream, const uint8_t* d_b0 = nullptr, const uint8_t* d_b1 = nullptr, uint8_t* d_out_b = nullptr) {
+    int rc;
+    if ((rc = ensure_mac_twiddles<Q>(ws, curve, n_total, stream))) return rc;
+    ProfScope ps("mac_mix", stream);
+    static const bool quad = !(getenv("PORLA_MAC_QUAD") && getenv("PORLA_MAC_QUAD")[0] == '0');
+    const unsigned sets = d_b0 ? 2u : 1u;               // the second array pair (MAC alignments beside the MAC commitments)
+    if constexpr (C::F30_LAZY) {
+        static const int quad_max_log = getenv("PORLA_MAC_MIX_QUAD_MAX") ? atoi(getenv("PORLA_MAC_MIX_QUAD_MAX")) : 14;
+        if (quad && len * sets <= ((size_t)1 << quad_max_log)) {   // latency bound: four lanes per element (k_mac_stage30_quad's ladder)
+            hipLaunchKernelGGL((k_mac_mix_quad<C>), dim3((unsigned)((len + MACQ_BF - 1) / MACQ_BF), sets), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream, d_a0,
+                               d_a1, (uint32_t)len, (const uint32_t*)ws->tws.p, (uint32_t)(n_total / len), d_out, d_b0, d_b1, d_out_b);
+            PORLA_HIP(hipGetLastError());
+            return PORLA_OK;
+        }
+        if (quad && sets == 2 && len <= ((size_t)1 << quad_max_log)) {
+            // two arrays of a length the four-lane kernel still takes one at a time (2^14 rows: 0.63 ms each; both in one launch of
+            // the one-lane kernel: 1.36 ms): two launches, one after the other
+            hipLaunchKernelGGL((k_mac_mix_quad<C>), dim3((unsigned)((len + MACQ_BF - 1) / MACQ_BF), 1), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream, d_a0, d_a1,
+                               (uint32_t)len, (const uint32_t*)ws->tws.p, (uint32_t)(n_total / len), d_out, d_b0, d_b1, d_out_b);
+            hipLaunchKernelGGL((k_mac_mix_quad<C>), dim3((unsigned)((len + MACQ_BF - 1) / MACQ_BF), 1), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream, d_b0, d_b1,
+                               (uint32_t)len, (const uint32_t*)ws->tws.p, (uint32_t)(n_total / len), d_out_b, d_b0, d_b1, d_out_b);
+            PORLA_HIP(hipGetLastError());
+            return PORLA_OK;
+        }
+    }
+    hipLaunchKernelGGL((k_mac_mix<C>), dim3((unsigned)((len + 63) / 64), sets), dim3(64), 0, stream, d_a0, d_a1, (uint32_t)len,
+                       (const uint32_t*)ws->tws.p, (uint32_t)(n_total / len), d_out, d_b0, d_b1, d_out_b);
+    PORLA_HIP(hipGetLastError());
+    return PORLA_OK;
 }
 
 // d_out_y != nullptr (with part == 0): BOTH parts from one butterfly network.  The network is linear over Z_q and the Y part is

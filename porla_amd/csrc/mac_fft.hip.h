@@ -252,11 +252,17 @@ k_mac_stage30(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restric
 // ---------------------------------------------------------------- the butterfly stage with FOUR LANES per butterfly
 // Below N = 2^16 rows a stage is one lone wave per SIMD walking a ladder of ~200 dependent group operations: its time is the
 // latency of those operations (1.08 ms with one lane per butterfly).  Here every group operation runs on the four lanes of a
-// quad (ec30.hip.h: xyzz30_add_quad 3.6 us instead of 7, xyzz30_dbl_quad 3 rounds of products instead of 9 in sequence); the
-// ladder is the same (endomorphism split, 33 signed 4-bit windows, one table of multiples, phi(P)'s entries by scaling X with
-// beta), its state -- table, accumulator, the operand being added -- lives in LDS, and the control flow is the same for every
-// butterfly of the block (a zero digit computes its addition and does not store it), so block barriers order the LDS traffic.
-constexpr int MACQ_BF = 64;                       // butterflies per block: 256 lanes = one wave on each SIMD of a compute unit; 11 slots of 128 B each = 88 KiB of LDS
+// quad (ec30.hip.h: 4 rounds of products per addition, 3 per doubling, instead of 14 / 9 in sequence).  The ladder is the same
+// (endomorphism split, 33 signed 4-bit windows, one table of multiples 1 .. 8 of P).
+// Round 5: the ACCUMULATOR LIVES IN REGISTERS (lane r of the quad holds coordinate r: xyzz30_dbl_quadreg / xyzz30_add_quadreg);
+// LDS holds only what is read at random: the table of multiples (memory form) and, beside it, the table's X coordinates times
+// beta -- the endomorphism's half reads its X there, so phi(d P) costs no product per addition (8 products once instead of one
+// per window) -- and the sign of a digit is a subtraction on the one lane that loads Y.  Through LDS (round 4) every one of the
+// ~200 operations packed, stored, fenced, re-loaded and unpacked the accumulator, and every addition staged its operand
+// through a second slot (one more product round + one more round trip): 0.52 ms per stage of 2^14 butterflies; now see DESIGN.md.
+// Quads follow their own control flow (a zero digit skips its addition, an accumulator at infinity its doublings): the lanes of
+// a quad always branch together, which is all the quad permutes need.
+constexpr int MACQ_BF = 64;                       // butterflies per block: 256 lanes = one wave on each SIMD of a compute unit
 
 // signed 4-bit digit i (0 .. 32) of the 128-bit magnitude m: ((m >> 4i) & 15) + carry, minus 16 above 8.  The carry into
 // window i is 1 exactly when the bits below it exceed 0x88..8 (the recoding with digits in (-8, 8] is unique: msm_small.hip.h).
@@ -283,17 +289,24 @@ __device__ __forceinline__ int mac_signed_digit(const uint32_t m[4], int i) {
 // The quad-lane kernels run one wave per SIMD (LDS: one block per compute unit), so the compiler would happily spend 212 registers
 // on them -- and then they fit beside nothing: next to the commitments of the same CRebuild (two 192-register waves per SIMD in the
 // guest-room form of k_fb_commit) 128 registers are free.  Held to 128 they start at once there (the arithmetic is one field
-// product per lane at a time: no spills).
+// product per lane at a time).
 #define MACQ_GUEST_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
 // ... and their LDS state is DYNAMIC shared memory (sizeof(MacQuadLds<M>) at the launch, mac_fft.hip:macq_lds_bytes): with the
-// 88 KiB declared statically the compiler knows that one block fits a compute unit, concludes "occupancy 1" and gives the kernel
-// descriptor 264 registers whatever the code uses (.amdhsa_next_free_vgpr 257 for 125 used) -- the guest would not fit again
+// state declared statically the compiler knows that one block fits a compute unit, concludes "occupancy 1" and gives the kernel
+// descriptor 264 registers whatever the code uses -- the guest would not fit again
 #define MACQ_LDS(L) extern __shared__ __align__(16) unsigned char macq_lds_raw[]; \
     MacQuadLds<M>& L = *reinterpret_cast<MacQuadLds<M>*>(macq_lds_raw)
-// LDS state of a block of MACQ_BF quads: table of multiples, accumulator, the operand being added, the butterfly's upper input
+// LDS state of a block of MACQ_BF quads.  Per quad: the table of multiples, the table's X coordinates times beta, 32 bytes of
+// padding (consecutive quads start 32 bytes further round the banks: the 16 quads of a wave read different banks when their
+// digits agree); per block: two slots for the rare general addition and the butterfly's upper input.
 template <class M>
 struct MacQuadLds {
-    XYZZ<M> tbl[MACQ_BF][8];
+    struct Quad {
+        XYZZ<M> tbl[8];
+        uint32_t bx[8][8];
+        uint32_t pad[8];
+    };
+    Quad qd[MACQ_BF];
     XYZZ<M> acc[MACQ_BF], tmp[MACQ_BF], um[MACQ_BF];
 };
 // every lane of a quad moves "its" coordinate (32 bytes) of a point
@@ -304,60 +317,146 @@ __device__ __forceinline__ void macq_copy_coord(XYZZ<M>* dst, const XYZZ<M>* src
     const uint4 v0 = a[0], v1 = a[1];
     d[0] = v0; d[1] = v1;
 }
-// *dst = (neg ? -1 : 1) * (phi ? (beta X, Y, ZZ, ZZZ) : (X, Y, ZZ, ZZZ)) of *src; infinity stays infinity (ZZ = ZZZ = 0)
-template <class M>
-__device__ __forceinline__ void macq_prepare(XYZZ<M>* dst, const XYZZ<M>* src, bool neg, bool phi, const F30<M>& beta30, uint32_t r,
-                                             uint32_t lane) {
-    bool z;
-    F30<M> v = xyzz30_load_coord<M>(src, (int)r, &z);
-    const uint32_t qz = (uint32_t)(__ballot(z && r == 2u) >> (lane & 60u)) & 0xfu;
-    if (qz) { macq_copy_coord<M>(dst, src, r); return; }
-    if (r == 0u && phi) v = f30_mul<M>(v, beta30);
-    if (r == 1u && neg) v = f30_sub<M, 4>(F30<M>{}, v);
-    xyzz30_store_coord<M>(dst, (int)r, v, false);
-}
-// L.acc[q] = sc * L.tbl[q][0]  (all lanes of the block; L.tbl[q][0] written and a barrier passed; ends behind a barrier)
 // A quad's LDS state is private to its four lanes, which sit in one wave: LDS operations of a wave complete in order, so between a
 // lane's store and another lane's load only the compiler has to be held back -- no s_barrier across the block's waves
-// (PORLA_MACQ_BLOCK_SYNC at build time brings the block-wide barrier back)
 __device__ __forceinline__ void macq_sync() {
-#ifdef PORLA_MACQ_BLOCK_SYNC
-    __syncthreads();
-#else
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-#endif
 }
+// one residue in the memory form (BN254: packed as it is; secp256k1: canonical) at d
+template <class M>
+__device__ __forceinline__ void macq_store_residue(uint32_t* d, const F30<M>& v) {
+    Fe<M> t;
+    if constexpr (M::PSEUDO_MERSENNE) t = f30_to_fe_canonical<M>(f30_pm_reduce<M>(v));
+    else f30_pack<M>(t.v, v);
+    store_words8(d, t.v);
+}
+template <class M>
+__device__ __forceinline__ F30<M> macq_load_residue(const uint32_t* s, bool* all_zero) {
+    const uint4* q = reinterpret_cast<const uint4*>(s);
+    const uint4 a = q[0], b = q[1];
+    const uint32_t t[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    *all_zero = (a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) == 0;
+    return f30_unpack<M>(t);
+}
+// does any lane of this lane's quad say so?
+__device__ __forceinline__ bool macq_quad_any(bool v, uint32_t lane) { return ((__ballot(v) >> (lane & 60u)) & 0xfull) != 0; }
+
+// (c, inf) += (neg ? -1 : 1) * e, where e is a finite memory-form point whose X is read at `ex` (e's own, or the beta table's):
+// the register-form addition, an accumulator at infinity (the result is the operand), and -- rare: equal x, i.e. the accumulator
+// is +-e -- the ordinary one-lane addition through the two LDS slots.  All four lanes of a quad call it together.
+template <class M>
+__device__ __forceinline__ void macq_add(F30<M>& c, bool& inf, const XYZZ<M>* e, const uint32_t* ex, bool neg, XYZZ<M>* slot_a,
+                                         XYZZ<M>* slot_b, uint32_t r, uint32_t lane) {
+    if (!inf) {
+        if (xyzz30_add_quadreg<M>(c, e, ex, neg, r, lane)) return;
+        macq_store_residue<M>(reinterpret_cast<uint32_t*>(slot_a) + 8 * r, c);
+    }
+    // the operand as a point of its own: X from ex, the sign applied to Y
+    bool z;
+    F30<M> v = macq_load_residue<M>(r == 0u ? ex : reinterpret_cast<const uint32_t*>(e) + 8 * r, &z);
+    if (neg && r == 1u) v = f30_sub<M, 4>(F30<M>{}, v);
+    if (inf) { c = v; inf = false; return; }
+    macq_store_residue<M>(reinterpret_cast<uint32_t*>(slot_b) + 8 * r, v);
+    macq_sync();
+    if (r == 0u) xyzz30_add_one_lane<M>(slot_a, slot_b, slot_a, false);
+    macq_sync();
+    c = macq_load_residue<M>(reinterpret_cast<const uint32_t*>(slot_a) + 8 * r, &z);
+    inf = macq_quad_any(z && r == 2u, lane);
+}
+
+// (c, inf) = sc * P on the four lanes of quad q; P = L.qd[q].tbl[0] (memory form, written by this quad's lanes, macq_sync or a
+// block barrier passed).  Lane r ends with coordinate r of the product; `inf` is the same on the four lanes.
 template <class C>
-__device__ __forceinline__ void macq_ladder(MacQuadLds<typename C::Fp>& L, uint32_t q, uint32_t r, uint32_t lane, const uint32_t sc[8]) {
+__device__ __forceinline__ void macq_ladder(MacQuadLds<typename C::Fp>& L, uint32_t q, uint32_t r, uint32_t lane, const uint32_t sc[8],
+                                            F30<typename C::Fp>& c, bool& inf) {
     using M = typename C::Fp;
     using G = typename C::Glv;
-    uint32_t m[2][4];
-    bool ng[2];
-    glv_split<G>(sc, m[0], ng[0], m[1], ng[1]);
-    const F30<M> beta30 = f30_const<M>(G::BETA_30);
+    typename MacQuadLds<M>::Quad& Q = L.qd[q];
+    inf = true;
+    bool z;
+    c = macq_load_residue<M>(reinterpret_cast<const uint32_t*>(&Q.tbl[0]) + 8 * r, &z);
+    if (macq_quad_any(z && r == 2u, lane)) return;                         // P is infinity: so is every multiple
+    uint32_t m0[4], m1[4];
+    bool ng0, ng1;
+    glv_split<G>(sc, m0, ng0, m1, ng1);
+    // tbl[i] = (i + 1) P: one doubling, six additions of P
+    bool tinf = false;
+    xyzz30_dbl_quadreg<M>(c, r);
+    macq_store_residue<M>(reinterpret_cast<uint32_t*>(&Q.tbl[1]) + 8 * r, c);
+#pragma unroll 1
+    for (int i = 2; i < 8; i++) {
+        macq_add<M>(c, tinf, &Q.tbl[0], reinterpret_cast<const uint32_t*>(&Q.tbl[0]), false, &L.acc[q], &L.tmp[q], r, lane);
+        macq_store_residue<M>(reinterpret_cast<uint32_t*>(&Q.tbl[i]) + 8 * r, c);
+    }
+    macq_sync();
+    // beta * X of the eight entries: two per lane
     {
-        uint4* d = reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(&L.acc[q]) + 8 * r);
-        d[0] = make_uint4(0, 0, 0, 0); d[1] = d[0];                        // infinity
+        const F30<M> beta30 = f30_const<M>(G::BETA_30);
+#pragma unroll 1
+        for (int t = 0; t < 2; t++) {
+            const uint32_t e = r + 4u * (uint32_t)t;
+            const F30<M> x = macq_load_residue<M>(reinterpret_cast<const uint32_t*>(&Q.tbl[e]), &z);
+            macq_store_residue<M>(&Q.bx[e][0], f30_mul<M>(x, beta30));
+        }
     }
-    for (int i = 1; i < 8; i++) {                                          // tbl[i] = (i + 1) P
-        xyzz30_add_quad<M>(&L.tbl[q][i - 1], &L.tbl[q][0], &L.tbl[q][i], false, true, lane);
-        macq_sync();
-    }
+    macq_sync();
+#pragma unroll 1
     for (int i = 32; i >= 0; i--) {
-        for (int d = 0; d < 4; d++) {
-            xyzz30_dbl_quad<M>(&L.acc[q], &L.acc[q], true, lane);
-            macq_sync();
+        if (!inf) {
+#pragma unroll 1
+            for (int d = 0; d < 4; d++) xyzz30_dbl_quadreg<M>(c, r);
         }
+#pragma unroll 1
         for (int h = 0; h < 2; h++) {
-            const int dg = mac_signed_digit(m[h], i);
-            const int mag = dg < 0 ? -dg : dg;
-            macq_prepare<M>(&L.tmp[q], &L.tbl[q][mag ? mag - 1 : 0], (dg < 0) != ng[h], h != 0, beta30, r, lane);
-            macq_sync();
-            xyzz30_add_quad<M>(&L.acc[q], &L.tmp[q], &L.acc[q], false, mag != 0, lane);
-            macq_sync();
+            uint32_t mh[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) mh[j] = h ? m1[j] : m0[j];
+            const int dg = mac_signed_digit(mh, i);
+            if (dg == 0) continue;
+            const uint32_t mag = (uint32_t)(dg < 0 ? -dg : dg) - 1u;
+            const XYZZ<M>* e = &Q.tbl[mag];
+            macq_add<M>(c, inf, e, h ? &Q.bx[mag][0] : reinterpret_cast<const uint32_t*>(e), (dg < 0) != (h ? ng1 : ng0), &L.acc[q],
+                        &L.tmp[q], r, lane);
         }
     }
+}
+// the ladder's result as a memory-form point at dst (LDS or global); all four lanes
+template <class M>
+__device__ __forceinline__ void macq_store_point(XYZZ<M>* dst, const F30<M>& c, bool inf, uint32_t r) {
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst) + 8 * r;
+    if (inf) {
+        uint4* d4 = reinterpret_cast<uint4*>(d);
+        d4[0] = make_uint4(0, 0, 0, 0); d4[1] = d4[0];
+    } else {
+        macq_store_residue<M>(d, c);
+    }
+}
+// the butterfly's two outputs  lo = um + tm,  hi = um - tm  from tm in registers (c, inf) and um in LDS (memory form); stored
+// (memory form) at lo / hi when `live`
+template <class M>
+__device__ __forceinline__ void macq_butterfly_out(const XYZZ<M>* um, XYZZ<M>* slot_a, XYZZ<M>* slot_b, const F30<M>& c, bool inf,
+                                                   XYZZ<M>* lo, XYZZ<M>* hi, bool live, uint32_t r, uint32_t lane) {
+    bool z;
+    const F30<M> u = macq_load_residue<M>(reinterpret_cast<const uint32_t*>(um) + 8 * r, &z);
+    const bool um_inf = macq_quad_any(z && r == 2u, lane);
+    if (inf) {                                                             // tm = infinity: both outputs are um
+        if (live) { macq_store_point<M>(lo, u, um_inf, r); macq_store_point<M>(hi, u, um_inf, r); }
+        return;
+    }
+    const F30<M> cn = r == 1u ? f30_sub<M, 4>(F30<M>{}, c) : c;            // -tm
+    if (um_inf) {
+        if (live) { macq_store_point<M>(lo, c, false, r); macq_store_point<M>(hi, cn, false, r); }
+        return;
+    }
+    F30<M> s = c;
+    bool s_inf = false;
+    macq_add<M>(s, s_inf, um, reinterpret_cast<const uint32_t*>(um), false, slot_a, slot_b, r, lane);
+    if (live) macq_store_point<M>(lo, s, s_inf, r);
+    s = cn;
+    s_inf = false;
+    macq_add<M>(s, s_inf, um, reinterpret_cast<const uint32_t*>(um), false, slot_a, slot_b, r, lane);
+    if (live) macq_store_point<M>(hi, s, s_inf, r);
 }
 
 template <class C>
@@ -383,34 +482,34 @@ k_mac_stage30_quad(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __re
         const uint4 a = w4[0], b = w4[1];
         sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
     }
-    macq_copy_coord<M>(&L.tbl[q][0], work + k + m2, r);
+    macq_copy_coord<M>(&L.qd[q].tbl[0], work + k + m2, r);
     macq_copy_coord<M>(&L.um[q], work + k, r);
-    __syncthreads();
-    macq_ladder<C>(L, q, r, lane, sc);
+    macq_sync();
+    F30<M> c;
+    bool inf;
+    macq_ladder<C>(L, q, r, lane, sc, c, inf);
     // MAC[k] = um + tm, MAC[k + m2] = um - tm
-    xyzz30_add_quad<M>(&L.um[q], &L.acc[q], work + k, false, valid, lane);
-    macq_prepare<M>(&L.tmp[q], &L.acc[q], true, false, F30<M>{}, r, lane);
-    __syncthreads();
-    xyzz30_add_quad<M>(&L.um[q], &L.tmp[q], work + k + m2, false, valid, lane);
+    macq_butterfly_out<M>(&L.um[q], &L.acc[q], &L.tmp[q], c, inf, work + k, work + k + m2, valid, r, lane);
 }
 
 // Stage 1 of the network with four lanes per butterfly: every twiddle is w^0 = 1 (tm = MAC[k+1]), so the stage is its two
-// additions and nothing else -- the 0.54 ms ladder of a general stage would multiply by one.  256 lanes = 64 butterflies per block.
+// additions and nothing else -- the ladder of a general stage would multiply by one.  256 lanes = 64 butterflies per block.
 template <class C>
 __global__ void __launch_bounds__(256) MACQ_GUEST_ATTR
 k_mac_stage1_quad(XYZZ<typename C::Fp>* __restrict__ work, uint32_t n) {
     using M = typename C::Fp;
-    __shared__ XYZZ<M> tp[64], tn[64];                                     // tm and -tm
+    __shared__ XYZZ<M> um[64], slot_a[64], slot_b[64];                     // 24 KiB: several blocks per compute unit
     const uint32_t q = threadIdx.x >> 2, r = threadIdx.x & 3u, lane = threadIdx.x & 63u;
     uint32_t t = blockIdx.x * 64 + q;
     const bool valid = t < n / 2;
     if (!valid) t = 0;
     const uint32_t k = 2 * t;
-    macq_copy_coord<M>(&tp[q], work + k + 1, r);
-    macq_prepare<M>(&tn[q], work + k + 1, true, false, F30<M>{}, r, lane);
-    __syncthreads();
-    xyzz30_add_quad<M>(work + k, &tn[q], work + k + 1, false, valid, lane);    // um - tm (tm's copies are in LDS)
-    xyzz30_add_quad<M>(work + k, &tp[q], work + k, false, valid, lane);        // um + tm, in place: a quad loads before it stores
+    macq_copy_coord<M>(&um[q], work + k, r);
+    bool z;
+    const F30<M> c = macq_load_residue<M>(reinterpret_cast<const uint32_t*>(work + k + 1) + 8 * r, &z);
+    const bool inf = macq_quad_any(z && r == 2u, lane);
+    macq_sync();
+    macq_butterfly_out<M>(&um[q], &slot_a[q], &slot_b[q], c, inf, work + k, work + k + 1, valid, r, lane);
 }
 
 // init scaling of the Y part (k_mac_load30 with use_wt) with four lanes per MAC: work[i] = wt * MAC[i]
@@ -427,11 +526,13 @@ k_mac_load30_quad(const uint8_t* __restrict__ in, uint32_t n, XYZZ<typename C::F
     uint32_t sc[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) sc[j] = wt.v[j];
-    if (FROM_WORK) macq_copy_coord<M>(&L.tbl[q][0], reinterpret_cast<const XYZZ<M>*>(in) + i, r);
-    else if (r == 0u) store_xyzz<M>(&L.tbl[q][0], load_affine_be_lazy<M>(in + (size_t)i * 64));
-    __syncthreads();
-    macq_ladder<C>(L, q, r, lane, sc);
-    if (valid) macq_copy_coord<M>(work + i, &L.acc[q], r);
+    if (FROM_WORK) macq_copy_coord<M>(&L.qd[q].tbl[0], reinterpret_cast<const XYZZ<M>*>(in) + i, r);
+    else if (r == 0u) store_xyzz<M>(&L.qd[q].tbl[0], load_affine_be_lazy<M>(in + (size_t)i * 64));
+    macq_sync();
+    F30<M> c;
+    bool inf;
+    macq_ladder<C>(L, q, r, lane, sc, c, inf);
+    if (valid) macq_store_point<M>(work + i, c, inf, r);
 }
 
 template <class M>
@@ -445,7 +546,7 @@ k_mac_mix_quad(const uint8_t* __restrict__ a0, const uint8_t* __restrict__ a1, u
                uint32_t tw_step, uint8_t* __restrict__ out, const uint8_t* __restrict__ b0, const uint8_t* __restrict__ b1,
                uint8_t* __restrict__ out_b) {
     using M = typename C::Fp;
-    __shared__ MacQuadLds<M> L;
+    MACQ_LDS(L);
     // gridDim.y == 2: Server::mix runs this butterfly on the MAC commitments AND on the MAC alignments with the same v^i
     // (Server.hpp:1281-1318) -- the second array pair rides in the same launch (a stage this short is latency: two for the price of one)
     if (blockIdx.y) { a0 = b0; a1 = b1; out = out_b; }
@@ -459,16 +560,15 @@ k_mac_mix_quad(const uint8_t* __restrict__ a0, const uint8_t* __restrict__ a1, u
         const uint4 a = w4[0], b = w4[1];
         sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
     }
-    if (r < 2u) store_xyzz<M>(r ? &L.um[q] : &L.tbl[q][0], load_affine_be_lazy<M>((r ? a0 : a1) + (size_t)i * 64));   // lanes 0 and 1 side by side
-    __syncthreads();
-    macq_ladder<C>(L, q, r, lane, sc);
-    xyzz30_add_quad<M>(&L.um[q], &L.acc[q], &L.tbl[q][1], false, true, lane);      // sum
-    macq_prepare<M>(&L.tmp[q], &L.acc[q], true, false, F30<M>{}, r, lane);
-    __syncthreads();
-    xyzz30_add_quad<M>(&L.um[q], &L.tmp[q], &L.tbl[q][2], false, true, lane);      // difference
-    __syncthreads();
+    if (r < 2u) store_xyzz<M>(r ? &L.um[q] : &L.qd[q].tbl[0], load_affine_be_lazy<M>((r ? a0 : a1) + (size_t)i * 64));   // lanes 0 and 1 side by side
+    macq_sync();
+    F30<M> c;
+    bool inf;
+    macq_ladder<C>(L, q, r, lane, sc, c, inf);
+    macq_butterfly_out<M>(&L.um[q], &L.acc[q], &L.tmp[q], c, inf, &L.qd[q].tbl[1], &L.qd[q].tbl[2], true, r, lane);      // sum, difference (the table is done with)
+    macq_sync();
     if (valid && r < 2u)                                                           // the two inversions side by side
-        store_affine_be<M>(out + ((size_t)i + (r ? len : 0)) * 64, xyzz30_to_xyzz<M>(xyzz30_load_lazy<M>(&L.tbl[q][1 + r])));
+        store_affine_be<M>(out + ((size_t)i + (r ? len : 0)) * 64, xyzz30_to_xyzz<M>(xyzz30_load_lazy<M>(&L.qd[q].tbl[1 + r])));
 }
 
 // 64-byte big-endian affine MACs -> XYZZ work array; part 1 (Y): times wt (Server.hpp:1528-1536)
