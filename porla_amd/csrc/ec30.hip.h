@@ -486,17 +486,21 @@ __device__ __forceinline__ void xyzz30_dbl_quad(const XYZZ<M>* p, XYZZ<M>* out, 
 // with Y3 formed on lane 1 (it holds T2 and receives T1), so the result lands where the next operation expects it: no permute.
 template <class M>
 __device__ __forceinline__ void xyzz30_dbl_quadreg(F30<M>& c, uint32_t r) {
-    const F30<M> U = f30_small_mul<M, 2>(c);                               // lane 1: 2Y
-    const F30<M> O1 = f30_sel<M>(r == 1u, U, c);
-    const F30<M> M1 = f30_mul<M>(O1, O1);                                  // XX, V, -, -
+    F30<M> O1;                                                             // lane 1: 2Y (a shift by the lane's own amount), else c
+    {
+        const uint32_t sh = r == 1u ? 1u : 0u;
+#pragma unroll
+        for (int i = 0; i < 9; i++) O1.v[i] = c.v[i] << sh;
+        f30_ripple<M>(O1);
+    }
+    const F30<M> M1 = f30_sqr<M>(O1);                                      // XX, V, -, -
     const F30<M> bV = f30_quad<M, 0x55>(M1);
     const F30<M> bXX = f30_quad<M, 0x00>(M1);
     const F30<M> Mm = f30_small_mul<M, 3>(bXX);                            // 3 X^2 (lanes 0 and 3 use it)
     const F30<M> M2 = f30_mul<M>(r == 3u ? Mm : O1, r == 3u ? Mm : bV);    // S, W, ZZ3, MM
     const F30<M> bW = f30_quad<M, 0x55>(M2);
     const F30<M> bMM = f30_quad<M, 0xFF>(M2);
-    const F30<M> S2 = f30_small_mul<M, 2>(M2);                             // lane 0: 2S
-    const F30<M> X3 = f30_sub<M, 3>(bMM, S2);                              // lane 0
+    const F30<M> X3 = f30_sub_twice<M, 3>(bMM, M2);                        // lane 0: MM - 2S
     const F30<M> D = f30_sub<M, 5>(M2, X3);                                // lane 0: S - X3
     const F30<M> M3 = f30_mul<M>(r == 0u ? Mm : bW, r == 0u ? D : c);      // T1, T2 = W Y, (W ZZ), ZZZ3 = W ZZZ
     const F30<M> bT1 = f30_quad<M, 0x00>(M3);
@@ -532,9 +536,8 @@ __device__ __forceinline__ bool xyzz30_add_quadreg(F30<M>& c, const XYZZ<M>* q, 
     if (neg) L = f30_sel<M>(r == 0u, f30_sub<M, 4>(F30<M>{}, L), L);    // lane 0: 4p - Y2
     const F30<M> t = f30_quad<M, 0x63>(c);                                // quad_perm [3, 0, 2, 1]: lane 0 <- ZZZ1, 1 <- X1, 2 <- ZZ1, 3 <- Y1
     const bool first = (r & 1u) != 0u;                                    // lanes 1 and 3 hold the accumulator's coordinate as FIRST factor
-    const F30<M> A = f30_sel<M>(first, t, L);                             // X1, X2, Y1, Y2       (lanes 1, 2, 3, 0)
-    const F30<M> B = f30_sel<M>(first, L, t);                             // ZZ2, ZZ1, ZZZ2, ZZZ1
-    const F30<M> M1 = f30_mul<M>(A, B);                                   // U1, U2, S1, S2
+    const F30<M> B = f30_sel<M>(first, L, t);                             // the ZZ / ZZZ factor: ZZ2, ZZ1, ZZZ2, ZZZ1 (lanes 1, 2, 3, 0)
+    const F30<M> M1 = f30_mul<M>(t, L);                                   // U1, U2, S1, S2 (a product does not care which factor is whose)
     const bool edge = (r == 1u) || (r == 0u);                             // roles a and d
     const F30<M> rcv = f30_quad<M, 0x1B>(f30_sel<M>(edge, B, M1));        // quad_perm [3, 2, 1, 0]: a <-> b (lanes 1, 2), c <-> d (lanes 3, 0)
     const F30<M> D = f30_sub<M, 2>(f30_sel<M>(r == 1u, rcv, M1), f30_sel<M>(r == 1u, M1, rcv));   // lane 1: P = U2 - U1, lane 0: R = S2 - S1

@@ -366,6 +366,20 @@ __device__ __forceinline__ F30<M> f30_sub(const F30<M>& a, const F30<M>& b) {
     f30_ripple<M>(r);
     return r;
 }
+// a - 2 b + K p in one pass, normal result.  a, b normal, 2 b <= (K-1) p + 2^240.  The table of K p is the one of f30_sub with
+// the borrow allowance doubled (limb 0 + 2^31, limbs 1..7 + 2^31 - 2, limb 8 - 2): every limb-wise sum stays below 2^32
+// (2^30 + 2^30 + 2^31 - 2) and non-negative.
+template <class M, int K>
+__device__ __forceinline__ F30<M> f30_sub_twice(const F30<M>& a, const F30<M>& b) {
+    F30<M> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const uint32_t extra = i == 0 ? (1u << 30) : (i < 8 ? (1u << 30) - 1u : 0xffffffffu);   // on top of f30_sub's own allowance
+        r.v[i] = a.v[i] + ((KP30<M, K>::T.v[i] + extra) - (b.v[i] << 1));
+    }
+    f30_ripple<M>(r);
+    return r;
+}
 // a + 2 b, normal result
 template <class M>
 __device__ __forceinline__ F30<M> f30_add2(const F30<M>& a, const F30<M>& b) {

@@ -85,7 +85,8 @@ static size_t macq_lds_bytes() {
     for (int d : done) seen = seen || d == dev;
     if (!seen) {
         const int bytes = (int)sizeof(MacQuadLds<M>);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mac_stage30_quad<C>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mac_stage30_quad<C, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mac_stage30_quad<C, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mac_load30_quad<C, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mac_load30_quad<C, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mac_mix_quad<C>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -203,8 +204,12 @@ static int mac_encode_core(MacWs* ws, int curve, const uint8_t* d_in, size_t n, 
             if (quad && s == 1)      // every twiddle of stage 1 is w^0 = 1: two additions per butterfly, no ladder
                 hipLaunchKernelGGL((k_mac_stage1_quad<C>), dim3((unsigned)((n / 2 + 63) / 64)), dim3(256), 0, stream, (XYZZ<M>*)ws->work.p,
                                    (uint32_t)n);
+            else if (quad && n <= ((size_t)1 << quad_max_log) && (n >> s) >= 16 && n >= 128)
+                // >= 16 butterflies per twiddle (and whole blocks of 64): a wave's 16 quads share their scalar -- the sparse ladder
+                hipLaunchKernelGGL((k_mac_stage30_quad<C, true>), dim3((unsigned)((n / 2 + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream,
+                                   (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->tws.p, (uint32_t)n, s);
             else if (quad && n <= ((size_t)1 << quad_max_log))
-                hipLaunchKernelGGL((k_mac_stage30_quad<C>), dim3((unsigned)((n / 2 + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream,
+                hipLaunchKernelGGL((k_mac_stage30_quad<C, false>), dim3((unsigned)((n / 2 + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream,
                                    (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->tws.p, (uint32_t)n, s);
             else
                 hipLaunchKernelGGL((k_mac_stage30<C>), dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, stream, (XYZZ<M>*)ws->work.p,

@@ -263,6 +263,7 @@ k_mac_stage30(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restric
 // Quads follow their own control flow (a zero digit skips its addition, an accumulator at infinity its doublings): the lanes of
 // a quad always branch together, which is all the quad permutes need.
 constexpr int MACQ_BF = 64;                       // butterflies per block: 256 lanes = one wave on each SIMD of a compute unit
+constexpr int MACQ_WNAF_LEN = 129;                // digits of a width-5 NAF of a 128-bit magnitude
 
 // signed 4-bit digit i (0 .. 32) of the 128-bit magnitude m: ((m >> 4i) & 15) + carry, minus 16 above 8.  The carry into
 // window i is 1 exactly when the bits below it exceed 0x88..8 (the recoding with digits in (-8, 8] is unique: msm_small.hip.h).
@@ -308,6 +309,7 @@ struct MacQuadLds {
     };
     Quad qd[MACQ_BF];
     XYZZ<M> acc[MACQ_BF], tmp[MACQ_BF], um[MACQ_BF];
+    uint16_t wdig[4][MACQ_WNAF_LEN + 3];        // the wave-uniform ladder's digit codes, one set per wave of the block
 };
 // every lane of a quad moves "its" coordinate (32 bytes) of a point
 template <class M>
@@ -421,6 +423,91 @@ __device__ __forceinline__ void macq_ladder(MacQuadLds<typename C::Fp>& L, uint3
         }
     }
 }
+// ---- the ladder when all 16 quads of a wave multiply by the SAME scalar (stages with >= 16 butterflies per twiddle: all but the
+// last four of a network).  Control flow is then the wave's, so a zero digit really costs nothing and the recoding can be sparse:
+// width-5 non-adjacent form of the two half-scalars over the table of ODD multiples P, 3P, .. 15P -- 128 doublings + ~43
+// additions instead of 132 + ~62 (a width-5 NAF with per-quad scalars would make the wave execute an addition at nearly every
+// bit: one quad's digit is everybody's instruction stream).  The scalar work (endomorphism split, recoding) is uniform too: the
+// compiler keeps it on the scalar unit; its 129 digit codes go through LDS, one set per wave.
+//   code of a position = low byte for k1, high byte for k2: 0 = zero digit, else 16 | sign << 3 | (|d| - 1) / 2
+__device__ __forceinline__ uint32_t mac_wnaf5_step(uint32_t (&k)[5], bool flip) {
+    uint32_t code = 0;
+    if (k[0] & 1u) {
+        const uint32_t low = k[0] & 31u;
+        const bool negd = low >= 16u;                                       // digit = low - 32
+        const uint32_t mag = negd ? 32u - low : low;
+        code = 16u | ((negd != flip) ? 8u : 0u) | ((mag - 1u) >> 1);
+        // k -= digit: clears the low five bits; a negative digit carries 32 upwards
+        uint64_t t = (uint64_t)(k[0] & ~31u) + (negd ? 32u : 0u);
+        k[0] = (uint32_t)t;
+#pragma unroll
+        for (int i = 1; i < 5; i++) { t = (uint64_t)k[i] + (t >> 32); k[i] = (uint32_t)t; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) k[i] = (k[i] >> 1) | (k[i + 1] << 31);
+    k[4] >>= 1;
+    return code;
+}
+template <class C>
+__device__ __forceinline__ void macq_ladder_uniform(MacQuadLds<typename C::Fp>& L, uint32_t q, uint32_t r, uint32_t lane, uint32_t wave,
+                                                    const uint32_t sc[8], F30<typename C::Fp>& c, bool& inf) {
+    using M = typename C::Fp;
+    using G = typename C::Glv;
+    typename MacQuadLds<M>::Quad& Q = L.qd[q];
+    // the recoding first (scalar unit; the table's arithmetic below does not wait for it)
+    {
+        uint32_t m0[4], m1[4];
+        bool ng0, ng1;
+        glv_split<G>(sc, m0, ng0, m1, ng1);
+        uint32_t k0[5] = {m0[0], m0[1], m0[2], m0[3], 0u}, k1[5] = {m1[0], m1[1], m1[2], m1[3], 0u};
+#pragma unroll 1
+        for (int i = 0; i < MACQ_WNAF_LEN; i++) {
+            const uint32_t code = mac_wnaf5_step(k0, ng0) | (mac_wnaf5_step(k1, ng1) << 8);
+            if (lane == 0u) L.wdig[wave][i] = (uint16_t)code;
+        }
+    }
+    inf = true;
+    bool z;
+    c = macq_load_residue<M>(reinterpret_cast<const uint32_t*>(&Q.tbl[0]) + 8 * r, &z);
+    const bool p_inf = macq_quad_any(z && r == 2u, lane);                  // P is infinity: so is every multiple
+    if (!p_inf) {
+        // tbl[i] = (2 i + 1) P: 2P (parked in the beta table's space), then seven additions of it
+        XYZZ<M>* two_p = reinterpret_cast<XYZZ<M>*>(&Q.bx[0][0]);
+        const F30<M> p_r = c;
+        xyzz30_dbl_quadreg<M>(c, r);
+        macq_store_residue<M>(reinterpret_cast<uint32_t*>(two_p) + 8 * r, c);
+        macq_sync();
+        c = p_r;
+        bool tinf = false;
+#pragma unroll 1
+        for (int i = 1; i < 8; i++) {
+            macq_add<M>(c, tinf, two_p, reinterpret_cast<const uint32_t*>(two_p), false, &L.acc[q], &L.tmp[q], r, lane);
+            macq_store_residue<M>(reinterpret_cast<uint32_t*>(&Q.tbl[i]) + 8 * r, c);
+        }
+        macq_sync();
+        const F30<M> beta30 = f30_const<M>(G::BETA_30);
+#pragma unroll 1
+        for (int t = 0; t < 2; t++) {
+            const uint32_t e = r + 4u * (uint32_t)t;
+            const F30<M> x = macq_load_residue<M>(reinterpret_cast<const uint32_t*>(&Q.tbl[e]), &z);
+            macq_store_residue<M>(&Q.bx[e][0], f30_mul<M>(x, beta30));
+        }
+    }
+    macq_sync();
+    if (p_inf) return;
+#pragma unroll 1
+    for (int i = MACQ_WNAF_LEN - 1; i >= 0; i--) {
+        const uint32_t code = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.wdig[wave][i]);
+        if (!inf) xyzz30_dbl_quadreg<M>(c, r);
+#pragma unroll 1
+        for (int h = 0; h < 2; h++) {
+            const uint32_t cd = (code >> (8 * h)) & 0xffu;
+            if (cd == 0u) continue;
+            const XYZZ<M>* e = &Q.tbl[cd & 7u];
+            macq_add<M>(c, inf, e, h ? &Q.bx[cd & 7u][0] : reinterpret_cast<const uint32_t*>(e), (cd & 8u) != 0u, &L.acc[q], &L.tmp[q], r, lane);
+        }
+    }
+}
 // the ladder's result as a memory-form point at dst (LDS or global); all four lanes
 template <class M>
 __device__ __forceinline__ void macq_store_point(XYZZ<M>* dst, const F30<M>& c, bool inf, uint32_t r) {
@@ -459,7 +546,9 @@ __device__ __forceinline__ void macq_butterfly_out(const XYZZ<M>* um, XYZZ<M>* s
     if (live) macq_store_point<M>(hi, s, s_inf, r);
 }
 
-template <class C>
+// UNIFORM (launched when n / 2^s >= 16): the 16 quads of a wave take butterflies of ONE twiddle index j (they differ in the block
+// of the stage they belong to), so the whole wave multiplies by one scalar: macq_ladder_uniform
+template <class C, bool UNIFORM>
 __global__ void __launch_bounds__(4 * MACQ_BF) MACQ_GUEST_ATTR
 k_mac_stage30_quad(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restrict__ tws, uint32_t n, int s) {
     using M = typename C::Fp;
@@ -473,8 +562,17 @@ k_mac_stage30_quad(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __re
     const bool valid = t < n / 2;
     if (!valid) t = 0;                                                     // padding quads compute butterfly 0 and store nothing
     const uint32_t m2 = 1u << (s - 1);
-    const uint32_t j = t & (m2 - 1);
-    const uint32_t k = ((t >> (s - 1)) << s) + j;
+    uint32_t j, k;
+    if constexpr (UNIFORM) {
+        // butterfly t = (rest, i16): j from the bits the wave shares, the stage's block number from the rest and the quad's place
+        const uint32_t rest = t >> 4;
+        j = rest & (m2 - 1);
+        k = ((((rest >> (s - 1)) << 4) | (t & 15u)) << s) + j;
+        j = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);              // (the same on all 64 lanes: tell the compiler)
+    } else {
+        j = t & (m2 - 1);
+        k = ((t >> (s - 1)) << s) + j;
+    }
     const uint32_t e = j * (n >> (s - 1));
     uint32_t sc[8];
     {
@@ -487,7 +585,8 @@ k_mac_stage30_quad(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __re
     macq_sync();
     F30<M> c;
     bool inf;
-    macq_ladder<C>(L, q, r, lane, sc, c, inf);
+    if constexpr (UNIFORM) macq_ladder_uniform<C>(L, q, r, lane, threadIdx.x >> 6, sc, c, inf);
+    else macq_ladder<C>(L, q, r, lane, sc, c, inf);
     // MAC[k] = um + tm, MAC[k + m2] = um - tm
     macq_butterfly_out<M>(&L.um[q], &L.acc[q], &L.tmp[q], c, inf, work + k, work + k + m2, valid, r, lane);
 }
@@ -531,7 +630,7 @@ k_mac_load30_quad(const uint8_t* __restrict__ in, uint32_t n, XYZZ<typename C::F
     macq_sync();
     F30<M> c;
     bool inf;
-    macq_ladder<C>(L, q, r, lane, sc, c, inf);
+    macq_ladder_uniform<C>(L, q, r, lane, threadIdx.x >> 6, sc, c, inf);   // one scalar (a kernel argument) for every MAC: the sparse ladder
     if (valid) macq_store_point<M>(work + i, c, inf, r);
 }
 
