@@ -652,7 +652,7 @@ def main():
                     rows_per_gpu=rows_n, coefficients_per_row=128, per_call_compute_digest_from_srs=per_call, host_rows=host_rows,
                     table={"window_bits": cshape[0], "windows_per_coefficient": cshape[1],
                            "GiB": round(128 * cshape[1] * (1 << (cshape[0] - 1)) * 64 / 2**30, 2) if cshape[0] else None,
-                           "budget": "PORLA_COMMIT_TABLE_GB (default 16 GiB)"},
+                           "budget": "PORLA_COMMIT_TABLE_GB (default: a fifth of the HBM)"},
                     equiv_Mmul_per_s=round(world * rows_n * 128 * args.steps / el / 1e6, 1), table_build_s=round(build_s, 3))
 
     # ---------------------------------------------------------------- BN254 MSM (headline)

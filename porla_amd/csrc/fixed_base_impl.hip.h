@@ -36,10 +36,12 @@ int FixedBase<C>::build(const Affine<typename C::Fp>* d_base, size_t n, int wind
     using M = typename C::Fp;
     n_points = 0;
     if (n == 0) return PORLA_OK;
-    // window_bits = 0 -> automatic: the widest window (<= 20 bits) whose table fits min(a quarter of the free HBM,
-    // PORLA_COMMIT_TABLE_GB GiB, default 16), then the narrowest one with the same window count -- 17 bits = 7.5 GiB for the
-    // 128-point BN254 SRS: a drop-in library should not take a fifth of the HBM on its first commit.  A caller that wants the last 10 % asks for it: PORLA_COMMIT_TABLE_GB=64 gives 20-bit
-    // windows (56 GB, 13 additions per coefficient instead of 15: 7.4 against 6.65 M commits/s; build 0.43 s against 0.14 s).
+    // window_bits = 0 -> automatic: the widest window (<= 20 bits) whose table fits min(a quarter of the free HBM, the cap), then
+    // the narrowest one with the same window count.  The cap is PORLA_COMMIT_TABLE_GB GiB when set, else A FIFTH OF THE DEVICE'S
+    // HBM: on the 288 GB of an MI355X that admits the 20-bit table of the 128-point SRS (52 GiB: 13 additions per coefficient
+    // instead of the 15 of the 17-bit, 7.5 GiB table; same box: 7.66 -> 8.58 M commitments/s, build 0.07 -> 0.33 s,
+    // profiles/r05_e_commit_table_budget.txt) -- the engine is laid out for this part's memory, and a caller that wants the HBM
+    // for something else says so (PORLA_COMMIT_TABLE_GB=16 gives the round-4 table back).
     int cc = window_bits;
     const bool automatic = cc <= 0;
     const char* env_w = getenv("PORLA_COMMIT_WINDOW");
@@ -58,7 +60,7 @@ int FixedBase<C>::build(const Affine<typename C::Fp>* d_base, size_t n, int wind
     size_t budget = free_b / 4;
     if (automatic && !env_set) {
         const char* g = getenv("PORLA_COMMIT_TABLE_GB");
-        const size_t cap = (size_t)((g ? atof(g) : 16.0) * 1073741824.0);
+        const size_t cap = g ? (size_t)(atof(g) * 1073741824.0) : total_b / 5;
         if (cap < budget) budget = cap;
     }
     for (;; cc--) {  // shrink the window until the table fits the budget
