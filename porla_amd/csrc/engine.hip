@@ -104,11 +104,11 @@ std::mutex g_ws_mu;  // the workspace registry; the use of a slot is serialised 
 static std::vector<Workspace*> g_ws;
 int g_window_override = 0;
 int g_small_mode = getenv("PORLA_MSM_SMALL") ? atoi(getenv("PORLA_MSM_SMALL")) : 1;
-int g_small_c = getenv("PORLA_MSM_SMALL_C") ? atoi(getenv("PORLA_MSM_SMALL_C")) : 0;
+int g_small_c = 0;        // porla_gpu_set_msm_small sets it
 int g_last_shape[3] = {0, 0, 0};
 int g_last_multi[2] = {0, 0};
 std::mutex g_multi_mu;   // one range-sharded host MSM at a time (it occupies the pipeline slots of every device it uses)
-int g_use_glv = getenv("PORLA_MSM_GLV") ? (getenv("PORLA_MSM_GLV")[0] == '1' ? 1 : 0) : -1;  // -1: per-curve default
+int g_use_glv = -1;       // -1: per-curve default; porla_gpu_set_msm_glv sets it
 
 int get_workspace_slot(int slot, Workspace** out) {
     if (slot < 0 || slot >= MSM_SLOTS) { set_last_error("porla: MSM slot out of range"); return PORLA_ERR_ARG; }

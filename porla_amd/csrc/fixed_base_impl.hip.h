@@ -147,7 +147,7 @@ int FixedBase<C>::commit_device(const uint8_t* d_rows, size_t n_rows, size_t n_c
     }
     // slices per row: enough lanes for TWO to three rounds of 256 CUs x 4 SIMDs x 3 waves -- with 196 608 (one round and a third:
     // 1024 blocks where 768 are resident) the last third ran at one wave per SIMD: 18.1-18.3 ms for 2^17 rows, 17.8 with 393 216
-    static const size_t target = getenv("PORLA_COMMIT_LANES") ? (size_t)atol(getenv("PORLA_COMMIT_LANES")) : (size_t)393216;
+    static const size_t target = 393216;
     // ... but not below 16 additions per lane once every SIMD has two waves anyway (131 072 rows): the fold of a slice pair costs
     // what the shorter chains save (the two-coefficient rows of the MAC batch: 0.455 -> 0.437 ms at 131 072 rows, no difference
     // at 65 536, and below that the slices win)
@@ -186,7 +186,7 @@ int FixedBase<C>::commit_device(const uint8_t* d_rows, size_t n_rows, size_t n_c
     last_S = S;
     if (d_out) {
         ProfScope ps("fb_finish", stream);
-        static const size_t spread = getenv("PORLA_FB_FINISH_SPREAD") ? (size_t)atol(getenv("PORLA_FB_FINISH_SPREAD")) : FB_FINISH_SPREAD;
+        static const size_t spread = FB_FINISH_SPREAD;
         if (n_rows <= spread)
             hipLaunchKernelGGL((k_fb_finish<C, 1>), dim3((unsigned)((n_rows + 63) / 64)), dim3(64), 0, stream,
                                (const XYZZ<M>*)partial, (uint32_t)n_rows, S, d_out);
@@ -242,12 +242,7 @@ int FixedBase<C>::commit_small(const uint8_t* const* row_ptrs, size_t n_rows, si
     volatile uint32_t* hdr = (volatile uint32_t*)hs;
     hdr[0] = 0;
     const uint32_t P = (uint32_t)(n_coeffs * (size_t)W);
-    // (512: one row 0.0615 ms, the audit 0.150 ms; 256: 0.060 / 0.142); anything outside 64..4096 -- or not a number -- means 256
-    static const uint32_t per_slice = []() -> uint32_t {
-        const char* e = getenv("PORLA_COMMIT_SMALL_PAIRS");
-        const long v = e ? strtol(e, nullptr, 10) : 256;
-        return v >= 64 && v <= 4096 ? (uint32_t)v : 256u;
-    }();
+    constexpr uint32_t per_slice = 256;      // (coefficient, window) pairs per slice (512: one row 0.0615 ms, the audit 0.150 ms; 256: 0.060 / 0.142)
     uint32_t SL = (P + per_slice - 1) / per_slice;
     if (SL < 1) SL = 1;
     if (SL > (uint32_t)FB_SMALL_MAX_SLICES) SL = FB_SMALL_MAX_SLICES;
@@ -300,7 +295,7 @@ int FixedBase<C>::commit_host(const uint8_t* rows, size_t n_rows, size_t n_coeff
     // copied in while chunk k is committed (the commits follow each other through `fence`), and chunk k's results are copied out
     // only after chunk k + 1 has been enqueued -- a pageable device-to-host copy holds the host thread until the data is there.
     // One copy of 512 MiB, then one commit, then one copy back took 48-51 ms for 2^17 rows (tools/bench_commit_host.py).
-    static const size_t chunk_bytes = getenv("PORLA_COMMIT_HOST_CHUNK") ? (size_t)atol(getenv("PORLA_COMMIT_HOST_CHUNK")) : ((size_t)64 << 20);
+    static const size_t chunk_bytes = (size_t)64 << 20;
     size_t chunk_rows = row_stride ? chunk_bytes / row_stride : n_rows;
     if (chunk_rows < HOST_FINISH_MAX_ROWS + 1) chunk_rows = HOST_FINISH_MAX_ROWS + 1;
     if (chunk_rows > n_rows) chunk_rows = n_rows;

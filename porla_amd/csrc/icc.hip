@@ -70,9 +70,8 @@ static int icc_mix_core(IccWs* ws, int curve, const uint8_t* d_a0, const uint8_t
     if ((rc = ws->fence.enter(stream))) return rc;
     if ((rc = ensure_twiddles<Q>(ws, curve, n_total, stream))) return rc;
     const size_t total = len * ncols;
-    // default: the reduced-radix kernel (icc30.hip.h:k_icc_mix30, a third of the field products); PORLA_ICC_MIX30=0: the 2^256-form one
-    static const bool mix30 = !(getenv("PORLA_ICC_MIX30") && getenv("PORLA_ICC_MIX30")[0] == '0');
-    if (mix30 && (ws->tw30_n != n_total || ws->tw30_curve != curve)) {
+    // the reduced-radix kernel (icc30.hip.h:k_icc_mix30) and its twiddle table
+    if (ws->tw30_n != n_total || ws->tw30_curve != curve) {
         if ((rc = ws->tw30.ensure(n_total * ICC30_SLOT_WORDS * 4))) return rc;
         hipLaunchKernelGGL((k_icc_twiddles30<Q>), dim3((unsigned)((n_total + 255) / 256)), dim3(256), 0, stream,
                            (const IccElem<Q>*)ws->tw.p, (uint32_t)n_total, (uint32_t*)ws->tw30.p);
@@ -81,12 +80,8 @@ static int icc_mix_core(IccWs* ws, int curve, const uint8_t* d_a0, const uint8_t
     }
     {
         ProfScope ps("icc_mix", stream);
-        if (mix30)
-            hipLaunchKernelGGL((k_icc_mix30<Q>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, d_a0, d_a1, (uint32_t)len,
-                               (uint32_t)ncols, (const uint32_t*)ws->tw30.p, (uint32_t)(n_total / len), d_out);
-        else
-            hipLaunchKernelGGL((k_icc_mix<Q>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, d_a0, d_a1, (uint32_t)len,
-                               (uint32_t)ncols, (const IccElem<Q>*)ws->tw.p, (uint32_t)(n_total / len), d_out);
+        hipLaunchKernelGGL((k_icc_mix30<Q>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, d_a0, d_a1, (uint32_t)len,
+                           (uint32_t)ncols, (const uint32_t*)ws->tw30.p, (uint32_t)(n_total / len), d_out);
     }
     PORLA_HIP(hipGetLastError());
     return ws->fence.leave(stream);
@@ -148,108 +143,53 @@ static int icc_encode_core(IccWs* ws, int curve, const uint8_t* d_rows, size_t n
     wt.q = fe_one<Q>();
     int use_wt = 0;
     if (part == 1) { wt = icc_wt<Q>(n, write_step, nullptr); use_wt = 1; }
-    static const int fused = !(getenv("PORLA_ICC_FUSED") && getenv("PORLA_ICC_FUSED")[0] == '0');
-    static const int f30 = !(getenv("PORLA_ICC_F30") && getenv("PORLA_ICC_F30")[0] == '0');
-    static const int split_on = !(getenv("PORLA_ICC_SPLIT") && getenv("PORLA_ICC_SPLIT")[0] == '0');
     IccOut out{d_x, d_al, d_sc, d_qres, scalar_le};
     if (out_y) {
         if (part != 0) { set_last_error("porla: the two-part encode takes part = 0"); return PORLA_ERR_ARG; }
-        if (!(fused && f30 && split_on)) {
-            // the other kernels have no two-part form: the Y part as its own encode
-            if ((rc = icc_encode_core<Q>(ws, curve, d_rows, n, ncols, write_step, 0, d_x, d_al, d_sc, scalar_le, stream, d_qres))) return rc;
-            return icc_encode_core<Q>(ws, curve, d_rows, n, ncols, write_step, 1, out_y->x, out_y->al, out_y->sc, out_y->scalar_le, stream,
-                                      out_y->qres);
-        }
         wt = icc_wt<Q>(n, write_step, nullptr);        // handed to the last pass; the network itself runs unscaled (use_wt = 0)
         if (!out_y->al && (out_y->x || out_y->sc) && (rc = ws->park_y.ensure(total * 32))) return rc;
     }
     const IccOut oy = out_y ? *out_y : IccOut{nullptr, nullptr, nullptr, nullptr, 0};
-    if (fused) {
-        // ceil(logn / 8) passes of (almost) equal stage counts, each through LDS tiles of 512 symbols; the first pass reads
-        // the raw chunks, the last one writes the outputs: the residue-pair working set only travels between passes.
-        // Default: the reduced-radix kernel of icc30.hip.h (72 bytes per symbol between the passes); PORLA_ICC_F30=0: icc.hip.h's.
-        // PORLA_ICC_SPLIT=0: the kernel of icc30.hip.h (both residues of a symbol side by side in 80-byte LDS slots, one stage per
-        // round trip); default: icc30_split.hip.h (one plane at a time, two stages per round trip)
-        const int split = split_on;
-        if (f30) {
-            if ((rc = ws->work.ensure(total * ICC30_PACK_WORDS * 4))) return rc;
-            if (split) {
-                if (ws->tw30s_n != n || ws->tw30s_curve != curve) {
-                    if ((rc = ws->tw30p.ensure(n * ICC30_PSLOT_WORDS * 4)) || (rc = ws->tw30q.ensure(n * ICC30_PSLOT_WORDS * 4))) return rc;
-                    hipLaunchKernelGGL((k_icc_twiddles30_planes<Q>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                                       (const IccElem<Q>*)ws->tw.p, (uint32_t)n, (uint32_t*)ws->tw30p.p, (uint32_t*)ws->tw30q.p);
-                    ws->tw30s_n = (uint32_t)n;
-                    ws->tw30s_curve = curve;
-                }
-            } else if (ws->tw30_n != n || ws->tw30_curve != curve) {
-                if ((rc = ws->tw30.ensure(n * ICC30_SLOT_WORDS * 4))) return rc;
-                hipLaunchKernelGGL((k_icc_twiddles30<Q>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                                   (const IccElem<Q>*)ws->tw.p, (uint32_t)n, (uint32_t*)ws->tw30.p);
-                ws->tw30_n = (uint32_t)n;
-                ws->tw30_curve = curve;
-            }
-        }
-        const int passes = (logn + 7) / 8;
-        int s = 1;
-        for (int pz = 0; pz < passes; pz++) {
-            const int ns = (logn - (s - 1) + (passes - pz) - 1) / (passes - pz);
-            int cc_log = ICC_TILE_LOG - ns;                                    // 2^ns rows x 2^cc_log columns = 512 symbols
-            while (cc_log > 0 && ((size_t)1 << (cc_log - 1)) >= ncols) cc_log--;   // no wider than the row
-            const size_t col_tiles = (ncols + ((size_t)1 << cc_log) - 1) >> cc_log;
-            const dim3 grid((unsigned)(col_tiles * (n >> ns)));
-            const bool first = pz == 0, last = pz == passes - 1;
-            ProfScope ps("icc_fused", stream, true);
+    // ceil(logn / 8) passes of (almost) equal stage counts, each through LDS tiles of 512 symbols (icc30_split.hip.h: one plane at
+    // a time, two stages per LDS round trip); the first pass reads the raw chunks, the last one writes the outputs: the two
+    // residue planes (9 words per symbol each) only travel between passes.
+    if ((rc = ws->work.ensure(total * ICC30_PACK_WORDS * 4))) return rc;
+    if (ws->tw30s_n != n || ws->tw30s_curve != curve) {
+        if ((rc = ws->tw30p.ensure(n * ICC30_PSLOT_WORDS * 4)) || (rc = ws->tw30q.ensure(n * ICC30_PSLOT_WORDS * 4))) return rc;
+        hipLaunchKernelGGL((k_icc_twiddles30_planes<Q>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                           (const IccElem<Q>*)ws->tw.p, (uint32_t)n, (uint32_t*)ws->tw30p.p, (uint32_t*)ws->tw30q.p);
+        ws->tw30s_n = (uint32_t)n;
+        ws->tw30s_curve = curve;
+    }
+    const int passes = (logn + 7) / 8;
+    int s = 1;
+    for (int pz = 0; pz < passes; pz++) {
+        const int ns = (logn - (s - 1) + (passes - pz) - 1) / (passes - pz);
+        int cc_log = ICC_TILE_LOG - ns;                                    // 2^ns rows x 2^cc_log columns = 512 symbols
+        while (cc_log > 0 && ((size_t)1 << (cc_log - 1)) >= ncols) cc_log--;   // no wider than the row
+        const size_t col_tiles = (ncols + ((size_t)1 << cc_log) - 1) >> cc_log;
+        const dim3 grid((unsigned)(col_tiles * (n >> ns)));
+        const bool first = pz == 0, last = pz == passes - 1;
+        ProfScope ps("icc_fused", stream, true);
 #define PORLA_ICC_LAUNCH(F, L)                                                                                              \
     do {                                                                                                                    \
-        if (f30 && split && L && out_y)                                                                                     \
+        if (L && out_y)                                                                                                     \
             hipLaunchKernelGGL((k_icc_split30<Q, F, L, L>), grid, dim3(ICC30_SPLIT_THREADS), 0, stream, (uint32_t*)ws->work.p, \
                                (uint32_t*)ws->work.p + total * ICC30_PLANE_WORDS, (const uint32_t*)ws->tw30p.p,            \
                                (const uint32_t*)ws->tw30q.p, (uint32_t)n, (uint32_t)ncols, s, ns, cc_log, d_rows, wt, use_wt, out, oy, \
                                (uint32_t*)ws->park_y.p);                                                                    \
-        else if (f30 && split)                                                                                              \
+        else                                                                                                                \
             hipLaunchKernelGGL((k_icc_split30<Q, F, L>), grid, dim3(ICC30_SPLIT_THREADS), 0, stream, (uint32_t*)ws->work.p, \
                                (uint32_t*)ws->work.p + total * ICC30_PLANE_WORDS, (const uint32_t*)ws->tw30p.p,            \
                                (const uint32_t*)ws->tw30q.p, (uint32_t)n, (uint32_t)ncols, s, ns, cc_log, d_rows, wt, use_wt, out, oy, \
                                (uint32_t*)nullptr);                                                                         \
-        else if (f30)                                                                                                       \
-            hipLaunchKernelGGL((k_icc_fused30<Q, F, L>), grid, dim3(256), 0, stream, (uint32_t*)ws->work.p,                 \
-                               (const uint32_t*)ws->tw30.p, (uint32_t)n, (uint32_t)ncols, s, ns, cc_log, d_rows, wt, use_wt, out); \
-        else                                                                                                                \
-            hipLaunchKernelGGL((k_icc_fused<Q, F, L>), grid, dim3(256), 0, stream, (IccElem<Q>*)ws->work.p,                 \
-                               (const IccElem<Q>*)ws->tw.p, (uint32_t)n, (uint32_t)ncols, s, ns, cc_log, d_rows, wt, use_wt, out); \
     } while (0)
-            if (first && last) PORLA_ICC_LAUNCH(true, true);
-            else if (first) PORLA_ICC_LAUNCH(true, false);
-            else if (last) PORLA_ICC_LAUNCH(false, true);
-            else PORLA_ICC_LAUNCH(false, false);
+        if (first && last) PORLA_ICC_LAUNCH(true, true);
+        else if (first) PORLA_ICC_LAUNCH(true, false);
+        else if (last) PORLA_ICC_LAUNCH(false, true);
+        else PORLA_ICC_LAUNCH(false, false);
 #undef PORLA_ICC_LAUNCH
-            s += ns;
-        }
-    } else {
-        {
-            ProfScope ps("icc_load", stream);
-            hipLaunchKernelGGL((k_icc_load<Q>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, d_rows,
-                               (IccElem<Q>*)ws->work.p, total, wt, use_wt);
-        }
-        int s = 1;
-        while (s + 1 <= logn) {
-            ProfScope ps("icc_stages_r4", stream);
-            size_t groups = (n >> 2) * ncols;
-            hipLaunchKernelGGL((k_icc_stages<Q, 2>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream,
-                               (IccElem<Q>*)ws->work.p, (const IccElem<Q>*)ws->tw.p, (uint32_t)n, (uint32_t)ncols, s);
-            s += 2;
-        }
-        if (s <= logn) {
-            ProfScope ps("icc_stages_r2", stream);
-            size_t groups = (n >> 1) * ncols;
-            hipLaunchKernelGGL((k_icc_stages<Q, 1>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream,
-                               (IccElem<Q>*)ws->work.p, (const IccElem<Q>*)ws->tw.p, (uint32_t)n, (uint32_t)ncols, s);
-        }
-        {
-            ProfScope ps("icc_finish", stream);
-            hipLaunchKernelGGL((k_icc_finish<Q>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
-                               (const IccElem<Q>*)ws->work.p, total, out);
-        }
+        s += ns;
     }
     PORLA_HIP(hipGetLastError());
     return PORLA_OK;

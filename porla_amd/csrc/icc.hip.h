@@ -14,9 +14,8 @@
 // 15 stages are two passes over the working set (32 B in + 2 x 64..72 B between the passes + the outputs per symbol), against
 // ~1 000 vector instructions per symbol and pass.  The first pass converts the raw 32-byte chunks on the way in, the last writes
 // the CRT / alignment outputs; the N-entry twiddle table stays L2-resident; lanes run along the columns of a row, so global
-// accesses are coalesced.  Two kernels share this tiling: k_icc_fused below (8 x 32-bit limbs, Montgomery radix 2^256) and the
-// default k_icc_fused30 of icc30.hip.h (9 x 30-bit limbs, radix 2^270, sparse reduction for p_icc).  The element-wise kernels of
-// this file (k_icc_load, k_icc_finish, k_icc_stages, k_icc_mix) serve the unfused fallback, Server::mix and HAdd.
+// accesses are coalesced.  The encode kernel is k_icc_split30 of icc30_split.hip.h (9 x 30-bit limbs, radix 2^270, sparse reduction
+// for p_icc, one residue plane at a time); the element-wise kernels of this file (k_icc_load, k_icc_finish) serve HAdd.
 // No MFMA: there is no contraction.
 #pragma once
 #include "fe.hip.h"
@@ -153,71 +152,6 @@ __global__ void k_icc_twiddles(IccElem<Q>* __restrict__ tw, uint32_t n, const Fe
     st_elem<Q>(tw + e, t);
 }
 
-// unit_tw: the twiddle is w^0 = 1 (j = 0: every butterfly of stage 1, half of stage 2, ...): no product
-template <class Q>
-__device__ __forceinline__ void butterfly(IccElem<Q>& a, IccElem<Q>& b, const IccElem<Q>& tw, bool neg_tw, bool unit_tw = false) {
-    Fe<IccFp> tp = b.p;
-    Fe<Q> tq = b.q;
-    if (!unit_tw) {
-        tp = fe_mul<IccFp>(tw.p, b.p);
-        tq = fe_mul<Q>(tw.q, b.q);
-    }
-    Fe<IccFp> sp = fe_add<IccFp>(a.p, tp), dp = fe_sub<IccFp>(a.p, tp);
-    Fe<Q> sq = fe_add<Q>(a.q, tq), dq = fe_sub<Q>(a.q, tq);
-    // multiplying by -tw swaps the two outputs
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        a.p.v[k] = neg_tw ? dp.v[k] : sp.v[k];
-        b.p.v[k] = neg_tw ? sp.v[k] : dp.v[k];
-        a.q.v[k] = neg_tw ? dq.v[k] : sq.v[k];
-        b.q.v[k] = neg_tw ? sq.v[k] : dq.v[k];
-    }
-}
-
-// Stages s and (if STAGES == 2) s+1 fused.  One thread: one column, rows base + {0, m2, 2*m2, 3*m2}.
-template <class Q, int STAGES>
-__global__ void __launch_bounds__(256)
-k_icc_stages(IccElem<Q>* __restrict__ work, const IccElem<Q>* __restrict__ tw, uint32_t n, uint32_t ncols, int s) {
-    const uint32_t m2 = 1u << (s - 1);
-    size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t groups = (size_t)(n >> STAGES) * ncols;
-    if (tid >= groups) return;
-    uint32_t col = (uint32_t)(tid % ncols);
-    uint32_t g = (uint32_t)(tid / ncols);
-    uint32_t low = g & (m2 - 1);
-    uint32_t high = g >> (s - 1);
-    uint32_t base = (high << (s - 1 + STAGES)) | low;   // STAGES zero bits inserted at position s-1
-    uint32_t j0 = low;                                   // = base mod m2
-    if (STAGES == 1) {
-        IccElem<Q>* pa = work + (size_t)base * ncols + col;
-        IccElem<Q>* pb = work + (size_t)(base + m2) * ncols + col;
-        IccElem<Q> a = ld_elem<Q>(pa), b = ld_elem<Q>(pb);
-        IccElem<Q> t1 = ld_elem<Q>(tw + (size_t)j0 * (n / m2) % n);
-        butterfly<Q>(a, b, t1, false);
-        st_elem<Q>(pa, a);
-        st_elem<Q>(pb, b);
-    } else {
-        IccElem<Q>* p0 = work + (size_t)base * ncols + col;
-        IccElem<Q>* p1 = work + (size_t)(base + m2) * ncols + col;
-        IccElem<Q>* p2 = work + (size_t)(base + 2 * m2) * ncols + col;
-        IccElem<Q>* p3 = work + (size_t)(base + 3 * m2) * ncols + col;
-        IccElem<Q> e0 = ld_elem<Q>(p0), e1 = ld_elem<Q>(p1), e2 = ld_elem<Q>(p2), e3 = ld_elem<Q>(p3);
-        // stage s: v = w^(N/m2), twiddle v^j0 for both pairs
-        IccElem<Q> t1 = ld_elem<Q>(tw + ((size_t)j0 * (n / m2)) % n);
-        butterfly<Q>(e0, e1, t1, false);
-        butterfly<Q>(e2, e3, t1, false);
-        // stage s+1: m2' = 2*m2, v' = w^(N/(2 m2)); pair (0,2): j = j0; pair (1,3): j = j0 + m2 -> exponent j0*N/m + N/2
-        // (the integer v'^(j0+m2) mod p_icc is what multiplies the q-residue, so it comes from the table:
-        //  "-v'^j0" would only be right for the p_icc residue)
-        const size_t e2i = ((size_t)j0 * (n / (2 * m2))) % n;
-        IccElem<Q> t2 = ld_elem<Q>(tw + e2i);
-        butterfly<Q>(e0, e2, t2, false);
-        IccElem<Q> t3 = ld_elem<Q>(tw + (e2i + n / 2) % n);
-        butterfly<Q>(e1, e3, t3, false);
-        st_elem<Q>(p0, e0); st_elem<Q>(p1, e1); st_elem<Q>(p2, e2); st_elem<Q>(p3, e3);
-    }
-}
-
 // value in [0, LCM) as 64 bytes little-endian from the residue pair: P = A mod p_icc (plain), pq_m = P mod q (Montgomery)
 template <class Q>
 __device__ __forceinline__ void icc_store_lcm_pt(const Fe<IccFp>& P, const Fe<Q>& t, uint8_t* dst);
@@ -319,87 +253,15 @@ __global__ void k_icc_finish(const IccElem<Q>* __restrict__ work, size_t total, 
     icc_finish_elem<Q>(ld_elem<Q>(work + i), i, o);
 }
 
-// LDS-fused stages s0 .. s0+ns-1 (ns <= 8).  A block owns a TILE: 2^ns rows {row_base + mid * 2^(s0-1)} (all values of the
-// ns row-index bits these stages pair up; the lower s0-1 bits `lo` and the upper bits `hi` are fixed per tile) x 2^cc_log
-// columns = 512 symbols = 32 KiB of LDS (4 blocks per CU).  The tile is read from HBM once, goes through ns butterfly stages in LDS and is
-// written back once: 15 stages cost 2 passes over the working set instead of 8.  FIRST fuses the conversion of the raw
-// 32-byte chunks (k_icc_load) into the first pass, LAST the CRT recombination / alignment outputs (k_icc_finish) into the last.
+// The LDS-fused encode (icc30_split.hip.h) gives a block a TILE: 2^ns rows {row_base + mid * 2^(s0-1)} (all values of the ns
+// row-index bits its stages pair up; the lower s0-1 bits `lo` and the upper bits `hi` are fixed per tile) x 2^cc_log columns =
+// 512 symbols.  The tile is read from HBM once, goes through ns butterfly stages in LDS and is written back once: 15 stages cost
+// 2 passes over the working set instead of 8.
 #ifndef PORLA_ICC_TILE
 #define PORLA_ICC_TILE 512
 #endif
 constexpr int ICC_TILE_ELEMS = PORLA_ICC_TILE;
 constexpr int ICC_TILE_LOG = PORLA_ICC_TILE == 1024 ? 10 : (PORLA_ICC_TILE == 512 ? 9 : 8);
-template <class Q, bool FIRST, bool LAST>
-__global__ void __launch_bounds__(256)
-k_icc_fused(IccElem<Q>* __restrict__ work, const IccElem<Q>* __restrict__ tw, uint32_t n, uint32_t ncols, int s0, int ns,
-            int cc_log, const uint8_t* __restrict__ raw, IccElem<Q> wt, int use_wt, IccOut out) {
-    __shared__ uint4 lds[ICC_TILE_ELEMS * 4];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t Cc = 1u << cc_log;
-    const uint32_t elems = (1u << ns) << cc_log;            // <= ICC_TILE_ELEMS
-    const uint32_t lo_bits = (uint32_t)(s0 - 1);
-    const uint32_t col_tiles = (ncols + Cc - 1) >> cc_log;
-    uint32_t tile = blockIdx.x;
-    const uint32_t ct = tile % col_tiles;
-    tile /= col_tiles;
-    const uint32_t lo = tile & ((1u << lo_bits) - 1u);
-    const uint32_t hi = tile >> lo_bits;
-    const uint32_t row_base = (hi << (lo_bits + ns)) + lo;
-    const uint32_t c0 = ct << cc_log;
-    for (uint32_t e = tid; e < elems; e += 256) {
-        const uint32_t mid = e >> cc_log, col = e & (Cc - 1);
-        if (c0 + col < ncols) {
-            const size_t gi = (size_t)(row_base + (mid << lo_bits)) * ncols + c0 + col;
-            if (FIRST) {   // the 32-byte chunk of the block file, converted on the way in (k_icc_load fused)
-                IccElem<Q> el = icc_load_elem<Q>(raw + 32 * gi, wt, use_wt);
-                uint32_t* pe = reinterpret_cast<uint32_t*>(&lds[e * 4]);
-                st_fe<IccFp>(pe, el.p); st_fe<Q>(pe + 8, el.q);
-            } else {
-                const uint4* src = reinterpret_cast<const uint4*>(work + gi);
-                uint4 a = src[0], b = src[1], c = src[2], d = src[3];
-                lds[e * 4 + 0] = a; lds[e * 4 + 1] = b; lds[e * 4 + 2] = c; lds[e * 4 + 3] = d;
-            }
-        }
-    }
-    __syncthreads();
-    for (int d = 0; d < ns; d++) {
-        const int s = s0 + d;
-        const uint32_t tw_step = n >> (s - 1);               // N / m2
-        for (uint32_t bf = tid; bf < elems / 2; bf += 256) {
-            const uint32_t col = bf & (Cc - 1), q = bf >> cc_log;
-            const uint32_t mid0 = ((q >> d) << (d + 1)) | (q & ((1u << d) - 1u));
-            const uint32_t mid1 = mid0 | (1u << d);
-            if (c0 + col < ncols) {
-                const uint32_t j = ((mid0 & ((1u << d) - 1u)) << lo_bits) + lo;    // row index mod m2
-                IccElem<Q> t1 = ld_elem<Q>(tw + (size_t)j * tw_step);
-                uint32_t* pa = reinterpret_cast<uint32_t*>(&lds[((mid0 << cc_log) + col) * 4]);
-                uint32_t* pb = reinterpret_cast<uint32_t*>(&lds[((mid1 << cc_log) + col) * 4]);
-                IccElem<Q> a, b;
-                a.p = ld_fe<IccFp>(pa); a.q = ld_fe<Q>(pa + 8);
-                b.p = ld_fe<IccFp>(pb); b.q = ld_fe<Q>(pb + 8);
-                butterfly<Q>(a, b, t1, false, j == 0);
-                st_fe<IccFp>(pa, a.p); st_fe<Q>(pa + 8, a.q);
-                st_fe<IccFp>(pb, b.p); st_fe<Q>(pb + 8, b.q);
-            }
-        }
-        __syncthreads();
-    }
-    for (uint32_t e = tid; e < elems; e += 256) {
-        const uint32_t mid = e >> cc_log, col = e & (Cc - 1);
-        if (c0 + col < ncols) {
-            const size_t gi = (size_t)(row_base + (mid << lo_bits)) * ncols + c0 + col;
-            if (LAST) {    // k_icc_finish fused: outputs straight from the tile
-                const uint32_t* pe = reinterpret_cast<const uint32_t*>(&lds[e * 4]);
-                IccElem<Q> el;
-                el.p = ld_fe<IccFp>(pe); el.q = ld_fe<Q>(pe + 8);
-                icc_finish_elem<Q>(el, gi, out);
-            } else {
-                uint4* dst = reinterpret_cast<uint4*>(work + gi);
-                dst[0] = lds[e * 4 + 0]; dst[1] = lds[e * 4 + 1]; dst[2] = lds[e * 4 + 2]; dst[3] = lds[e * 4 + 3];
-            }
-        }
-    }
-}
 
 // value of LIMBS (17..24) 32-bit limbs reduced into Montgomery form mod M: Horner over 256-bit digits with R = 2^256
 template <class M, int LIMBS>
@@ -423,41 +285,6 @@ __device__ __forceinline__ Fe<M> icc_reduce512(const uint32_t a[16]) {
     // Montgomery product with R2 takes any 256-bit operand: x -> x * R mod M
     Fe<M> acc = fe_mul<M>(d1, r2);
     return fe_add<M>(fe_mul<M>(acc, r2), fe_mul<M>(d0, r2));
-}
-
-// Server::mix data part (Server.hpp:1269-1278): out[i] = (A0[i] + v^i A1[i]) % LCM, out[i+len] = (A0[i] - v^i A1[i]) % LCM,
-// v = w^(N/len); symbols in and out are 64-byte little-endian values < LCM.  One thread: one (row i, column).
-template <class Q>
-__global__ void __launch_bounds__(256)
-k_icc_mix(const uint8_t* __restrict__ a0, const uint8_t* __restrict__ a1, uint32_t len, uint32_t ncols,
-          const IccElem<Q>* __restrict__ tw, uint32_t tw_step, uint8_t* __restrict__ out) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)len * ncols) return;
-    const uint32_t i = (uint32_t)(t / ncols);
-    uint32_t va[16], vb[16];
-    const uint4* pa = reinterpret_cast<const uint4*>(a0 + 64 * t);
-    const uint4* pb = reinterpret_cast<const uint4*>(a1 + 64 * t);
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        uint4 x = pa[k], y = pb[k];
-        va[4 * k] = x.x; va[4 * k + 1] = x.y; va[4 * k + 2] = x.z; va[4 * k + 3] = x.w;
-        vb[4 * k] = y.x; vb[4 * k + 1] = y.y; vb[4 * k + 2] = y.z; vb[4 * k + 3] = y.w;
-    }
-    IccElem<Q> ea, eb;
-    ea.p = icc_reduce512<IccFp>(va); ea.q = icc_reduce512<Q>(va);
-    eb.p = icc_reduce512<IccFp>(vb); eb.q = icc_reduce512<Q>(vb);
-    IccElem<Q> twi = ld_elem<Q>(tw + (size_t)i * tw_step);
-    butterfly<Q>(ea, eb, twi, false);
-#pragma unroll 1
-    for (int h = 0; h < 2; h++) {
-        const IccElem<Q>& e = h ? eb : ea;
-        Fe<IccFp> P = fe_from_mont<IccFp>(e.p);
-        Fe<Q> pq;
-#pragma unroll
-        for (int k = 0; k < 8; k++) pq.v[k] = P.v[k];
-        fe_reduce_plain<Q>(pq.v, Q::MAX_Q_P + 1);
-        icc_store_lcm<Q>(e, P, fe_to_mont<Q>(pq), out + 64 * (t + (size_t)h * len * ncols));
-    }
 }
 
 // rows_in = N x N identity (32-byte LE chunks): entry (i, i) = 1

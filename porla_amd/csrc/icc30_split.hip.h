@@ -1,11 +1,11 @@
 // The ICC encode kernel of the reduced-radix form with the two residues of a symbol treated as two PLANES and two butterfly
 // stages per LDS round trip -- the same network (Server::CRebuild_Cached, porla/Server/Server.hpp:1548-1687 X part, :1691-1830
 // Y part; the twiddle product t = vi * X[k+m2] of :1649-1655), the same tiles and passes, the same arithmetic per residue as
-// icc30.hip.h:k_icc_fused30, so the outputs are bit for bit the same.  What changes is how a block holds its tile:
+// the round-2 kernel that held both residues side by side, so the outputs are bit for bit the same.  What changes is how a block holds its tile:
 //
 //   * Z/LCM = Z/p_icc x Z/q: nothing couples the residue mod p_icc and the residue mod q of a symbol before the finish step.
 //     A block therefore runs the ns stages of its tile for the p_icc plane first and for the q plane second, through ONE LDS
-//     region of 512 slots x 40 bytes = 20 KiB (k_icc_fused30: 80-byte slots, 40 KiB).  Eight 128-lane blocks fit a CU instead of
+//     region of 512 slots x 40 bytes = 20 KiB (the side-by-side form of round 2: 80-byte slots, 40 KiB).  Eight 128-lane blocks fit a CU instead of
 //     four 256-lane ones with half the symbols per lane in flight: the product of fe30.hip.h is one dependent chain of
 //     multiply-adds, a lone wave issues it at half rate, and a SIMD needs two READY waves to keep its multiplier busy -- with
 //     four resident waves that each spend a fifth of their life in an LDS round trip or at a barrier it often has one.

@@ -31,31 +31,8 @@ using Fr = Bn254Fr;
 namespace {
 
 // compute_digest hoisted over rows (main.go:70-89): out[r] = big-endian bytes of alpha * f_r(tau) mod r, f_r given by n
-// coefficients of 32 big-endian bytes (fr.SetBytes: reduced mod r), Horner from the top coefficient.  One lane per row.
-__global__ void __launch_bounds__(256)
-k_kzg_eval_rows(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_coeffs, Fe<Bn254Fr> tau, Fe<Bn254Fr> alpha,
-                uint8_t* __restrict__ out, uint32_t out_stride, const uint8_t* __restrict__ second) {
-    using F = Bn254Fr;
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rows) return;
-    const uint8_t* row = rows + (size_t)r * n_coeffs * 32;
-    Fe<F> acc = fe_zero<F>();
-    for (uint32_t i = n_coeffs; i-- > 0;) {
-        Fe<F> c;
-        load_be256(c.v, row + (size_t)i * 32);
-        fe_reduce_plain<F>(c.v, 6);
-        acc = fe_add<F>(fe_mul<F>(acc, tau), fe_to_mont<F>(c));
-    }
-    acc = fe_from_mont<F>(fe_mul<F>(acc, alpha));
-    store_be256(out + (size_t)r * out_stride, acc.v);
-    if (second) {           // the MAC batch: the row's second scalar rides along (out_stride = 64)
-        const uint4* src = (const uint4*)(second + (size_t)r * 32);
-        uint4* dst = (uint4*)(out + (size_t)r * out_stride + 32);
-        dst[0] = src[0]; dst[1] = src[1];
-    }
-}
-
-// The same evaluation with EIGHT lanes per row in the reduced-radix plain stream of icc30.hip.h (modulus r = IccBn254Fr's q):
+// coefficients of 32 big-endian bytes (fr.SetBytes: reduced mod r).
+// The evaluation with EIGHT lanes per row in the reduced-radix plain stream (rows longer than KZG_LAZY_MAX_COEFFS) of icc30.hip.h (modulus r = IccBn254Fr's q):
 //   f(tau) = sum_{j<8} tau^j g_j(tau^8),   g_j(x) = sum_k c_{8k+j} x^k
 // lane j runs Horner over its 16 coefficients with tau^8 in the 2^270 form -- acc * (tau^8 2^270) / 2^270 + c: the stream stays plain,
 // a raw 256-bit coefficient is added unreduced (SetBytes' reduction happens in the last step), ONE product per coefficient where
@@ -349,10 +326,7 @@ struct CommitQueue {
     bool contended = false;      // a caller found a batch in flight since the last batch was formed
 };
 CommitQueue cq;
-inline int commit_linger_us() {
-    static const int v = getenv("PORLA_COMMIT_LINGER_US") ? atoi(getenv("PORLA_COMMIT_LINGER_US")) : 12;
-    return v < 0 ? 0 : (v > 1000 ? 1000 : v);
-}
+constexpr int COMMIT_LINGER_US = 12;
 
 int commit_coalesced(const uint8_t* row, uint8_t out[64]) {
     CommitQueue::Item it;
@@ -366,26 +340,17 @@ int commit_coalesced(const uint8_t* row, uint8_t out[64]) {
         if (cq.contended) {
             // Several threads are calling (the reference's pool threads, Server.hpp:550-560): the callers of the batch that just
             // finished are on their way back.  Without a pause the first one back leads a batch of whoever happens to be queued
-            // (sizes 1 .. 8 evenly, PORLA_COMMIT_STATS=1 prints the histogram); 12 us let them form ONE batch: 59 k -> 87 k
+            // (sizes 1 .. 8 evenly); 12 us let them form ONE batch: 59 k -> 87 k
             // commits/s from 8 C threads, 33 k -> 46 k from 4 (profiles/r02_t_commit_queue_linger.txt).  A lone caller never waits.
             cq.contended = false;
             lk.unlock();
             const auto t0 = std::chrono::steady_clock::now();
-            while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(commit_linger_us())) __builtin_ia32_pause();
+            while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(COMMIT_LINGER_US)) __builtin_ia32_pause();
             lk.lock();
         }
         std::vector<CommitQueue::Item*> batch;
         const size_t take = cq.q.size() < (size_t)FB_SMALL_MAX_ROWS ? cq.q.size() : (size_t)FB_SMALL_MAX_ROWS;
         batch.assign(cq.q.begin(), cq.q.begin() + (long)take);
-        {   // PORLA_COMMIT_STATS=1: batch-size histogram on stderr at exit (measurement aid)
-            static const bool stats = getenv("PORLA_COMMIT_STATS") != nullptr;
-            if (stats) {
-                static unsigned long hist[FB_SMALL_MAX_ROWS + 1];
-                static bool reg = false;
-                hist[take]++;
-                if (!reg) { reg = true; atexit([] { for (int i = 1; i <= FB_SMALL_MAX_ROWS; i++) if (hist[i]) fprintf(stderr, "[commit queue] batches of %d rows: %lu\n", i, hist[i]); }); }
-            }
-        }
         cq.q.erase(cq.q.begin(), cq.q.begin() + (long)take);
         lk.unlock();
         int rc;
@@ -789,12 +754,10 @@ static int kzg_eval_rows_launch(KzgState::Dev* kd, const void* d_rows, size_t n_
     // fence is recorded after its commit's last kernel; the three client-side tables share d_eval, so enter all of them)
     if ((rc = kd->fb_g.fence.enter(stream))) return rc;
     if ((rc = kd->fb_gh.fence.enter(stream))) return rc;
-    static const bool eval30 = !(getenv("PORLA_KZG_EVAL30") && getenv("PORLA_KZG_EVAL30")[0] == '0');
-    static const bool lazy = eval30 && !(getenv("PORLA_KZG_EVAL_LAZY") && getenv("PORLA_KZG_EVAL_LAZY")[0] == '0');
     // x 2^270 mod r = from_mont(x R * (2^270 R) / R)
     static constexpr uint32_t C270[8] = {0x0ffead6fu, 0x36c69455u, 0x37577218u, 0xb1e9be3cu, 0xdf11f427u, 0x9e7d8ca3u, 0xed6d3304u, 0x279be39au};   // 2^270 mod r
     const uint32_t n_coeffs = (uint32_t)g.n_samples;
-    if (lazy && n_coeffs <= KZG_LAZY_MAX_COEFFS) {
+    if (n_coeffs <= KZG_LAZY_MAX_COEFFS) {
         const uint32_t entries = (n_coeffs + 7) / 8 * 8;
         if (!kd->d_tau29 || kd->tau29_n != n_coeffs || memcmp(kd->tau29_tau.v, g.tau.v, sizeof(g.tau.v)) != 0) {
             std::vector<uint32_t> tab((size_t)entries * KZG_LAZY_ENTRY_WORDS, 0u);
@@ -830,8 +793,8 @@ static int kzg_eval_rows_launch(KzgState::Dev* kd, const void* d_rows, size_t n_
         return PORLA_OK;
     }
     ProfScope ps("kzg_eval_rows", stream);
-    if (eval30) {
-        // tau^j, tau^8 and alpha in the 2^270 form
+    {
+        // longer rows: Horner with eight lanes per row; tau^j, tau^8 and alpha in the 2^270 form
         Fe<Fr> c270;
         for (int w = 0; w < 8; w++) c270.v[w] = C270[w];
         c270 = fe_to_mont<Fr>(c270);
@@ -846,10 +809,6 @@ static int kzg_eval_rows_launch(KzgState::Dev* kd, const void* d_rows, size_t n_
         to270(g.alpha, K.alpha);
         hipLaunchKernelGGL(k_kzg_eval_rows30, dim3((unsigned)((8 * n_rows + 255) / 256)), dim3(256), 0, stream, (const uint8_t*)d_rows,
                            (uint32_t)n_rows, (uint32_t)g.n_samples, K, (uint8_t*)kd->d_eval, out_stride, (const uint8_t*)d_second);
-    } else {
-        hipLaunchKernelGGL(k_kzg_eval_rows, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, (const uint8_t*)d_rows,
-                           (uint32_t)n_rows, (uint32_t)g.n_samples, g.tau, g.alpha, (uint8_t*)kd->d_eval, out_stride,
-                           (const uint8_t*)d_second);
     }
     return PORLA_OK;
 }
@@ -1102,15 +1061,6 @@ int porla_kzg_audit_device(const void* d_rows64, const uint64_t* d_idx64, const 
     const size_t n = kzg_n_samples();
     if (n == 0) { set_last_error("porla: SRS not initialised (call init_SRS / init_SRS_from_data first)"); return PORLA_ERR_STATE; }
     std::lock_guard<std::mutex> lk(g_audit_call_mu);
-    // PORLA_AUDIT_TRACE=1: host-side time of each step of the call, printed to stderr
-    static const bool trace = getenv("PORLA_AUDIT_TRACE") != nullptr;
-    auto t_last = std::chrono::steady_clock::now();
-    auto lap = [&](const char* what) {
-        if (!trace) return;
-        const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[audit] %-28s %7.1f us\n", what, std::chrono::duration<double, std::micro>(now - t_last).count());
-        t_last = now;
-    };
     int dev = 0;
     PORLA_HIP(hipGetDevice(&dev));
     AuditPinned* pin = nullptr;
@@ -1151,26 +1101,22 @@ int porla_kzg_audit_device(const void* d_rows64, const uint64_t* d_idx64, const 
     // the other way round the combine was seen to wait ~85 us behind them), then the pair starts on the audit slot's own stream
     rc = porla_audit_combine_device(d_rows64, d_idx64, d_coef64, n64, d_rows32, d_idx32, d_coef32, n32, n, 0, nullptr, nullptr,
                                     pin_dev, (uint8_t*)pin_dev + 32 * n, stream);
-    lap("combine enqueued");
     if (rc == PORLA_OK && pair) {
         rc = msm_pair_gather_begin<Bn254G1>(MSM_AUDIT_SLOT, (const uint8_t*)d_mac_store, (const uint8_t*)d_align_store, d_mac_idx,
                                                 d_mac_coef, n_macs, aw->own_stream);
         pair_begun = rc == PORLA_OK;
-        lap("pair begun");
     }
     if (rc == PORLA_OK && hipStreamSynchronize(stream) != hipSuccess) {
         set_last_error("porla: hipStreamSynchronize failed in the audit");
         rc = PORLA_ERR_HIP;
     }
     if (rc) { (void)collect_pair(); return rc; }
-    lap("combine + wait");
     std::vector<uint8_t> three(3 * 32 * n);
     memcpy(three.data(), h_c, 32 * n);
     memcpy(three.data() + 32 * n, h_b, 32 * n);
     kzg_open_rows(h_b, n, random_point, three.data() + 64 * n, proof_point, proof_claim);
     if (b_out) memcpy(b_out, h_b, 32 * n);
     uint8_t outs[192];
-    lap("opening on the host");
     // the three row sums stay projective until the pair's two sums are in: ONE inversion normalises all five points
     XYZZ<Fp> five[5];
     bool raw3 = false;
@@ -1188,7 +1134,6 @@ int porla_kzg_audit_device(const void* d_rows64, const uint64_t* d_idx64, const 
     } else {
         rc = commit_rows(three.data(), false, 3, n, outs, nullptr);
     }
-    lap("three commitments");
     int rc2;
     if (raw3) {
         rc2 = msm_pair_end<Bn254G1>(MSM_AUDIT_SLOT, &five[3], &five[4]);
@@ -1203,7 +1148,6 @@ int porla_kzg_audit_device(const void* d_rows64, const uint64_t* d_idx64, const 
     } else {
         rc2 = collect_pair();
     }
-    lap("pair collected");
     if (rc) return rc;
     if (rc2) return rc2;
     if (!pair) {

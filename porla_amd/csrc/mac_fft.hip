@@ -37,7 +37,15 @@ template <class C> struct FbOf;
 template <> struct FbOf<Bn254G1> { static FixedBase<Bn254G1>& get(MacWs* w) { return w->fb_bn; } };
 template <> struct FbOf<Secp256k1G> { static FixedBase<Secp256k1G>& get(MacWs* w) { return w->fb_secp; } };
 static std::mutex g_mac_mu;
-static size_t g_matrix_max = getenv("PORLA_MAC_MATRIX_MAX") ? (size_t)atol(getenv("PORLA_MAC_MATRIX_MAX")) : 512;
+static size_t g_matrix_max = 512;     // porla_icc_mac_set_matrix_max changes it
+// Up to 2^16 rows a stage is latency bound (one or two waves per SIMD even with four lanes per butterfly): the quad-lane kernels
+// (2^16 rows: 16.7 ms against 18.5 ms with one lane per butterfly; 2^17 rows: 35.4 against 22.2); the element-wise kernels switch
+// earlier (`own`).  PORLA_MAC_QUAD_MAX (log2 of the row count, default 16; 0 = one lane per butterfly everywhere) moves the
+// boundary -- the tests use it to run the large-N kernels at sizes the oracle finishes in seconds.
+static int macq_max_log(int own) {
+    static const int v = getenv("PORLA_MAC_QUAD_MAX") ? atoi(getenv("PORLA_MAC_QUAD_MAX")) : 16;
+    return v < own ? v : own;
+}
 static std::vector<MacWs*> g_mac_ws;
 
 static int get_mac_ws(MacWs** out) {
@@ -101,26 +109,23 @@ static int mac_mix_core(MacWs* ws, int curve, const uint8_t* d_a0, const uint8_t
     int rc;
     if ((rc = ensure_mac_twiddles<Q>(ws, curve, n_total, stream))) return rc;
     ProfScope ps("mac_mix", stream);
-    static const bool quad = !(getenv("PORLA_MAC_QUAD") && getenv("PORLA_MAC_QUAD")[0] == '0');
     const unsigned sets = d_b0 ? 2u : 1u;               // the second array pair (MAC alignments beside the MAC commitments)
-    if constexpr (C::F30_LAZY) {
-        static const int quad_max_log = getenv("PORLA_MAC_MIX_QUAD_MAX") ? atoi(getenv("PORLA_MAC_MIX_QUAD_MAX")) : 14;
-        if (quad && len * sets <= ((size_t)1 << quad_max_log)) {   // latency bound: four lanes per element (k_mac_stage30_quad's ladder)
-            hipLaunchKernelGGL((k_mac_mix_quad<C>), dim3((unsigned)((len + MACQ_BF - 1) / MACQ_BF), sets), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream, d_a0,
-                               d_a1, (uint32_t)len, (const uint32_t*)ws->tws.p, (uint32_t)(n_total / len), d_out, d_b0, d_b1, d_out_b);
-            PORLA_HIP(hipGetLastError());
-            return PORLA_OK;
-        }
-        if (quad && sets == 2 && len <= ((size_t)1 << quad_max_log)) {
-            // two arrays of a length the four-lane kernel still takes one at a time (2^14 rows: 0.63 ms each; both in one launch of
-            // the one-lane kernel: 1.36 ms): two launches, one after the other
-            hipLaunchKernelGGL((k_mac_mix_quad<C>), dim3((unsigned)((len + MACQ_BF - 1) / MACQ_BF), 1), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream, d_a0, d_a1,
-                               (uint32_t)len, (const uint32_t*)ws->tws.p, (uint32_t)(n_total / len), d_out, d_b0, d_b1, d_out_b);
-            hipLaunchKernelGGL((k_mac_mix_quad<C>), dim3((unsigned)((len + MACQ_BF - 1) / MACQ_BF), 1), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream, d_b0, d_b1,
-                               (uint32_t)len, (const uint32_t*)ws->tws.p, (uint32_t)(n_total / len), d_out_b, d_b0, d_b1, d_out_b);
-            PORLA_HIP(hipGetLastError());
-            return PORLA_OK;
-        }
+    const size_t quad_max = (size_t)1 << macq_max_log(14);
+    if (macq_max_log(14) > 0 && len * sets <= quad_max) {   // latency bound: four lanes per element (k_mac_stage30_quad's ladder)
+        hipLaunchKernelGGL((k_mac_mix_quad<C>), dim3((unsigned)((len + MACQ_BF - 1) / MACQ_BF), sets), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream, d_a0,
+                           d_a1, (uint32_t)len, (const uint32_t*)ws->tws.p, (uint32_t)(n_total / len), d_out, d_b0, d_b1, d_out_b);
+        PORLA_HIP(hipGetLastError());
+        return PORLA_OK;
+    }
+    if (macq_max_log(14) > 0 && sets == 2 && len <= quad_max) {
+        // two arrays of a length the four-lane kernel still takes one at a time (2^14 rows: 0.63 ms each; both in one launch of
+        // the one-lane kernel: 1.36 ms): two launches, one after the other
+        hipLaunchKernelGGL((k_mac_mix_quad<C>), dim3((unsigned)((len + MACQ_BF - 1) / MACQ_BF), 1), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream, d_a0, d_a1,
+                           (uint32_t)len, (const uint32_t*)ws->tws.p, (uint32_t)(n_total / len), d_out, d_b0, d_b1, d_out_b);
+        hipLaunchKernelGGL((k_mac_mix_quad<C>), dim3((unsigned)((len + MACQ_BF - 1) / MACQ_BF), 1), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream, d_b0, d_b1,
+                           (uint32_t)len, (const uint32_t*)ws->tws.p, (uint32_t)(n_total / len), d_out_b, d_b0, d_b1, d_out_b);
+        PORLA_HIP(hipGetLastError());
+        return PORLA_OK;
     }
     hipLaunchKernelGGL((k_mac_mix<C>), dim3((unsigned)((len + 63) / 64), sets), dim3(64), 0, stream, d_a0, d_a1, (uint32_t)len,
                        (const uint32_t*)ws->tws.p, (uint32_t)(n_total / len), d_out, d_b0, d_b1, d_out_b);
@@ -161,8 +166,7 @@ static int mac_encode_core(MacWs* ws, int curve, const uint8_t* d_in, size_t n, 
         fb.keep_build_buffers = true;
         hipLaunchKernelGGL((k_points_to_mont<C, false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_in,
                            (Affine<M>*)ws->mont.p, (uint32_t)n);
-        static const int mw = getenv("PORLA_MAC_MATRIX_WINDOW") ? atoi(getenv("PORLA_MAC_MATRIX_WINDOW")) : 8;
-        if ((rc = fb.build((const Affine<M>*)ws->mont.p, n, mw, stream))) return rc;
+        if ((rc = fb.build((const Affine<M>*)ws->mont.p, n, 8, stream))) return rc;      // 8-bit windows: the table is rebuilt per call
         return fb.commit_device((const uint8_t*)ws->F.p, n, n, n * 32, d_out, stream);
     }
     if ((rc = ws->work.ensure(n * sizeof(XYZZ<M>)))) return rc;
@@ -177,45 +181,33 @@ static int mac_encode_core(MacWs* ws, int curve, const uint8_t* d_in, size_t n, 
         fe_reduce_plain<Q>(wt.v, 8);
         use_wt = part == 1;
     }
+    const bool quad_path = macq_max_log(16) > 0 && n <= ((size_t)1 << macq_max_log(16));
     {
         ProfScope ps("mac_load", stream);
-        if constexpr (C::F30_LAZY) {
-            static const bool quad = !(getenv("PORLA_MAC_QUAD") && getenv("PORLA_MAC_QUAD")[0] == '0');
-            if (use_wt && quad && n <= ((size_t)1 << 14))
-                hipLaunchKernelGGL((k_mac_load30_quad<C>), dim3((unsigned)((n + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream, d_in,
-                                   (uint32_t)n, (XYZZ<M>*)ws->work.p, wt);
-            else if (use_wt)
-                hipLaunchKernelGGL((k_mac_load30<C, true>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_in, (uint32_t)n,
-                                   (XYZZ<M>*)ws->work.p, wt);
-            else
-                hipLaunchKernelGGL((k_mac_load30<C, false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_in, (uint32_t)n,
-                                   (XYZZ<M>*)ws->work.p, wt);
-        } else
-            hipLaunchKernelGGL((k_mac_load<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_in, (uint32_t)n,
-                               (XYZZ<M>*)ws->work.p, wt, use_wt);
+        if (use_wt && macq_max_log(14) > 0 && n <= ((size_t)1 << macq_max_log(14)))
+            hipLaunchKernelGGL((k_mac_load30_quad<C>), dim3((unsigned)((n + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream, d_in,
+                               (uint32_t)n, (XYZZ<M>*)ws->work.p, wt);
+        else if (use_wt)
+            hipLaunchKernelGGL((k_mac_load30<C, true>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_in, (uint32_t)n,
+                               (XYZZ<M>*)ws->work.p, wt);
+        else
+            hipLaunchKernelGGL((k_mac_load30<C, false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_in, (uint32_t)n,
+                               (XYZZ<M>*)ws->work.p, wt);
     }
     for (int s = 1; s <= logn; s++) {
         ProfScope ps("mac_stage", stream);
-        if constexpr (C::F30_LAZY) {
-            // up to 2^16 rows a stage is latency bound (one or two waves per SIMD even with four lanes per butterfly): the quad-lane
-            // ladder (2^16 rows: 16.7 ms against 18.5 ms with one lane per butterfly; 2^17 rows: 35.4 against 22.2)
-            static const bool quad = !(getenv("PORLA_MAC_QUAD") && getenv("PORLA_MAC_QUAD")[0] == '0');
-            static const int quad_max_log = getenv("PORLA_MAC_QUAD_MAX") ? atoi(getenv("PORLA_MAC_QUAD_MAX")) : 16;
-            if (quad && s == 1)      // every twiddle of stage 1 is w^0 = 1: two additions per butterfly, no ladder
-                hipLaunchKernelGGL((k_mac_stage1_quad<C>), dim3((unsigned)((n / 2 + 63) / 64)), dim3(256), 0, stream, (XYZZ<M>*)ws->work.p,
-                                   (uint32_t)n);
-            else if (quad && n <= ((size_t)1 << quad_max_log) && (n >> s) >= 16 && n >= 128)
-                // >= 16 butterflies per twiddle (and whole blocks of 64): a wave's 16 quads share their scalar -- the sparse ladder
-                hipLaunchKernelGGL((k_mac_stage30_quad<C, true>), dim3((unsigned)((n / 2 + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream,
-                                   (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->tws.p, (uint32_t)n, s);
-            else if (quad && n <= ((size_t)1 << quad_max_log))
-                hipLaunchKernelGGL((k_mac_stage30_quad<C, false>), dim3((unsigned)((n / 2 + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream,
-                                   (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->tws.p, (uint32_t)n, s);
-            else
-                hipLaunchKernelGGL((k_mac_stage30<C>), dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, stream, (XYZZ<M>*)ws->work.p,
-                                   (const uint32_t*)ws->tws.p, (uint32_t)n, s);
-        } else
-            hipLaunchKernelGGL((k_mac_stage<C>), dim3((unsigned)((n / 2 + 63) / 64)), dim3(64), 0, stream, (XYZZ<M>*)ws->work.p,
+        if (quad_path && s == 1)      // every twiddle of stage 1 is w^0 = 1: two additions per butterfly, no ladder
+            hipLaunchKernelGGL((k_mac_stage1_quad<C>), dim3((unsigned)((n / 2 + 63) / 64)), dim3(256), 0, stream, (XYZZ<M>*)ws->work.p,
+                               (uint32_t)n);
+        else if (quad_path && (n >> s) >= 16 && n >= 128)
+            // >= 16 butterflies per twiddle (and whole blocks of 64): a wave's 16 quads share their scalar -- the sparse ladder
+            hipLaunchKernelGGL((k_mac_stage30_quad<C, true>), dim3((unsigned)((n / 2 + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream,
+                               (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->tws.p, (uint32_t)n, s);
+        else if (quad_path)
+            hipLaunchKernelGGL((k_mac_stage30_quad<C, false>), dim3((unsigned)((n / 2 + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream,
+                               (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->tws.p, (uint32_t)n, s);
+        else
+            hipLaunchKernelGGL((k_mac_stage30<C>), dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, stream, (XYZZ<M>*)ws->work.p,
                                (const uint32_t*)ws->tws.p, (uint32_t)n, s);
     }
     {
@@ -224,26 +216,19 @@ static int mac_encode_core(MacWs* ws, int curve, const uint8_t* d_in, size_t n, 
                            (uint32_t)n, d_out);
     }
     if (d_out_y) {
-        if constexpr (C::F30_LAZY) {
-            if ((rc = ws->work_y.ensure(n * sizeof(XYZZ<M>)))) return rc;
-            {
-                ProfScope ps("mac_scale", stream);
-                static const bool quad = !(getenv("PORLA_MAC_QUAD") && getenv("PORLA_MAC_QUAD")[0] == '0');
-                static const int scale_quad_max = getenv("PORLA_MAC_SCALE_QUAD_MAX") ? atoi(getenv("PORLA_MAC_SCALE_QUAD_MAX")) : 15;
-                if (quad && n <= ((size_t)1 << scale_quad_max))
-                    hipLaunchKernelGGL((k_mac_load30_quad<C, true>), dim3((unsigned)((n + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream,
-                                       (const uint8_t*)ws->work.p, (uint32_t)n, (XYZZ<M>*)ws->work_y.p, wt);
-                else
-                    hipLaunchKernelGGL((k_mac_scale30<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, (const XYZZ<M>*)ws->work.p,
-                                       (uint32_t)n, (XYZZ<M>*)ws->work_y.p, wt);
-            }
-            ProfScope ps("mac_finish", stream);
-            hipLaunchKernelGGL((k_mac_finish<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, (const XYZZ<M>*)ws->work_y.p,
-                               (uint32_t)n, d_out_y);
-        } else {
-            set_last_error("porla: the two-part MAC encode needs the reduced-radix ladder");
-            return PORLA_ERR_STATE;
+        if ((rc = ws->work_y.ensure(n * sizeof(XYZZ<M>)))) return rc;
+        {
+            ProfScope ps("mac_scale", stream);
+            if (macq_max_log(15) > 0 && n <= ((size_t)1 << macq_max_log(15)))
+                hipLaunchKernelGGL((k_mac_load30_quad<C, true>), dim3((unsigned)((n + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream,
+                                   (const uint8_t*)ws->work.p, (uint32_t)n, (XYZZ<M>*)ws->work_y.p, wt);
+            else
+                hipLaunchKernelGGL((k_mac_scale30<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, (const XYZZ<M>*)ws->work.p,
+                                   (uint32_t)n, (XYZZ<M>*)ws->work_y.p, wt);
         }
+        ProfScope ps("mac_finish", stream);
+        hipLaunchKernelGGL((k_mac_finish<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, (const XYZZ<M>*)ws->work_y.p,
+                           (uint32_t)n, d_out_y);
     }
     PORLA_HIP(hipGetLastError());
     return PORLA_OK;

@@ -8,10 +8,10 @@
 // The multiplier is the INTEGER v^j mod p_icc handed to the group as a scalar (convert_ZZ_to_scalar, utils.h:307-318),
 // i.e. reduced mod the group order by fr.SetBytes (main.go:209) / the secp256k1 scalar.
 //
-// MI355X: N/2 independent scalar multiplications per stage, log2 N dependent stages.  One lane owns one butterfly; the
-// scalar multiplication is a signed fixed-window (4-bit) ladder over extended-Jacobian points kept in HBM between
-// stages (128 B per MAC), so a stage is N/2 * (256 doublings + ~64 additions) and is VALU (integer multiply) bound;
-// HBM traffic is 2 * 128 B per MAC per stage.  Stage twiddles with value 1 (j = 0) skip the ladder.
+// MI355X: N/2 independent scalar multiplications per stage, log2 N dependent stages; extended-Jacobian points (128 B per MAC, the
+// lazy memory form of ec30.hip.h) stay in HBM between stages: 2 * 128 B per MAC per stage, against ~2 000 field products per
+// butterfly -- VALU (integer multiply) bound.  Up to 2^16 rows a butterfly runs on the four lanes of a quad with its accumulator
+// in registers (k_mac_stage30_quad), above that one lane per butterfly (k_mac_stage30).
 #pragma once
 #include "fixed_base.hip.h"
 #include "icc.hip.h"
@@ -42,59 +42,7 @@ __global__ void k_mac_twiddles(uint32_t* __restrict__ tws, uint32_t n, const Fe<
     d[1] = make_uint4(t[4], t[5], t[6], t[7]);
 }
 
-template <class M>
-__device__ __forceinline__ XYZZ<M> xyzz_neg(const XYZZ<M>& p) {
-    XYZZ<M> r = p;
-    r.y = fe_neg<M>(p.y);
-    return r;
-}
-
-// k * P, k < 2^256 plain limbs: signed 4-bit fixed windows, most significant first (65 digits cover the carry)
-template <class M>
-__device__ __noinline__ XYZZ<M> xyzz_scalar_mul(XYZZ<M> P, const uint32_t k[8]) {
-    uint32_t nz = 0;
-#pragma unroll
-    for (int i = 1; i < 8; i++) nz |= k[i];
-    if (nz == 0 && k[0] == 1) return P;
-    if (nz == 0 && k[0] == 0) return xyzz_inf<M>();
-    XYZZ<M> tbl[8];
-    tbl[0] = P;
-#pragma unroll 1
-    for (int i = 1; i < 8; i++) {
-        tbl[i] = tbl[i - 1];
-        xyzz_add_cold<M>(&tbl[i], &P);
-    }
-    // signed digits, least significant first: d in [-8, 8]
-    int8_t dig[65];
-    uint32_t carry = 0;
-#pragma unroll 1
-    for (int i = 0; i < 64; i++) {
-        uint32_t limb = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) limb = (j == (i >> 3)) ? k[j] : limb;
-        uint32_t d = ((limb >> ((i & 7) * 4)) & 15u) + carry;
-        if (d > 8) { dig[i] = (int8_t)((int)d - 16); carry = 1; }
-        else { dig[i] = (int8_t)d; carry = 0; }
-    }
-    dig[64] = (int8_t)carry;
-    XYZZ<M> acc = xyzz_inf<M>();
-#pragma unroll 1
-    for (int i = 64; i >= 0; i--) {
-        if (!xyzz_is_inf<M>(acc)) {
-#pragma unroll 1
-            for (int d = 0; d < 4; d++) xyzz_double_cold<M>(&acc);
-        }
-        int d = dig[i];
-        if (d != 0) {
-            XYZZ<M> t = tbl[(d < 0 ? -d : d) - 1];
-            if (d < 0) t.y = fe_neg<M>(t.y);
-            xyzz_add_cold<M>(&acc, &t);
-        }
-    }
-    return acc;
-}
-
-// ---------------------------------------------------------------- the same ladder in the reduced-radix form (C::F30_LAZY)
+// ---------------------------------------------------------------- the scalar-multiplication ladder, one lane per point (large N)
 // k * P with the curve's endomorphism: k = k1 + lambda k2 (glv.hip.h; |k1|, |k2| < 2^128), then ONE joint ladder over both
 // halves -- 33 signed 4-bit windows, 4 doublings each, and per window at most one addition from the table of P's multiples
 // and one from the same table with X scaled by beta (= the table of phi(P)): 132 doublings + <= 66 additions instead of
@@ -670,56 +618,6 @@ k_mac_mix_quad(const uint8_t* __restrict__ a0, const uint8_t* __restrict__ a1, u
         store_affine_be<M>(out + ((size_t)i + (r ? len : 0)) * 64, xyzz30_to_xyzz<M>(xyzz30_load_lazy<M>(&L.qd[q].tbl[1 + r])));
 }
 
-// 64-byte big-endian affine MACs -> XYZZ work array; part 1 (Y): times wt (Server.hpp:1528-1536)
-template <class C>
-__global__ void __launch_bounds__(64)
-k_mac_load(const uint8_t* __restrict__ in, uint32_t n, XYZZ<typename C::Fp>* __restrict__ work, MacScalar wt, int use_wt) {
-    using M = typename C::Fp;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Affine<M> a;
-    load_be256(a.x.v, in + (size_t)i * 64);
-    load_be256(a.y.v, in + (size_t)i * 64 + 32);
-    fe_reduce_plain<M>(a.x.v, 6);
-    fe_reduce_plain<M>(a.y.v, 6);
-    a.x = fe_to_mont<M>(a.x);
-    a.y = fe_to_mont<M>(a.y);
-    XYZZ<M> p = xyzz_from_affine<M>(a);
-    if (use_wt) {
-        uint32_t k[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) k[j] = wt.v[j];
-        p = xyzz_scalar_mul<M>(p, k);
-    }
-    store_xyzz<M>(work + i, p);
-}
-
-// stage s: m = 2^s, m2 = m/2; butterfly t <-> (j = t % m2, k = (t / m2) * m + j); twiddle exponent e = j * (n / m2)
-template <class C>
-__global__ void __launch_bounds__(64)
-k_mac_stage(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restrict__ tws, uint32_t n, int s) {
-    using M = typename C::Fp;
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n / 2) return;
-    const uint32_t m2 = 1u << (s - 1);
-    const uint32_t j = t & (m2 - 1);
-    const uint32_t k = ((t >> (s - 1)) << s) + j;
-    const uint32_t e = j * (n >> (s - 1));
-    uint32_t sc[8];
-    const uint4* q = reinterpret_cast<const uint4*>(tws + (size_t)e * 8);
-    uint4 a = q[0], b = q[1];
-    sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
-    XYZZ<M> hi = load_xyzz<M>(work + k + m2);
-    XYZZ<M> tm = xyzz_scalar_mul<M>(hi, sc);
-    XYZZ<M> um = load_xyzz<M>(work + k);
-    XYZZ<M> sum = um;
-    xyzz_add_cold<M>(&sum, &tm);
-    XYZZ<M> ntm = xyzz_neg<M>(tm);
-    xyzz_add_cold<M>(&um, &ntm);
-    store_xyzz<M>(work + k, sum);
-    store_xyzz<M>(work + k + m2, um);
-}
-
 template <class M>
 __device__ __forceinline__ void store_affine_be(uint8_t* dst, const XYZZ<M>& p) {
     if (xyzz_is_inf<M>(p)) {
@@ -737,18 +635,6 @@ __device__ __forceinline__ void store_affine_be(uint8_t* dst, const XYZZ<M>& p) 
     store_be256(dst + 32, y.v);
 }
 
-template <class M>
-__device__ __forceinline__ XYZZ<M> load_affine_be(const uint8_t* src) {
-    Affine<M> a;
-    load_be256(a.x.v, src);
-    load_be256(a.y.v, src + 32);
-    fe_reduce_plain<M>(a.x.v, 6);
-    fe_reduce_plain<M>(a.y.v, 6);
-    a.x = fe_to_mont<M>(a.x);
-    a.y = fe_to_mont<M>(a.y);
-    return xyzz_from_affine<M>(a);
-}
-
 // MAC part of Server::mix (Server.hpp:1281-1318): out[i] = A0[i] + v^i * A1[i], out[i+len] = A0[i] - v^i * A1[i], v = w^(N/len);
 // 64-byte big-endian affine points in and out.  One lane per i.
 template <class C>
@@ -764,26 +650,15 @@ k_mac_mix(const uint8_t* __restrict__ a0, const uint8_t* __restrict__ a1, uint32
     const uint4* q = reinterpret_cast<const uint4*>(tws + (size_t)i * tw_step * 8);
     uint4 a = q[0], b = q[1];
     sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
-    if constexpr (C::F30_LAZY) {      // the reduced-radix ladder (mac30_scalar_mul)
-        XYZZ<M> hi = load_affine_be_lazy<M>(a1 + (size_t)i * 64);
-        XYZZ<M> tm;
-        mac30_scalar_mul<C>(&tm, &hi, sc);
-        XYZZ<M> sum = load_affine_be_lazy<M>(a0 + (size_t)i * 64);
-        XYZZ<M> dif = sum;
-        xyzz30_add_mem<M>(&sum, &tm, 0, 0, nullptr);
-        xyzz30_add_mem<M>(&dif, &tm, 1, 0, nullptr);
-        store_affine_be<M>(out + (size_t)i * 64, xyzz30_to_xyzz<M>(xyzz30_load_lazy<M>(&sum)));
-        store_affine_be<M>(out + ((size_t)i + len) * 64, xyzz30_to_xyzz<M>(xyzz30_load_lazy<M>(&dif)));
-    } else {
-        XYZZ<M> tm = xyzz_scalar_mul<M>(load_affine_be<M>(a1 + (size_t)i * 64), sc);
-        XYZZ<M> um = load_affine_be<M>(a0 + (size_t)i * 64);
-        XYZZ<M> sum = um;
-        xyzz_add_cold<M>(&sum, &tm);
-        XYZZ<M> ntm = xyzz_neg<M>(tm);
-        xyzz_add_cold<M>(&um, &ntm);
-        store_affine_be<M>(out + (size_t)i * 64, sum);
-        store_affine_be<M>(out + ((size_t)i + len) * 64, um);
-    }
+    XYZZ<M> hi = load_affine_be_lazy<M>(a1 + (size_t)i * 64);
+    XYZZ<M> tm;
+    mac30_scalar_mul<C>(&tm, &hi, sc);
+    XYZZ<M> sum = load_affine_be_lazy<M>(a0 + (size_t)i * 64);
+    XYZZ<M> dif = sum;
+    xyzz30_add_mem<M>(&sum, &tm, 0, 0, nullptr);
+    xyzz30_add_mem<M>(&dif, &tm, 1, 0, nullptr);
+    store_affine_be<M>(out + (size_t)i * 64, xyzz30_to_xyzz<M>(xyzz30_load_lazy<M>(&sum)));
+    store_affine_be<M>(out + ((size_t)i + len) * 64, xyzz30_to_xyzz<M>(xyzz30_load_lazy<M>(&dif)));
 }
 
 // XYZZ work array -> 64-byte big-endian affine MACs (infinity = 64 zero bytes, main.go:224-230)
@@ -794,7 +669,7 @@ k_mac_finish(const XYZZ<typename C::Fp>* __restrict__ work, uint32_t n, uint8_t*
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     XYZZ<M> p = load_xyzz<M>(work + i);
-    if constexpr (C::F30_LAZY) p = xyzz30_to_xyzz<M>(xyzz30_load_lazy<M>(&p));   // the reduced-radix ladder's work array
+    p = xyzz30_to_xyzz<M>(xyzz30_load_lazy<M>(&p));                              // the work array's lazy memory form
     uint8_t* dst = out + (size_t)i * 64;
     if (xyzz_is_inf<M>(p)) {
         uint4 z = make_uint4(0, 0, 0, 0);

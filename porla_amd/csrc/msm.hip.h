@@ -626,37 +626,7 @@ k_size_order(const uint32_t* __restrict__ counts, uint32_t nb, const uint32_t* _
 }
 
 // ONE THREAD PER WORK ITEM, items taken in size order.
-template <class C>
-__global__ void __launch_bounds__(256)
-k_bucket_sum(const Affine<typename C::Fp>* __restrict__ pts, const uint32_t* __restrict__ entries,
-             const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
-             const uint2* __restrict__ order, const uint32_t* __restrict__ chunk_base,
-             const uint32_t* __restrict__ ctrl, XYZZ<typename C::Fp>* __restrict__ buckets,
-             XYZZ<typename C::Fp>* __restrict__ chunk_out) {
-    using M = typename C::Fp;
-    uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= ctrl[3]) return;
-    uint2 item = order[tid];
-    const uint32_t b = item.x;
-    const uint32_t first = item.y * CHUNK;
-    uint32_t cnt = counts[b] - first;
-    if (cnt > CHUNK) cnt = CHUNK;
-    const uint32_t* e = entries + starts[b] + first;
-    XYZZ<M> acc = xyzz_inf<M>();
-    uint32_t ent = e[0];
-    for (uint32_t k = 0; k < cnt; k++) {
-        uint32_t cur = ent;
-        if (k + 1 < cnt) ent = e[k + 1];          // next index is in flight while this point is accumulated
-        Affine<M> a = load_affine<M>(pts, cur & 0x7fffffffu);
-        a = aff_neg_if<M>(a, (cur >> 31) != 0);
-        xyzz_madd<M>(acc, a);
-    }
-    const uint32_t cb = chunk_base[b];
-    if (cb == NO_CHUNK) store_xyzz<M>(buckets + b, acc);
-    else store_xyzz<M>(chunk_out + cb + item.y, acc);
-}
-
-// The same accumulation in the reduced-radix field form (ec30.hip.h): the points arrive in the 2^270 Montgomery form
+// The accumulation in the reduced-radix field form (ec30.hip.h): the points arrive in the 2^270 Montgomery form
 // (k_points_to_mont<.., F30>), the item's sum leaves in the lazy memory form of ec30.hip.h, which the combine and tree kernels
 // of this curve read; the last tree level converts to the 2^256 form for the host.
 template <class C>

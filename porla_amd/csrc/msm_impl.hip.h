@@ -15,18 +15,14 @@ namespace porla {
 
 static inline int ilog2(size_t n) { int l = 0; while (n >>= 1) l++; return l; }
 
-// threads of the per-window tail block: the tail takes over at the first level whose additions per window fit one pass
-static inline uint32_t tree_tail_threads() {
-    static const uint32_t t = getenv("PORLA_TREE_TAIL") ? (uint32_t)atoi(getenv("PORLA_TREE_TAIL")) : 256u;
-    uint32_t r = (t + 63) / 64 * 64;
-    return r < 64 ? 64 : (r > 1024 ? 1024 : r);
-}
-// quad = four lanes per addition (curves with the reduced-radix memory form): a pass of the tail holds threads / 4 additions
-static inline bool tree_quad() {
-    static const bool q = !(getenv("PORLA_TREE_QUAD") && getenv("PORLA_TREE_QUAD")[0] == '0');
-    return q;
-}
-constexpr uint32_t TREE_QUAD_MAX_TASKS = 16384;    // levels up to this many additions run four lanes per addition
+// threads of the per-window tail block: the tail takes over at the first level whose additions per window fit one pass (four
+// lanes per addition).  Same-box sweep of a blocking 2^20-pair MSM, profiles/r05_f_tree_tail_sweep.txt: 256 threads 1.58 ms,
+// 512 threads 1.53-1.55, 1 024 threads 1.55-1.64 (one block per window then holds a compute unit for eight levels).
+static inline uint32_t tree_tail_threads() { return 512u; }
+// quad = four lanes per addition: a pass of the tail holds threads / 4 additions
+static inline bool tree_quad() { return true; }
+constexpr uint32_t TREE_QUAD_MAX_TASKS = 16384;         // levels up to this many additions run four lanes per addition ...
+constexpr uint32_t TREE_QUAD_MAX_TASKS_LONE = 65536;    // ... for a caller that waits for this MSM alone (idle lanes to spend on latency; same sweep)
 static inline uint32_t tree_tail_start(uint32_t B, uint32_t nlev, bool quad) {
     const uint32_t cap = quad ? tree_tail_threads() / 4 : tree_tail_threads();
     uint32_t l = 0;
@@ -122,11 +118,10 @@ static int msm_small_launch(Workspace* ws, const uint8_t* d_scalars, const uint8
     ((volatile uint32_t*)ws->h_windows)[0] = 0;
     {
         ProfScope ps("small_msm", stream, true);
-        static const unsigned one_env = getenv("PORLA_MSM_SMALL_BLOCKS") ? (unsigned)atoi(getenv("PORLA_MSM_SMALL_BLOCKS")) : 0u;
         // up to 4 096 pairs 192 blocks are as fast as 256 (3 200 pairs: 0.1045 / 0.1046 ms with abs(int32) coefficients, 0.163 / 0.171
         // with 256-bit scalars; 16 384 pairs: 0.284 against 0.262) and leave a quarter of the chip to whatever short kernels run
-        // beside this one (PORLA_MSM_SMALL_BLOCKS overrides)
-        const unsigned one_blocks = (one_env >= 1 && one_env <= (unsigned)SMALL_BLOCKS) ? one_env : (n <= 4096 ? 192u : (unsigned)SMALL_BLOCKS);
+        // beside this one
+        const unsigned one_blocks = n <= 4096 ? 192u : (unsigned)SMALL_BLOCKS;
         hipLaunchKernelGGL((k_small_msm<C>), dim3(one_blocks), dim3(SMALL_THREADS), 0, stream, d_scalars, d_points_be, (uint32_t)n,
                            g_small_c | (g_use_glv == 0 ? 0x100 : 0), (XYZZ<M>*)ws->small_part.p, counters, (uint32_t*)h_dev,
                            (XYZZ<M>*)((uint8_t*)h_dev + SMALL_HDR_WORDS * 4), ws->small_seq, (const uint8_t*)nullptr, 0u);
@@ -171,10 +166,8 @@ static int msm_small_pair_launch(Workspace* ws, const uint8_t* d_scalars, const 
         // blocks per point set: at the audit's sizes 96 (192 of the chip's 256 compute units) -- the sets are as fast as with 128 each
         // (0.120 against 0.124 ms at 3 200 pairs) and the audit's other chain, which runs beside this kernel (row combine, the
         // three commitments: short launches that need a compute unit NOW), no longer queues behind 256 long-lived blocks:
-        // 0.183 -> 0.151 ms per audit (PORLA_MSM_PAIR_BLOCKS overrides)
-        static const unsigned pair_env = getenv("PORLA_MSM_PAIR_BLOCKS") ? (unsigned)atoi(getenv("PORLA_MSM_PAIR_BLOCKS")) : 0u;
-        unsigned pair_blocks = pair_env ? pair_env : (n <= 8192 ? 96u : (unsigned)SMALL_BLOCKS / 2);
-        if (pair_blocks < 1 || pair_blocks > (unsigned)SMALL_BLOCKS / 2) pair_blocks = SMALL_BLOCKS / 2;
+        // 0.183 -> 0.151 ms per audit
+        const unsigned pair_blocks = n <= 8192 ? 96u : (unsigned)SMALL_BLOCKS / 2;
         hipLaunchKernelGGL((k_small_msm<C>), dim3(pair_blocks, 2), dim3(SMALL_THREADS), 0, stream, d_scalars, d_points_a, (uint32_t)n,
                            g_small_c | (g_use_glv == 0 ? 0x100 : 0) | (bits_hint << 16), (XYZZ<M>*)ws->small_part.p, counters,
                            (uint32_t*)h_dev, (XYZZ<M>*)((uint8_t*)h_dev + SMALL_HDR_WORDS * 4), ws->small_seq, d_points_b, SMALL_PAIR_STRIDE);
@@ -208,8 +201,6 @@ static int msm_small_pair_finish(Workspace* ws, int which, XYZZ<typename C::Fp>*
     return PORLA_OK;
 }
 
-#define PORLA_TRACE(tag) do { if (trace_on) { auto now = std::chrono::steady_clock::now(); \
-    fprintf(stderr, "[trace slot %d] %-18s %8.1f us\n", ws->slot, tag, std::chrono::duration<double, std::micro>(now - t_tr).count()); t_tr = now; } } while (0)
 // The shape several ranges of one input share when their bucket sums are merged before ONE reduction (msm_host_multi): the
 // split flag and the scalar length are those of the whole input, the window width is given.
 struct MsmShape {
@@ -245,8 +236,6 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
                       const MsmShape* forced = nullptr, XYZZ<typename C::Fp>* bucket_out = nullptr, bool accumulate = false,
                       hipEvent_t after = nullptr) {
     using M = typename C::Fp;
-    static const bool trace_on = getenv("PORLA_TRACE_LAUNCH") != nullptr;
-    auto t_tr = std::chrono::steady_clock::now();
     ws->pend_W = 0;
     if (n == 0) return PORLA_OK;
     if (n >= (1ull << 30)) { set_last_error("porla: MSM length must be < 2^30 per call (range-split larger inputs)"); return PORLA_ERR_ARG; }
@@ -328,15 +317,13 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
         if ((rc = ws->buckets.ensure(nb * sizeof(XYZZ<M>)))) return rc;
         bk = (XYZZ<M>*)ws->buckets.p;
     }
-    PORLA_TRACE("alloc");
     uint32_t* ctrl = (uint32_t*)ws->cursor.p;
     PORLA_HIP(hipMemsetAsync(ctrl, 0, CTRL_WORDS * 4, stream));
     const Affine<M>* pts = (const Affine<M>*)ws->pts.p;
     // The conversion of the points is independent of the digit / sort chain and only the accumulation reads its output: for a
     // caller that waits for this one MSM it runs on the workspace's second stream beside that chain (with another MSM in flight
     // the other MSM already fills the gaps, as for the tree split below)
-    static const bool front_split_on = !(getenv("PORLA_FRONT_SPLIT") && getenv("PORLA_FRONT_SPLIT")[0] == '0');
-    const bool front_split = front_split_on && ws->lone && !forced && n >= ((size_t)1 << 18);
+    const bool front_split = ws->lone && !forced && n >= ((size_t)1 << 18);
     hipStream_t pst = stream;
     if (front_split) {
         if (!ws->aux_stream) PORLA_HIP(hipStreamCreateWithFlags(&ws->aux_stream, hipStreamNonBlocking));
@@ -356,7 +343,6 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
                                (Affine<M>*)ws->pts.p, n32);
     }
     if (front_split) PORLA_HIP(hipEventRecord(ws->front_join_ev, ws->aux_stream));
-    PORLA_TRACE("to_mont");
     const int lowbits = sort_lowbits(c, n_sub, W);
     const int P = 1 << (c - 1 - lowbits);
     {
@@ -368,7 +354,6 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
         unsigned wg = T_tiles < 256 ? 256u / T_tiles : 1u;
         if (wg > 16) wg = 16;
         if (wg > (unsigned)W) wg = (unsigned)W;
-        if (getenv("PORLA_DIGITS_WG")) wg = (unsigned)atoi(getenv("PORLA_DIGITS_WG"));
         if (glv)
             hipLaunchKernelGGL((k_digits_partition<C, true>), dim3(T_tiles, wg), dim3(TILE_THREADS), 0, stream, d_scalars, n32, c, W,
                                lowbits, (uint32_t*)ws->keys.p, (uint16_t*)ws->tile_off.p);
@@ -382,7 +367,6 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
                            (const uint16_t*)ws->tile_off.p, T_tiles, tile_cap, c, lowbits, (uint32_t*)ws->counts.p,
                            (uint32_t*)ws->starts.p, (uint32_t*)ws->entries.p, ctrl);
     }
-    PORLA_TRACE("sort");
     {
         ProfScope ps("size_order", stream);
         hipLaunchKernelGGL(k_size_hist, dim3(nblk), dim3(1024), 0, stream, (const uint32_t*)ws->counts.p, (uint32_t)nb,
@@ -393,7 +377,6 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
                            (const uint32_t*)ws->blk_off.p, nblk, (uint2*)ws->order.p, (uint32_t*)ws->fill.p,
                            (uint32_t*)ws->heavy.p, ctrl, accumulate ? (uint4*)nullptr : (uint4*)bk);
     }
-    PORLA_TRACE("size_order");
     if (accumulate) {
         if (!C::F30_LAZY) { set_last_error("porla: merged pair ranges need the reduced-radix bucket form"); return PORLA_ERR_STATE; }
         if (after) PORLA_HIP(hipStreamWaitEvent(stream, after, 0));
@@ -401,25 +384,17 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
     if (front_split) PORLA_HIP(hipStreamWaitEvent(stream, ws->front_join_ev, 0));
     {
         ProfScope ps("bucket_sum", stream, true);
-        if constexpr (C::F30_BUCKETS)
-            hipLaunchKernelGGL((k_bucket_sum30<C>), dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, stream, pts,
-                               (const uint32_t*)ws->entries.p, (const uint32_t*)ws->starts.p,
-                               (const uint32_t*)ws->counts.p, (const uint2*)ws->order.p, (const uint32_t*)ws->fill.p,
-                               (const uint32_t*)ctrl, bk, (XYZZ<M>*)ws->chunk_out.p, accumulate ? 1u : 0u);
-        else
-            hipLaunchKernelGGL((k_bucket_sum<C>), dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, stream, pts,
-                               (const uint32_t*)ws->entries.p, (const uint32_t*)ws->starts.p,
-                               (const uint32_t*)ws->counts.p, (const uint2*)ws->order.p, (const uint32_t*)ws->fill.p,
-                               (const uint32_t*)ctrl, bk, (XYZZ<M>*)ws->chunk_out.p);
+        hipLaunchKernelGGL((k_bucket_sum30<C>), dim3((unsigned)((max_items + 255) / 256)), dim3(256), 0, stream, pts,
+                           (const uint32_t*)ws->entries.p, (const uint32_t*)ws->starts.p,
+                           (const uint32_t*)ws->counts.p, (const uint2*)ws->order.p, (const uint32_t*)ws->fill.p,
+                           (const uint32_t*)ctrl, bk, (XYZZ<M>*)ws->chunk_out.p, accumulate ? 1u : 0u);
     }
-    PORLA_TRACE("bucket_sum");
     {
         ProfScope ps("bucket_combine", stream);
         hipLaunchKernelGGL((k_bucket_combine<C>), dim3(2048), dim3(64), 0, stream, (const uint32_t*)ws->heavy.p,
                            (const uint32_t*)ws->fill.p, (const uint32_t*)ws->counts.p, (const uint32_t*)ctrl,
                            (const XYZZ<M>*)ws->chunk_out.p, bk, accumulate ? 1u : 0u);
     }
-    PORLA_TRACE("combine");
     PORLA_HIP(hipGetLastError());
     if (forced) return PORLA_OK;
     return msm_tree_launch<C>(ws, bk, c, W, glv, stream);
@@ -430,8 +405,6 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
 template <class C>
 static int msm_tree_launch(Workspace* ws, const XYZZ<typename C::Fp>* buckets, int c, int W, bool glv, hipStream_t stream) {
     using M = typename C::Fp;
-    static const bool trace_on = getenv("PORLA_TRACE_LAUNCH") != nullptr;
-    auto t_tr = std::chrono::steady_clock::now();
     int rc;
     const uint32_t B = 1u << (c - 1);
     const size_t nb = (size_t)W * B;
@@ -450,10 +423,9 @@ static int msm_tree_launch(Workspace* ws, const XYZZ<typename C::Fp>* buckets, i
     // The windows are independent trees.  With enough buckets they run as TWO halves on two streams: the first levels of a tree
     // are throughput bound, the last ones (quad levels, the tail) latency bound -- side by side the latency-bound levels of one
     // half run under the large levels of the other.
-    static const int split_env = getenv("PORLA_TREE_SPLIT") ? atoi(getenv("PORLA_TREE_SPLIT")) : 2;
     // (only for a caller that waits for this one device-resident MSM: -1.7 % at 2^18 and 2^20 pairs; with a second MSM in
     // flight -- the two-phase API -- the other MSM already fills those gaps and the extra stream costs 5 % of the pipelined rate)
-    const int parts = (split_env >= 2 && ws->lone && W >= 4 && nb >= ((size_t)1 << 18)) ? 2 : 1;
+    const int parts = (ws->lone && W >= 4 && nb >= ((size_t)1 << 18)) ? 2 : 1;
     if (parts == 2) {
         if (!ws->aux_stream) PORLA_HIP(hipStreamCreateWithFlags(&ws->aux_stream, hipStreamNonBlocking));
         if (!ws->fork_ev) PORLA_HIP(hipEventCreateWithFlags(&ws->fork_ev, hipEventDisableTiming));
@@ -490,17 +462,13 @@ static int msm_tree_launch(Workspace* ws, const XYZZ<typename C::Fp>* buckets, i
                 const size_t tasks = (size_t)(l + 1) * a.n;
                 if constexpr (C::F30_LAZY) {
                     // a caller that waits for this MSM alone has idle lanes to spend on latency: more levels on four lanes per
-                    // addition (PORLA_TREE_QUAD_MAX_LONE); with another MSM in flight the extra lane work would cost throughput
-                    static const size_t quad_max_lone = getenv("PORLA_TREE_QUAD_MAX_LONE") ? (size_t)atol(getenv("PORLA_TREE_QUAD_MAX_LONE"))
-                                                                                            : (size_t)TREE_QUAD_MAX_TASKS;
-                    if (quad && tasks <= (ws->lone ? quad_max_lone : (size_t)TREE_QUAD_MAX_TASKS)) {
+                    // addition; with another MSM in flight the extra lane work would cost throughput
+                    if (quad && tasks <= (ws->lone ? (size_t)TREE_QUAD_MAX_TASKS_LONE : (size_t)TREE_QUAD_MAX_TASKS)) {
                         hipLaunchKernelGGL((k_tree_level_quad<C>), dim3((unsigned)((4 * tasks + 255) / 256)), dim3(256), 0, st, a);
-                        PORLA_TRACE("tree_level");
                         continue;
                     }
                 }
                 hipLaunchKernelGGL((k_tree_level<C>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, st, a);
-                PORLA_TRACE("tree_level");
             }
         }
         {
@@ -523,7 +491,6 @@ static int msm_tree_launch(Workspace* ws, const XYZZ<typename C::Fp>* buckets, i
             } else {
                 hipLaunchKernelGGL((k_tree_tail<C, false>), dim3(Wp), dim3(threads), 0, st, t);
             }
-            PORLA_TRACE("tree_tail");
         }
         // no copy packet: the last level stores its W * c results straight into the pinned host buffer (a D2H hipMemcpyAsync
         // was seen to block the launching thread for milliseconds while another MSM is in flight)
@@ -537,7 +504,6 @@ static int msm_tree_launch(Workspace* ws, const XYZZ<typename C::Fp>* buckets, i
     }
     if (!ws->done) PORLA_HIP(hipEventCreateWithFlags(&ws->done, hipEventDisableTiming));
     PORLA_HIP(hipEventRecord(ws->done, stream));
-    PORLA_TRACE("event");
     ws->pend_W = W;
     ws->pend_c = c;
     g_last_shape[0] = c; g_last_shape[1] = W; g_last_shape[2] = glv ? 1 : 0;
@@ -671,11 +637,11 @@ static int msm_host_launch(Workspace* ws, const uint8_t* scalars, const uint8_t*
 
 // pairs per range below which splitting further (or taking another device) costs more than it hides
 static inline size_t msm_multi_min_range() {
-    static const size_t v = getenv("PORLA_MSM_MIN_RANGE") ? (size_t)atoll(getenv("PORLA_MSM_MIN_RANGE")) : ((size_t)1 << 17);
+    static const size_t v = (size_t)1 << 17;
     return v < 1 ? 1 : v;
 }
 static inline int msm_multi_pipeline() {   // ranges per device when the caller leaves the shard count to the engine
-    static const int v = getenv("PORLA_MSM_PIPELINE") ? atoi(getenv("PORLA_MSM_PIPELINE")) : 4;
+    static const int v = 4;
     return v < 1 ? 1 : (v > 64 ? 64 : v);
 }
 extern std::mutex g_multi_mu;
@@ -756,7 +722,6 @@ int msm_host_multi(const uint8_t* scalars, const uint8_t* points, size_t n, int 
         }
         const bool shared = R >= 2 && msm_multi_shared_buckets();
         MsmShape shape = msm_full_shape<C>(max_cnt);
-        if (getenv("PORLA_MSM_MULTI_C")) { int cc = atoi(getenv("PORLA_MSM_MULTI_C")); if (cc >= 2 && cc <= 20) { shape.c = cc; shape.W = (shape.bits + 1 + cc - 1) / cc; } }
         const size_t nb = (size_t)shape.W << (shape.c - 1);
         XYZZ<M>* acc = nullptr;
         if (!r && shared) {

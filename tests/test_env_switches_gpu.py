@@ -1,11 +1,15 @@
-"""GPU box: the documented off-switches still give the oracle's bytes.  Every switch is read once per process, so each case is a
-child process: PORLA_MSM_SHARED_BUCKETS=0 (one complete MSM per host range), PORLA_MSM_SMALL=0 (general path at audit sizes),
-PORLA_ICC_F30=0 (8 x 32-bit ICC kernel), PORLA_ICC_SPLIT=0 (the reduced-radix kernel with both residues side by side in LDS:
-icc30.hip.h), PORLA_MAC_QUAD=0 (one lane per MAC butterfly), PORLA_ICC_MIX30=0 (Server::mix's data part in the 2^256 field form), PORLA_KZG_EVAL30=0 (the digest batch's Horner
-evaluation with one lane per row), PORLA_KZG_EVAL_LAZY=0 (Horner with eight lanes per row instead of the dot product with the
-reduction at the end), PORLA_COMMIT_SMALL=0 (batch kernels for
-single rows), PORLA_NO_ADX=1 (portable host field products), PORLA_TREE_SPLIT=1 (reduction tree on one stream),
-PORLA_FRONT_SPLIT=0 (point conversion on the MSM's own stream)."""
+"""GPU box: every behaviour switch the library still reads from the environment (DESIGN.md s8 lists them) gives the oracle's
+bytes.  A switch is read once per process, so each case is a child pytest:
+  PORLA_MSM_SHARED_BUCKETS=0  one complete MSM per host range instead of ranges accumulating into one bucket set
+  PORLA_MSM_SMALL=0           the general bucket path at audit sizes (instead of the single-launch MSM)
+  PORLA_MAC_QUAD_MAX=0        one lane per MAC butterfly / per mix element / per scaled MAC: the kernels N > 2^16 rows take
+  PORLA_MAC_QUAD_MAX=5        the boundary inside the tests' sizes (both families in one encode's neighbourhood)
+  PORLA_COMMIT_SMALL=0        batch kernels for single rows (instead of the single-launch commitment)
+  PORLA_COMMIT_TABLE_GB=1     a table budget that forces narrow windows (the shrink loop of FixedBase::build)
+  PORLA_COMMIT_WINDOW=11      a fixed window width
+  PORLA_NO_ADX=1              portable host field products
+The operational ones (PORLA_MSM_DEVICES, PORLA_MSM_SPLIT_MIN: tests/test_msm_multi_gpu.py; PORLA_RCCL_LIB,
+PORLA_DIST_INIT_TIMEOUT_S: tests/test_sharded_gloo.py / the two-rank bench tests) are covered where they act."""
 import os
 import subprocess
 import sys
@@ -19,16 +23,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = {
     "PORLA_MSM_SHARED_BUCKETS=0": "tests/test_msm_multi_gpu.py -k 'forced_shards or degenerate'",
     "PORLA_MSM_SMALL=0": "tests/test_msm_small_gpu.py -k 'audit or shape or sizes'",
-    "PORLA_ICC_F30=0": "tests/test_icc_gpu.py -k 'not full'",
-    "PORLA_ICC_SPLIT=0": "tests/test_icc_gpu.py tests/test_golden_gpu.py -k 'icc or crebuild or edge or three_passes'",
-    "PORLA_MAC_QUAD=0": "tests/test_mac_fft_gpu.py tests/test_mix_gpu.py",
-    "PORLA_ICC_MIX30=0": "tests/test_mix_gpu.py tests/test_hadd_gpu.py",
-    "PORLA_KZG_EVAL30=0": "tests/test_fixed_base_gpu.py tests/test_golden_gpu.py -k 'digest or kzg'",
-    "PORLA_KZG_EVAL_LAZY=0": "tests/test_fixed_base_gpu.py tests/test_golden_gpu.py -k 'digest or kzg'",
+    "PORLA_MAC_QUAD_MAX=0": "tests/test_mac_fft_gpu.py tests/test_mix_gpu.py",
+    "PORLA_MAC_QUAD_MAX=5": "tests/test_mac_fft_gpu.py",
     "PORLA_COMMIT_SMALL=0": "tests/test_fixed_base_gpu.py -k 'small or single or coalesc or row'",
+    "PORLA_COMMIT_TABLE_GB=1": "tests/test_fixed_base_gpu.py tests/test_golden_gpu.py -k 'commit or kzg or digest'",
+    "PORLA_COMMIT_WINDOW=11": "tests/test_fixed_base_gpu.py -k 'commit or batch'",
     "PORLA_NO_ADX=1": "tests/test_msm_bn254_gpu.py -k 'edge or audit_like or kat or eip'",
-    "PORLA_TREE_SPLIT=1": "tests/test_msm_bn254_gpu.py -k 'full or 2p20 or uniform'",
-    "PORLA_FRONT_SPLIT=0": "tests/test_msm_bn254_gpu.py -k 'full or 2p20 or uniform'",
 }
 
 

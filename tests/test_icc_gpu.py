@@ -108,25 +108,6 @@ def test_three_passes_and_worst_case_operand_growth(curve, n, ncols, part, ws):
     assert got[1] == want[1] and got[2] == want[2]
 
 
-def test_both_field_forms_agree(monkeypatch):
-    """the 8 x 32-bit kernel (PORLA_ICC_F30=0, read once per process) is kept: a child process runs it on the same input"""
-    import os
-    import subprocess
-    import sys
-    from porla_amd import icc
-    n, ncols = 512, 128
-    rows = rows_bytes(n, ncols, seed=4242)
-    a = icc.crebuild_host(rows, n, ncols, "bn254", 11, 1)
-    code = ("import sys, hashlib; sys.path.insert(0, %r)\n"
-            "from tests.test_icc_gpu import rows_bytes\nfrom porla_amd import icc\n"
-            "r = icc.crebuild_host(rows_bytes(%d, %d, seed=4242), %d, %d, 'bn254', 11, 1)\n"
-            "print(hashlib.sha256(r[0] + r[1] + r[2]).hexdigest())\n" % (common.ROOT, n, ncols, n, ncols))
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
-                         env=dict(os.environ, PORLA_ICC_F30="0"))
-    assert out.returncode == 0, out.stderr[-2000:]
-    assert out.stdout.strip().splitlines()[-1] == hashlib.sha256(a[0] + a[1] + a[2]).hexdigest()
-
-
 @pytest.mark.parametrize("curve", ["bn254", "secp256k1"])
 @pytest.mark.parametrize("n,ncols,ws", [(2, 128, 1), (16, 3, 5), (256, 128, 77), (2048, 16, 1234567), (1 << 17, 3, 99991)])
 def test_both_parts_from_one_network(curve, n, ncols, ws):
