@@ -175,7 +175,10 @@ int porla_secp256k1_tree_fold(const uint8_t *sums_affine, int windows, int windo
  *           or a partial from porla_*_msm_device_partial / _device_end(slot, out, 1) handed to porla_*_dist_fold
  *   all   : porla_dist_finalize()
  * porla_dist_init is bounded: a peer that never arrives makes it fail with PORLA_ERR_STATE after PORLA_DIST_INIT_TIMEOUT_S
- * (default 180 s) instead of waiting forever; the process should then exit (the pending RCCL call cannot be cancelled). */
+ * (default 180 s) instead of waiting forever.  The pending RCCL call cannot be cancelled: its helper thread is marked abandoned
+ * (a communicator it still obtains is aborted at once), every later porla_dist_* call of the process fails with
+ * PORLA_ERR_STATE, and the caller must leave with a non-zero _exit() -- not exit(): static destructors would run under a
+ * thread that is still inside RCCL -- and continue, if at all, in a fresh child process. */
 int porla_dist_unique_id(uint8_t id_out[PORLA_DIST_ID_BYTES]);
 int porla_dist_init(const uint8_t id[PORLA_DIST_ID_BYTES], int rank, int world);
 int porla_dist_info(int *rank, int *world);     /* world = 0 before porla_dist_init */

@@ -29,6 +29,7 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;          // optional: only the timed-out initialisation's helper uses it
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -38,6 +39,7 @@ struct DistState {
     Rccl lib;
     ncclComm_t comm = nullptr;
     int rank = 0, world = 0, device = -1;
+    bool poisoned = false;       // an initialisation timed out: a helper thread may still sit inside RCCL (see porla_dist_init)
     hipStream_t stream = nullptr;
     uint8_t* d_send = nullptr;   // 96 B
     uint8_t* d_recv = nullptr;   // world * 96 B
@@ -66,6 +68,7 @@ int load_rccl() {
     D.lib.GetUniqueId = (decltype(D.lib.GetUniqueId))sym("ncclGetUniqueId");
     D.lib.CommInitRank = (decltype(D.lib.CommInitRank))sym("ncclCommInitRank");
     D.lib.CommDestroy = (decltype(D.lib.CommDestroy))sym("ncclCommDestroy");
+    D.lib.CommAbort = (decltype(D.lib.CommAbort))sym("ncclCommAbort");
     D.lib.AllGather = (decltype(D.lib.AllGather))sym("ncclAllGather");
     D.lib.GetErrorString = (decltype(D.lib.GetErrorString))sym("ncclGetErrorString");
     if (!D.lib.GetUniqueId || !D.lib.CommInitRank || !D.lib.CommDestroy || !D.lib.AllGather || !D.lib.GetErrorString) {
@@ -95,6 +98,7 @@ void free_buffers() {
 
 // all ranks' partials into out (world * 96 bytes); D.mu held
 int allgather_locked(const uint8_t partial[PORLA_JACOBIAN_BYTES], uint8_t* out) {
+    if (D.poisoned) { set_last_error("porla: porla_dist_init timed out earlier in this process: leave with a non-zero _exit()"); return PORLA_ERR_STATE; }
     if (!D.comm) { set_last_error("porla: porla_dist_init first"); return PORLA_ERR_STATE; }
     int cur = -1;
     PORLA_HIP(hipGetDevice(&cur));
@@ -152,6 +156,10 @@ int porla_dist_init(const uint8_t id_in[PORLA_DIST_ID_BYTES], int rank, int worl
     int rc = ensure_device();
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(D.mu);
+    if (D.poisoned) {
+        set_last_error("porla: an earlier porla_dist_init timed out in this process; leave with a non-zero _exit and start a fresh process");
+        return PORLA_ERR_STATE;
+    }
     if (D.comm) { set_last_error("porla: porla_dist_init called twice (porla_dist_finalize first)"); return PORLA_ERR_STATE; }
     if ((rc = load_rccl())) return rc;
     PORLA_HIP(hipGetDevice(&D.device));
@@ -159,17 +167,31 @@ int porla_dist_init(const uint8_t id_in[PORLA_DIST_ID_BYTES], int rank, int worl
     memcpy(id.internal, id_in, NCCL_UNIQUE_ID_BYTES);
     // ncclCommInitRank is collective and has no timeout of its own: a peer that never arrives would leave this rank waiting
     // forever.  It runs on a helper thread; if it has not returned after PORLA_DIST_INIT_TIMEOUT_S (default 180 s) the call
-    // fails with PORLA_ERR_STATE -- the helper cannot be cancelled and stays behind, so the caller is expected to exit.
+    // fails with PORLA_ERR_STATE.  The helper cannot be cancelled: it is marked ABANDONED (should RCCL hand it a communicator
+    // later, it aborts that communicator at once -- no peer is left believing in a group this rank has given up), the state is
+    // POISONED (every later porla_dist_* call fails: no second helper on the same id), and the caller must leave the process
+    // with a non-zero _exit() -- a plain exit() would run static destructors under a thread that is still inside RCCL -- and
+    // continue, if at all, in a fresh child process (never a re-exec of this one: it has initialised the GPU).
     double limit_s = 180.0;
     if (const char* t = getenv("PORLA_DIST_INIT_TIMEOUT_S")) { double v = atof(t); if (v > 0) limit_s = v; }
-    struct Pending { std::mutex mu; std::condition_variable cv; bool done = false; ncclResult_t r = ncclSuccess; ncclComm_t comm = nullptr; };
+    struct Pending {
+        std::mutex mu; std::condition_variable cv;
+        bool done = false, abandoned = false;
+        ncclResult_t r = ncclSuccess; ncclComm_t comm = nullptr;
+    };
     auto pend = std::make_shared<Pending>();
     const int device = D.device;
     auto init_fn = D.lib.CommInitRank;
-    std::thread([pend, device, init_fn, world, id, rank]() {
+    auto abort_fn = D.lib.CommAbort ? D.lib.CommAbort : D.lib.CommDestroy;
+    std::thread([pend, device, init_fn, abort_fn, world, id, rank]() {
         ncclComm_t c = nullptr;
         ncclResult_t r = hipSetDevice(device) == hipSuccess ? init_fn(&c, world, id, rank) : ncclUnhandledCudaError;
-        std::lock_guard<std::mutex> lk(pend->mu);
+        std::unique_lock<std::mutex> lk(pend->mu);
+        if (pend->abandoned) {                  // nobody will ever take this communicator: tear it down now
+            lk.unlock();
+            if (r == ncclSuccess && c) (void)abort_fn(c);
+            return;
+        }
         pend->r = r; pend->comm = c; pend->done = true;
         pend->cv.notify_all();
     }).detach();
@@ -177,8 +199,11 @@ int porla_dist_init(const uint8_t id_in[PORLA_DIST_ID_BYTES], int rank, int worl
     {
         std::unique_lock<std::mutex> lk(pend->mu);
         if (!pend->cv.wait_for(lk, std::chrono::duration<double>(limit_s), [&] { return pend->done; })) {
-            char buf[160];
-            snprintf(buf, sizeof buf, "porla: ncclCommInitRank (rank %d of %d) did not return within %.0f s", rank, world, limit_s);
+            pend->abandoned = true;
+            D.poisoned = true;
+            char buf[224];
+            snprintf(buf, sizeof buf, "porla: ncclCommInitRank (rank %d of %d) did not return within %.0f s; the process must now "
+                     "leave with a non-zero _exit()", rank, world, limit_s);
             set_last_error(buf);
             return PORLA_ERR_STATE;
         }

@@ -4,15 +4,15 @@
 // group elements and the MSM result stays bit-exact.
 //
 // Value bounds (multiples of p; a product's result is < p + 2^246, written "1"):
-//   X1 <= 5, Y1 <= 3 (the accumulator, see X3 / Y3 below), ZZ1, ZZZ1 <= 1, X2, Y2 < 1
+//   X1 <= 5, Y1 <= 4 (the accumulator: Y3 <= 3 below, 4p - Y <= 4 after xyzz30_flip_finish or a negation), ZZ1, ZZZ1 <= 1, X2, Y2 < 1
 //   U2 = X2 ZZ1, S2 = Y2 ZZZ1                      <= 1
 //   P  = U2 - X1 + 6p                              <= 7
-//   R  = S2 - Y1 + 4p                              <= 5
-//   PP = P^2, PPP = P PP, Q = X1 PP, RR = R^2      <= 1
+//   Rn = Y1 - S2 + 2p = -R                         <= 6   (the sign-alternating form below; Y1 is the minuend, so its 4p needs no allowance)
+//   PP = P^2, PPP = P PP, Q = X1 PP, RR = Rn^2     <= 1
 //   E  = PPP + 2 Q                                 <= 3
 //   X3 = RR - E + 4p                               <= 5
 //   D  = Q - X3 + 6p                               <= 7
-//   Y3 = R D - Y1 PPP + 2p                         <= 3
+//   Y3 = R D - Y1 PPP                              <= 1 as one two-product reduction (-Y3 = Rn D + Y1 PPP), <= 3 as T1 - T2 + 2p in the full addition
 // Everything is below 8p < 2^257, so limb 8 stays below 2^18 as the products require.
 #pragma once
 #include "ec.hip.h"
@@ -55,41 +55,8 @@ __device__ __noinline__ XYZZ30<M> xyzz30_double_affine(F30<M> ax, F30<M> ay) {
     return r;
 }
 
-// p += a (a affine in the 2^270 form, not infinity)
-template <class M>
-__device__ __forceinline__ void xyzz30_madd(XYZZ30<M>& p, const F30<M>& ax, const F30<M>& ay) {
-    if (p.inf) {
-        p.x = ax; p.y = ay;
-        p.zz = f30_const<M>(M::R1_30); p.zzz = p.zz;
-        p.inf = false;
-        return;
-    }
-    F30<M> U2 = f30_mul<M>(ax, p.zz);
-    F30<M> S2 = f30_mul<M>(ay, p.zzz);
-    F30<M> Pp = f30_sub<M, 6>(U2, p.x);
-    F30<M> Rr = f30_sub<M, 4>(S2, p.y);
-    F30<M> PP = f30_sqr<M>(Pp);
-    if (f30_product_is_zero<M>(PP)) {               // same x: the same point (double it) or its negative (infinity)
-        F30<M> RR = f30_sqr<M>(Rr);
-        if (f30_product_is_zero<M>(RR)) p = xyzz30_double_affine<M>(ax, ay);
-        else p.inf = true;
-        return;
-    }
-    F30<M> PPP = f30_mul<M>(Pp, PP);
-    F30<M> Q = f30_mul<M>(p.x, PP);
-    F30<M> RR = f30_sqr<M>(Rr);
-    F30<M> E = f30_add2<M>(PPP, Q);
-    F30<M> X3 = f30_sub<M, 4>(RR, E);
-    F30<M> D = f30_sub<M, 6>(Q, X3);
-    F30<M> T1 = f30_mul<M>(Rr, D);
-    F30<M> T2 = f30_mul<M>(p.y, PPP);
-    p.x = X3;
-    p.y = f30_sub<M, 2>(T1, T2);
-    p.zz = f30_mul<M>(p.zz, PP);
-    p.zzz = f30_mul<M>(p.zzz, PPP);
-}
-
-// The same addition for a RUN of additions into one accumulator (the bucket sums, the rows of a fixed-base commitment), with
+// The mixed addition p += a (a affine in the 2^270 form) for a RUN of additions into one accumulator (the bucket sums, the rows of a
+// fixed-base commitment), with
 // Y3 = R D - Y1 PPP as ONE two-product reduction (f30_mul2_mont) and no subtraction behind it:
 //   with Rn = Y1 - S2 = -R the sum  Rn D + Y1 PPP  is -Y3, so (X3, Rn D + Y1 PPP, ZZ3, ZZZ3) is a valid representation of
 //   -(p + a).  The accumulator therefore changes sign with every addition; `flip` says whether it currently holds the negative of
@@ -168,7 +135,9 @@ __device__ __forceinline__ XYZZ30<M> xyzz30_infinity() {
     p.inf = true;
     return p;
 }
-// the true sum: Y -> 4p - Y (<= 4p < 2^256, still storable in the lazy memory form) when the accumulator holds its negative
+// the true sum: Y -> 4p - Y (<= 4p) when the accumulator holds its negative.  BN254: 4p < 2^256, storable as it is in the lazy memory
+// form; secp256k1 (4p > 2^256): xyzz30_store_lazy reduces every residue canonically on the way out, so the bound never reaches memory.
+// Consumers: 2 Y <= 8p in a doubling -- inside the products' budgets (tools/check_fe30_bounds.py:check_value_ranges)
 template <class M>
 __device__ __forceinline__ void xyzz30_flip_finish(XYZZ30<M>& p, bool flip) {
     if (flip && !p.inf) p.y = f30_sub<M, 4>(F30<M>{}, p.y);
@@ -203,7 +172,7 @@ __device__ __noinline__ XYZZ30<M> xyzz30_double(F30<M> x, F30<M> y, F30<M> zz, F
     return xyzz30_double_body<M>(x, y, zz, zzz);
 }
 
-// p += q (add-2008-s), all exceptional cases.  Bounds as for the mixed form: X <= 5, Y <= 3, ZZ, ZZZ <= 1 on both sides;
+// p += q (add-2008-s), all exceptional cases.  Bounds as for the mixed form: X <= 5, Y <= 4 (products only), ZZ, ZZZ <= 1 on both sides;
 //   U1 = X1 ZZ2, U2 = X2 ZZ1, S1 = Y1 ZZZ2, S2 = Y2 ZZZ1 (<= 1);  P = U2 - U1 + 2p (<= 3);  R = S2 - S1 + 2p (<= 3);
 //   Q = U1 PP;  X3 = RR - (PPP + 2Q) + 4p (<= 5);  Y3 = R (Q - X3 + 6p) - S1 PPP + 2p (<= 3)
 template <class M>

@@ -979,26 +979,42 @@ int porla_kzg_crebuild_stage_device(const void* d_rows_in, size_t n_rows, unsign
     StageSide* side = nullptr;
     for (auto& m : g_stage_side) if (m.device == dev) side = &m;
     if (!side) {
+        // built completely before it is registered; a failure half way destroys what exists (no stream or event is leaked)
         StageSide m;
         m.device = dev;
-        PORLA_HIP(hipStreamCreateWithFlags(&m.s, hipStreamNonBlocking));
-        PORLA_HIP(hipEventCreateWithFlags(&m.fork, hipEventDisableTiming));
-        PORLA_HIP(hipEventCreateWithFlags(&m.join, hipEventDisableTiming));
+        hipError_t e = hipStreamCreateWithFlags(&m.s, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&m.fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&m.join, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            if (m.join) (void)hipEventDestroy(m.join);
+            if (m.fork) (void)hipEventDestroy(m.fork);
+            if (m.s) (void)hipStreamDestroy(m.s);
+            return ::porla::hip_fail(e, "crebuild stage: side stream / events", __FILE__, __LINE__);
+        }
         g_stage_side.push_back(m);
         side = &g_stage_side.back();
     }
     hipStream_t stream = (hipStream_t)hip_stream;
     PORLA_HIP(hipEventRecord(side->fork, stream));
     PORLA_HIP(hipStreamWaitEvent(side->s, side->fork, 0));
-    if ((rc = porla_icc_mac_encode_xy_device(d_macs_in, n_rows, 0, write_step, d_macs_x, d_macs_y, side->s))) return rc;
-    PORLA_HIP(hipEventRecord(side->join, side->s));
+    // From here on the side stream may hold work that writes d_macs_x / d_macs_y: EVERY exit joins it back into hip_stream, also the
+    // failing ones -- a caller that gets an error may free its buffers as soon as hip_stream has drained, and the next call's
+    // fork / join records must not interleave with a stage still running
+    rc = porla_icc_mac_encode_xy_device(d_macs_in, n_rows, 0, write_step, d_macs_x, d_macs_y, side->s);
+    hipError_t je = hipEventRecord(side->join, side->s);
     uint8_t* sc = (uint8_t*)d_scalars_xy;
-    if ((rc = porla_icc_encode_xy_device(d_rows_in, n_rows, n_cols, 0, write_step, nullptr, d_aligned_x, sc, nullptr, d_aligned_y,
-                                         sc + 32 * n_rows * n_cols, 0, stream))) return rc;
+    if (!rc)
+        rc = porla_icc_encode_xy_device(d_rows_in, n_rows, n_cols, 0, write_step, nullptr, d_aligned_x, sc, nullptr, d_aligned_y,
+                                        sc + 32 * n_rows * n_cols, 0, stream);
     // both parts' alignment scalars lie back to back: ONE batch of 2 n rows
-    if ((rc = commit_rows(sc, true, 2 * n_rows, n_cols, (uint8_t*)d_commits_xy, stream, /*guest_room=*/true))) return rc;
-    PORLA_HIP(hipStreamWaitEvent(stream, side->join, 0));
-    return PORLA_OK;
+    if (!rc) rc = commit_rows(sc, true, 2 * n_rows, n_cols, (uint8_t*)d_commits_xy, stream, /*guest_room=*/true);
+    if (je == hipSuccess) je = hipStreamWaitEvent(stream, side->join, 0);
+    if (je != hipSuccess) {
+        // the join itself failed: fall back to a host wait so that no side work outlives the call
+        (void)hipStreamSynchronize(side->s);
+        if (!rc) rc = ::porla::hip_fail(je, "crebuild stage: join of the side stream", __FILE__, __LINE__);
+    }
+    return rc;
 }
 
 // rows resident on the device, results wanted on the host NOW (the audit's align_MAC commitment, Server.hpp:903 -> :550-560, on the

@@ -65,6 +65,9 @@ def test_reduced_radix_column_sums_fit_64_bits():
     assert cb.MUL2_CHAIN == g30.MUL2_CHAIN and cb.PM_MUL2_CHAIN == g30.PM_MUL2_CHAIN[0] == g30.PM_MUL2_CHAIN[1]
     assert all(cb.check_mul2(name, p) for name, p in cb.MODULI.items() if name != "p_icc") and cb.check_pm_mul2()
     assert not cb.check_mul2("no chain", cb.MODULI["bn254_p"], chain=(99, 99))       # ... and they are needed
+    # the operand ranges the group law leans on (2 Y <= 8 p in a doubling, X <= 5 p, Y <= 4 p in the lazy memory form) against the
+    # products' budgets, and the borrow-free subtraction tables incl. the doubled one of f30_sub_twice (advisor r4)
+    assert cb.check_value_ranges() and cb.check_sub_tables()
     src = open(os.path.join(CSRC, "fe30.hip.h")).read()
     assert "F30_MUL2_CHAIN_LO = %d, F30_MUL2_CHAIN_HI = %d" % cb.MUL2_CHAIN in src and "F30_PM_MUL2_CHAIN = %d" % cb.PM_MUL2_CHAIN in src
     # and the generated assembly is what the generator produces

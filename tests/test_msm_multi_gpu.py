@@ -7,6 +7,7 @@ import os
 import socket
 import subprocess
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -217,3 +218,42 @@ def test_rccl_from_cxx_two_ranks():
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0 and "ok" in o, o
+
+
+TIMEOUT_WORKER = r"""
+import os, sys
+sys.path.insert(0, os.environ["PORLA_ROOT"])
+import torch
+torch.cuda.set_device(0)
+from porla_amd import multiexp as mx
+uid = mx.dist_unique_id()
+msgs = []
+for attempt in range(2):
+    try:
+        mx.dist_init(uid, 0, 2)              # rank 0 of a world of two whose other rank never comes
+        msgs.append("unexpected success")
+    except Exception as e:
+        msgs.append(str(e))
+try:
+    mx.dist_fold("bn254", bytes(96))
+    msgs.append("unexpected success")
+except Exception as e:
+    msgs.append(str(e))
+print("\n".join(msgs), flush=True)
+os._exit(7)                                  # what the header prescribes after a timed-out initialisation
+"""
+
+
+def test_dist_init_times_out_poisons_the_state_and_the_process_leaves():
+    """porla_dist_init with a peer that never arrives (advisor r4): bounded by PORLA_DIST_INIT_TIMEOUT_S, after which the helper
+    thread inside ncclCommInitRank is abandoned, a retry with the same id is REFUSED (no second helper on one communicator), the
+    collectives refuse too, and the process leaves with _exit"""
+    env = dict(os.environ, PORLA_ROOT=common.ROOT, PORLA_DIST_INIT_TIMEOUT_S="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", TIMEOUT_WORKER], env=env, capture_output=True, text=True, timeout=300)
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert r.returncode == 7, r.stdout[-1500:] + r.stderr[-1500:]
+    assert len(lines) >= 3 and "did not return within 4 s" in lines[0], lines
+    assert "timed out" in lines[1] and "fresh process" in lines[1], lines
+    assert "timed out" in lines[2], lines
+    assert time.time() - t0 < 120

@@ -31,6 +31,14 @@
 #include "inv30.hip.h"
 
 using namespace porla;
+
+// the plain mixed addition (the library keeps only the sign-alternating run form since round 5): one addition, sign restored
+template <class M>
+__device__ __forceinline__ void xyzz30_madd(XYZZ30<M>& p, const F30<M>& ax, const F30<M>& ay) {
+    bool flip = false;
+    xyzz30_madd_flip<M>(p, flip, ax, ay);
+    xyzz30_flip_finish<M>(p, flip);
+}
 using M = Bn254Fp;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)

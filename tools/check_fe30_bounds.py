@@ -83,11 +83,62 @@ def check_pm_mul2(top_bits=19, chain=PM_MUL2_CHAIN):
     print("special-form mul2: worst column %.6f x 2^64 (a single accumulator would reach %.10f), fold R[9] < 2^26: %s  %s"
           % (worst / 2**64, unchained / 2**64, r9_ok, "ok" if ok else "OVERFLOW"))
     return ok
+SECP_P = 2**256 - 2**32 - 977
+
+
+def check_value_ranges():
+    """the operand ranges the group law of ec30.hip.h leans on (comments there: X <= 5p, Y <= 4p, U = 2Y <= 8p in a doubling,
+    D = Q - X3 + 6p <= 7p + eps in an addition) against what a product accepts: value < 2^258 (limb 8 < 2^18) for BN254,
+    < 2^259 (limb 8 < 2^19) for secp256k1; and what the lazy MEMORY form can hold (256 bits: BN254 stores X <= 5p, Y <= 4p
+    unreduced, secp256k1 reduces on the way out); eps = the slack of a product's result (2^247 / 2^50)"""
+    ok = True
+    bn = MODULI["bn254_p"]
+    for name, p, budget, eps in (("bn254_p", bn, 2**258, 2**247), ("secp256k1_p", SECP_P, 2**259, 2**50)):
+        worst = max(2 * (4 * p), 7 * p + 8 * eps, 5 * p + 4 * eps)       # U = 2 Y (Y <= 4p), D, X
+        good = worst < budget
+        print("%-12s largest product operand of the group law %.3f x budget  %s" % (name, worst / budget, "ok" if good else "TOO LARGE"))
+        ok = ok and good
+    mem = 5 * bn + 2**247 < 2**256 and 4 * bn < 2**256
+    print("bn254_p      lazy memory form: X <= 5p + eps and Y <= 4p fit 256 bits: %s" % ("ok" if mem else "NO"))
+    return ok and mem
+
+
+def check_sub_tables():
+    """borrow-free subtractions a + (K p' - b) of fe30.hip.h: every limb of the K p table of f30_sub exceeds a normal limb of b
+    (limbs 0..7) and the top limb exceeds b's for b <= (K - 1) p + 2^247; f30_sub_twice (a - 2 b, allowance doubled) stays
+    inside 32 bits per limb, carries included"""
+    ok = True
+    for name, p in (("bn254_p", MODULI["bn254_p"]), ("secp256k1_p", SECP_P)):
+        for K in (2, 3, 4, 5, 6):
+            kp = K * p
+            T = [(kp >> (30 * i)) & MASK for i in range(8)] + [kp >> 240]
+            T[0] += 2**30
+            for i in range(1, 8):
+                T[i] += 2**30 - 1
+            T[8] -= 1
+            assert sum(t << (30 * i) for i, t in enumerate(T)) == kp
+            b_top = ((K - 1) * p + 2**247) >> 240
+            good = all(T[i] >= MASK for i in range(8)) and T[8] >= b_top and max(T[:8]) + MASK + 3 < 2**32
+            ok = ok and good
+        # f30_sub_twice<3>: X3 = MM - 2 S + 3 p of a doubling
+        kp = 3 * p
+        T = [(kp >> (30 * i)) & MASK for i in range(8)] + [kp >> 240]
+        T2 = [T[0] + 2**31] + [t + 2**31 - 2 for t in T[1:8]] + [T[8] - 2]
+        assert sum(t << (30 * i) for i, t in enumerate(T2)) == kp
+        two_b_top = (2 * (p + 2**247)) >> 240
+        good = all(T2[i] >= 2 * MASK for i in range(8)) and T2[8] >= two_b_top and max(T2[:8]) + MASK + 3 < 2**32          # + a normal limb of a + a carry of at most 3
+        print("%-12s subtraction tables (K = 2..6, and the doubled one of f30_sub_twice<3>): %s" % (name, "ok" if ok and good else "BAD"))
+        ok = ok and good
+    return ok
+
+
 if __name__ == "__main__":
     import sys
     ok = all([check(n, p) for n, p in MODULI.items()])
     ok = all([check_mul2(n, p) for n, p in MODULI.items() if n != "p_icc"]) and ok
     ok = check_pm_mul2() and ok
     ok = all([check("icc:" + n, p, 23, 17) for n, p in ICC_MODULI.items()]) and ok
+    ok = check_value_ranges() and ok
+    ok = check_sub_tables() and ok
     # result bound of the ICC product: a b / 2^270 + p < p + 2^249 for a < 2^263, b < 2^256: limb 8 stays far below 2^30
     sys.exit(0 if ok else 1)

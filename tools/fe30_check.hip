@@ -67,7 +67,9 @@ __global__ void k_madd30(uint32_t* io, int iters) {
     for (int i = 0; i < 8; i++) { ax.v[i] = io[tid * 9 + i]; ay.v[i] = io[tid * 9 + i] ^ 0x01010101u; }
     ax.v[7] &= 0x0fffffff; ay.v[7] &= 0x0fffffff;
     XYZZ30<M> p; p.inf = true;
-    for (int i = 0; i < iters; i++) { xyzz30_madd<M>(p, f30_from_fe<M>(ax), f30_from_fe<M>(ay)); ax.v[1] += 1; }
+    bool flip = false;
+    for (int i = 0; i < iters; i++) { xyzz30_madd_flip<M>(p, flip, f30_from_fe<M>(ax), f30_from_fe<M>(ay)); ax.v[1] += 1; }
+    xyzz30_flip_finish<M>(p, flip);
     XYZZ<M> o = xyzz30_to_xyzz<M>(p);
     for (int i = 0; i < 8; i++) io[tid * 9 + i] = o.x.v[i] ^ o.y.v[i] ^ o.zz.v[i] ^ o.zzz.v[i];
 }
