@@ -60,6 +60,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 MSM_BYTES_PER_PAIR = 96       # 32-B scalar + 64-B affine point
 COMMIT_BYTES_PER_ROW = 4096 + 64  # 128 x 32-B coefficients in, 64-B point out (SRS table resident)
+# field products a MAC butterfly EXECUTES, averaged over the 15 launches of a 2^15-MAC encode (mac_fft.hip.h): stage 1 two additions
+# (14 fe_mul each); stages 2..11 the wave-uniform sparse ladder: 128 doublings (9) + ~43 + 8 table + 2 butterfly additions;
+# stages 12..15 the fixed-window ladder: 132 doublings + ~62 + 7 + 2 additions
+MAC_FE_MULTS_PER_BUTTERFLY = (28 + 10 * (128 * 9 + 53 * 14) + 4 * (132 * 9 + 71 * 14)) / 15.0
 ICC_BYTES_PER_ELEMENT = 64    # 32 B in + 32 B out
 # fallback when the in-run measurement is unavailable: back-to-back 256-bit modular products, G/s per GPU, in the reduced-radix
 # form of fe30.hip.h (profiles/r01_l_ubench_fe30.txt): BN254 180.7 G products/s and 213.6 G squares/s -> 186.5 for the 8M + 2S
@@ -1155,20 +1159,27 @@ def main():
         mx.profile_enable(False)
         return ms, {k: round(t / max(c, 1), 4) for k, t, c in prof}, {k: round(t / 5, 4) for k, t, c in prof}
 
-    def hbm_roofline(per_launch, per_call, algo_bytes_per_call, note, workload=None):
+    def hbm_roofline(per_launch, per_call, algo_bytes_per_call, note, workload=None, fe_mults_per_launch=None, field=None):
         if not per_launch:
             return None
         dom = max(per_call, key=per_call.get)
         traffic = pmc_traffic(dom, workload) if workload else None
         launches = max(1, round(per_call[dom] / per_launch[dom])) if per_launch[dom] else 1
         ach = algo_bytes_per_call / launches / (per_launch[dom] * 1e-3) / 1e9 if per_launch[dom] else None
-        return {"bound": "hbm", "kernel": KERNEL_SYMBOL.get(dom, dom), "achieved": round(ach, 3) if ach else None, "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 6) if ach else None, "traffic": traffic,
-                "traffic_source": ("committed rocprofv3 --pmc passes (profiles/pmc_latest_%s.json), per launch of the kernel, not "
-                                   "collected in this run" % workload) if traffic else "no counter pass committed for this leg",
-                "kernel_ms": per_launch[dom],
-                "launches_per_call": launches, "algorithmic_bytes_per_call": algo_bytes_per_call,
-                "all_kernels_ms_per_call": per_call, "note": note}
+        r = {"bound": "hbm", "kernel": KERNEL_SYMBOL.get(dom, dom), "achieved": round(ach, 3) if ach else None, "peak": HBM_PEAK_GBPS,
+             "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 6) if ach else None, "traffic": traffic,
+             "traffic_source": ("committed rocprofv3 --pmc passes (profiles/pmc_latest_%s.json), per launch of the kernel, not "
+                                "collected in this run" % workload) if traffic else "no counter pass committed for this leg",
+             "kernel_ms": per_launch[dom],
+             "launches_per_call": launches, "algorithmic_bytes_per_call": algo_bytes_per_call,
+             "all_kernels_ms_per_call": per_call, "note": note}
+        if fe_mults_per_launch and fe_peak and field and per_launch[dom]:
+            # the mandated fraction prices HBM; what bounds these kernels is the integer multiplier: the same supplement as the MSM legs
+            g = fe_mults_per_launch / (per_launch[dom] * 1e-3) / 1e9
+            pk = fe_peak[field]
+            r["int_multiplier"] = {"achieved": round(g, 2), "peak": pk["mix_8M_2S"], "unit": "G fe_mul/s (256-bit modular)",
+                                   "frac": round(g / pk["mix_8M_2S"], 4), "peak_source": pk["source"]}
+        return r
 
     SECP_G = bytes.fromhex("79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798"
                            "483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8")      # group_impl.h:28-33
@@ -1217,7 +1228,9 @@ def main():
                                  "compute_commitment, not libsecp256k1) over %d threads; %.2f s wall" % (sample, cores, cpu_s)}
             rl = hbm_roofline(per_launch, per_call, COMMIT_BYTES_PER_ROW * rows_n,
                               "algorithmic bytes = 4 096 B of coefficients + 64 B out per row (generator table resident); the kernel "
-                              "is bound by the integer multiplier, as k_fb_commit of the KZG leg", workload="ipa_commits")
+                              "is bound by the integer multiplier, as k_fb_commit of the KZG leg", workload="ipa_commits",
+                              fe_mults_per_launch=10.0 * rows_n * 128 * info["windows"],
+                              field="secp256k1")
             return {"metric": "IPA Pedersen commitments/s (128-coefficient rows against the 128 secp256k1 generators)",
                     "value": round(rows_n / ms * 1e3, 1), "unit": "commits/s", "ms_per_step": round(ms, 4), "scaling": "weak",
                     "dtype": "u32x9 (30-bit limbs, 256-bit modular integer)",
@@ -1267,7 +1280,8 @@ def main():
                                     "roofline": hbm_roofline(per_launch, per_call, 128 * n,
                                                              "algorithmic bytes = 64 B in + 64 B out per MAC; the network is a chain of "
                                                              "dependent group operations bound by the integer multiplier",
-                                                             workload="mac_encode" if curve == "bn254" else None),
+                                                             workload="mac_encode" if curve == "bn254" else None,
+                                                             fe_mults_per_launch=(n // 2) * MAC_FE_MULTS_PER_BUTTERFLY, field=curve),
                                     "cpu_baseline": cpu, "bit_exact_vs_oracle": ok}
         out["value"] = out["curves"]["bn254"]["value"]
         out["ms_per_step"] = out["curves"]["bn254"]["ms_per_step"]

@@ -242,7 +242,7 @@ __device__ __forceinline__ void icc30_plane(uint32_t* lds, const IccTile& T, con
 // pointers -- instead of a second run of every pass.  use_wt must be 0 (the network is the X part's); wt256 is the scaling.
 // A mod p_icc of the Y part waits for the q plane in out_y.al or, when the caller does not want it, in park_y (32 B per symbol).
 template <class Q, bool FIRST, bool LAST, bool XY = false>
-__global__ void __launch_bounds__(ICC30_SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ void __launch_bounds__(ICC30_SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(XY ? 3 : 4, 4)))
 k_icc_split30(uint32_t* __restrict__ work_p, uint32_t* __restrict__ work_q, const uint32_t* __restrict__ twp,
               const uint32_t* __restrict__ twq, uint32_t n, uint32_t ncols, int s0, int ns, int cc_log,
               const uint8_t* __restrict__ raw, IccElem<Q> wt256, int use_wt, IccOut out, IccOut out_y, uint32_t* __restrict__ park_y) {

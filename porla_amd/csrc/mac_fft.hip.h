@@ -238,8 +238,8 @@ __device__ __forceinline__ int mac_signed_digit(const uint32_t m[4], int i) {
 // The quad-lane kernels run one wave per SIMD (LDS: one block per compute unit), so the compiler would happily spend 212 registers
 // on them -- and then they fit beside nothing: next to the commitments of the same CRebuild (two 192-register waves per SIMD in the
 // guest-room form of k_fb_commit) 128 registers are free.  Held to 128 they start at once there (the arithmetic is one field
-// product per lane at a time).
-#define MACQ_GUEST_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+// product per lane at a time).  secp256k1 has no such neighbour and a fold that wants more registers: C::MACQ_WAVES = 2 there.
+#define MACQ_GUEST_ATTR __attribute__((amdgpu_waves_per_eu(C::MACQ_WAVES, C::MACQ_WAVES)))
 // ... and their LDS state is DYNAMIC shared memory (sizeof(MacQuadLds<M>) at the launch, mac_fft.hip:macq_lds_bytes): with the
 // state declared statically the compiler knows that one block fits a compute unit, concludes "occupancy 1" and gives the kernel
 // descriptor 264 registers whatever the code uses -- the guest would not fit again

@@ -53,6 +53,7 @@ struct Bn254G1 {
     // combine and tree kernels
     static constexpr bool F30_LAZY = true;
     static constexpr int BUCKET_SUM_WAVES = 4;   // waves per SIMD k_bucket_sum30 is compiled for
+    static constexpr int MACQ_WAVES = 4;         // the quad-lane MAC kernels: 128 registers, they run beside the commitments of a CRebuild (mac_fft.hip.h)
 };
 struct Secp256k1G {
     using Fp = Secp256k1Fp;
@@ -68,6 +69,7 @@ struct Secp256k1G {
     static constexpr bool F30_BUCKETS = true;    // special-form product on 30-bit limbs: 194 against 133 G products/s
     static constexpr bool F30_LAZY = true;       // memory form: canonical residues (5p > 2^256: an unreduced X does not fit 32 bytes)
     static constexpr int BUCKET_SUM_WAVES = 3;   // the fold's temporaries do not fit 128 registers
+    static constexpr int MACQ_WAVES = 2;         // no combined CRebuild stage on this curve: the quad-lane MAC kernels take the registers the fold wants (no spills)
 };
 
 constexpr uint32_t KEY_NONE = 0xffffffffu;

@@ -239,7 +239,7 @@ try:
     msgs.append("unexpected success")
 except Exception as e:
     msgs.append(str(e))
-print("\n".join(msgs), flush=True)
+print("\n".join("MSG " + m.replace("\n", " ") for m in msgs), flush=True)
 os._exit(7)                                  # what the header prescribes after a timed-out initialisation
 """
 
@@ -251,9 +251,9 @@ def test_dist_init_times_out_poisons_the_state_and_the_process_leaves():
     env = dict(os.environ, PORLA_ROOT=common.ROOT, PORLA_DIST_INIT_TIMEOUT_S="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
     t0 = time.time()
     r = subprocess.run([sys.executable, "-c", TIMEOUT_WORKER], env=env, capture_output=True, text=True, timeout=300)
-    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    lines = [l[4:] for l in r.stdout.splitlines() if l.startswith("MSG ")]      # (RCCL prints its version banner on stdout)
     assert r.returncode == 7, r.stdout[-1500:] + r.stderr[-1500:]
-    assert len(lines) >= 3 and "did not return within 4 s" in lines[0], lines
+    assert len(lines) == 3 and "did not return within 4 s" in lines[0], lines
     assert "timed out" in lines[1] and "fresh process" in lines[1], lines
     assert "timed out" in lines[2], lines
     assert time.time() - t0 < 120
