@@ -206,14 +206,19 @@ def emit(full, legs_out, single_leg=False):
     return out
 
 
-def pmc_traffic(slot, workload):
-    """HBM-side bytes per launch of `slot`'s kernel from the committed PMC summary of this workload, or None"""
+CURVE_TAGS = {"bn254": ("Bn254",), "secp256k1": ("Secp256k1",)}      # template arguments that name the curve in a kernel symbol
+
+
+def pmc_traffic(slot, workload, curve=None):
+    """HBM-side bytes per launch of `slot`'s kernel from the committed PMC summary of this workload, or None; `curve`: only the
+    instantiations of that curve (a leg that runs both curves in one process has both in its counter file)"""
     path = os.path.join(ROOT, "profiles", PMC_FILE.get(workload, "pmc_latest_%s.json" % workload))
     sym = KERNEL_SYMBOL.get(slot, slot)
     try:
         d = json.load(open(path))
-        fetch = [v for k, v in d["fetch"].items() if sym in k and "FETCH_SIZE" in k]
-        write = [v for k, v in d["write"].items() if sym in k and "WRITE_SIZE" in k]
+        tags = CURVE_TAGS.get(curve, ("",))
+        fetch = [v for k, v in d["fetch"].items() if sym in k and "FETCH_SIZE" in k and any(t in k for t in tags)]
+        write = [v for k, v in d["write"].items() if sym in k and "WRITE_SIZE" in k and any(t in k for t in tags)]
         if not fetch or not write:
             return None
         # per launch, averaged over every instantiation of the kernel that ran (the ICC encode launches a first-pass and a
@@ -1159,11 +1164,11 @@ def main():
         mx.profile_enable(False)
         return ms, {k: round(t / max(c, 1), 4) for k, t, c in prof}, {k: round(t / 5, 4) for k, t, c in prof}
 
-    def hbm_roofline(per_launch, per_call, algo_bytes_per_call, note, workload=None, fe_mults_per_launch=None, field=None):
+    def hbm_roofline(per_launch, per_call, algo_bytes_per_call, note, workload=None, fe_mults_per_launch=None, field=None, curve=None):
         if not per_launch:
             return None
         dom = max(per_call, key=per_call.get)
-        traffic = pmc_traffic(dom, workload) if workload else None
+        traffic = pmc_traffic(dom, workload, curve) if workload else None
         launches = max(1, round(per_call[dom] / per_launch[dom])) if per_launch[dom] else 1
         ach = algo_bytes_per_call / launches / (per_launch[dom] * 1e-3) / 1e9 if per_launch[dom] else None
         r = {"bound": "hbm", "kernel": KERNEL_SYMBOL.get(dom, dom), "achieved": round(ach, 3) if ach else None, "peak": HBM_PEAK_GBPS,
@@ -1280,7 +1285,7 @@ def main():
                                     "roofline": hbm_roofline(per_launch, per_call, 128 * n,
                                                              "algorithmic bytes = 64 B in + 64 B out per MAC; the network is a chain of "
                                                              "dependent group operations bound by the integer multiplier",
-                                                             workload="mac_encode" if curve == "bn254" else None,
+                                                             workload="mac_encode", curve=curve,
                                                              fe_mults_per_launch=(n // 2) * MAC_FE_MULTS_PER_BUTTERFLY, field=curve),
                                     "cpu_baseline": cpu, "bit_exact_vs_oracle": ok}
         out["value"] = out["curves"]["bn254"]["value"]
@@ -1353,7 +1358,7 @@ def main():
                                                              256 * length * n_cols,
                                                              "the data kernel: 2 x 64 B in + 2 x 64 B out per butterfly; the call's wall time is "
                                                              "set by the point butterflies beside it (a chain of dependent group operations)",
-                                                             workload="server_mix" if curve == "bn254" else None),
+                                                             workload="server_mix", curve=curve),
                                     "kernels_ms_per_call": per_call, "cpu_baseline": cpu, "bit_exact_vs_oracle": ok}
         for k in ("value", "ms_per_step", "roofline", "cpu_baseline"):
             out[k] = out["curves"]["bn254"][k]
