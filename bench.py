@@ -392,6 +392,7 @@ def main():
     # which RCCL refuses) the partials go over gloo on the host.
     collective = "none (single GPU)"
     use_cxx_dist = False
+    hard_exit = False          # an in-library ncclCommInitRank timed out: its helper thread is still inside RCCL (include/porla_gpu.h)
     if world > 1:
         collective = "torch.distributed %s all_gather" % backend
         if backend == "nccl" and os.environ.get("PORLA_DIST_CXX", "1") != "0":
@@ -415,6 +416,7 @@ def main():
                     inited = True
                 except Exception as e:  # noqa: BLE001
                     print("rank %d: ncclCommInitRank from C++ failed (%s)" % (rank, e), file=sys.stderr)
+                    hard_exit = "did not return within" in str(e)
                 use_cxx_dist = all_ok(inited)
                 if use_cxx_dist:
                     collective = "ncclAllGather from C++ (porla_dist_*, RCCL over xGMI)"
@@ -1429,10 +1431,15 @@ def main():
             mx.dist_finalize()
         dist.barrier()
         dist.destroy_process_group()
-    if failed:
-        sys.exit(1)
-    if any(l in BASELINE_CONFIG_LEGS for l in legs_failed):
-        sys.exit(3)
+    code = 1 if failed else (3 if any(l in BASELINE_CONFIG_LEGS for l in legs_failed) else 0)
+    if hard_exit:
+        # the run went on over torch.distributed's collectives, but a thread of this process still sits inside RCCL: static
+        # destructors must not run under it -- leave without them (everything is printed and flushed)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(code)
+    if code:
+        sys.exit(code)
 
 
 if __name__ == "__main__":

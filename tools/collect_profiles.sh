@@ -14,4 +14,6 @@ done
 for f in bench_default_line bench_crebuild; do
   [ -f gpurun_out/${TAG}_$f.json ] && grep "^{" gpurun_out/${TAG}_$f.json > profiles/${TAG}_$f.json
 done
+# the default run's whole stdout: the `LEG <name> {...}` lines carry every leg's full object, the last line is the compact one
+[ -f gpurun_out/${TAG}_bench_default_line.json ] && cp gpurun_out/${TAG}_bench_default_line.json profiles/${TAG}_bench_default_stdout.txt
 ls -la profiles/${TAG}_* | wc -l
