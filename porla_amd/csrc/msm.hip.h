@@ -863,7 +863,7 @@ struct TreeTailArgs {
     uint32_t nlev;
 };
 template <class C, bool QUAD>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(512)
 k_tree_tail(TreeTailArgs<typename C::Fp> a) {
     using M = typename C::Fp;
     const uint32_t w = blockIdx.x;

@@ -485,12 +485,7 @@ static int msm_tree_launch(Workspace* ws, const XYZZ<typename C::Fp>* buckets, i
             uint32_t threads = (need + 63) / 64 * 64;
             if (threads > tree_tail_threads()) threads = tree_tail_threads();
             if (threads < 64) threads = 64;
-            if constexpr (C::F30_LAZY) {
-                if (quad) hipLaunchKernelGGL((k_tree_tail<C, true>), dim3(Wp), dim3(threads), 0, st, t);
-                else hipLaunchKernelGGL((k_tree_tail<C, false>), dim3(Wp), dim3(threads), 0, st, t);
-            } else {
-                hipLaunchKernelGGL((k_tree_tail<C, false>), dim3(Wp), dim3(threads), 0, st, t);
-            }
+            hipLaunchKernelGGL((k_tree_tail<C, true>), dim3(Wp), dim3(threads), 0, st, t);
         }
         // no copy packet: the last level stores its W * c results straight into the pinned host buffer (a D2H hipMemcpyAsync
         // was seen to block the launching thread for milliseconds while another MSM is in flight)
