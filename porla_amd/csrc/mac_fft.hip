@@ -103,6 +103,27 @@ static size_t macq_lds_bytes() {
     return sizeof(MacQuadLds<M>);
 }
 
+template <class C>
+static size_t maco_lds_bytes() {
+    using M = typename C::Fp;
+    static std::mutex mu;
+    static std::vector<int> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return sizeof(MacOctLds<M>);
+    std::lock_guard<std::mutex> lk(mu);
+    bool seen = false;
+    for (int d : done) seen = seen || d == dev;
+    if (!seen) {
+        const int bytes = (int)sizeof(MacOctLds<M>);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mac_stage30_oct<C>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mac_mix_oct<C>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        done.push_back(dev);
+    }
+    return sizeof(MacOctLds<M>);
+}
+// butterflies (or mix elements) up to which a launch leaves half the chip idle at four lanes each: eight lanes per butterfly
+constexpr size_t MACO_MAX_BUTTERFLIES = 8192;      // same-box A/B against four lanes: profiles/r05_k_mac_octet_ab.txt
+
 template <class C, class Q>
 static int mac_mix_core(MacWs* ws, int curve, const uint8_t* d_a0, const uint8_t* d_a1, size_t len, size_t n_total, uint8_t* d_out,
                         hipStream_t stream, const uint8_t* d_b0 = nullptr, const uint8_t* d_b1 = nullptr, uint8_t* d_out_b = nullptr) {
@@ -111,6 +132,12 @@ static int mac_mix_core(MacWs* ws, int curve, const uint8_t* d_a0, const uint8_t
     ProfScope ps("mac_mix", stream);
     const unsigned sets = d_b0 ? 2u : 1u;               // the second array pair (MAC alignments beside the MAC commitments)
     const size_t quad_max = (size_t)1 << macq_max_log(14);
+    if (macq_max_log(14) > 0 && len * sets <= quad_max && len * sets <= MACO_MAX_BUTTERFLIES) {   // half the chip idle at four lanes: eight
+        hipLaunchKernelGGL((k_mac_mix_oct<C>), dim3((unsigned)((len + MACO_BF - 1) / MACO_BF), sets), dim3(8 * MACO_BF), maco_lds_bytes<C>(), stream, d_a0,
+                           d_a1, (uint32_t)len, (const uint32_t*)ws->tws.p, (uint32_t)(n_total / len), d_out, d_b0, d_b1, d_out_b);
+        PORLA_HIP(hipGetLastError());
+        return PORLA_OK;
+    }
     if (macq_max_log(14) > 0 && len * sets <= quad_max) {   // latency bound: four lanes per element (k_mac_stage30_quad's ladder)
         hipLaunchKernelGGL((k_mac_mix_quad<C>), dim3((unsigned)((len + MACQ_BF - 1) / MACQ_BF), sets), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream, d_a0,
                            d_a1, (uint32_t)len, (const uint32_t*)ws->tws.p, (uint32_t)(n_total / len), d_out, d_b0, d_b1, d_out_b);
@@ -202,6 +229,10 @@ static int mac_encode_core(MacWs* ws, int curve, const uint8_t* d_in, size_t n, 
         else if (quad_path && (n >> s) >= 16 && n >= 128)
             // >= 16 butterflies per twiddle (and whole blocks of 64): a wave's 16 quads share their scalar -- the sparse ladder
             hipLaunchKernelGGL((k_mac_stage30_quad<C, true>), dim3((unsigned)((n / 2 + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream,
+                               (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->tws.p, (uint32_t)n, s);
+        else if (quad_path && n / 2 <= MACO_MAX_BUTTERFLIES)
+            // per-butterfly scalars and at most 2^13 butterflies: eight lanes each (the two half-scalar ladders side by side)
+            hipLaunchKernelGGL((k_mac_stage30_oct<C>), dim3((unsigned)((n / 2 + MACO_BF - 1) / MACO_BF)), dim3(8 * MACO_BF), maco_lds_bytes<C>(), stream,
                                (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->tws.p, (uint32_t)n, s);
         else if (quad_path)
             hipLaunchKernelGGL((k_mac_stage30_quad<C, false>), dim3((unsigned)((n / 2 + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream,

@@ -539,6 +539,176 @@ k_mac_stage30_quad(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __re
     macq_butterfly_out<M>(&L.um[q], &L.acc[q], &L.tmp[q], c, inf, work + k, work + k + m2, valid, r, lane);
 }
 
+template <class M>
+__device__ __forceinline__ void store_affine_be(uint8_t* dst, const XYZZ<M>& p);     // below
+
+// ---------------------------------------------------------------- EIGHT lanes per butterfly (launches that leave half the chip idle)
+// 2^13 butterflies and fewer (a stage of N <= 2^14 rows, Server::mix on two arrays of 2^12) give the quad-lane kernels at most one
+// wave on every other SIMD: lanes are free, latency is everything.  The endomorphism split k P = k1 P + k2 phi(P) is two INDEPENDENT
+// 128-bit ladders: here an OCTET owns a butterfly -- quad 0 walks k1 over the table of P's multiples, quad 1 walks k2 over the same
+// table with the beta-scaled X coordinates, each with its own accumulator in registers (33 windows of 4 doublings + ONE addition
+// instead of two); quad 1 hands its sum over through LDS, quad 0 adds it, hands tm back, and the two quads form one output each
+// (um + tm | um - tm).  ~570 product rounds in sequence instead of ~700.  The two quads of an octet sit in one wave: the LDS traffic
+// between them needs no block barrier (macq_sync).  32 octets per block: 68 KiB of LDS, two blocks per compute unit.
+constexpr int MACO_BF = 32;
+// (these kernels only run where the chip is under-filled: no neighbour to leave registers to -- two waves per SIMD, 256 registers)
+#define MACO_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+template <class M>
+struct MacOctLds {
+    typename MacQuadLds<M>::Quad qd[MACO_BF];   // per octet: table of multiples + beta-scaled X
+    XYZZ<M> acc[2 * MACO_BF], tmp[2 * MACO_BF];  // per quad: the slots of the rare general addition
+    XYZZ<M> um[MACO_BF], xch[MACO_BF];           // per octet: the butterfly's upper input; what the quads hand each other
+};
+#define MACO_LDS(L) extern __shared__ __align__(16) unsigned char macq_lds_raw[]; \
+    MacOctLds<M>& L = *reinterpret_cast<MacOctLds<M>*>(macq_lds_raw)
+
+// one half-scalar's ladder on a quad: (c, inf) = (neg ? -1 : 1) * m * T, T = the point whose multiples are in Q.tbl (phi: its image
+// under the endomorphism -- X is read from Q.bx)
+template <class M>
+__device__ __forceinline__ void macq_ladder_half(typename MacQuadLds<M>::Quad& Q, XYZZ<M>* slot_a, XYZZ<M>* slot_b, const uint32_t m[4],
+                                                 bool neg, bool phi, uint32_t r, uint32_t lane, F30<M>& c, bool& inf) {
+    inf = true;
+#pragma unroll 1
+    for (int i = 32; i >= 0; i--) {
+        if (!inf) {
+#pragma unroll 1
+            for (int d = 0; d < 4; d++) xyzz30_dbl_quadreg<M>(c, r);
+        }
+        const int dg = mac_signed_digit(m, i);
+        if (dg == 0) continue;
+        const uint32_t mag = (uint32_t)(dg < 0 ? -dg : dg) - 1u;
+        const XYZZ<M>* e = &Q.tbl[mag];
+        macq_add<M>(c, inf, e, phi ? &Q.bx[mag][0] : reinterpret_cast<const uint32_t*>(e), (dg < 0) != neg, slot_a, slot_b, r, lane);
+    }
+}
+// dst = um + (c, inf) (memory form), um in LDS; all four lanes of a quad
+template <class M>
+__device__ __forceinline__ void macq_sum_out(const XYZZ<M>* um, XYZZ<M>* slot_a, XYZZ<M>* slot_b, F30<M> c, bool inf, XYZZ<M>* dst,
+                                             bool live, uint32_t r, uint32_t lane) {
+    bool z;
+    const F30<M> u = macq_load_residue<M>(reinterpret_cast<const uint32_t*>(um) + 8 * r, &z);
+    const bool um_inf = macq_quad_any(z && r == 2u, lane);
+    if (inf) { if (live) macq_store_point<M>(dst, u, um_inf, r); return; }
+    if (!um_inf) macq_add<M>(c, inf, um, reinterpret_cast<const uint32_t*>(um), false, slot_a, slot_b, r, lane);
+    if (live) macq_store_point<M>(dst, c, inf, r);
+}
+// The octet's whole butterfly: P = L.qd[o].tbl[0] and um = L.um[o] are in LDS (written by this octet's lanes, macq_sync passed);
+// quad 0 (half = 0) leaves um + sc P at lo, quad 1 leaves um - sc P at hi (memory form, LDS or global) when `live`.
+template <class C>
+__device__ __forceinline__ void maco_butterfly(MacOctLds<typename C::Fp>& L, uint32_t o, uint32_t half, uint32_t r, uint32_t lane,
+                                               const uint32_t sc[8], XYZZ<typename C::Fp>* lo, XYZZ<typename C::Fp>* hi, bool live) {
+    using M = typename C::Fp;
+    using G = typename C::Glv;
+    typename MacQuadLds<M>::Quad& Q = L.qd[o];
+    const uint32_t qi = 2u * o + half;                                     // this quad's slots
+    F30<M> c;
+    bool inf = true, z;
+    c = macq_load_residue<M>(reinterpret_cast<const uint32_t*>(&Q.tbl[0]) + 8 * r, &z);
+    const bool p_inf = macq_quad_any(z && r == 2u, lane);                  // (both quads read the same point: the same answer)
+    if (!p_inf) {
+        uint32_t m0[4], m1[4];
+        bool ng0, ng1;
+        glv_split<G>(sc, m0, ng0, m1, ng1);
+        if (half == 0u) {                                                  // quad 0 builds the table: 2P, then 3P .. 8P
+            bool tinf = false;
+            xyzz30_dbl_quadreg<M>(c, r);
+            macq_store_residue<M>(reinterpret_cast<uint32_t*>(&Q.tbl[1]) + 8 * r, c);
+#pragma unroll 1
+            for (int i = 2; i < 8; i++) {
+                macq_add<M>(c, tinf, &Q.tbl[0], reinterpret_cast<const uint32_t*>(&Q.tbl[0]), false, &L.acc[qi], &L.tmp[qi], r, lane);
+                macq_store_residue<M>(reinterpret_cast<uint32_t*>(&Q.tbl[i]) + 8 * r, c);
+            }
+        }
+        macq_sync();
+        {   // beta * X of the eight entries: one per lane of the octet
+            const uint32_t e = 4u * half + r;
+            const F30<M> x = macq_load_residue<M>(reinterpret_cast<const uint32_t*>(&Q.tbl[e]), &z);
+            macq_store_residue<M>(&Q.bx[e][0], f30_mul<M>(x, f30_const<M>(G::BETA_30)));
+        }
+        macq_sync();
+        uint32_t mh[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) mh[j] = half ? m1[j] : m0[j];
+        macq_ladder_half<M>(Q, &L.acc[qi], &L.tmp[qi], mh, half ? ng1 : ng0, half != 0u, r, lane, c, inf);
+    }
+    // quad 1 -> quad 0: k2 phi(P); quad 0: tm = k1 P + that, handed back; then one output each
+    if (half) macq_store_point<M>(&L.xch[o], c, inf, r);
+    macq_sync();
+    if (half == 0u) {
+        const F30<M> other = macq_load_residue<M>(reinterpret_cast<const uint32_t*>(&L.xch[o]) + 8 * r, &z);
+        const bool other_inf = macq_quad_any(z && r == 2u, lane);
+        if (!other_inf) {
+            if (inf) { c = other; inf = false; }
+            else macq_add<M>(c, inf, &L.xch[o], reinterpret_cast<const uint32_t*>(&L.xch[o]), false, &L.acc[qi], &L.tmp[qi], r, lane);
+        }
+    }
+    macq_sync();                                                           // (quad 0 has read the slot before it writes it)
+    if (half == 0u) macq_store_point<M>(&L.xch[o], c, inf, r);
+    macq_sync();
+    if (half) {
+        c = macq_load_residue<M>(reinterpret_cast<const uint32_t*>(&L.xch[o]) + 8 * r, &z);
+        inf = macq_quad_any(z && r == 2u, lane);
+        if (!inf && r == 1u) c = f30_sub<M, 4>(F30<M>{}, c);               // -tm
+    }
+    macq_sum_out<M>(&L.um[o], &L.acc[qi], &L.tmp[qi], c, inf, half ? hi : lo, live, r, lane);
+}
+
+template <class C>
+__global__ void __launch_bounds__(8 * MACO_BF) MACO_ATTR
+k_mac_stage30_oct(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restrict__ tws, uint32_t n, int s) {
+    using M = typename C::Fp;
+    MACO_LDS(L);
+    __builtin_amdgcn_s_setprio(3);                                         // (as k_mac_stage30_quad: a latency-bound wave must win the issue arbitration)
+    const uint32_t o = threadIdx.x >> 3, half = (threadIdx.x >> 2) & 1u, r = threadIdx.x & 3u, lane = threadIdx.x & 63u;
+    uint32_t t = blockIdx.x * MACO_BF + o;
+    const bool valid = t < n / 2;
+    if (!valid) t = 0;
+    const uint32_t m2 = 1u << (s - 1);
+    const uint32_t j = t & (m2 - 1);
+    const uint32_t k = ((t >> (s - 1)) << s) + j;
+    const uint32_t e = j * (n >> (s - 1));
+    uint32_t sc[8];
+    {
+        const uint4* w4 = reinterpret_cast<const uint4*>(tws + (size_t)e * 8);
+        const uint4 a = w4[0], b = w4[1];
+        sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
+    }
+    if (half) macq_copy_coord<M>(&L.um[o], work + k, r);
+    else macq_copy_coord<M>(&L.qd[o].tbl[0], work + k + m2, r);
+    macq_sync();
+    maco_butterfly<C>(L, o, half, r, lane, sc, work + k, work + k + m2, valid);
+}
+
+// Server::mix's MAC part with eight lanes per i (k_mac_mix_quad's work): lanes 0 / 4 convert the two inputs on the way in, invert for
+// the two outputs
+template <class C>
+__global__ void __launch_bounds__(8 * MACO_BF) MACO_ATTR
+k_mac_mix_oct(const uint8_t* __restrict__ a0, const uint8_t* __restrict__ a1, uint32_t len, const uint32_t* __restrict__ tws,
+              uint32_t tw_step, uint8_t* __restrict__ out, const uint8_t* __restrict__ b0, const uint8_t* __restrict__ b1,
+              uint8_t* __restrict__ out_b) {
+    using M = typename C::Fp;
+    MACO_LDS(L);
+    __builtin_amdgcn_s_setprio(3);                                         // (the data part of the same mix runs beside this kernel)
+    if (blockIdx.y) { a0 = b0; a1 = b1; out = out_b; }                      // the second array pair of a mix (see k_mac_mix_quad)
+    const uint32_t o = threadIdx.x >> 3, half = (threadIdx.x >> 2) & 1u, r = threadIdx.x & 3u, lane = threadIdx.x & 63u;
+    uint32_t i = blockIdx.x * MACO_BF + o;
+    const bool valid = i < len;
+    if (!valid) i = 0;
+    uint32_t sc[8];
+    {
+        const uint4* w4 = reinterpret_cast<const uint4*>(tws + (size_t)i * tw_step * 8);
+        const uint4 a = w4[0], b = w4[1];
+        sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
+    }
+    if (r == 0u) store_xyzz<M>(half ? &L.um[o] : &L.qd[o].tbl[0], load_affine_be_lazy<M>((half ? a0 : a1) + (size_t)i * 64));
+    macq_sync();
+    // the sums land in the table's entries 1 and 2 (the table is done with by then: each quad writes its own entry last)
+    maco_butterfly<C>(L, o, half, r, lane, sc, &L.qd[o].tbl[1], &L.qd[o].tbl[2], true);
+    macq_sync();
+    if (valid && r == 0u)                                                  // the two inversions side by side (lanes 0 and 4)
+        store_affine_be<M>(out + ((size_t)i + (half ? len : 0)) * 64, xyzz30_to_xyzz<M>(xyzz30_load_lazy<M>(&L.qd[o].tbl[1 + half])));
+}
+
 // Stage 1 of the network with four lanes per butterfly: every twiddle is w^0 = 1 (tm = MAC[k+1]), so the stage is its two
 // additions and nothing else -- the ladder of a general stage would multiply by one.  256 lanes = 64 butterflies per block.
 template <class C>
@@ -566,6 +736,7 @@ __global__ void __launch_bounds__(4 * MACQ_BF) MACQ_GUEST_ATTR
 k_mac_load30_quad(const uint8_t* __restrict__ in, uint32_t n, XYZZ<typename C::Fp>* __restrict__ work, MacScalar wt) {
     using M = typename C::Fp;
     MACQ_LDS(L);
+    __builtin_amdgcn_s_setprio(3);                                         // (beside the commitments of a CRebuild, as the stage kernel)
     const uint32_t q = threadIdx.x >> 2, r = threadIdx.x & 3u, lane = threadIdx.x & 63u;
     uint32_t i = blockIdx.x * MACQ_BF + q;
     const bool valid = i < n;
@@ -582,8 +753,6 @@ k_mac_load30_quad(const uint8_t* __restrict__ in, uint32_t n, XYZZ<typename C::F
     if (valid) macq_store_point<M>(work + i, c, inf, r);
 }
 
-template <class M>
-__device__ __forceinline__ void store_affine_be(uint8_t* dst, const XYZZ<M>& p);     // below
 
 // Server::mix's MAC part (k_mac_mix below) with four lanes per i: the butterfly out[i] = A0[i] + v^i A1[i], out[i + len] = A0[i] -
 // v^i A1[i] on 64-byte affine points -- lanes 0 / 1 convert the two inputs on the way in and invert for the two outputs
@@ -596,6 +765,7 @@ k_mac_mix_quad(const uint8_t* __restrict__ a0, const uint8_t* __restrict__ a1, u
     MACQ_LDS(L);
     // gridDim.y == 2: Server::mix runs this butterfly on the MAC commitments AND on the MAC alignments with the same v^i
     // (Server.hpp:1281-1318) -- the second array pair rides in the same launch (a stage this short is latency: two for the price of one)
+    __builtin_amdgcn_s_setprio(3);                                         // (the data part of the same mix runs beside this kernel)
     if (blockIdx.y) { a0 = b0; a1 = b1; out = out_b; }
     const uint32_t q = threadIdx.x >> 2, r = threadIdx.x & 3u, lane = threadIdx.x & 63u;
     uint32_t i = blockIdx.x * MACQ_BF + q;
