@@ -39,9 +39,11 @@ every result sees, with its own per-kernel breakdown), `audit_size_msm` (128 / 1
 issues), `host_boundary` (compute_multi_exp on caller-owned pageable host buffers, PCIe included).
 `--workload X` prints leg X alone as the line (`crebuild`: the device-resident last encode stage, tools/bench_crebuild.py).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel of the workload, timed with HIP events on the
-launch stream inside the library over the timed region; `traffic` comes from the committed rocprofv3 PMC passes
-(profiles/pmc_latest*.json: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, KiB -> bytes, per launch);
+The LAST stdout line is ONE compact JSON object (rank 0; <= 6 000 bytes: compact_line); the full result goes to bench_legs.json
+(--legs-out) and to earlier `LEG <name> {...}` lines.  `roofline` is for the dominant kernel of the workload, timed with HIP events on
+the launch stream inside the library over the timed region; `traffic` of the headline and of the BASELINE-configuration legs comes from
+two rocprofv3 --pmc passes made in this run (pmc_in_run: child runs of the same workload after the timed regions), of the other legs
+from the committed passes (profiles/pmc_latest*.json: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, KiB -> bytes, per launch);
 `int_multiplier.peak` is measured in this run on this box (porla_amd/fe30_check --peak: back-to-back products of the field
 form the kernels use); `cpu_baseline` is the oracle (CPU restatement -- NOT gnark / libsecp256k1 / NTL) timed on this box's
 host cores.
@@ -97,6 +99,7 @@ def _compact_roofline(rl):
     if not isinstance(rl, dict):
         return None
     out = {k: rl.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms")}
+    out["traffic_in_run"] = "collected in this run" in (rl.get("traffic_source") or "")
     im = rl.get("int_multiplier")
     if isinstance(im, dict):
         out["int_multiplier"] = {"achieved": im.get("achieved"), "peak": im.get("peak"), "unit": "G fe_mul/s", "frac": im.get("frac")}
@@ -237,6 +240,45 @@ def pmc_traffic(slot, workload, curve=None):
         return None
 
 
+def pmc_in_run(symbol, bench_args, timeout_s=240):
+    """HBM-side bytes per launch of the kernel whose name contains `symbol`, collected NOW: two child runs of this script under
+    `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950; the program itself follows `--`, no trace domain is
+    combined with the counters).  Returns (bytes per launch, launches counted) or (None, reason).  rocprofv3 reports KiB;
+    gfx950's FETCH_SIZE counts a 128-byte request as 64 bytes -> doubled (MI355X_MICROARCH.md, HBM)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCPROFILER", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is itself under a profiler"
+    per = {}
+    launches = 0
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="porla_pmc_")
+        try:
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "run", "--", sys.executable,
+                   os.path.abspath(__file__)] + bench_args
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd="/tmp", env=dict(child_env(), TMPDIR="/tmp"))
+            tot, cnt = 0.0, 0
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if symbol in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                        tot += float(row.get("Counter_Value", 0))
+                        cnt += 1
+            if cnt == 0:
+                return None, "no %s rows for %s (rocprofv3 rc %d)" % (counter, symbol, r.returncode)
+            per[counter] = tot / cnt
+            launches = cnt
+        except Exception as e:  # noqa: BLE001
+            return None, "%s pass failed: %r" % (counter, e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return int((2 * per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024), launches
+
+
 def child_env():
     """environment for the measurement children (plain-C harness, host-boundary script): the parent's, minus a preloaded profiler"""
     return {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCPROF", "ROCPROFILER", "ROCP_"))}
@@ -333,6 +375,8 @@ def main():
     ap.add_argument("--no-host-boundary", action="store_true", help="bn254_msm: skip the compute_multi_exp-on-host-buffers leg")
     ap.add_argument("--in-flight", type=int, default=2, help="bn254_msm: independent MSMs in flight (1 = blocking calls; 2 = the "
                     "audit's pair of MSMs, Server.hpp:900-901, overlapped on two streams)")
+    ap.add_argument("--no-pmc", action="store_true", help="bn254_msm: do not collect the dominant kernel's counter traffic in this run "
+                    "(two short child runs under rocprofv3 --pmc); the committed passes are reported instead")
     ap.add_argument("--legs-out", default=os.path.join(ROOT, "bench_legs.json"),
                     help="where the FULL result (every leg's per-kernel breakdown, notes, samples) is written; the last stdout line is "
                          "the compact headline object (<= %d bytes)" % LINE_LIMIT)
@@ -564,6 +608,21 @@ def main():
                                            "uses (8M + 2S mix)"}
         return r
 
+    def traffic_in_run(rl, child_args):
+        """replace rl['traffic'] (committed passes) by two rocprofv3 --pmc passes of `child_args` made now; N = 1, rank 0 only"""
+        if not rl or world != 1 or rank != 0 or args.no_pmc:
+            return rl
+        sym = rl["kernel"]
+        got, info = pmc_in_run(sym, child_args + ["--no-cpu", "--no-pmc", "--steps", "3", "--warmup", "1", "--legs-out", ""])
+        if got:
+            rl["traffic_committed_passes"] = rl.get("traffic")
+            rl["traffic"] = got
+            rl["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes collected in this run (%d launches of %s per "
+                                    "pass; FETCH_SIZE doubled per the gfx950 correction)" % (info, sym))
+        else:
+            rl["traffic_source"] = (rl.get("traffic_source") or "") + "; in-run collection unavailable: %s" % info
+        return rl
+
     def msm_fe_mults(n):
         # one mixed addition (10 fe_mul) per (sub-scalar, window) digit; zero digits (2^-c of them) are not subtracted
         c, windows, glv = mx.last_msm_shape()
@@ -666,7 +725,8 @@ def main():
                                  "(fixed-base window table resident in HBM)" % args.log2rows,
                      "rows_per_gpu": rows_n, "sharding": "row range per rank, no collective" if world > 1 else "single GPU",
                      "table_build_s": round(build_s, 3)},
-                    roofline(kern, COMMIT_BYTES_PER_ROW * rows_n, "kzg_commit", 10.0 * rows_n * 128 * cshape[1]), cpu, ok,
+                    traffic_in_run(roofline(kern, COMMIT_BYTES_PER_ROW * rows_n, "kzg_commit", 10.0 * rows_n * 128 * cshape[1]),
+                                   ["--workload", "kzg_commit", "--no-host-boundary", "--log2rows", str(args.log2rows)]), cpu, ok,
                     rows_per_gpu=rows_n, coefficients_per_row=128, per_call_compute_digest_from_srs=per_call, host_rows=host_rows,
                     table={"window_bits": cshape[0], "windows_per_coefficient": cshape[1],
                            "GiB": round(128 * cshape[1] * (1 << (cshape[0] - 1)) * 64 / 2**30, 2) if cshape[0] else None,
@@ -810,6 +870,10 @@ def main():
                 # scalars (rank g: SHA-256 stream starting at g * 2^20) against the oracle
                 all_sc = sc + b"".join(common.synth_scalars(n, start=g * n) for g in range(1, world))
                 verified = common.oracle_msm(all_sc, pt * world, world * n, threads=common.ncpu()) == result
+        rl_head = roofline(kern, MSM_BYTES_PER_PAIR * n, "bn254_msm", fe_mults)
+        # the counter traffic of the dominant kernel from THIS run on THIS box (two short child runs under rocprofv3 --pmc, after the
+        # timed region); the committed passes stay beside it for comparison
+        rl_head = traffic_in_run(rl_head, ["--workload", "bn254_msm", "--no-legs", "--no-commits", "--no-host-boundary", "--log2n", str(args.log2n)])
         return line("BN254 G1 MSM Mscalar-mul/s at 2^20 pts", round(world * n * args.steps / el / 1e6, 3), "Mmul/s", el, "weak",
                     "u32x8 (256-bit modular integer)",
                     {"workload": "KZG scheme, single 2^%d-point BN254 G1 MSM per GPU, inputs resident in HBM, "
@@ -817,7 +881,7 @@ def main():
                      "pairs_per_gpu": n, "msm_in_flight": depth,
                      "sharding": "input-pair range per rank + all-gather of 96-B Jacobian partials, folded on every host"
                      if world > 1 else "single GPU", "collective": collective, "input_gen_s": round(gen_s, 1)},
-                    roofline(kern, MSM_BYTES_PER_PAIR * n, "bn254_msm", fe_mults), cpu, verified,
+                    rl_head, cpu, verified,
                     result=result.hex() if result else None,
                     blocking_ms_per_step=round(blocking_ms, 4) if blocking_ms else None,
                     blocking_Mmul_s=round(world * n / blocking_ms / 1e3, 1) if blocking_ms else None,
@@ -1043,7 +1107,8 @@ def main():
                     {"workload": "IPA scheme, 2^%d-point secp256k1 ecmult_multi per GPU (points 2^i*G, scalars "
                                  "SHA-256(\"ecmult\"||i) as bench_ecmult.c), blocking calls, inputs resident in HBM" % args.log2n,
                      "pairs_per_gpu": n, "input_gen_s": round(gen_s, 1)},
-                    roofline(kern, MSM_BYTES_PER_PAIR * n, "secp256k1_msm", fe_mults), cpu, verified,
+                    traffic_in_run(roofline(kern, MSM_BYTES_PER_PAIR * n, "secp256k1_msm", fe_mults),
+                                   ["--workload", "secp256k1_msm", "--log2n", str(args.log2n)]), cpu, verified,
                     result=result.hex() if result else None, audit_size_msm=ipa_sizes)
 
     # ---------------------------------------------------------------- ICC encode (config 5)
@@ -1086,7 +1151,8 @@ def main():
                    "CRebuild_Cached + align_MAC scalars in Z/LCM, not NTL) over %d threads; %.2f s wall"
                    % (sample_rows, cores, cpu_s)}
         passes = max(1, ((n_rows.bit_length() - 1) + 7) // 8)      # LDS-fused passes per encode = launches of the dominant kernel
-        rl = roofline(kern, ICC_BYTES_PER_ELEMENT * n_rows * n_cols / passes, "icc")
+        rl = traffic_in_run(roofline(kern, ICC_BYTES_PER_ELEMENT * n_rows * n_cols / passes, "icc"),
+                            ["--workload", "icc", "--log2rows", str(args.log2rows)])
         if rl:
             rl["note"] = ("an encode is %d launches of the dominant kernel; `achieved` prices the encode's algorithmic bytes / %d "
                           "per launch, `traffic` is the per-launch average of the counters; the kernel is bound by VALU issue "

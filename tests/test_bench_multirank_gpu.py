@@ -104,6 +104,10 @@ def test_single_rank_bench_line_prices_the_kernel_it_timed(tmp_path):
     for leg in ("secp256k1_msm", "icc", "config3", "audit_combine", "kzg_audit", "mac_encode", "server_mix"):
         assert set(c[leg]) >= {"value", "unit", "ms_per_step", "frac", "int_frac", "traffic_ratio", "cpu", "bit_exact"}, leg
         assert c[leg]["bit_exact"] is True and c[leg]["value"] > 0, leg
+    # the headline kernel's counter traffic comes from two rocprofv3 --pmc passes made IN this run (or says why not)
+    full_rl = json.load(open(legs))["roofline"]
+    assert c["roofline"]["traffic_in_run"] is True, full_rl["traffic_source"]
+    assert 10 < c["roofline"]["traffic"] / (96 * (1 << 20)) < 60 and full_rl["traffic_committed_passes"] > 0
     d = json.load(open(legs))                       # the full result: what the line summarises
     assert d["value"] == c["value"] and d["roofline"]["frac"] == c["roofline"]["frac"]
     assert d["n_gpus"] == 1 and d["bit_exact_vs_oracle"] is True and d["vs_baseline"] is None
