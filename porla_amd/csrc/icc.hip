@@ -150,7 +150,7 @@ static int icc_encode_core(IccWs* ws, int curve, const uint8_t* d_rows, size_t n
         if (!out_y->al && (out_y->x || out_y->sc) && (rc = ws->park_y.ensure(total * 32))) return rc;
     }
     const IccOut oy = out_y ? *out_y : IccOut{nullptr, nullptr, nullptr, nullptr, 0};
-    // ceil(logn / 8) passes of (almost) equal stage counts, each through LDS tiles of 512 symbols (icc30_split.hip.h: one plane at
+    // ceil(logn / 8) passes of (almost) equal stage counts, each through LDS tiles of ICC_TILE_ELEMS = 1 024 symbols (icc30_split.hip.h: one plane at
     // a time, two stages per LDS round trip); the first pass reads the raw chunks, the last one writes the outputs: the two
     // residue planes (9 words per symbol each) only travel between passes.
     if ((rc = ws->work.ensure(total * ICC30_PACK_WORDS * 4))) return rc;
@@ -165,7 +165,7 @@ static int icc_encode_core(IccWs* ws, int curve, const uint8_t* d_rows, size_t n
     int s = 1;
     for (int pz = 0; pz < passes; pz++) {
         const int ns = (logn - (s - 1) + (passes - pz) - 1) / (passes - pz);
-        int cc_log = ICC_TILE_LOG - ns;                                    // 2^ns rows x 2^cc_log columns = 512 symbols
+        int cc_log = ICC_TILE_LOG - ns;                                    // 2^ns rows x 2^cc_log columns = ICC_TILE_ELEMS symbols
         while (cc_log > 0 && ((size_t)1 << (cc_log - 1)) >= ncols) cc_log--;   // no wider than the row
         const size_t col_tiles = (ncols + ((size_t)1 << cc_log) - 1) >> cc_log;
         const dim3 grid((unsigned)(col_tiles * (n >> ns)));

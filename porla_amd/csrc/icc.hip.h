@@ -255,13 +255,13 @@ __global__ void k_icc_finish(const IccElem<Q>* __restrict__ work, size_t total, 
 
 // The LDS-fused encode (icc30_split.hip.h) gives a block a TILE: 2^ns rows {row_base + mid * 2^(s0-1)} (all values of the ns
 // row-index bits its stages pair up; the lower s0-1 bits `lo` and the upper bits `hi` are fixed per tile) x 2^cc_log columns =
-// 512 symbols.  The tile is read from HBM once, goes through ns butterfly stages in LDS and is written back once: 15 stages cost
+// ICC_TILE_ELEMS symbols.  The tile is read from HBM once, goes through ns butterfly stages in LDS and is written back once: 15 stages cost
 // 2 passes over the working set instead of 8.
 #ifndef PORLA_ICC_TILE
-#define PORLA_ICC_TILE 512
-#endif
+#define PORLA_ICC_TILE 1024        // round 5: 1 024 symbols (4 .. 8 columns of a row per tile: 144 .. 288 contiguous bytes per plane and row) -- same-box
+#endif                              // A/B against 512 and 2 048: 0.583 / 0.566 / 0.579 ms per 2^15 x 128 encode (profiles/r05_o_icc_tile_ab.txt)
 constexpr int ICC_TILE_ELEMS = PORLA_ICC_TILE;
-constexpr int ICC_TILE_LOG = PORLA_ICC_TILE == 1024 ? 10 : (PORLA_ICC_TILE == 512 ? 9 : 8);
+constexpr int ICC_TILE_LOG = PORLA_ICC_TILE == 2048 ? 11 : (PORLA_ICC_TILE == 1024 ? 10 : (PORLA_ICC_TILE == 512 ? 9 : 8));
 
 // value of LIMBS (17..24) 32-bit limbs reduced into Montgomery form mod M: Horner over 256-bit digits with R = 2^256
 template <class M, int LIMBS>

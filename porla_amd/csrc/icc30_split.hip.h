@@ -5,8 +5,8 @@
 //
 //   * Z/LCM = Z/p_icc x Z/q: nothing couples the residue mod p_icc and the residue mod q of a symbol before the finish step.
 //     A block therefore runs the ns stages of its tile for the p_icc plane first and for the q plane second, through ONE LDS
-//     region of 512 slots x 40 bytes = 20 KiB (the side-by-side form of round 2: 80-byte slots, 40 KiB).  Eight 128-lane blocks fit a CU instead of
-//     four 256-lane ones with half the symbols per lane in flight: the product of fe30.hip.h is one dependent chain of
+//     region of ICC_TILE_ELEMS slots x 40 bytes (1 024: 40 KiB; round 3-4: 512 slots, 20 KiB) (the side-by-side form of round 2: 80-byte slots, 40 KiB).  Four 256-lane blocks fit a CU (round 3-4: eight 128-lane ones) with half
+//     the symbols per lane in flight of the side-by-side form: the product of fe30.hip.h is one dependent chain of
 //     multiply-adds, a lone wave issues it at half rate, and a SIMD needs two READY waves to keep its multiplier busy -- with
 //     four resident waves that each spend a fifth of their life in an LDS round trip or at a barrier it often has one.
 //   * RADIX 4 in registers: a lane reads the four symbols {m, m + 2^d, m + 2^(d+1), m + 3 2^d} of a tile once, runs stage d on
@@ -29,7 +29,10 @@ namespace porla {
 
 constexpr int ICC30_PLANE_WORDS = 9;      // a plane's symbol in the work set between the passes
 constexpr int ICC30_PSLOT_WORDS = 10;     // LDS / twiddle slot of a plane (8-byte accesses, stride 10 words: conflict-free)
-constexpr int ICC30_SPLIT_THREADS = 128;
+#ifndef PORLA_ICC_SPLIT_THREADS
+#define PORLA_ICC_SPLIT_THREADS (PORLA_ICC_TILE / 4)
+#endif
+constexpr int ICC30_SPLIT_THREADS = PORLA_ICC_SPLIT_THREADS;      // a quarter of the tile: one radix-4 unit per lane and round
 
 template <class M>
 __device__ __forceinline__ F30<M> icc30_ld_pslot(const uint32_t* s) {          // 8-byte aligned
@@ -235,7 +238,7 @@ __device__ __forceinline__ void icc30_plane(uint32_t* lds, const IccTile& T, con
     }
 }
 
-// LDS-fused stages s0 .. s0+ns-1 of a tile of 2^ns rows x 2^cc_log columns (<= 512 symbols), both planes; grid = tiles
+// LDS-fused stages s0 .. s0+ns-1 of a tile of 2^ns rows x 2^cc_log columns (<= ICC_TILE_ELEMS symbols), both planes; grid = tiles
 // XY (last pass only): the outputs of BOTH parts from this one network.  The network is linear over Z/LCM and the Y part is the X
 // part's network on chunks scaled by wt (Server.hpp:1494, :1512-1522, then the same stages :1691-1830), so Y_k = wt X_k mod LCM,
 // residue by residue: one product per plane and symbol on the last round's registers, then the same finish step with `out_y`'s
