@@ -1152,7 +1152,7 @@ def main():
                    "kind": "port", "sample": "a %d-row x 128-column encode (oracle/icc_ref.c, CPU restatement of "
                    "CRebuild_Cached + align_MAC scalars in Z/LCM, not NTL) over %d threads; %.2f s wall"
                    % (sample_rows, cores, cpu_s)}
-        passes = max(1, ((n_rows.bit_length() - 1) + 7) // 8)      # LDS-fused passes per encode = launches of the dominant kernel
+        passes = max(1, ((n_rows.bit_length() - 1) + 8) // 9)      # LDS-fused passes per encode (<= 9 stages each) = launches of the dominant kernel
         rl = traffic_in_run(roofline(kern, ICC_BYTES_PER_ELEMENT * n_rows * n_cols / passes, "icc"),
                             ["--workload", "icc", "--log2rows", str(args.log2rows)])
         if rl:

@@ -161,7 +161,10 @@ static int icc_encode_core(IccWs* ws, int curve, const uint8_t* d_rows, size_t n
         ws->tw30s_n = (uint32_t)n;
         ws->tw30s_curve = curve;
     }
-    const int passes = (logn + 7) / 8;
+    // at most ICC_TILE_LOG - 1 stages per pass (a tile keeps two columns of a row side by side): 2^9 rows are one pass, 2^10 .. 2^18
+    // two, beyond that three
+    constexpr int max_ns = ICC_TILE_LOG - 1;
+    const int passes = (logn + max_ns - 1) / max_ns;
     int s = 1;
     for (int pz = 0; pz < passes; pz++) {
         const int ns = (logn - (s - 1) + (passes - pz) - 1) / (passes - pz);

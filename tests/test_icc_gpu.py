@@ -91,9 +91,10 @@ def test_full_size_2_22_elements():
 
 
 @pytest.mark.parametrize("curve", ["bn254", "secp256k1"])
-@pytest.mark.parametrize("n,ncols,part,ws", [(1 << 17, 3, 0, 0), (1 << 18, 1, 1, 99991), (1 << 16, 5, 1, 7)])
+@pytest.mark.parametrize("n,ncols,part,ws", [(1 << 17, 3, 0, 0), (1 << 18, 1, 1, 99991), (1 << 16, 5, 1, 7), (1 << 19, 1, 0, 12345), (1 << 19, 2, 1, 3)])
 def test_three_passes_and_worst_case_operand_growth(curve, n, ncols, part, ws):
-    """more than 16 stages = three LDS-fused passes (the middle-pass instantiation of the kernel) and the longest chains of
+    """up to 9 stages per LDS-fused pass (round 5): 2^16 .. 2^18 rows are two long passes, 2^19 rows three (the middle-pass
+    instantiation of the kernel); and the longest chains of
     unreduced butterflies of the reduced-radix kernel (icc30.hip.h: rows that meet only unit twiddles are brought back every fourth
     stage); inputs at the top of the range (every chunk 2^256 - 1 or p_icc - 1) make every sum as large as it can get"""
     from porla_amd import icc
