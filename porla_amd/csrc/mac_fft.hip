@@ -237,8 +237,12 @@ static int mac_encode_core(MacWs* ws, int curve, const uint8_t* d_in, size_t n, 
         else if (quad_path)
             hipLaunchKernelGGL((k_mac_stage30_quad<C, false>), dim3((unsigned)((n / 2 + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream,
                                (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->tws.p, (uint32_t)n, s);
+        else if (s > 1 && (n >> s) >= 64 && ((n / 2) & 255) == 0)
+            // one lane per butterfly, >= 64 butterflies per twiddle: a wave shares its scalar -- the sparse ladder
+            hipLaunchKernelGGL((k_mac_stage30<C, true>), dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, stream, (XYZZ<M>*)ws->work.p,
+                               (const uint32_t*)ws->tws.p, (uint32_t)n, s);
         else
-            hipLaunchKernelGGL((k_mac_stage30<C>), dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, stream, (XYZZ<M>*)ws->work.p,
+            hipLaunchKernelGGL((k_mac_stage30<C, false>), dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, stream, (XYZZ<M>*)ws->work.p,
                                (const uint32_t*)ws->tws.p, (uint32_t)n, s);
     }
     {

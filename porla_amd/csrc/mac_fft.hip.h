@@ -22,6 +22,30 @@ namespace porla {
 // host would have to wait for before it may reuse its temporary
 struct MacScalar { uint32_t v[8]; };
 
+// ---- width-5 non-adjacent form of a 128-bit magnitude, one position per call (least significant first); used where a whole wave
+// multiplies by ONE scalar, so that control flow is the wave's and a zero digit costs nothing (macq_ladder_uniform,
+// mac30_scalar_mul_uniform).  Code of a position: 0 = zero digit, else 16 | sign << 3 | (|d| - 1) / 2 (index into the table of odd
+// multiples P, 3P, .. 15P); `flip` folds the half-scalar's own sign in.
+constexpr int MACQ_WNAF_LEN = 129;                // digits of a width-5 NAF of a 128-bit magnitude
+__device__ __forceinline__ uint32_t mac_wnaf5_step(uint32_t (&k)[5], bool flip) {
+    uint32_t code = 0;
+    if (k[0] & 1u) {
+        const uint32_t low = k[0] & 31u;
+        const bool negd = low >= 16u;                                       // digit = low - 32
+        const uint32_t mag = negd ? 32u - low : low;
+        code = 16u | ((negd != flip) ? 8u : 0u) | ((mag - 1u) >> 1);
+        // k -= digit: clears the low five bits; a negative digit carries 32 upwards
+        uint64_t t = (uint64_t)(k[0] & ~31u) + (negd ? 32u : 0u);
+        k[0] = (uint32_t)t;
+#pragma unroll
+        for (int i = 1; i < 5; i++) { t = (uint64_t)k[i] + (t >> 32); k[i] = (uint32_t)t; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) k[i] = (k[i] >> 1) | (k[i + 1] << 31);
+    k[4] >>= 1;
+    return code;
+}
+
 
 // plain little-endian limbs of (w^e mod p_icc) mod q for e in [0, n)   (cf. k_icc_twiddles in icc.hip.h)
 template <class Q>
@@ -112,6 +136,69 @@ __device__ __noinline__ void mac30_scalar_mul(XYZZ<typename C::Fp>* out, const X
     }
 }
 
+// The same product for a scalar that is THE SAME ON ALL 64 LANES of the wave (the stages of a large network where >= 64 butterflies
+// share a twiddle; the init scaling): width-5 NAF of the two half-scalars over the table of odd multiples -- 128 doublings + ~43
+// additions instead of 132 + ~62 (1 910 field products instead of 2 210) -- with the recoding on the scalar unit, its 129 codes in
+// `codes` (LDS, this wave's own), and runs of zero digits doubled in one call.
+template <class C>
+__device__ __noinline__ void mac30_scalar_mul_uniform(XYZZ<typename C::Fp>* out, const XYZZ<typename C::Fp>* P, const uint32_t k[8],
+                                                      uint16_t* codes) {
+    using M = typename C::Fp;
+    using G = typename C::Glv;
+    {
+        uint32_t m0[4], m1[4];
+        bool ng0, ng1;
+        glv_split<G>(k, m0, ng0, m1, ng1);
+        uint32_t k0[5] = {m0[0], m0[1], m0[2], m0[3], 0u}, k1[5] = {m1[0], m1[1], m1[2], m1[3], 0u};
+#pragma unroll 1
+        for (int i = 0; i < MACQ_WNAF_LEN; i++) {
+            const uint32_t code = mac_wnaf5_step(k0, ng0) | (mac_wnaf5_step(k1, ng1) << 8);
+            if ((threadIdx.x & 63u) == 0u) codes[i] = (uint16_t)code;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    Fe<M> bplain, r2;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { bplain.v[i] = G::BETA[i]; r2.v[i] = M::R2_30[i]; }
+    const F30<M> beta30 = f30_from_fe<M>(fe_mul_call<M>(bplain, r2));
+    uint4* o4 = reinterpret_cast<uint4*>(out);
+    const uint4* p4 = reinterpret_cast<const uint4*>(P);
+    XYZZ<M> tbl[8], two_p;                                                // (2 i + 1) P, and 2 P
+    {
+        uint4* t4 = reinterpret_cast<uint4*>(&tbl[0]);
+        uint4* d4 = reinterpret_cast<uint4*>(&two_p);
+#pragma unroll
+        for (int i = 0; i < 8; i++) { t4[i] = p4[i]; d4[i] = p4[i]; }
+    }
+    xyzz30_double_mem<M>(&two_p, 1);
+#pragma unroll 1
+    for (int i = 1; i < 8; i++) {
+        const uint4* s4 = reinterpret_cast<const uint4*>(&tbl[i - 1]);
+        uint4* d4 = reinterpret_cast<uint4*>(&tbl[i]);
+#pragma unroll
+        for (int j = 0; j < 8; j++) d4[j] = s4[j];
+        xyzz30_add_mem<M>(&tbl[i], &two_p, 0, 0, &beta30);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) o4[i] = make_uint4(0, 0, 0, 0);          // infinity
+    int run = 0;
+#pragma unroll 1
+    for (int i = MACQ_WNAF_LEN - 1; i >= 0; i--) {
+        const uint32_t code = (uint32_t)__builtin_amdgcn_readfirstlane((int)codes[i]);
+        run++;
+        if (code == 0u) continue;
+        xyzz30_double_mem<M>(out, run);                                   // (an accumulator at infinity stays where it is)
+        run = 0;
+#pragma unroll 1
+        for (int h = 0; h < 2; h++) {
+            const uint32_t cd = (code >> (8 * h)) & 0xffu;
+            if (cd) xyzz30_add_mem<M>(out, &tbl[cd & 7u], (cd >> 3) & 1u, (uint32_t)h, &beta30);
+        }
+    }
+    if (run) xyzz30_double_mem<M>(out, run);
+}
+
 // 64-byte big-endian affine point -> lazy memory form (residues in the 2^270 form; infinity = all zero)
 template <class M>
 __device__ __forceinline__ XYZZ<M> load_affine_be_lazy(const uint8_t* src) {
@@ -149,7 +236,8 @@ k_mac_load30(const uint8_t* __restrict__ in, uint32_t n, XYZZ<typename C::Fp>* _
 #pragma unroll
         for (int j = 0; j < 8; j++) k[j] = wt.v[j];
         XYZZ<M> r;
-        mac30_scalar_mul<C>(&r, &p, k);
+        __shared__ uint16_t wdig[MACQ_WNAF_LEN + 3];                      // (64 lanes = one wave per block; one scalar for every MAC)
+        mac30_scalar_mul_uniform<C>(&r, &p, k, wdig);
         p = r;
     }
     store_xyzz<M>(work + i, p);
@@ -167,19 +255,30 @@ k_mac_scale30(const XYZZ<typename C::Fp>* __restrict__ in, uint32_t n, XYZZ<type
 #pragma unroll
     for (int j = 0; j < 8; j++) k[j] = wt.v[j];
     XYZZ<M> r;
-    mac30_scalar_mul<C>(&r, &p, k);
+    __shared__ uint16_t wdig[MACQ_WNAF_LEN + 3];                          // (64 lanes = one wave per block; one scalar for every MAC)
+    mac30_scalar_mul_uniform<C>(&r, &p, k, wdig);
     store_xyzz<M>(out + i, r);
 }
 
-template <class C>
+// UNIFORM (launched when n / 2^s >= 64 and n / 2 is a multiple of 256): the 64 lanes of a wave take butterflies of ONE twiddle index j
+// (they differ in the block of the stage they belong to): mac30_scalar_mul_uniform
+template <class C, bool UNIFORM>
 __global__ void __launch_bounds__(256)      // (launched with 256 lanes: 21.1 against 22.2 ms at N = 2^17 with 64)
 k_mac_stage30(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restrict__ tws, uint32_t n, int s) {
     using M = typename C::Fp;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n / 2) return;
     const uint32_t m2 = 1u << (s - 1);
-    const uint32_t j = t & (m2 - 1);
-    const uint32_t k = ((t >> (s - 1)) << s) + j;
+    uint32_t j, k;
+    if constexpr (UNIFORM) {
+        const uint32_t rest = t >> 6;
+        j = rest & (m2 - 1);
+        k = ((((rest >> (s - 1)) << 6) | (t & 63u)) << s) + j;
+        j = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);              // (the same on all 64 lanes: tell the compiler)
+    } else {
+        j = t & (m2 - 1);
+        k = ((t >> (s - 1)) << s) + j;
+    }
     const uint32_t e = j * (n >> (s - 1));
     uint32_t sc[8];
     const uint4* q = reinterpret_cast<const uint4*>(tws + (size_t)e * 8);
@@ -188,7 +287,10 @@ k_mac_stage30(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restric
     XYZZ<M> hi = load_xyzz<M>(work + k + m2);
     XYZZ<M> tm;
     if (s == 1) tm = hi;                            // stage 1: every twiddle is w^0 = 1 (uniform over the launch): no ladder
-    else mac30_scalar_mul<C>(&tm, &hi, sc);
+    else if constexpr (UNIFORM) {
+        __shared__ uint16_t wdig[4][MACQ_WNAF_LEN + 3];
+        mac30_scalar_mul_uniform<C>(&tm, &hi, sc, wdig[threadIdx.x >> 6]);
+    } else mac30_scalar_mul<C>(&tm, &hi, sc);
     XYZZ<M> sum = load_xyzz<M>(work + k);
     XYZZ<M> dif = sum;
     xyzz30_add_mem<M>(&sum, &tm, 0, 0, nullptr);
@@ -211,7 +313,6 @@ k_mac_stage30(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restric
 // Quads follow their own control flow (a zero digit skips its addition, an accumulator at infinity its doublings): the lanes of
 // a quad always branch together, which is all the quad permutes need.
 constexpr int MACQ_BF = 64;                       // butterflies per block: 256 lanes = one wave on each SIMD of a compute unit
-constexpr int MACQ_WNAF_LEN = 129;                // digits of a width-5 NAF of a 128-bit magnitude
 
 // signed 4-bit digit i (0 .. 32) of the 128-bit magnitude m: ((m >> 4i) & 15) + carry, minus 16 above 8.  The carry into
 // window i is 1 exactly when the bits below it exceed 0x88..8 (the recoding with digits in (-8, 8] is unique: msm_small.hip.h).
@@ -378,24 +479,6 @@ __device__ __forceinline__ void macq_ladder(MacQuadLds<typename C::Fp>& L, uint3
 // bit: one quad's digit is everybody's instruction stream).  The scalar work (endomorphism split, recoding) is uniform too: the
 // compiler keeps it on the scalar unit; its 129 digit codes go through LDS, one set per wave.
 //   code of a position = low byte for k1, high byte for k2: 0 = zero digit, else 16 | sign << 3 | (|d| - 1) / 2
-__device__ __forceinline__ uint32_t mac_wnaf5_step(uint32_t (&k)[5], bool flip) {
-    uint32_t code = 0;
-    if (k[0] & 1u) {
-        const uint32_t low = k[0] & 31u;
-        const bool negd = low >= 16u;                                       // digit = low - 32
-        const uint32_t mag = negd ? 32u - low : low;
-        code = 16u | ((negd != flip) ? 8u : 0u) | ((mag - 1u) >> 1);
-        // k -= digit: clears the low five bits; a negative digit carries 32 upwards
-        uint64_t t = (uint64_t)(k[0] & ~31u) + (negd ? 32u : 0u);
-        k[0] = (uint32_t)t;
-#pragma unroll
-        for (int i = 1; i < 5; i++) { t = (uint64_t)k[i] + (t >> 32); k[i] = (uint32_t)t; }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) k[i] = (k[i] >> 1) | (k[i + 1] << 31);
-    k[4] >>= 1;
-    return code;
-}
 template <class C>
 __device__ __forceinline__ void macq_ladder_uniform(MacQuadLds<typename C::Fp>& L, uint32_t q, uint32_t r, uint32_t lane, uint32_t wave,
                                                     const uint32_t sc[8], F30<typename C::Fp>& c, bool& inf) {
