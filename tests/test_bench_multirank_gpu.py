@@ -76,6 +76,19 @@ def test_two_rank_bench_line_under_an_external_torchrun(tmp_path):
     _check_two_rank_line(r, str(tmp_path / "legs.json"))
 
 
+def test_a_failed_rank_preflight_stops_the_job_before_any_timed_region(tmp_path):
+    """the N-rank preflight (every rank contributes (g + 1) G, the fold must be N (N + 1) / 2 G everywhere): a rank whose partial is
+    wrong (test hook) makes every rank's fold differ -- each names itself, the job exits 4, and no JSON line is printed"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(PORLA_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", PORLA_BENCH_PREFLIGHT_BREAK="1")
+    cmd = [sys.executable, os.path.join(common.ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-commits", "--no-legs",
+           "--legs-out", str(tmp_path / "legs.json")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=common.ROOT)
+    assert r.returncode != 0, r.stdout[-1000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "rank preflight" in r.stderr and "rank 0 of 2" in r.stderr and "rank 1 of 2" in r.stderr and "no timed region is entered" in r.stderr
+
+
 def test_a_failed_baseline_leg_fails_the_run(tmp_path):
     """a BASELINE-config leg that throws is named in `legs_failed` and the run exits non-zero -- the line is still printed"""
     env = dict(os.environ, PORLA_BENCH_FAIL_LEG="icc")
