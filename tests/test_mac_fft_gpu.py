@@ -56,6 +56,28 @@ def test_matches_oracle(curve, n, ws, form):
 
 
 @pytest.mark.parametrize("curve", ["bn254", "secp256k1"])
+@pytest.mark.parametrize("n", [1024, 4096])
+def test_degenerate_inputs_through_every_ladder_kernel(curve, n):
+    """round 5's ladders keep the accumulator in registers and leave the register form only for equal-x operands (P + P, P - P) and
+    infinity: inputs made of ONE point repeated (stage 1: every um + tm is a doubling, every um - tm infinity; later stages meet
+    2^k P against 2^k P and infinity against infinity), of a point alternating with its negative, and of infinity alternating with a
+    point -- through the stage-1 kernel, the wave-uniform quad ladder, the eight-lane kernel (per-butterfly scalars) and, with
+    PORLA_MAC_QUAD_MAX=0 (tests/test_env_switches_gpu.py), the one-lane kernels"""
+    from porla_amd import icc, lib
+    lib.porla_icc_mac_set_matrix_max(0)
+    try:
+        base = macs_for(curve, 2)
+        p, q = base[:64], base[64:128]
+        neg_p = icc.mac_crebuild_host(bytes(64) + p, 2, curve, 0, 0)[64:128]        # stage 1 of a 2-row network: O - P
+        for name, macs in (("one point", p * n), ("P, -P", (p + neg_p) * (n // 2)), ("O, P", (bytes(64) + p) * (n // 2)),
+                           ("P, P, Q, Q", (p + p + q + q) * (n // 4))):
+            for part in (0, 1):
+                assert icc.mac_crebuild_host(macs, n, curve, 5, part) == oracle_mac(macs, n, curve, part, 5), (name, part)
+    finally:
+        lib.porla_icc_mac_set_matrix_max(2048)
+
+
+@pytest.mark.parametrize("curve", ["bn254", "secp256k1"])
 def test_infinity_and_repeated_macs(curve, form):
     """fresh levels hold infinity MACs (bn254_set_infinity, Server.hpp:1533-1534); equal MACs exercise P + P and P - P"""
     from porla_amd import icc
