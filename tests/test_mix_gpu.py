@@ -53,6 +53,24 @@ def test_mac_mix(curve, length, n_total):
     assert got == want.raw
 
 
+@pytest.mark.parametrize("curve", ["bn254", "secp256k1"])
+@pytest.mark.parametrize("length,n_total", [(64, 64), (2048, 1 << 15), (16384, 1 << 15)])
+def test_mac_mix_of_a_block_with_itself_and_with_infinity(curve, length, n_total):
+    """the equal-x exits of the register-form additions: A1 = A0 (row 0 multiplies by v^0 = 1: A0 + A0 is a doubling, A0 - A0 infinity),
+    A0 = infinity throughout, and both blocks one repeated point -- at lengths that take the eight-lane kernel (<= 2^13 elements), the
+    four-lane one (2^14) and, with n_total = length, a twiddle step of one"""
+    from porla_amd import icc
+    from tests.test_mac_fft_gpu import macs_for
+    a0 = macs_for(curve, min(length, 256)) * (length // min(length, 256))
+    one = a0[:64] * length
+    for name, x0, x1 in (("A1 = A0", a0, a0), ("A0 = O", bytes(64 * length), a0), ("one point", one, one)):
+        got = icc.mac_mix_host(x0, x1, length, n_total, curve)
+        want = ctypes.create_string_buffer(2 * length * 64)
+        common.oracle().oracle_icc_mac_mix(x0, x1, ctypes.c_size_t(length), ctypes.c_size_t(n_total), icc.CURVE[curve], want,
+                                           common.ncpu())
+        assert got == want.raw, name
+
+
 def test_mac_mix_with_an_empty_upper_block():
     """algebraic identity: mixing A0 with a block of infinity MACs (a fresh level, Server.hpp:1533-1534) returns A0 twice"""
     from porla_amd import icc
