@@ -166,20 +166,15 @@ k_fb_normalize(const XYZZ<typename C::Fp>* __restrict__ scratch, size_t n, Affin
 // rows: row r, coefficient i at rows + r*row_stride + 32*i, 32 bytes big-endian (bn254_scalar, utils.h:307-318;
 //       fr.SetBytes semantics: reduced mod the group order, porla/main.go:110).
 // grid.x covers rows (lane = row), grid.y = slice s of the coefficient range; partial[r*S + s] = slice sum.
-// (-DPORLA_FB_COMMIT_4WAVES: 128 registers + 272 B of scratch for four waves per SIMD instead of 145 + 192 B for three -- measured
-// SLOWER, 19.7-20.0 against 18.95-19.1 ms for 2^17 rows on one box, profiles/r03_q_fb_commit_4waves_ab.txt)
-#ifdef PORLA_FB_COMMIT_4WAVES
-#define PORLA_FB_COMMIT_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
-#else
-#define PORLA_FB_COMMIT_ATTR
-#endif
+// (three waves per SIMD at ~161 registers; held to 128 registers for four waves it measured SLOWER: 19.7-20.0 against 18.95-19.1 ms
+// for 2^17 rows on one box, profiles/r03_q_fb_commit_4waves_ab.txt)
 // GUEST_ROOM: the kernel declares 192 vector registers (it uses ~161): a SIMD then holds TWO of its waves instead of three and
 // keeps 128 registers free -- room for one wave of another kernel.  The last stage of a CRebuild runs the MAC butterflies (one
 // latency-bound wave per SIMD, 123 registers, 15 dependent launches) BESIDE the commitments: with three 161-register waves per
 // SIMD the chip had no slot for them, and every one of the 15 stage launches waited for a block of this kernel to retire
 // (3.6-4.8 ms instead of 0.6): the two streams ran one after the other.
 template <class C, bool GUEST_ROOM = false>
-__global__ void __launch_bounds__(256) PORLA_FB_COMMIT_ATTR
+__global__ void __launch_bounds__(256)
 k_fb_commit(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_coeffs, size_t row_stride,
             const Affine<typename C::Fp>* __restrict__ table, int c, int W, uint32_t S,
             XYZZ<typename C::Fp>* __restrict__ partial) {
@@ -217,10 +212,8 @@ k_fb_commit(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_coeffs
     };
     Affine<M> cur;
     bool cur_valid = false, cur_neg = false;
-#ifndef PORLA_FB_DEPTH1
     Affine<M> mid;
     bool mid_valid = false, mid_neg = false;
-#endif
     uint32_t tn[8];
     if (i0 < i1) load_be256(tn, row + (size_t)i0 * 32);
     for (uint32_t i = i0; i < i1; i++) {
@@ -274,7 +267,6 @@ k_fb_commit(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_coeffs
                 nxt_valid = true;
                 nxt = load_affine<M>(tab_i + (size_t)w * Bh, mag - 1);
             }
-#ifndef PORLA_FB_DEPTH1
             // two gathers in flight: the entry added now was requested two windows ago (18.6 -> 18.4 ms for 2^17 rows against one
             // in flight, profiles/r03_q_fb_commit_4waves_ab.txt; 160 registers, still three waves per SIMD)
             if (cur_valid) madd_entry(cur, cur_neg);
@@ -282,18 +274,10 @@ k_fb_commit(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_coeffs
             cur_valid = mid_valid; cur_neg = mid_neg;
             if (nxt_valid) mid = nxt;
             mid_valid = nxt_valid; mid_neg = nxt_neg;
-#else
-            if (cur_valid) madd_entry(cur, cur_neg);
-            if (nxt_valid) cur = nxt;
-            cur_valid = nxt_valid;
-            cur_neg = nxt_neg;
-#endif
         }
     }
     if (cur_valid) madd_entry(cur, cur_neg);
-#ifndef PORLA_FB_DEPTH1
     if (mid_valid) madd_entry(mid, mid_neg);
-#endif
     if constexpr (C::F30_BUCKETS) {
         xyzz30_flip_finish<M>(acc, flip);
         // a slice partial goes to k_fb_fold in the reduced-radix memory form (no conversion products here, reduced-radix additions

@@ -1,9 +1,10 @@
 // MAC-side ICC encode: launch logic + C ABI (include/porla_gpu.h: porla_icc_mac_encode_device / _host).
 //
 // Two forms of the same linear map over the group (bit-exact on the affine result):
-//   ladder (N > PORLA_MAC_MATRIX_MAX, default 2048): stage by stage, one lane per butterfly (mac_fft.hip.h); a stage costs
-//          one 256-bit scalar multiplication of LATENCY (~2.9 ms for a lone wave), so small N is latency-bound;
-//   matrix (N <= 2048): out_k = sum_i F[k][i] * MAC_i with F = the butterfly network as an N x N matrix over Z_q (the
+//   ladder (N > 512 rows; porla_icc_mac_set_matrix_max moves the boundary): stage by stage, four or eight lanes per butterfly up to
+//          2^16 rows, one above (mac_fft.hip.h); a stage costs one 256-bit scalar multiplication of LATENCY, so small N is
+//          latency-bound;
+//   matrix (N <= 512): out_k = sum_i F[k][i] * MAC_i with F = the butterfly network as an N x N matrix over Z_q (the
 //          data-side encode applied to the identity, cached per (N, curve, part, wt)); evaluated as N commitments
 //          against the per-call base {MAC_i} with the batched fixed-base kernels (fixed_base.hip.h, 8-bit windows):
 //          N^2 * 32 independent mixed additions instead of log2(N) dependent ladders -- throughput- not latency-bound.
