@@ -118,6 +118,7 @@ static size_t maco_lds_bytes() {
         const int bytes = (int)sizeof(MacOctLds<M>);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mac_stage30_oct<C>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mac_mix_oct<C>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mac_stage30_oct_uniform<C>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         done.push_back(dev);
     }
     return sizeof(MacOctLds<M>);
@@ -227,6 +228,10 @@ static int mac_encode_core(MacWs* ws, int curve, const uint8_t* d_in, size_t n, 
         if (quad_path && s == 1)      // every twiddle of stage 1 is w^0 = 1: two additions per butterfly, no ladder
             hipLaunchKernelGGL((k_mac_stage1_quad<C>), dim3((unsigned)((n / 2 + 63) / 64)), dim3(256), 0, stream, (XYZZ<M>*)ws->work.p,
                                (uint32_t)n);
+        else if (quad_path && (n >> s) >= 16 && n >= 128 && n / 2 <= MACO_MAX_BUTTERFLIES)
+            // ... and at most 2^13 butterflies: eight lanes each, the two half-scalar ladders in different waves
+            hipLaunchKernelGGL((k_mac_stage30_oct_uniform<C>), dim3((unsigned)(n / 2 / MACO_BF)), dim3(8 * MACO_BF), maco_lds_bytes<C>(), stream,
+                               (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->tws.p, (uint32_t)n, s);
         else if (quad_path && (n >> s) >= 16 && n >= 128)
             // >= 16 butterflies per twiddle (and whole blocks of 64): a wave's 16 quads share their scalar -- the sparse ladder
             hipLaunchKernelGGL((k_mac_stage30_quad<C, true>), dim3((unsigned)((n / 2 + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream,

@@ -641,6 +641,7 @@ struct MacOctLds {
     typename MacQuadLds<M>::Quad qd[MACO_BF];   // per octet: table of multiples + beta-scaled X
     XYZZ<M> acc[2 * MACO_BF], tmp[2 * MACO_BF];  // per quad: the slots of the rare general addition
     XYZZ<M> um[MACO_BF], xch[MACO_BF];           // per octet: the butterfly's upper input; what the quads hand each other
+    uint16_t wdig[4][MACQ_WNAF_LEN + 3];         // k_mac_stage30_oct_uniform: one half-scalar's digit codes per wave
 };
 #define MACO_LDS(L) extern __shared__ __align__(16) unsigned char macq_lds_raw[]; \
     MacOctLds<M>& L = *reinterpret_cast<MacOctLds<M>*>(macq_lds_raw)
@@ -760,6 +761,107 @@ k_mac_stage30_oct(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __res
     else macq_copy_coord<M>(&L.qd[o].tbl[0], work + k + m2, r);
     macq_sync();
     maco_butterfly<C>(L, o, half, r, lane, sc, work + k, work + k + m2, valid);
+}
+
+// The same eight lanes per butterfly for the stages of a small network where >= 16 butterflies share a twiddle (N <= 2^14: the
+// four-lane kernel leaves half the chip idle there too).  The two quads of an octet sit in DIFFERENT waves here -- waves 0 and 2 of the
+// block walk k1, waves 1 and 3 walk k2 -- so that every wave multiplies by one half-scalar and keeps the sparse recoding's
+// advantage (side by side in one wave the two digit streams would make the wave execute an addition whenever EITHER has a
+// non-zero digit); the hand-overs between the quads are block barriers, which every wave reaches.
+template <class C>
+__global__ void __launch_bounds__(8 * MACO_BF) MACO_ATTR
+k_mac_stage30_oct_uniform(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restrict__ tws, uint32_t n, int s) {
+    using M = typename C::Fp;
+    using G = typename C::Glv;
+    MACO_LDS(L);
+    __builtin_amdgcn_s_setprio(3);
+    const uint32_t wave = threadIdx.x >> 6, half = wave & 1u, lane = threadIdx.x & 63u, r = lane & 3u;
+    const uint32_t o = (wave >> 1) * 16u + (lane >> 2);                   // octet of the block: 16 per wave pair
+    const uint32_t qi = 2u * o + half;
+    // n / 2 is a multiple of 32 and 16 octets share a twiddle (the launch condition): no padding octets
+    const uint32_t t = blockIdx.x * MACO_BF + o;
+    const uint32_t m2 = 1u << (s - 1);
+    const uint32_t rest = t >> 4;
+    const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)(rest & (m2 - 1)));
+    const uint32_t k = ((((rest >> (s - 1)) << 4) | (t & 15u)) << s) + j;
+    const uint32_t e = j * (n >> (s - 1));
+    uint32_t sc[8];
+    {
+        const uint4* w4 = reinterpret_cast<const uint4*>(tws + (size_t)e * 8);
+        const uint4 a = w4[0], b = w4[1];
+        sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
+    }
+    typename MacQuadLds<M>::Quad& Q = L.qd[o];
+    if (half) macq_copy_coord<M>(&L.um[o], work + k, r);
+    else macq_copy_coord<M>(&Q.tbl[0], work + k + m2, r);
+    {   // this wave's half-scalar, recoded (scalar unit)
+        uint32_t m0[4], m1[4];
+        bool ng0, ng1;
+        glv_split<G>(sc, m0, ng0, m1, ng1);
+        uint32_t kk[5] = {half ? m1[0] : m0[0], half ? m1[1] : m0[1], half ? m1[2] : m0[2], half ? m1[3] : m0[3], 0u};
+        const bool ng = half ? ng1 : ng0;
+#pragma unroll 1
+        for (int i = 0; i < MACQ_WNAF_LEN; i++) {
+            const uint32_t code = mac_wnaf5_step(kk, ng);
+            if (lane == 0u) L.wdig[wave][i] = (uint16_t)code;
+        }
+    }
+    __syncthreads();
+    F30<M> c;
+    bool inf = true, z;
+    c = macq_load_residue<M>(reinterpret_cast<const uint32_t*>(&Q.tbl[0]) + 8 * r, &z);
+    const bool p_inf = macq_quad_any(z && r == 2u, lane);
+    if (half == 0u && !p_inf) {                                           // tbl[i] = (2 i + 1) P: 2P (parked in the beta table's space), then + 2P
+        XYZZ<M>* two_p = reinterpret_cast<XYZZ<M>*>(&Q.bx[0][0]);
+        const F30<M> p_r = c;
+        xyzz30_dbl_quadreg<M>(c, r);
+        macq_store_residue<M>(reinterpret_cast<uint32_t*>(two_p) + 8 * r, c);
+        macq_sync();
+        c = p_r;
+        bool tinf = false;
+#pragma unroll 1
+        for (int i = 1; i < 8; i++) {
+            macq_add<M>(c, tinf, two_p, reinterpret_cast<const uint32_t*>(two_p), false, &L.acc[qi], &L.tmp[qi], r, lane);
+            macq_store_residue<M>(reinterpret_cast<uint32_t*>(&Q.tbl[i]) + 8 * r, c);
+        }
+    }
+    __syncthreads();
+    if (!p_inf) {                                                         // beta * X of the eight entries: one per lane of the octet
+        const uint32_t en = 4u * half + r;
+        const F30<M> x = macq_load_residue<M>(reinterpret_cast<const uint32_t*>(&Q.tbl[en]), &z);
+        macq_store_residue<M>(&Q.bx[en][0], f30_mul<M>(x, f30_const<M>(G::BETA_30)));
+    }
+    __syncthreads();
+    if (!p_inf) {
+#pragma unroll 1
+        for (int i = MACQ_WNAF_LEN - 1; i >= 0; i--) {
+            const uint32_t cd = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.wdig[wave][i]);
+            if (!inf) xyzz30_dbl_quadreg<M>(c, r);
+            if (cd == 0u) continue;
+            const XYZZ<M>* en = &Q.tbl[cd & 7u];
+            macq_add<M>(c, inf, en, half ? &Q.bx[cd & 7u][0] : reinterpret_cast<const uint32_t*>(en), (cd & 8u) != 0u, &L.acc[qi], &L.tmp[qi],
+                        r, lane);
+        }
+    }
+    if (half) macq_store_point<M>(&L.xch[o], c, inf, r);
+    __syncthreads();
+    if (half == 0u) {
+        const F30<M> other = macq_load_residue<M>(reinterpret_cast<const uint32_t*>(&L.xch[o]) + 8 * r, &z);
+        const bool other_inf = macq_quad_any(z && r == 2u, lane);
+        if (!other_inf) {
+            if (inf) { c = other; inf = false; }
+            else macq_add<M>(c, inf, &L.xch[o], reinterpret_cast<const uint32_t*>(&L.xch[o]), false, &L.acc[qi], &L.tmp[qi], r, lane);
+        }
+        macq_sync();                                                       // (the four lanes have read the slot before any of them writes it)
+        macq_store_point<M>(&L.xch[o], c, inf, r);
+    }
+    __syncthreads();
+    if (half) {
+        c = macq_load_residue<M>(reinterpret_cast<const uint32_t*>(&L.xch[o]) + 8 * r, &z);
+        inf = macq_quad_any(z && r == 2u, lane);
+        if (!inf && r == 1u) c = f30_sub<M, 4>(F30<M>{}, c);               // -tm
+    }
+    macq_sum_out<M>(&L.um[o], &L.acc[qi], &L.tmp[qi], c, inf, half ? work + k + m2 : work + k, true, r, lane);
 }
 
 // Server::mix's MAC part with eight lanes per i (k_mac_mix_quad's work): lanes 0 / 4 convert the two inputs on the way in, invert for
