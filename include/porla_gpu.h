@@ -339,8 +339,9 @@ int porla_icc_mac_encode_xy_host(const uint8_t *macs_in, size_t n_rows, int curv
                                  uint8_t *macs_x_out, uint8_t *macs_y_out);
 int porla_icc_mac_encode_host(const uint8_t *macs_in, size_t n_rows, int curve, unsigned long long write_step, int part,
                               uint8_t *macs_out);
-/* tuning: row counts <= n_rows use the matrix form (N commitments against the per-call base, throughput-bound), larger
- * ones the stage-by-stage ladder form (default 2048; 0 = always ladder).  Both are bit-exact. */
+/* row counts <= n_rows use the matrix form (N commitments against the per-call base), larger ones the stage-by-stage ladder
+ * form.  Default 0 = always the ladder, which since round 5 is the faster one at every size; the matrix form stays as an
+ * independent formulation of the same map (the tests run both).  Both are bit-exact. */
 int porla_icc_mac_set_matrix_max(size_t n_rows);
 
 /* ---- Server::mix, the incremental form of one butterfly stage between two sub-levels (Server.hpp:1209-1328) ----

@@ -1,10 +1,11 @@
 // MAC-side ICC encode: launch logic + C ABI (include/porla_gpu.h: porla_icc_mac_encode_device / _host).
 //
 // Two forms of the same linear map over the group (bit-exact on the affine result):
-//   ladder (N > 512 rows; porla_icc_mac_set_matrix_max moves the boundary): stage by stage, four or eight lanes per butterfly up to
-//          2^16 rows, one above (mac_fft.hip.h); a stage costs one 256-bit scalar multiplication of LATENCY, so small N is
-//          latency-bound;
-//   matrix (N <= 512): out_k = sum_i F[k][i] * MAC_i with F = the butterfly network as an N x N matrix over Z_q (the
+//   ladder (the default at every N since round 5): stage by stage, four or eight lanes per butterfly up to 2^16 rows, one above
+//          (mac_fft.hip.h); a stage costs one 256-bit scalar multiplication of LATENCY (0.27 ms on eight lanes);
+//   matrix (N <= porla_icc_mac_set_matrix_max rows; kept as an independent formulation the tests run beside the ladder -- with the
+//          round-5 ladders it is slower at every size: 16 rows 2.99 against 1.03 ms, 256 rows 3.19 / 2.20, 512 rows 3.80 / 2.51,
+//          tools/bench_mac_forms.py): out_k = sum_i F[k][i] * MAC_i with F = the butterfly network as an N x N matrix over Z_q (the
 //          data-side encode applied to the identity, cached per (N, curve, part, wt)); evaluated as N commitments
 //          against the per-call base {MAC_i} with the batched fixed-base kernels (fixed_base.hip.h, 8-bit windows):
 //          N^2 * 32 independent mixed additions instead of log2(N) dependent ladders -- throughput- not latency-bound.
@@ -38,7 +39,7 @@ template <class C> struct FbOf;
 template <> struct FbOf<Bn254G1> { static FixedBase<Bn254G1>& get(MacWs* w) { return w->fb_bn; } };
 template <> struct FbOf<Secp256k1G> { static FixedBase<Secp256k1G>& get(MacWs* w) { return w->fb_secp; } };
 static std::mutex g_mac_mu;
-static size_t g_matrix_max = 512;     // porla_icc_mac_set_matrix_max changes it
+static size_t g_matrix_max = 0;       // rows up to which the matrix form runs: none by default (round 5); porla_icc_mac_set_matrix_max changes it
 // Up to 2^16 rows a stage is latency bound (one or two waves per SIMD even with four lanes per butterfly): the quad-lane kernels
 // (2^16 rows: 16.7 ms against 18.5 ms with one lane per butterfly; 2^17 rows: 35.4 against 22.2); the element-wise kernels switch
 // earlier (`own`).  PORLA_MAC_QUAD_MAX (log2 of the row count, default 16; 0 = one lane per butterfly everywhere) moves the

@@ -43,7 +43,7 @@ def form(request):
     from porla_amd import lib
     lib.porla_icc_mac_set_matrix_max(2048 if request.param == "matrix" else 0)
     yield request.param
-    lib.porla_icc_mac_set_matrix_max(2048)
+    lib.porla_icc_mac_set_matrix_max(0)              # the default: no matrix form
 
 
 @pytest.mark.parametrize("curve", ["bn254", "secp256k1"])
@@ -74,7 +74,7 @@ def test_degenerate_inputs_through_every_ladder_kernel(curve, n):
             for part in (0, 1):
                 assert icc.mac_crebuild_host(macs, n, curve, 5, part) == oracle_mac(macs, n, curve, part, 5), (name, part)
     finally:
-        lib.porla_icc_mac_set_matrix_max(2048)
+        lib.porla_icc_mac_set_matrix_max(0)              # the default: no matrix form
 
 
 @pytest.mark.parametrize("curve", ["bn254", "secp256k1"])

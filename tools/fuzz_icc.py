@@ -99,19 +99,19 @@ while time.time() < t_end:
         want = ctypes.create_string_buffer(64 * n)
         if rnd.random() < 0.4:
             # both halves from one network (porla_icc_mac_encode_xy_host: Y_k = wt * X_k) against the oracle's two encodes; the
-            # ladder form too at these small sizes every fourth time (the matrix form is the default up to 512 rows)
+            # matrix form too at these small sizes every fourth time (the ladder is the default at every size)
             from porla_amd import lib
-            ladder = rnd.random() < 0.25
-            if ladder:
-                lib.porla_icc_mac_set_matrix_max(0)
-            gx, gy = icc.mac_crebuild_xy_host(m, n, curve, ws)
-            if ladder:
+            matrix = rnd.random() < 0.25
+            if matrix:
                 lib.porla_icc_mac_set_matrix_max(512)
+            gx, gy = icc.mac_crebuild_xy_host(m, n, curve, ws)
+            if matrix:
+                lib.porla_icc_mac_set_matrix_max(0)
             ok = True
             for p_, g_ in ((0, gx), (1, gy)):
                 L.oracle_icc_mac_crebuild(m, ctypes.c_size_t(n), cid, p_, ctypes.c_uint64(ws), want, NCPU)
                 ok = ok and g_ == want.raw
-            desc = "xy n=%d ws=%d ladder=%s" % (n, ws, ladder)
+            desc = "xy n=%d ws=%d matrix=%s" % (n, ws, matrix)
         else:
             got = icc.mac_crebuild_host(m, n, curve, ws, part)
             L.oracle_icc_mac_crebuild(m, ctypes.c_size_t(n), cid, part, ctypes.c_uint64(ws), want, NCPU)
