@@ -23,9 +23,9 @@ namespace porla {
 
 struct MacWs {
     int device = -1;
-    Buf work, work_y, tws, wpow, in, out, out_y;
-    uint32_t tw_n = 0;
-    int tw_curve = -1;
+    Buf work, work_y, tws, codes, wpow, in, out, out_y;      // codes: the twiddles' digit codes (mac_fft.hip.h:k_mac_wnaf_codes)
+    uint32_t tw_n = 0, codes_n = 0;
+    int tw_curve = -1, codes_curve = -1;
     // matrix form
     Buf F, mont;
     size_t F_n = 0;
@@ -79,6 +79,24 @@ static int ensure_mac_twiddles(MacWs* ws, int curve, size_t n, hipStream_t strea
                        (uint32_t)n, (const Fe<IccFp>*)ws->wpow.p, logn);
     ws->tw_n = (uint32_t)n;
     ws->tw_curve = curve;
+    ws->codes_n = 0;
+    return PORLA_OK;
+}
+
+// the digit codes of the twiddles the wave-uniform stages multiply by (exponents that are multiples of 32), made once per (N, curve)
+// behind the twiddle table on the same stream
+template <class C>
+static int ensure_mac_codes(MacWs* ws, int curve, size_t n, hipStream_t stream) {
+    if (ws->codes_n == n && ws->codes_curve == curve) return PORLA_OK;
+    const size_t entries = n >> MACQ_CODES_EXP_SHIFT;
+    if (entries == 0) return PORLA_OK;                     // (no stage of so small a network is wave-uniform)
+    int rc;
+    if ((rc = ws->codes.ensure(entries * MACQ_CODES_STRIDE * sizeof(uint16_t)))) return rc;
+    ProfScope ps("mac_twiddles", stream);
+    hipLaunchKernelGGL((k_mac_wnaf_codes<C>), dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, stream, (const uint32_t*)ws->tws.p,
+                       (uint32_t)entries, (uint16_t*)ws->codes.p);
+    ws->codes_n = (uint32_t)n;
+    ws->codes_curve = curve;
     return PORLA_OK;
 }
 
@@ -201,6 +219,8 @@ static int mac_encode_core(MacWs* ws, int curve, const uint8_t* d_in, size_t n, 
     }
     if ((rc = ws->work.ensure(n * sizeof(XYZZ<M>)))) return rc;
     if ((rc = ensure_mac_twiddles<Q>(ws, curve, n, stream))) return rc;
+    if ((rc = ensure_mac_codes<C>(ws, curve, n, stream))) return rc;
+    const uint16_t* codes = (const uint16_t*)ws->codes.p;
     int use_wt = 0;
     MacScalar wt{};
     if (part == 1 || d_out_y) {
@@ -232,25 +252,25 @@ static int mac_encode_core(MacWs* ws, int curve, const uint8_t* d_in, size_t n, 
         else if (quad_path && (n >> s) >= 16 && n >= 128 && n / 2 <= MACO_MAX_BUTTERFLIES)
             // ... and at most 2^13 butterflies: eight lanes each, the two half-scalar ladders in different waves
             hipLaunchKernelGGL((k_mac_stage30_oct_uniform<C>), dim3((unsigned)(n / 2 / MACO_BF)), dim3(8 * MACO_BF), maco_lds_bytes<C>(), stream,
-                               (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->tws.p, (uint32_t)n, s);
+                               (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->tws.p, (uint32_t)n, s, codes);
         else if (quad_path && (n >> s) >= 16 && n >= 128)
             // >= 16 butterflies per twiddle (and whole blocks of 64): a wave's 16 quads share their scalar -- the sparse ladder
             hipLaunchKernelGGL((k_mac_stage30_quad<C, true>), dim3((unsigned)((n / 2 + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream,
-                               (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->tws.p, (uint32_t)n, s);
+                               (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->tws.p, (uint32_t)n, s, codes);
         else if (quad_path && n / 2 <= MACO_MAX_BUTTERFLIES)
             // per-butterfly scalars and at most 2^13 butterflies: eight lanes each (the two half-scalar ladders side by side)
             hipLaunchKernelGGL((k_mac_stage30_oct<C>), dim3((unsigned)((n / 2 + MACO_BF - 1) / MACO_BF)), dim3(8 * MACO_BF), maco_lds_bytes<C>(), stream,
                                (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->tws.p, (uint32_t)n, s);
         else if (quad_path)
             hipLaunchKernelGGL((k_mac_stage30_quad<C, false>), dim3((unsigned)((n / 2 + MACQ_BF - 1) / MACQ_BF)), dim3(4 * MACQ_BF), macq_lds_bytes<C>(), stream,
-                               (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->tws.p, (uint32_t)n, s);
+                               (XYZZ<M>*)ws->work.p, (const uint32_t*)ws->tws.p, (uint32_t)n, s, codes);
         else if (s > 1 && (n >> s) >= 64 && ((n / 2) & 255) == 0)
             // one lane per butterfly, >= 64 butterflies per twiddle: a wave shares its scalar -- the sparse ladder
             hipLaunchKernelGGL((k_mac_stage30<C, true>), dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, stream, (XYZZ<M>*)ws->work.p,
-                               (const uint32_t*)ws->tws.p, (uint32_t)n, s);
+                               (const uint32_t*)ws->tws.p, (uint32_t)n, s, codes);
         else
             hipLaunchKernelGGL((k_mac_stage30<C, false>), dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, stream, (XYZZ<M>*)ws->work.p,
-                               (const uint32_t*)ws->tws.p, (uint32_t)n, s);
+                               (const uint32_t*)ws->tws.p, (uint32_t)n, s, codes);
     }
     {
         ProfScope ps("mac_finish", stream);

@@ -48,6 +48,40 @@ __device__ __forceinline__ uint32_t mac_wnaf5_step(uint32_t (&k)[5], bool flip) 
 
 
 // plain little-endian limbs of (w^e mod p_icc) mod q for e in [0, n)   (cf. k_icc_twiddles in icc.hip.h)
+// The recoding of a TWIDDLE does not depend on the butterfly: the stages whose waves share a twiddle (>= 16 butterflies per twiddle
+// on four / eight lanes, >= 64 on one) read their 129 digit codes from a table made once per (N, curve) beside the twiddles
+// themselves -- entry t = the codes of exponent 32 t (those stages only use exponents that are multiples of 32), low byte k1, high
+// byte k2, MACQ_CODES_STRIDE 16-bit words per entry.  In the kernel the endomorphism split and the 2 x 129 recoding steps were ~10 k
+// scalar instructions per wave and stage: 6-8 % of a uniform stage's time (SQ counters, profiles/r05_w_*).
+constexpr int MACQ_CODES_STRIDE = 132;            // 16-bit words per entry (264 bytes: 8-byte aligned)
+constexpr int MACQ_CODES_EXP_SHIFT = 5;           // entry = exponent >> 5
+template <class C>
+__global__ void k_mac_wnaf_codes(const uint32_t* __restrict__ tws, uint32_t entries, uint16_t* __restrict__ codes) {
+    using G = typename C::Glv;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= entries) return;
+    uint32_t sc[8];
+    const uint4* w4 = reinterpret_cast<const uint4*>(tws + ((size_t)t << MACQ_CODES_EXP_SHIFT) * 8);
+    const uint4 a = w4[0], b = w4[1];
+    sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
+    uint32_t m0[4], m1[4];
+    bool ng0, ng1;
+    glv_split<G>(sc, m0, ng0, m1, ng1);
+    uint32_t k0[5] = {m0[0], m0[1], m0[2], m0[3], 0u}, k1[5] = {m1[0], m1[1], m1[2], m1[3], 0u};
+    uint16_t* dst = codes + (size_t)t * MACQ_CODES_STRIDE;
+#pragma unroll 1
+    for (int i = 0; i < MACQ_WNAF_LEN; i++) dst[i] = (uint16_t)(mac_wnaf5_step(k0, ng0) | (mac_wnaf5_step(k1, ng1) << 8));
+    for (int i = MACQ_WNAF_LEN; i < MACQ_CODES_STRIDE; i++) dst[i] = 0;
+}
+// a wave copies its twiddle's entry into its LDS code array (66 32-bit words: two rounds of the wave); ends with the wave's fence
+__device__ __forceinline__ void mac_codes_to_lds(uint16_t* lds_codes, const uint16_t* __restrict__ entry, uint32_t lane) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(entry);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(lds_codes);
+    for (uint32_t i = lane; i < MACQ_CODES_STRIDE / 2; i += 64) dst[i] = src[i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <class Q>
 __global__ void k_mac_twiddles(uint32_t* __restrict__ tws, uint32_t n, const Fe<IccFp>* __restrict__ wpow, int logn) {
     uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -142,10 +176,12 @@ __device__ __noinline__ void mac30_scalar_mul(XYZZ<typename C::Fp>* out, const X
 // `codes` (LDS, this wave's own), and runs of zero digits doubled in one call.
 template <class C>
 __device__ __noinline__ void mac30_scalar_mul_uniform(XYZZ<typename C::Fp>* out, const XYZZ<typename C::Fp>* P, const uint32_t k[8],
-                                                      uint16_t* codes) {
+                                                      uint16_t* codes, const uint16_t* __restrict__ pre = nullptr) {
     using M = typename C::Fp;
     using G = typename C::Glv;
-    {
+    if (pre) {                                                            // the twiddle's entry of the code table (k is not read)
+        mac_codes_to_lds(codes, pre, threadIdx.x & 63u);
+    } else {
         uint32_t m0[4], m1[4];
         bool ng0, ng1;
         glv_split<G>(k, m0, ng0, m1, ng1);
@@ -236,7 +272,7 @@ k_mac_load30(const uint8_t* __restrict__ in, uint32_t n, XYZZ<typename C::Fp>* _
 #pragma unroll
         for (int j = 0; j < 8; j++) k[j] = wt.v[j];
         XYZZ<M> r;
-        __shared__ uint16_t wdig[MACQ_WNAF_LEN + 3];                      // (64 lanes = one wave per block; one scalar for every MAC)
+        __shared__ __align__(8) uint16_t wdig[MACQ_CODES_STRIDE];          // (64 lanes = one wave per block; one scalar for every MAC)
         mac30_scalar_mul_uniform<C>(&r, &p, k, wdig);
         p = r;
     }
@@ -255,7 +291,7 @@ k_mac_scale30(const XYZZ<typename C::Fp>* __restrict__ in, uint32_t n, XYZZ<type
 #pragma unroll
     for (int j = 0; j < 8; j++) k[j] = wt.v[j];
     XYZZ<M> r;
-    __shared__ uint16_t wdig[MACQ_WNAF_LEN + 3];                          // (64 lanes = one wave per block; one scalar for every MAC)
+    __shared__ __align__(8) uint16_t wdig[MACQ_CODES_STRIDE];              // (64 lanes = one wave per block; one scalar for every MAC)
     mac30_scalar_mul_uniform<C>(&r, &p, k, wdig);
     store_xyzz<M>(out + i, r);
 }
@@ -264,7 +300,8 @@ k_mac_scale30(const XYZZ<typename C::Fp>* __restrict__ in, uint32_t n, XYZZ<type
 // (they differ in the block of the stage they belong to): mac30_scalar_mul_uniform
 template <class C, bool UNIFORM>
 __global__ void __launch_bounds__(256)      // (launched with 256 lanes: 21.1 against 22.2 ms at N = 2^17 with 64)
-k_mac_stage30(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restrict__ tws, uint32_t n, int s) {
+k_mac_stage30(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restrict__ tws, uint32_t n, int s,
+              const uint16_t* __restrict__ codes) {
     using M = typename C::Fp;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n / 2) return;
@@ -288,8 +325,8 @@ k_mac_stage30(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restric
     XYZZ<M> tm;
     if (s == 1) tm = hi;                            // stage 1: every twiddle is w^0 = 1 (uniform over the launch): no ladder
     else if constexpr (UNIFORM) {
-        __shared__ uint16_t wdig[4][MACQ_WNAF_LEN + 3];
-        mac30_scalar_mul_uniform<C>(&tm, &hi, sc, wdig[threadIdx.x >> 6]);
+        __shared__ __align__(8) uint16_t wdig[4][MACQ_CODES_STRIDE];
+        mac30_scalar_mul_uniform<C>(&tm, &hi, sc, wdig[threadIdx.x >> 6], codes + (size_t)(e >> MACQ_CODES_EXP_SHIFT) * MACQ_CODES_STRIDE);
     } else mac30_scalar_mul<C>(&tm, &hi, sc);
     XYZZ<M> sum = load_xyzz<M>(work + k);
     XYZZ<M> dif = sum;
@@ -358,7 +395,7 @@ struct MacQuadLds {
     };
     Quad qd[MACQ_BF];
     XYZZ<M> acc[MACQ_BF], tmp[MACQ_BF], um[MACQ_BF];
-    uint16_t wdig[4][MACQ_WNAF_LEN + 3];        // the wave-uniform ladder's digit codes, one set per wave of the block
+    uint16_t wdig[4][MACQ_CODES_STRIDE];        // the wave-uniform ladder's digit codes, one set per wave of the block
 };
 // every lane of a quad moves "its" coordinate (32 bytes) of a point
 template <class M>
@@ -481,12 +518,15 @@ __device__ __forceinline__ void macq_ladder(MacQuadLds<typename C::Fp>& L, uint3
 //   code of a position = low byte for k1, high byte for k2: 0 = zero digit, else 16 | sign << 3 | (|d| - 1) / 2
 template <class C>
 __device__ __forceinline__ void macq_ladder_uniform(MacQuadLds<typename C::Fp>& L, uint32_t q, uint32_t r, uint32_t lane, uint32_t wave,
-                                                    const uint32_t sc[8], F30<typename C::Fp>& c, bool& inf) {
+                                                    const uint32_t sc[8], F30<typename C::Fp>& c, bool& inf,
+                                                    const uint16_t* __restrict__ pre = nullptr) {
     using M = typename C::Fp;
     using G = typename C::Glv;
     typename MacQuadLds<M>::Quad& Q = L.qd[q];
-    // the recoding first (scalar unit; the table's arithmetic below does not wait for it)
-    {
+    // the digit codes first: the twiddle's entry of the code table (stages), or recoded here on the scalar unit (the init scaling)
+    if (pre) {
+        mac_codes_to_lds(L.wdig[wave], pre, lane);
+    } else {
         uint32_t m0[4], m1[4];
         bool ng0, ng1;
         glv_split<G>(sc, m0, ng0, m1, ng1);
@@ -581,7 +621,8 @@ __device__ __forceinline__ void macq_butterfly_out(const XYZZ<M>* um, XYZZ<M>* s
 // of the stage they belong to), so the whole wave multiplies by one scalar: macq_ladder_uniform
 template <class C, bool UNIFORM>
 __global__ void __launch_bounds__(4 * MACQ_BF) MACQ_GUEST_ATTR
-k_mac_stage30_quad(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restrict__ tws, uint32_t n, int s) {
+k_mac_stage30_quad(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restrict__ tws, uint32_t n, int s,
+                   const uint16_t* __restrict__ codes) {
     using M = typename C::Fp;
     MACQ_LDS(L);
     // a stage is one wave per SIMD walking ~200 dependent group operations: when another kernel shares the chip (the
@@ -616,7 +657,8 @@ k_mac_stage30_quad(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __re
     macq_sync();
     F30<M> c;
     bool inf;
-    if constexpr (UNIFORM) macq_ladder_uniform<C>(L, q, r, lane, threadIdx.x >> 6, sc, c, inf);
+    if constexpr (UNIFORM) macq_ladder_uniform<C>(L, q, r, lane, threadIdx.x >> 6, sc, c, inf,
+                                                   codes + (size_t)(e >> MACQ_CODES_EXP_SHIFT) * MACQ_CODES_STRIDE);
     else macq_ladder<C>(L, q, r, lane, sc, c, inf);
     // MAC[k] = um + tm, MAC[k + m2] = um - tm
     macq_butterfly_out<M>(&L.um[q], &L.acc[q], &L.tmp[q], c, inf, work + k, work + k + m2, valid, r, lane);
@@ -641,7 +683,7 @@ struct MacOctLds {
     typename MacQuadLds<M>::Quad qd[MACO_BF];   // per octet: table of multiples + beta-scaled X
     XYZZ<M> acc[2 * MACO_BF], tmp[2 * MACO_BF];  // per quad: the slots of the rare general addition
     XYZZ<M> um[MACO_BF], xch[MACO_BF];           // per octet: the butterfly's upper input; what the quads hand each other
-    uint16_t wdig[4][MACQ_WNAF_LEN + 3];         // k_mac_stage30_oct_uniform: one half-scalar's digit codes per wave
+    uint16_t wdig[4][MACQ_CODES_STRIDE];         // k_mac_stage30_oct_uniform: the twiddle's digit codes per wave (it reads its half's byte)
 };
 #define MACO_LDS(L) extern __shared__ __align__(16) unsigned char macq_lds_raw[]; \
     MacOctLds<M>& L = *reinterpret_cast<MacOctLds<M>*>(macq_lds_raw)
@@ -770,7 +812,8 @@ k_mac_stage30_oct(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __res
 // non-zero digit); the hand-overs between the quads are block barriers, which every wave reaches.
 template <class C>
 __global__ void __launch_bounds__(8 * MACO_BF) MACO_ATTR
-k_mac_stage30_oct_uniform(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restrict__ tws, uint32_t n, int s) {
+k_mac_stage30_oct_uniform(XYZZ<typename C::Fp>* __restrict__ work, const uint32_t* __restrict__ tws, uint32_t n, int s,
+                          const uint16_t* __restrict__ codes) {
     using M = typename C::Fp;
     using G = typename C::Glv;
     MACO_LDS(L);
@@ -785,27 +828,11 @@ k_mac_stage30_oct_uniform(XYZZ<typename C::Fp>* __restrict__ work, const uint32_
     const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)(rest & (m2 - 1)));
     const uint32_t k = ((((rest >> (s - 1)) << 4) | (t & 15u)) << s) + j;
     const uint32_t e = j * (n >> (s - 1));
-    uint32_t sc[8];
-    {
-        const uint4* w4 = reinterpret_cast<const uint4*>(tws + (size_t)e * 8);
-        const uint4 a = w4[0], b = w4[1];
-        sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
-    }
+    (void)tws;
     typename MacQuadLds<M>::Quad& Q = L.qd[o];
     if (half) macq_copy_coord<M>(&L.um[o], work + k, r);
     else macq_copy_coord<M>(&Q.tbl[0], work + k + m2, r);
-    {   // this wave's half-scalar, recoded (scalar unit)
-        uint32_t m0[4], m1[4];
-        bool ng0, ng1;
-        glv_split<G>(sc, m0, ng0, m1, ng1);
-        uint32_t kk[5] = {half ? m1[0] : m0[0], half ? m1[1] : m0[1], half ? m1[2] : m0[2], half ? m1[3] : m0[3], 0u};
-        const bool ng = half ? ng1 : ng0;
-#pragma unroll 1
-        for (int i = 0; i < MACQ_WNAF_LEN; i++) {
-            const uint32_t code = mac_wnaf5_step(kk, ng);
-            if (lane == 0u) L.wdig[wave][i] = (uint16_t)code;
-        }
-    }
+    mac_codes_to_lds(L.wdig[wave], codes + (size_t)(e >> MACQ_CODES_EXP_SHIFT) * MACQ_CODES_STRIDE, lane);   // (this wave reads its half's byte)
     __syncthreads();
     F30<M> c;
     bool inf = true, z;
@@ -835,7 +862,7 @@ k_mac_stage30_oct_uniform(XYZZ<typename C::Fp>* __restrict__ work, const uint32_
     if (!p_inf) {
 #pragma unroll 1
         for (int i = MACQ_WNAF_LEN - 1; i >= 0; i--) {
-            const uint32_t cd = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.wdig[wave][i]);
+            const uint32_t cd = ((uint32_t)__builtin_amdgcn_readfirstlane((int)L.wdig[wave][i]) >> (8u * half)) & 0xffu;
             if (!inf) xyzz30_dbl_quadreg<M>(c, r);
             if (cd == 0u) continue;
             const XYZZ<M>* en = &Q.tbl[cd & 7u];
