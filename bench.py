@@ -161,7 +161,7 @@ def compact_line(full, legs_file=None):
     out["roofline"] = _compact_roofline(full.get("roofline"))
     out["cpu_baseline"] = _compact_cpu(full.get("cpu_baseline"))
     out["bit_exact_vs_oracle"] = full.get("bit_exact_vs_oracle")
-    for k in ("blocking_ms_per_step", "blocking_Mmul_s", "preflight"):
+    for k in ("blocking_ms_per_step", "blocking_Mmul_s", "preflight", "run_wall_s"):
         if k in full:
             out[k] = full[k]
     hb = full.get("host_boundary")
@@ -358,6 +358,7 @@ def launch_ranks(n, argv):
 
 
 def main():
+    t_main = time.perf_counter()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -375,6 +376,8 @@ def main():
     ap.add_argument("--no-host-boundary", action="store_true", help="bn254_msm: skip the compute_multi_exp-on-host-buffers leg")
     ap.add_argument("--in-flight", type=int, default=2, help="bn254_msm: independent MSMs in flight (1 = blocking calls; 2 = the "
                     "audit's pair of MSMs, Server.hpp:900-901, overlapped on two streams)")
+    ap.add_argument("--min-warm-s", type=float, default=0.25,
+                    help="every timed region warms up for at least this long (W steps, then more of the same); 0: exactly W steps")
     ap.add_argument("--no-pmc", action="store_true", help="bn254_msm: do not collect the dominant kernel's counter traffic in this run "
                     "(two short child runs under rocprofv3 --pmc); the committed passes are reported instead")
     ap.add_argument("--legs-out", default=os.path.join(ROOT, "bench_legs.json"),
@@ -532,8 +535,10 @@ def main():
     preflight = rank_preflight() if world > 1 else None
 
     stream = torch.cuda.current_stream().cuda_stream
-    # legs (never the headline, which does exactly W warmup steps): warm up for at least this long -- see timed()
-    leg_warm_s = 0.0 if args.workload != "bn254_msm" else 0.05
+    # every timed region warms up for at least this long (W steps, then more of the same until the time has passed) -- see timed();
+    # --warmup 0 switches it off
+    leg_warm_s = args.min_warm_s
+    head_warm_s = args.min_warm_s
 
     def to_dev(b):
         return torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
@@ -547,23 +552,30 @@ def main():
     def timed(step, drain=None, min_warm_s=0.0):
         """W warmup + K timed steps, barrier + synchronize on both sides, MAX over ranks; returns (seconds, kernel ms, last
         result).  `drain` (pipelined steps) retires whatever is still in flight: the timed region contains K complete steps.
-        `min_warm_s` (the legs, never the headline): keep warming up until that much wall time has passed -- a leg starts after
-        seconds of host work (its predecessor's CPU baseline) with the GPU idle and its clocks down, and W steps of a 0.6 ms
-        kernel do not bring them back"""
+        `min_warm_s`: the warm-up goes on -- with further untimed steps of the same kind -- until the device has been busy for that
+        long.  A timed region starts after seconds of host work (input generation, the previous leg's CPU baseline) with the GPU idle
+        and its clocks down, and W = 5 steps of a 1.4 ms MSM (7 ms) do not bring them back: the same 20 steps measure 716-719 Mmul/s
+        after 5 warm-up steps and 757-763 after 200 (same box; the accumulation kernel 1.01 against 0.94 ms) -- the latter is the
+        sustained rate the 100-step runs see.  The line says how many warm-up steps ran (`warmup_steps_run`)."""
         res = None
         t_w = time.perf_counter()
         for _ in range(args.warmup):
             res = step()
+        timed.warm_steps = args.warmup
         if min_warm_s and args.warmup:
-            # the SAME number of extra steps on every rank (a step may contain a collective): from this rank's pace, MAX over ranks
-            per = max((time.perf_counter() - t_w) / args.warmup, 1e-5)
-            extra = max(0, min(2000, int((min_warm_s - (time.perf_counter() - t_w)) / per) + 1))
+            # the SAME number of extra steps on every rank (a step may contain a collective): from this rank's pace, MAX over ranks.
+            # The pace is taken with the device drained: a step that only enqueues returns in microseconds (and would ask for
+            # thousands of extra steps)
+            torch.cuda.synchronize()
+            per = max((time.perf_counter() - t_w) / args.warmup, 1e-4)
+            extra = max(0, min(500, int((min_warm_s - (time.perf_counter() - t_w)) / per) + 1))
             if world > 1:
                 t = torch.tensor([extra], dtype=torch.int64, device=coll_dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 extra = int(t.item())
             for _ in range(extra):
                 res = step()
+            timed.warm_steps += extra
         if drain:
             res = drain() or res
         sync()
@@ -637,7 +649,9 @@ def main():
         if not rl or world != 1 or rank != 0 or args.no_pmc:
             return rl
         sym = rl["kernel"]
-        got, info = pmc_in_run(sym, child_args + ["--no-cpu", "--no-pmc", "--steps", "3", "--warmup", "1", "--legs-out", ""])
+        t_pmc = time.perf_counter()
+        got, info = pmc_in_run(sym, child_args + ["--no-cpu", "--no-pmc", "--steps", "3", "--warmup", "1", "--min-warm-s", "0", "--legs-out", ""])
+        rl["traffic_passes_wall_s"] = round(time.perf_counter() - t_pmc, 1)
         if got:
             rl["traffic_committed_passes"] = rl.get("traffic")
             rl["traffic"] = got
@@ -805,7 +819,8 @@ def main():
                 res = retire()
             return res
 
-        el, kern, result = timed(step, drain)
+        el, kern, result = timed(step, drain, min_warm_s=head_warm_s)
+        warm_steps_run = timed.warm_steps
         fe_mults = msm_fe_mults(n)        # read now: the audit-size MSMs below run with another (window, GLV) shape
         # the same MSM as blocking calls (one in flight): what a caller that waits for every result sees, and ITS per-kernel
         # breakdown (the one above is taken with `depth` MSMs contending for the chip)
@@ -902,7 +917,7 @@ def main():
                     "u32x8 (256-bit modular integer)",
                     {"workload": "KZG scheme, single 2^%d-point BN254 G1 MSM per GPU, inputs resident in HBM, "
                                  "output 64-B affine point" % args.log2n,
-                     "pairs_per_gpu": n, "msm_in_flight": depth,
+                     "pairs_per_gpu": n, "msm_in_flight": depth, "warmup_steps_run": warm_steps_run, "min_warmup_s": head_warm_s,
                      "sharding": "input-pair range per rank + all-gather of 96-B Jacobian partials, folded on every host"
                      if world > 1 else "single GPU", "collective": collective, "input_gen_s": round(gen_s, 1)},
                     rl_head, cpu, verified,
@@ -1515,7 +1530,11 @@ def main():
     legs = {"bn254_msm": leg_bn254_msm, "strong_2p20": leg_strong_2p20, "kzg_commit": leg_kzg_commit, "secp256k1_msm": leg_secp256k1_msm, "icc": leg_icc,
             "config3": leg_config3, "audit_combine": leg_audit_combine, "client_mac_batch": leg_client_mac_batch,
             "ipa_commits": leg_ipa_commits, "mac_encode": leg_mac_encode, "server_mix": leg_server_mix}
+    t_leg = time.perf_counter()
     out = legs[args.workload]()
+    out["wall_s"] = round(time.perf_counter() - t_leg, 1)      # this leg's share of the run (setup, timed regions, CPU baseline, counter passes)
+    if rank == 0:
+        print("[bench] %s: %.1f s" % (args.workload, out["wall_s"]), file=sys.stderr, flush=True)
     for k, v in (("n_gpus", world), ("steps", args.steps), ("warmup", args.warmup), ("higher_is_better", True), ("vs_baseline", None),
                  ("data", "synthetic")):
         out.setdefault(k, v)               # (a leg printed alone as the line: the contract's keys it leaves to the line)
@@ -1543,7 +1562,11 @@ def main():
             try:
                 if os.environ.get("PORLA_BENCH_FAIL_LEG") == name:      # test hook: the failed-leg path of this loop
                     raise RuntimeError("injected failure (PORLA_BENCH_FAIL_LEG)")
+                t_leg = time.perf_counter()
                 leg = fn()
+                leg["wall_s"] = round(time.perf_counter() - t_leg, 1)
+                if rank == 0:
+                    print("[bench] %s: %.1f s" % (name, leg["wall_s"]), file=sys.stderr, flush=True)
             except Exception as e:  # noqa: BLE001  (a leg must not take the headline down with it: the line is still printed)
                 if world > 1:
                     raise                      # ... except where the ranks would fall out of step
@@ -1563,6 +1586,7 @@ def main():
         # a leg that threw is named on the line; one that measures a BASELINE.json configuration also fails the run (rc 3) -- a
         # missing configuration must not pass silently.  A result that differs from the oracle fails the run with rc 1.
         out["legs_failed"] = legs_failed
+        out["run_wall_s"] = round(time.perf_counter() - t_main, 1)     # this process, argument parsing to the line (per leg: wall_s in the legs file)
         if preflight:
             out["preflight"] = preflight
         emit(out, args.legs_out, single_leg=args.workload != "bn254_msm")

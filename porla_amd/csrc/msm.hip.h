@@ -254,7 +254,7 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* wsum /
 template <class C, bool GLV>
 __global__ void __launch_bounds__(TILE_THREADS)
 k_digits_partition(const uint8_t* __restrict__ scalars, uint32_t n, int c, int W, int lowbits,
-                   uint32_t* __restrict__ tile_items, uint16_t* __restrict__ tile_off) {
+                   uint32_t* __restrict__ tile_items, uint16_t* __restrict__ tile_off, uint32_t* __restrict__ ctrl) {
     constexpr int SUBS = GLV ? 2 : 1;
     constexpr int LIMBS = GLV ? 4 : 8;
     constexpr int NSUB = TILE_SPT * SUBS;
@@ -262,6 +262,9 @@ k_digits_partition(const uint8_t* __restrict__ scalars, uint32_t n, int c, int W
     __shared__ uint32_t cursor[MAX_PARTS];
     __shared__ uint32_t stage[TILE * SUBS];
     const uint32_t tile = blockIdx.x, T = gridDim.x, tid = threadIdx.x;
+    // the control words of the kernels behind this one (sort cursor, item counters: see CTRL_WORDS below) start at zero -- cleared
+    // here instead of by a memset packet in front of the chain (a 9-us fill kernel on a lone caller's critical path)
+    if (tile == 0 && blockIdx.y == 0 && tid < 4 + 128) ctrl[tid] = 0;
     const int P = 1 << (c - 1 - lowbits);
     const uint32_t B = 1u << (c - 1);
     const uint32_t mask = (1u << c) - 1;
@@ -540,7 +543,8 @@ k_partition_sort(const uint32_t* __restrict__ tile_items, const uint16_t* __rest
 //   ctrl[0] entries cursor   ctrl[1] chunk-output cursor   ctrl[2] number of multi-item buckets   ctrl[3] number of items
 //   ctrl[4 .. 4+CHUNK)  items per size row (row r <-> size CHUNK - r)
 constexpr int CHUNK = 128;
-constexpr int CTRL_WORDS = 4 + CHUNK;
+constexpr int CTRL_WORDS = 4 + CHUNK;   // (k_digits_partition clears 4 + 128 words)
+static_assert(CTRL_WORDS == 4 + 128, "k_digits_partition clears the control words");
 constexpr uint32_t NO_CHUNK = 0xffffffffu;
 
 // per-1024-bucket block: histogram of item sizes; layout row-major [row][block], row = CHUNK - size

@@ -317,8 +317,7 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
         if ((rc = ws->buckets.ensure(nb * sizeof(XYZZ<M>)))) return rc;
         bk = (XYZZ<M>*)ws->buckets.p;
     }
-    uint32_t* ctrl = (uint32_t*)ws->cursor.p;
-    PORLA_HIP(hipMemsetAsync(ctrl, 0, CTRL_WORDS * 4, stream));
+    uint32_t* ctrl = (uint32_t*)ws->cursor.p;     // cleared by k_digits_partition
     const Affine<M>* pts = (const Affine<M>*)ws->pts.p;
     // The conversion of the points is independent of the digit / sort chain and only the accumulation reads its output: for a
     // caller that waits for this one MSM it runs on the workspace's second stream beside that chain (with another MSM in flight
@@ -356,10 +355,10 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
         if (wg > (unsigned)W) wg = (unsigned)W;
         if (glv)
             hipLaunchKernelGGL((k_digits_partition<C, true>), dim3(T_tiles, wg), dim3(TILE_THREADS), 0, stream, d_scalars, n32, c, W,
-                               lowbits, (uint32_t*)ws->keys.p, (uint16_t*)ws->tile_off.p);
+                               lowbits, (uint32_t*)ws->keys.p, (uint16_t*)ws->tile_off.p, ctrl);
         else
             hipLaunchKernelGGL((k_digits_partition<C, false>), dim3(T_tiles, wg), dim3(TILE_THREADS), 0, stream, d_scalars, n32, c, W,
-                               lowbits, (uint32_t*)ws->keys.p, (uint16_t*)ws->tile_off.p);
+                               lowbits, (uint32_t*)ws->keys.p, (uint16_t*)ws->tile_off.p, ctrl);
     }
     {
         ProfScope ps("partition_sort", stream);
