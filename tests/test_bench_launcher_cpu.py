@@ -126,3 +126,36 @@ def test_emit_prints_the_compact_line_last_and_writes_the_legs_file(tmp_path, ca
     bench.emit(full["icc"], str(tmp_path / "icc.json"), single_leg=True)
     out = capsys.readouterr().out.rstrip().splitlines()
     assert len(out) == 1 and json.loads(out[0]) == full["icc"]
+
+
+def test_round5_result_keeps_warmup_and_wall_time_on_the_line():
+    """the final round-5 default run (LEG lines + compact line, profiles/r05_z_bench_default_stdout.txt): rebuilding the compact line
+    from the full legs gives the line that was printed; it says how long the warm-up really was and what the run cost in wall time"""
+    import json
+    sys.path.insert(0, common.ROOT)
+    import bench
+    lines = open(os.path.join(common.ROOT, "profiles", "r05_z_bench_default_stdout.txt")).read().splitlines()
+    printed = json.loads([l for l in lines if l.startswith("{")][-1])
+    full = json.loads([l for l in lines if l.startswith("LEG headline ")][0][len("LEG headline "):])
+    for l in lines:
+        if l.startswith("LEG ") and not l.startswith("LEG headline "):
+            name, obj = l[4:].split(" ", 1)
+            full[name] = json.loads(obj)
+    again = bench.compact_line(full, printed.get("legs_file"))
+    assert len(json.dumps(printed)) < 6000
+    for k in ("value", "ms_per_step", "roofline", "cpu_baseline", "kzg_commits", "icc", "config3", "run_wall_s", "legs_failed"):
+        assert again[k] == printed[k], k
+    cfg = printed["config"]
+    assert cfg["min_warmup_s"] == 0.25 and cfg["warmup_steps_run"] >= printed["warmup"]
+    assert 0 < printed["run_wall_s"] < 300          # the default run finishes within minutes
+    assert all(full[leg]["wall_s"] < 60 for leg in ("kzg_commits", "secp256k1_msm", "icc", "config3"))
+
+
+def test_counter_pass_children_do_not_extend_their_warmup():
+    """the `rocprofv3 --pmc` child runs of bench.py must run exactly their W warm-up steps (a warm-up floor under the counters once
+    took a 4-minute timeout per pass): the child arguments switch it off, and the floor's pace is taken with the device drained"""
+    src = open(BENCH).read()
+    child = src[src.index("def traffic_in_run"):src.index("def msm_fe_mults")]
+    assert '"--min-warm-s", "0"' in child and '"--no-pmc"' in child
+    timed = src[src.index("    def timed("):src.index("    def breakdown(")]
+    assert timed.index("torch.cuda.synchronize()") < timed.index("per = max(")
