@@ -122,6 +122,9 @@ def _traffic_ratio(rl):
     try:
         if rl.get("touched_bytes_per_launch"):
             return round(rl["traffic"] / rl["touched_bytes_per_launch"], 2)
+        for k in ("algorithmic_bytes_per_launch", "algorithmic_bytes"):        # legs that state the launch's bytes themselves
+            if rl.get(k):
+                return round(rl["traffic"] / rl[k], 2)
         return round(rl["traffic"] / (rl["achieved"] * rl["kernel_ms"] * 1e6), 2)
     except (TypeError, KeyError, ZeroDivisionError):
         return None
@@ -1072,6 +1075,8 @@ def main():
             # rather than one from a launch of another size
             rl3["traffic"] = None
             rl3["traffic_source"] = "not collected at this leg's range size (profiles/pmc_latest.json is a 2^20-pair launch)"
+            # ... unless this run can collect it itself (N = 1: two short child runs of this leg under rocprofv3 --pmc)
+            rl3 = traffic_in_run(rl3, ["--workload", "config3", "--log2job", str(args.log2job)])
         return line("BN254 G1 MSM Mscalar-mul/s, one 2^%d-pair job over all GPUs" % args.log2job,
                     round(total * args.steps / el / 1e6, 3), "Mmul/s", el, "strong", "u32x8 (256-bit modular integer)",
                     {"workload": "KZG audit over 2^%d blocks: ONE 2^%d-pair BN254 G1 MSM, pair range [g 2^%d / N, (g+1) 2^%d / N) on "
