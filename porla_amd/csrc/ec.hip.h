@@ -148,9 +148,7 @@ template <class M>
 PORLA_HD Affine<M> aff_neg_if(const Affine<M>& a, bool neg) {
     Affine<M> r;
     r.x = a.x;
-    Fe<M> ny = fe_neg<M>(a.y);
-#pragma unroll
-    for (int i = 0; i < 8; i++) r.y.v[i] = neg ? ny.v[i] : a.y.v[i];
+    r.y = fe_neg_if<M>(a.y, neg);
     return r;
 }
 

@@ -111,16 +111,41 @@ PORLA_HD Fe<M> fe_one() {  // Montgomery one
     return r;
 }
 
+// One word of a borrow / carry chain.  The device pass goes through the compiler's carry builtins, which become v_sub_co / v_subb_co
+// (v_add_co / v_addc_co): ONE instruction per word.  The 64-bit difference form `d = (uint64_t)a - b - br; br = d >> 63` compiles to
+// five per word on gfx950 (sign-extended 64-bit adds and the moves that build their operands: 38 instructions for an 8-word
+// subtraction against 15) -- that was a twentieth of the ICC encode's instruction stream (its finish step: profiles/README.md, round 5).
+PORLA_HD uint32_t sbb32(uint32_t a, uint32_t b, uint32_t& br) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned out;
+    const uint32_t d = __builtin_subc(a, b, br, &out);
+    br = out;
+    return d;
+#else
+    const uint64_t d = (uint64_t)a - b - br;
+    br = (uint32_t)(d >> 63);
+    return (uint32_t)d;
+#endif
+}
+PORLA_HD uint32_t adc32(uint32_t a, uint32_t b, uint32_t& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned out;
+    const uint32_t x = __builtin_addc(a, b, c, &out);
+    c = out;
+    return x;
+#else
+    const uint64_t x = (uint64_t)a + b + c;
+    c = (uint32_t)(x >> 32);
+    return (uint32_t)x;
+#endif
+}
+
 // t - P with borrow out; returns borrow (1 if t < P)
 template <class M>
 PORLA_HD uint32_t sub_p(uint32_t s[8], const uint32_t t[8]) {
     uint32_t br = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t d = (uint64_t)t[i] - M::P[i] - br;
-        s[i] = (uint32_t)d;
-        br = (uint32_t)(d >> 63);
-    }
+    for (int i = 0; i < 8; i++) s[i] = sbb32(t[i], M::P[i], br);
     return br;
 }
 
@@ -169,11 +194,7 @@ PORLA_HD Fe<M> fe_add(const Fe<M>& a, const Fe<M>& b) {
     uint32_t t[8], s[8];
     uint32_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t x = (uint64_t)a.v[i] + b.v[i] + c;
-        t[i] = (uint32_t)x;
-        c = (uint32_t)(x >> 32);
-    }
+    for (int i = 0; i < 8; i++) t[i] = adc32(a.v[i], b.v[i], c);
     uint32_t br = sub_p<M>(s, t);
     bool ge = (M::SPARE_BITS > 0) ? (br == 0) : (c != 0 || br == 0);
     Fe<M> r;
@@ -190,27 +211,45 @@ PORLA_HD Fe<M> fe_sub(const Fe<M>& a, const Fe<M>& b) {
     uint32_t t[8];
     uint32_t br = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t d = (uint64_t)a.v[i] - b.v[i] - br;
-        t[i] = (uint32_t)d;
-        br = (uint32_t)(d >> 63);
-    }
+    for (int i = 0; i < 8; i++) t[i] = sbb32(a.v[i], b.v[i], br);
     uint32_t mask = 0u - br;  // add P back when the subtraction borrowed
     uint32_t c = 0;
     Fe<M> r;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t x = (uint64_t)t[i] + (M::P[i] & mask) + c;
-        r.v[i] = (uint32_t)x;
-        c = (uint32_t)(x >> 32);
-    }
+    for (int i = 0; i < 8; i++) r.v[i] = adc32(t[i], M::P[i] & mask, c);
     return r;
 }
 
+// -a: P - a in ONE borrow chain, 0 for a = 0 -- word for word what the two-chain form (0 - a, then + P where that borrowed) gives
+// for every 256-bit a, in 24 instructions instead of 38
 template <class M>
 PORLA_HD Fe<M> fe_neg(const Fe<M>& a) {
-    Fe<M> z = fe_zero<M>();
-    return fe_sub<M>(z, a);  // 0 - 0 = 0, else P - a
+    Fe<M> r;
+    uint32_t br = 0, nz = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        r.v[i] = sbb32(M::P[i], a.v[i], br);
+        nz |= a.v[i];
+    }
+    const uint32_t keep = nz ? 0xffffffffu : 0u;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] &= keep;
+    return r;
+}
+// neg ? -a : a with the zero test folded into the select
+template <class M>
+PORLA_HD Fe<M> fe_neg_if(const Fe<M>& a, bool neg) {
+    Fe<M> r;
+    uint32_t br = 0, nz = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        r.v[i] = sbb32(M::P[i], a.v[i], br);
+        nz |= a.v[i];
+    }
+    const bool take = neg && nz != 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = take ? r.v[i] : a.v[i];
+    return r;
 }
 
 template <class M>
@@ -499,6 +538,30 @@ PORLA_HD uint32_t bswap32(uint32_t x) {
 }
 
 // plain (non-Montgomery) value < 2^256 reduced into [0, P): at most `maxq` conditional subtractions
+// t < (K + 1) P  ->  t mod P without a data-dependent loop: a quotient estimate from the top words, one product-and-subtract, one
+// conditional subtraction.  qe = floor(t7 / (P7 + 1)) <= floor(t / P) <= qe + 1: the real ratios t7 / (P7 + 1) <= t / P < (t7 + 1) / P7
+// differ by (t7 + P7 + 1) / (P7 (P7 + 1)) < 2^-25 for P7 >= 2^29 and t7 < 2^32, so their floors differ by at most one.
+// (The ICC finish step: A mod p_icc below 4.3 q took five rounds of fe_reduce_plain's loop in every wave.)
+template <class M, int K>
+PORLA_HD void fe_reduce_small(uint32_t t[8]) {
+    static_assert(M::P[7] >= (1u << 29), "the quotient estimate needs a modulus of more than 253 bits");
+    if constexpr (K > 0 && M::P[7] != 0xffffffffu) {
+        const uint32_t qe = t[7] / (M::P[7] + 1u);
+        uint64_t carry = 0;
+        uint32_t br = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint64_t m = (uint64_t)qe * M::P[i] + carry;
+            carry = m >> 32;
+            t[i] = sbb32(t[i], (uint32_t)m, br);
+        }
+    }
+    uint32_t s[8];
+    const uint32_t br = sub_p<M>(s, t);
+#pragma unroll
+    for (int i = 0; i < 8; i++) t[i] = br ? t[i] : s[i];
+}
+
 template <class M>
 PORLA_HD void fe_reduce_plain(uint32_t t[8], int maxq) {
     for (int q = 0; q < maxq; q++) {

@@ -174,7 +174,7 @@ k_fb_normalize(const XYZZ<typename C::Fp>* __restrict__ scratch, size_t n, Affin
 // SIMD the chip had no slot for them, and every one of the 15 stage launches waited for a block of this kernel to retire
 // (3.6-4.8 ms instead of 0.6): the two streams ran one after the other.
 template <class C, bool GUEST_ROOM = false>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GUEST_ROOM ? 2 : C::FB_COMMIT_WAVES, 4)))
 k_fb_commit(const uint8_t* __restrict__ rows, uint32_t n_rows, uint32_t n_coeffs, size_t row_stride,
             const Affine<typename C::Fp>* __restrict__ table, int c, int W, uint32_t S,
             XYZZ<typename C::Fp>* __restrict__ partial) {

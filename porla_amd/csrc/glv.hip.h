@@ -103,11 +103,7 @@ PORLA_HD void glv_muladd(uint32_t acc[8], const uint32_t c[4], const uint32_t m[
     if (SUB) {
         uint32_t br = 0;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            uint64_t d = (uint64_t)acc[i] - p[i] - br;
-            acc[i] = (uint32_t)d;
-            br = (uint32_t)(d >> 63);
-        }
+        for (int i = 0; i < 8; i++) acc[i] = sbb32(acc[i], p[i], br);
     } else {
         uint32_t cy = 0;
 #pragma unroll

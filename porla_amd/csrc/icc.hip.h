@@ -181,11 +181,7 @@ __device__ __forceinline__ void icc_store_lcm_pt(const Fe<IccFp>& P, const Fe<Q>
     // A = P + t
     uint32_t c2 = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        uint64_t x = (uint64_t)P.v[k] + t.v[k] + c2;
-        A[k] = (uint32_t)x;
-        c2 = (uint32_t)(x >> 32);
-    }
+    for (int k = 0; k < 8; k++) A[k] = adc32(P.v[k], t.v[k], c2);
     A[8] = c2;
     // A += u << 248   (248 = 7*32 + 24)
     uint32_t c3 = 0;
@@ -193,9 +189,7 @@ __device__ __forceinline__ void icc_store_lcm_pt(const Fe<IccFp>& P, const Fe<Q>
     for (int k = 0; k < 9; k++) {
         uint32_t lo = u[k] << 24;
         uint32_t hi = (k > 0) ? (u[k - 1] >> 8) : 0;
-        uint64_t x = (uint64_t)A[7 + k] + (lo | hi) + c3;
-        A[7 + k] = (uint32_t)x;
-        c3 = (uint32_t)(x >> 32);
+        A[7 + k] = adc32(A[7 + k], lo | hi, c3);
     }
     // top word of (u << 248): u[8] >> 8 lands in A[16] which must be zero because A < LCM < 2^512
     uint4* o = reinterpret_cast<uint4*>(dst);

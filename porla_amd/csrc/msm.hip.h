@@ -53,6 +53,7 @@ struct Bn254G1 {
     // combine and tree kernels
     static constexpr bool F30_LAZY = true;
     static constexpr int BUCKET_SUM_WAVES = 4;   // waves per SIMD k_bucket_sum30 is compiled for
+    static constexpr int FB_COMMIT_WAVES = 3;    // ... and k_fb_commit (fixed_base.hip.h: 161-169 registers by build; 168 is the most three waves leave each)
     static constexpr int MACQ_WAVES = 4;         // the quad-lane MAC kernels: 128 registers, they run beside the commitments of a CRebuild (mac_fft.hip.h)
 };
 struct Secp256k1G {
@@ -69,6 +70,7 @@ struct Secp256k1G {
     static constexpr bool F30_BUCKETS = true;    // special-form product on 30-bit limbs: 194 against 133 G products/s
     static constexpr bool F30_LAZY = true;       // memory form: canonical residues (5p > 2^256: an unreduced X does not fit 32 bytes)
     static constexpr int BUCKET_SUM_WAVES = 3;   // the fold's temporaries do not fit 128 registers
+    static constexpr int FB_COMMIT_WAVES = 2;    // k_fb_commit: ~205 registers
     static constexpr int MACQ_WAVES = 2;         // no combined CRebuild stage on this curve: the quad-lane MAC kernels take the registers the fold wants (no spills)
 };
 
@@ -284,11 +286,7 @@ k_digits_partition(const uint8_t* __restrict__ scalars, uint32_t n, int c, int W
                 uint32_t s[8];
                 uint32_t br = 0;
 #pragma unroll
-                for (int q2 = 0; q2 < 8; q2++) {
-                    uint64_t d = (uint64_t)k[q2] - C::ORDER[q2] - br;
-                    s[q2] = (uint32_t)d;
-                    br = (uint32_t)(d >> 63);
-                }
+                for (int q2 = 0; q2 < 8; q2++) s[q2] = sbb32(k[q2], C::ORDER[q2], br);
                 if (br) break;
 #pragma unroll
                 for (int q2 = 0; q2 < 8; q2++) k[q2] = s[q2];

@@ -225,11 +225,7 @@ k_small_msm(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ poi
                 uint32_t d[8];
                 uint32_t br = 0;
 #pragma unroll
-                for (int q2 = 0; q2 < 8; q2++) {
-                    uint64_t x = (uint64_t)k[q2] - C::ORDER[q2] - br;
-                    d[q2] = (uint32_t)x;
-                    br = (uint32_t)(x >> 63);
-                }
+                for (int q2 = 0; q2 < 8; q2++) d[q2] = sbb32(k[q2], C::ORDER[q2], br);
                 if (br) break;
 #pragma unroll
                 for (int q2 = 0; q2 < 8; q2++) k[q2] = d[q2];
