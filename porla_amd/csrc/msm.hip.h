@@ -401,13 +401,15 @@ k_digits_partition(const uint8_t* __restrict__ scalars, uint32_t n, int c, int W
     }
 }
 
-// grid = W * P blocks of 1024 threads (16 waves; wave v takes tiles v, v+16, ...)
-static __global__ void __launch_bounds__(1024)
+// grid = W * P blocks of 1024 threads (16 waves; wave v takes tiles v, v+16, ...).  STAGE_CAP / MAX_LOW: the staging area and the
+// bucket counters in LDS -- the full size (one block per compute unit) or half of each (two: msm_impl.hip.h)
+template <int STAGE_CAP, int MAX_LOW>
+__global__ void __launch_bounds__(1024)
 k_partition_sort(const uint32_t* __restrict__ tile_items, const uint16_t* __restrict__ tile_off, uint32_t T, uint32_t tile_cap,
                  int c, int lowbits, uint32_t* __restrict__ counts, uint32_t* __restrict__ starts,
                  uint32_t* __restrict__ entries, uint32_t* __restrict__ cursor) {
-    __shared__ uint32_t cnt[SORT_MAX_LOW];
-    __shared__ uint32_t stage[SORT_STAGE_CAP];
+    __shared__ uint32_t cnt[MAX_LOW];
+    __shared__ uint32_t stage[STAGE_CAP];
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t base_sh, total_sh;
     const int P = 1 << (c - 1 - lowbits);
@@ -481,7 +483,7 @@ k_partition_sort(const uint32_t* __restrict__ tile_items, const uint16_t* __rest
     __syncthreads();
     // the partition's indices are staged in LDS and written out as one coalesced range when they fit (scattered 4-byte
     // stores cost ~6.5x their size in HBM write traffic); larger partitions store directly
-    const bool staged = total_sh <= (uint32_t)SORT_STAGE_CAP;
+    const bool staged = total_sh <= (uint32_t)STAGE_CAP;
     if (first < nlow) {
         uint32_t run = base_sh + excl;
         for (uint32_t k = 0; k < per; k++) {

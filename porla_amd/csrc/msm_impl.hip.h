@@ -342,7 +342,19 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
                                (Affine<M>*)ws->pts.p, n32);
     }
     if (front_split) PORLA_HIP(hipEventRecord(ws->front_join_ev, ws->aux_stream));
-    const int lowbits = sort_lowbits(c, n_sub, W);
+    int lowbits = sort_lowbits(c, n_sub, W);
+    // Half-size partitions -- twice the blocks, half the staging area (78 KiB of LDS): TWO sort blocks per compute unit, whose
+    // load -> LDS-atomic chains then overlap -- where a partition's expected entries fit the smaller staging area and a tile's run
+    // of a partition still holds 64 items (one coalesced load per wave).  Same box, profiles/r05_ag_sort_half_ab.txt: blocking calls of
+    // 2^18 / 2^19 / 2^20 pairs -2 % / -2.3 % / -1.2 %, three in flight -1 % / -2.3 % / 0; 2^21 pairs (32-item runs) would lose 1.5 %.
+    bool sort_half = false;
+    {
+        const int lb2 = lowbits - 1, parts_log = c - 1 - lb2;
+        if (lb2 >= 0 && lb2 <= 11 && parts_log <= 7 && (n_sub >> parts_log) <= 16384 && (tile_cap >> parts_log) >= 64) {
+            lowbits = lb2;
+            sort_half = true;
+        }
+    }
     const int P = 1 << (c - 1 - lowbits);
     {
         ProfScope ps("digits_partition", stream);
@@ -362,9 +374,14 @@ static int msm_launch(Workspace* ws, const uint8_t* d_scalars, const uint8_t* d_
     }
     {
         ProfScope ps("partition_sort", stream);
-        hipLaunchKernelGGL(k_partition_sort, dim3((unsigned)(W * P)), dim3(1024), 0, stream, (const uint32_t*)ws->keys.p,
-                           (const uint16_t*)ws->tile_off.p, T_tiles, tile_cap, c, lowbits, (uint32_t*)ws->counts.p,
-                           (uint32_t*)ws->starts.p, (uint32_t*)ws->entries.p, ctrl);
+        if (sort_half)
+            hipLaunchKernelGGL((k_partition_sort<SORT_STAGE_CAP / 2, SORT_MAX_LOW / 2>), dim3((unsigned)(W * P)), dim3(1024), 0, stream,
+                               (const uint32_t*)ws->keys.p, (const uint16_t*)ws->tile_off.p, T_tiles, tile_cap, c, lowbits,
+                               (uint32_t*)ws->counts.p, (uint32_t*)ws->starts.p, (uint32_t*)ws->entries.p, ctrl);
+        else
+            hipLaunchKernelGGL((k_partition_sort<SORT_STAGE_CAP, SORT_MAX_LOW>), dim3((unsigned)(W * P)), dim3(1024), 0, stream,
+                               (const uint32_t*)ws->keys.p, (const uint16_t*)ws->tile_off.p, T_tiles, tile_cap, c, lowbits,
+                               (uint32_t*)ws->counts.p, (uint32_t*)ws->starts.p, (uint32_t*)ws->entries.p, ctrl);
     }
     {
         ProfScope ps("size_order", stream);
