@@ -127,6 +127,29 @@ __device__ __forceinline__ bool xyzz30_madd_flip_fast(XYZZ30<M>& p, bool& flip, 
     flip = !flip;
     return true;
 }
+// The same step for an accumulator that IS an affine point (just copied in: ZZ = ZZZ = the unit): U2 = X2, S2 = Y2, ZZ3 = PP, ZZZ3 = PPP --
+// the four products with the unit drop out (4M + 2S instead of 8M + 2S; mmadd-2008-s).  One addition per work item: with ~16 entries
+// per bucket that is a fifteenth of all additions at 45 % less.  Bounds: X2, Y2 canonical (<= 1) stand where U2, S2 (<= 1) stood.
+// Returns false, p untouched, in the exceptional cases.
+template <class M>
+__device__ __forceinline__ bool xyzz30_mmadd_flip_fast(XYZZ30<M>& p, bool& flip, const F30<M>& ax, const F30<M>& ay, bool a_is_inf) {
+    F30<M> Pp = f30_sub<M, 6>(ax, p.x);
+    F30<M> Rn = f30_sub<M, 2>(p.y, ay);
+    F30<M> PP = f30_sqr<M>(Pp);
+    if (a_is_inf || p.inf || f30_product_is_zero<M>(PP)) return false;
+    F30<M> PPP = f30_mul<M>(Pp, PP);
+    F30<M> Q = f30_mul<M>(p.x, PP);
+    F30<M> RR = f30_sqr<M>(Rn);
+    F30<M> E = f30_add2<M>(PPP, Q);
+    F30<M> X3 = f30_sub<M, 4>(RR, E);
+    F30<M> D = f30_sub<M, 6>(Q, X3);
+    p.y = f30_mul2<M>(Rn, D, p.y, PPP);             // -Y3
+    p.x = X3;
+    p.zz = PP;
+    p.zzz = PPP;
+    flip = !flip;
+    return true;
+}
 template <class M>
 __device__ __forceinline__ XYZZ30<M> xyzz30_infinity() {
     XYZZ30<M> p;

@@ -676,6 +676,17 @@ k_bucket_sum30(const Affine<typename C::Fp>* __restrict__ pts, const uint32_t* _
             acc.inf = false;
         }
         k = 1;
+        // the item's second entry meets an accumulator that is still an affine point: the short form (ec30.hip.h:xyzz30_mmadd_flip_fast).
+        // An exceptional case leaves everything as it was and the loops below take the entry
+        if (!acc.inf && cnt > 1) {
+            const uint32_t cur2 = ent;
+            uint32_t nxt = cur2;
+            if (cnt > 2) nxt = e[2];
+            Affine<M> a2 = load_affine<M>(pts, cur2 & 0x7fffffffu);
+            const bool a2_inf = aff_is_inf<M>(a2);
+            a2 = aff_neg_if<M>(a2, xyzz30_flip_neg<M>((cur2 >> 31) != 0, flip));
+            if (xyzz30_mmadd_flip_fast<M>(acc, flip, f30_from_fe<M>(a2.x), f30_from_fe<M>(a2.y), a2_inf)) { ent = nxt; k = 2; }
+        }
     }
     {
         // the fast loop: straight-line additions; a lane that meets an exceptional case leaves it with that entry still to do
