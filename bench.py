@@ -641,7 +641,7 @@ def main():
             pk = fe_peak[WORKLOAD_FIELD[workload]]
             r["int_multiplier"] = {"achieved": round(g, 2), "peak": pk["mix_8M_2S"], "unit": "G fe_mul/s (256-bit modular)",
                                    "frac": round(g / pk["mix_8M_2S"], 4), "peak_source": pk["source"],
-                                   "note": "mixed addition = 8M + 2S = 10 fe_mul (the ALGORITHMIC count of the group law; since "
+                                   "note": "mixed addition = 8M + 2S = 10 fe_mul, a bucket's first entry a copy (0), its second 4M + 2S = 6 (the ALGORITHMIC count of the group law; since "
                                            "round 4 the kernel computes R D - Y1 PPP with one reduction, ~9.4 product-equivalents of "
                                            "instructions per addition); peak = back-to-back product rate of the field form the kernel "
                                            "uses (8M + 2S mix)"}
@@ -665,9 +665,18 @@ def main():
         return rl
 
     def msm_fe_mults(n):
-        # one mixed addition (10 fe_mul) per (sub-scalar, window) digit; zero digits (2^-c of them) are not subtracted
+        # what the accumulation kernel multiplies, counted by the group law: per (sub-scalar, window) digit one mixed addition
+        # (8M + 2S = 10 fe_mul) -- except a bucket's FIRST entry, which is a copy (0), and its SECOND, which meets an affine
+        # accumulator (4M + 2S = 6).  Buckets filled by uniformly random digits: Poisson with mean `load`.  Zero digits (2^-c of
+        # them) are not subtracted.
+        import math
         c, windows, glv = mx.last_msm_shape()
-        return 10.0 * n * (2 if glv else 1) * windows
+        subs = 2 if glv else 1
+        buckets = windows * float(1 << (c - 1))
+        load = n * subs / float(1 << (c - 1))
+        nonempty = buckets * (1.0 - math.exp(-load))
+        two_plus = buckets * (1.0 - math.exp(-load) * (1.0 + load))
+        return 10.0 * (n * subs * windows - nonempty) - 4.0 * two_plus
 
     def line(metric, value, unit, el, scaling, dtype, config, rl, cpu, verified, **extra):
         d = {"metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
