@@ -86,6 +86,11 @@ int         porla_gpu_set_msm_small(int on, int window_bits);
 int         porla_gpu_set_msm_glv(int on);
 /* diagnostic: window bits, window count and GLV flag of the most recently launched MSM (what the automatic choice was) */
 int         porla_gpu_last_msm_shape(int *c, int *windows, int *glv);
+/* diagnostic: HOST execution of the 8 x 32-bit field helpers the kernels are built from (borrow / carry chains, negation, the
+ * bounded reduction of the ICC finish step), for the CPU test suite.  op 0: reduce a value below 5 x modulus (modulus 0 = BN254
+ * group order) or below the modulus + 2^256 - n (modulus 1 = secp256k1 group order: one conditional subtraction) to its residue;
+ * 1: negate; 2: conditional negate (taken); 3: a - b; 4: a + b (operands canonical).  32-byte little-endian values. */
+int         porla_diag_fe_op(int op, int modulus, const uint8_t a_le[32], const uint8_t b_le[32], uint8_t out_le[32]);
 /* diagnostic: the scalar split the digit kernel applies (host execution of the same code): scalar mod n = k1 + lambda*k2,
  * magnitudes as 16-byte big-endian, signs as 0/1.  curve: 0 = BN254, 1 = secp256k1. */
 int         porla_glv_split(int curve, const uint8_t scalar_be[32], uint8_t k1_mag_be[16], int *k1_neg,

@@ -244,6 +244,7 @@ using namespace porla;
 namespace {
 struct IccSecp256k1FnHost {  // secp256k1 group order, only P is needed (fe_reduce_plain)
     static constexpr uint32_t P[8] = {0xd0364141u, 0xbfd25e8cu, 0xaf48a03bu, 0xbaaedce6u, 0xfffffffeu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    static constexpr int SPARE_BITS = 0;          // (fe_add of porla_diag_fe_op)
 };
 }  // namespace
 
@@ -346,6 +347,36 @@ int porla_glv_split(int curve, const uint8_t scalar_be[32], uint8_t k1_mag_be[16
         }
     }
     *k1_neg = n1; *k2_neg = n2;
+    return PORLA_OK;
+}
+
+// diagnostics: HOST execution of the 8 x 32-bit helpers the kernels use (fe.hip.h), for the CPU suite -- the same source, the
+// portable branch of sbb32 / adc32.  op 0: fe_reduce_small (value below (K + 1) modulus -> value mod modulus; modulus 0 = the BN254
+// group order with K = 4, as the ICC finish step reduces A mod p_icc; 1 = the secp256k1 group order with K = 0);
+// op 1: fe_neg; op 2: fe_neg_if(., true); op 3: fe_sub(a, b); op 4: fe_add(a, b).  Values are 32-byte little-endian.
+int porla_diag_fe_op(int op, int modulus, const uint8_t a_le[32], const uint8_t b_le[32], uint8_t out_le[32]) {
+    if (!a_le || !out_le || (modulus != 0 && modulus != 1) || op < 0 || op > 4 || (op >= 3 && !b_le)) return PORLA_ERR_ARG;
+    uint32_t a[8], b[8] = {0, 0, 0, 0, 0, 0, 0, 0}, r[8];
+    for (int i = 0; i < 8; i++) {
+        a[i] = (uint32_t)a_le[4 * i] | ((uint32_t)a_le[4 * i + 1] << 8) | ((uint32_t)a_le[4 * i + 2] << 16) | ((uint32_t)a_le[4 * i + 3] << 24);
+        if (b_le) b[i] = (uint32_t)b_le[4 * i] | ((uint32_t)b_le[4 * i + 1] << 8) | ((uint32_t)b_le[4 * i + 2] << 16) | ((uint32_t)b_le[4 * i + 3] << 24);
+    }
+    auto run = [&](auto tag, auto ktag) {
+        using M = decltype(tag);
+        constexpr int K = decltype(ktag)::value;
+        Fe<M> x, y, z;
+        for (int i = 0; i < 8; i++) { x.v[i] = a[i]; y.v[i] = b[i]; }
+        if (op == 0) { for (int i = 0; i < 8; i++) r[i] = a[i]; fe_reduce_small<M, K>(r); return; }
+        if (op == 1) z = fe_neg<M>(x);
+        else if (op == 2) z = fe_neg_if<M>(x, true);
+        else if (op == 3) z = fe_sub<M>(x, y);
+        else z = fe_add<M>(x, y);
+        for (int i = 0; i < 8; i++) r[i] = z.v[i];
+    };
+    if (modulus == 0) run(Bn254Fr{}, std::integral_constant<int, 4>{});
+    else run(IccSecp256k1FnHost{}, std::integral_constant<int, 0>{});
+    for (int i = 0; i < 8; i++)
+        for (int k = 0; k < 4; k++) out_le[4 * i + k] = (uint8_t)(r[i] >> (8 * k));
     return PORLA_OK;
 }
 

@@ -62,6 +62,7 @@ def _declare(L):
     L.porla_gpu_last_msm_shape.argtypes = [ctypes.POINTER(ctypes.c_int)] * 3; L.porla_gpu_last_msm_shape.restype = ctypes.c_int
     L.porla_glv_split.argtypes = [ctypes.c_int, u8p, u8p, ctypes.POINTER(ctypes.c_int), u8p, ctypes.POINTER(ctypes.c_int)]
     L.porla_glv_split.restype = ctypes.c_int
+    L.porla_diag_fe_op.argtypes = [ctypes.c_int, ctypes.c_int, u8p, u8p, u8p]; L.porla_diag_fe_op.restype = ctypes.c_int
     for curve in ("bn254", "secp256k1"):
         f = getattr(L, "porla_%s_msm_device_begin" % curve); f.argtypes = [ctypes.c_int, vp, vp, sz, vp]; f.restype = ctypes.c_int
         f = getattr(L, "porla_%s_msm_device_end" % curve); f.argtypes = [ctypes.c_int, u8p, ctypes.c_int]; f.restype = ctypes.c_int
